@@ -1,0 +1,197 @@
+"""Generate tests/golden/*.npz by RUNNING the genuine reference (/root/reference) in this container.
+
+Usage (authoring container only; the reference does not exist on the GPU box):
+    cd /root/repo && python oracle/make_golden.py
+
+The reference needs 7 third-party modules that are not installed here; `oracle/shims/` provides
+stand-ins (see oracle/shims/README.md for which of them carry arithmetic and are therefore
+"parity unpinned").  Fixtures are DATA ONLY: seeded inputs + the reference's outputs.  Model weights
+are not stored: every parameter is formula-filled from its state_dict name
+(oracle/pidm_oracle.formula_fill), so the tests can rebuild the identical weights.
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "shims"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle.pidm_oracle import fill_state_dict  # noqa: E402
+
+# --- genuine reference imports -------------------------------------------------------------------
+from src.unet_model import Unet3D  # noqa: E402
+from src.denoising_utils import DenoisingDiffusion  # noqa: E402
+from src.residuals_darcy import ResidualsDarcy  # noqa: E402
+from src.grad_utils import GradientsHelper  # noqa: E402
+import src.denoising_utils as du  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def seeded(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# G1: schedule tables ------------------------------------------------------------------------------
+def g1():
+    out = {}
+    for n in (100, 1000):
+        dd = DenoisingDiffusion(n, "cpu").diff_dict
+        for k, v in dd.items():
+            out[f"n{n}/{k}"] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "g1_schedule.npz"), **out)
+
+
+# G2/G3/G4: stencil engine + Darcy residual --------------------------------------------------------
+def g2_g3():
+    P = 64
+    h = 1.0 / (P - 1)
+    gh = GradientsHelper(d0=h, d1=-h, fd_acc=2, periodic=False, device="cpu")
+    x8 = seeded((2, 8, 8), 11)
+    gh8 = GradientsHelper(d0=0.25, d1=-0.25, fd_acc=2, periodic=False, device="cpu")
+    out = {"x8": npy(x8)}
+    for mode in ("d_d0", "d_d1", "d_d00", "d_d11"):
+        out[f"x8/{mode}"] = npy(gh8.stencil_gradients(x8, mode=mode))
+    x64 = seeded((1, 64, 64), 12)
+    out["x64"] = npy(x64)
+    for mode in ("d_d0", "d_d1", "d_d00", "d_d11"):
+        out[f"x64/{mode}"] = npy(gh.stencil_gradients(x64, mode=mode))
+    np.savez_compressed(os.path.join(OUT, "g2_stencils.npz"), **out)
+
+    res = ResidualsDarcy(model=None, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True,
+                         device="cpu", bcs="none", domain_length=1.0)
+    x0 = seeded((2, 2, P, P), 13)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    x0[:, 0] *= 0.1
+    x0.requires_grad_(True)
+    r = res.compute_residual(x0, pass_through=True)["residual"]
+    (g,) = torch.autograd.grad((r ** 2).sum(), x0)
+    np.savez_compressed(os.path.join(OUT, "g3_darcy_residual.npz"), x0=npy(x0), residual=npy(r),
+                        grad_sumsq=npy(g), f_s=npy(res.f_s), trap=npy(res.trapezoidal_weights))
+
+
+# G5/G6: UNet forward + grads with formula-filled weights -----------------------------------------
+PROBES = ["init_conv.weight", "downs.0.0.block1.proj.weight", "downs.1.0.block1.proj.weight",
+          "downs.1.0.res_conv.weight", "downs.0.2.fn.fn.to_qkv.weight", "downs.0.2.fn.fn.to_out.weight",
+          "downs.0.2.fn.norm.gamma", "downs.0.3.weight", "ups.0.3.weight", "time_mlp.3.weight",
+          "time_mlp.1.weight", "downs.0.0.mlp.1.weight", "mid_spatial_attn.fn.fn.fn.to_qkv.weight",
+          "mid_spatial_attn.fn.fn.fn.to_out.weight", "mid_spatial_attn.fn.norm.gamma",
+          "downs.0.0.block1.norm.weight", "downs.0.0.block1.norm.bias", "final_conv.1.weight",
+          "final_conv.0.res_conv.weight", "ups.3.0.block1.proj.weight", "mid_block1.block2.proj.weight"]
+
+
+def unet_case(tag, dim, P, B, tvals, channels=2, out_dim=None, sigmoid=False, full_out=True):
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=channels, out_dim=out_dim, sigmoid_last_channel=sigmoid)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    x = seeded((B, channels, P, P), 21)
+    t = torch.tensor(tvals, dtype=torch.long)
+    x_bxyc = x.permute(0, 2, 3, 1).reshape(B, P * P, channels)
+    out = m(x_bxyc, t)
+    w = seeded(tuple(out.shape), 22)
+    loss = (out * w).sum()
+    loss.backward()
+    d = {"x": npy(x), "t": npy(t), "w": npy(w)}
+    if full_out:
+        d["out"] = npy(out)
+    else:
+        d["out_probe"] = npy(out[:, :, ::8, ::8])
+        d["out_sum"] = np.array(out.double().sum().item())
+        d["out_abs_sum"] = np.array(out.double().abs().sum().item())
+    names, norms = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    d["grad_names"] = np.array(names)
+    d["grad_norms"] = np.array(norms)
+    for k in PROBES:
+        p = dict(m.named_parameters())[k]
+        if p.grad is not None:
+            d["grad/" + k] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "out", tuple(out.shape), "n_grads", len(names))
+
+
+# G7: full model_estimation_loss with injected RNG --------------------------------------------------
+def g7(tag, dim, P, B, tvals, n_steps=100):
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(n_steps, "cpu")
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True,
+                         device="cpu", bcs="none", domain_length=1.0)
+    x0 = seeded((B, 2, P, P), 31)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = seeded((B, 2, P, P), 32)
+    t = torch.tensor(tvals, dtype=torch.long)
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda *a, **k: eps.clone()
+    try:
+        loss, data_l, res_l, ineq_l, opt_l = diff.model_estimation_loss(
+            x0, residual_func=res, c_data=1.0, c_residual=1e-3, c_ineq=0.0, lambda_opt=0.0)
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    loss.backward()
+    names, norms = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    d = dict(x0=npy(x0), eps=npy(eps), t=npy(t), loss=np.array(loss.item()), data_loss=np.array(data_l),
+             residual_abs_mean=np.array(res_l), grad_names=np.array(names), grad_norms=np.array(norms))
+    for k in PROBES[:6]:
+        p = dict(m.named_parameters())[k]
+        d["grad/" + k] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "loss", loss.item(), data_l, res_l)
+
+
+# G8: sampler ------------------------------------------------------------------------------------------
+def g8(tag, dim, P, B, n_steps=5):
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(n_steps, "cpu")
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True,
+                         device="cpu", bcs="none", domain_length=1.0)
+    noises = [seeded((B, 2, P, P), 40 + i) for i in range(n_steps + 1)]
+    it = iter(noises)
+    orig_randn, orig_randn_like = torch.randn, torch.randn_like
+    torch.randn = lambda *a, **k: next(it).clone()
+    torch.randn_like = lambda *a, **k: next(it).clone()
+    try:
+        (x_seq, interm), aux = diff.p_sample_loop(None, (B, 2, P, P), save_output=True, surpress_noise=True,
+                                                  residual_func=res, eval_residuals=True)
+    finally:
+        torch.randn, torch.randn_like = orig_randn, orig_randn_like
+    d = dict(noises=np.stack([npy(n) for n in noises]), x_seq=np.stack([npy(x) for x in x_seq]),
+             interm=np.stack([npy(x) for x in interm]), residual=npy(aux["residual"]))
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "x_final abs mean", float(np.abs(d["x_seq"][-1]).mean()))
+
+
+if __name__ == "__main__":
+    g1()
+    g2_g3()
+    unet_case("g5_unet_dim8_p16", dim=8, P=16, B=2, tvals=[3, 50])
+    unet_case("g5b_unet_dim16_p32", dim=16, P=32, B=2, tvals=[0, 99], full_out=True)
+    unet_case("g6_unet_dim32_p64", dim=32, P=64, B=2, tvals=[17, 78], full_out=False)
+    g7("g7_loss_dim8_p16", dim=8, P=16, B=3, tvals=[0, 37, 99])
+    g7("g7b_loss_dim32_p64", dim=32, P=64, B=2, tvals=[5, 60])
+    g8("g8_sampler_dim8_p16", dim=8, P=16, B=2, n_steps=5)
+    print("golden vectors written to", OUT)

@@ -1,0 +1,420 @@
+"""CPU oracle for the UNet + PDE-residual hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU restatement (torch-CPU fp32 functional ops + numpy) of the reference
+algorithm for the hot path of jhbastek/PhysicsInformedDiffusionModels.  It is the *checker* for the HIP
+kernels: only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+The product package (`physicsinformeddiffusionmodels_amd/`) never imports anything from `oracle/`.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * UNet forward/backward, diffusion schedule, q-sample, loss algebra, ancestral step, the Darcy
+    residual assembly: PINNED against the genuine reference executed in the authoring container
+    (`oracle/make_golden.py` imports /root/reference and writes `tests/golden/*.npz`;
+    `tests/test_oracle_vs_golden.py` checks this file against those vectors).
+  * Finite-difference coefficient VALUES (third-party `findiff`, not installed, no lockfile): PARITY
+    UNPINNED - textbook acc-2 coefficients, cross-checked by polynomial exactness.
+  * Q4 element stiffness (third-party `solidspy`): PARITY UNPINNED - restated from first principles,
+    known answer k[0,0]=0.494505 for the unit square (E=1, nu=0.3).
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic parameter fill (so that no weights need to be committed as fixtures)
+# ----------------------------------------------------------------------------------------------
+def formula_fill(name: str, shape, scale: float | None = None) -> torch.Tensor:
+    """Deterministic fp32 tensor for a state_dict entry: PCG64 stream seeded by crc32(name)."""
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+    n = int(np.prod(shape)) if len(shape) else 1
+    a = rng.standard_normal(n).astype(np.float32).reshape(tuple(shape))
+    if scale is None:
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        if name.endswith("norm.weight") or name.endswith("gamma"):
+            a = 1.0 + 0.1 * a
+        elif name.endswith("bias"):
+            a = 0.05 * a
+        else:
+            a = a / math.sqrt(max(fan_in, 1))
+    else:
+        a = a * scale
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def fill_state_dict(sd: dict) -> dict:
+    """Return {name: formula-filled tensor} for every floating entry of a state_dict."""
+    out = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            out[k] = formula_fill(k, tuple(v.shape)).to(v.dtype)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a1: diffusion schedule  (src/denoising_utils.py:315-370)
+# ----------------------------------------------------------------------------------------------
+def cosine_betas(n_steps: int) -> torch.Tensor:
+    """src/denoising_utils.py:362-369 (fp32 op order preserved)."""
+    s = 0.008
+    x = torch.linspace(0, n_steps, n_steps + 1)
+    ac = torch.cos(((x / n_steps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = 1 - (ac[1:] / ac[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+def diffusion_tables(n_steps: int) -> dict:
+    """src/denoising_utils.py:315-352: the 18 per-timestep fp32 vectors."""
+    d = {}
+    b = cosine_betas(n_steps)
+    d["betas"] = b
+    d["alphas"] = 1.0 - b
+    d["sqrt_recip_alphas"] = torch.sqrt(1.0 / d["alphas"])
+    ap = torch.cumprod(d["alphas"], 0)
+    d["alphas_prod"] = ap
+    d["alphas_prod_p"] = torch.cat([torch.ones(1), ap[:-1]], 0)
+    d["alphas_bar_sqrt"] = torch.sqrt(ap)
+    d["sqrt_recip_alphas_cumprod"] = torch.sqrt(1.0 / ap)
+    d["sqrt_recipm1_alphas_cumprod"] = torch.sqrt(1.0 / ap - 1)
+    d["one_minus_alphas_bar_log"] = torch.log(1 - ap)
+    d["one_minus_alphas_bar_sqrt"] = torch.sqrt(1 - ap)
+    app = F.pad(ap[:-1], (1, 0), value=1.0)
+    d["alphas_prod_prev"] = app
+    d["posterior_mean_coef1"] = b * torch.sqrt(app) / (1.0 - ap)
+    d["posterior_mean_coef2"] = (1.0 - app) * torch.sqrt(d["alphas"]) / (1.0 - ap)
+    d["noise_mean_coeff"] = torch.sqrt(1.0 / d["alphas"]) * (1.0 - d["alphas"]) / torch.sqrt(1.0 - ap)
+    pv = b * (1.0 - app) / (1.0 - ap)
+    d["posterior_variance"] = pv
+    pvc = pv.clone()
+    pvc[0] = pv[1]
+    d["posterior_variance_clipped"] = pvc
+    d["posterior_log_variance_clipped"] = torch.log(pvc)
+    snr = ap / (1.0 - ap)
+    d["p2_loss_weight"] = torch.minimum(snr, torch.ones_like(snr) * 5.0)
+    return d
+
+
+# ----------------------------------------------------------------------------------------------
+# a5/a6: Darcy residual, direct-stencil form (src/residuals_darcy.py:106-207, src/grad_utils.py:27-175)
+# ----------------------------------------------------------------------------------------------
+def _d1(a: torch.Tensor, axis: int, h: float) -> torch.Tensor:
+    """1st derivative, 2nd-order accurate: central interior, one-sided 3-point at both edges."""
+    a = a.movedim(axis, -1)
+    out = torch.empty_like(a)
+    out[..., 1:-1] = (a[..., 2:] - a[..., :-2]) * (0.5 / h)
+    out[..., 0] = (-1.5 * a[..., 0] + 2.0 * a[..., 1] - 0.5 * a[..., 2]) / h
+    out[..., -1] = (1.5 * a[..., -1] - 2.0 * a[..., -2] + 0.5 * a[..., -3]) / h
+    return out.movedim(-1, axis)
+
+
+def _d2(a: torch.Tensor, axis: int, h: float) -> torch.Tensor:
+    """2nd derivative, 2nd-order accurate: central interior, one-sided 4-point at both edges."""
+    a = a.movedim(axis, -1)
+    out = torch.empty_like(a)
+    h2 = h * h
+    out[..., 1:-1] = (a[..., 2:] - 2.0 * a[..., 1:-1] + a[..., :-2]) / h2
+    out[..., 0] = (2.0 * a[..., 0] - 5.0 * a[..., 1] + 4.0 * a[..., 2] - a[..., 3]) / h2
+    out[..., -1] = (2.0 * a[..., -1] - 5.0 * a[..., -2] + 4.0 * a[..., -3] - a[..., -4]) / h2
+    return out.movedim(-1, axis)
+
+
+def darcy_source_field(P: int) -> torch.Tensor:
+    """f_s on pixel centres (k+1/2)/P: +10 where both coords<=0.125, -10 where both>=0.875.
+    src/residuals_darcy.py:41-53,95-104.  Returns [P,P]."""
+    w, r = 0.125, 10.0
+    ps = 1.0 / P
+    x = torch.linspace(ps / 2, 1.0 - ps / 2, steps=P)
+    X, Y = torch.meshgrid(x, x, indexing="ij")
+    c1 = torch.abs(X - 0.5 * w) <= 0.5 * w
+    c2 = torch.abs(X - 1 + 0.5 * w) <= 0.5 * w
+    c3 = torch.abs(Y - 0.5 * w) <= 0.5 * w
+    c4 = torch.abs(Y - 1 + 0.5 * w) <= 0.5 * w
+    f = torch.zeros_like(X)
+    f[torch.logical_and(c1, c3)] = r
+    f[torch.logical_and(c2, c4)] = -r
+    return f
+
+
+def darcy_residual(x0: torch.Tensor, domain_length: float = 1.0, pixels_at_boundary: bool = True,
+                   reverse_d1: bool = True) -> torch.Tensor:
+    """x0 [B,2,P,P] (ch0 = pressure p, ch1 = permeability K) -> residual [B,P*P,3] = (eq, bc0, bc1).
+    src/residuals_darcy.py:137-183 with the stencil engine of src/grad_utils.py:64-146."""
+    B, C, P, _ = x0.shape
+    h0 = domain_length / (P - 1) if pixels_at_boundary else domain_length / P
+    h1 = -h0 if reverse_d1 else h0
+    p, K = x0[:, 0], x0[:, 1]
+    p0, p1 = _d1(p, 1, h0), _d1(p, 2, h1)
+    p00, p11 = _d2(p, 1, h0), _d2(p, 2, h1)
+    K0, K1 = _d1(K, 1, h0), _d1(K, 2, h1)
+    fs = darcy_source_field(P).to(x0.dtype)
+    eq = (-K * p00 - K0 * p0) + (-K * p11 - K1 * p1) - fs
+    bc0 = torch.zeros_like(p)
+    bc1 = torch.zeros_like(p)
+    bc0[:, 0, :] = -p0[:, 0, :]
+    bc0[:, -1, :] = p0[:, -1, :]
+    if reverse_d1:
+        bc1[:, :, 0] = p1[:, :, 0]
+        bc1[:, :, -1] = -p1[:, :, -1]
+    else:
+        bc1[:, :, 0] = -p1[:, :, 0]
+        bc1[:, :, -1] = p1[:, :, -1]
+    return torch.stack([eq, bc0, bc1], dim=-1).reshape(B, P * P, 3)
+
+
+# ----------------------------------------------------------------------------------------------
+# a7: UNet forward, functional (src/unet_model.py:542-623 and the blocks it calls)
+# ----------------------------------------------------------------------------------------------
+class UnetCfg:
+    def __init__(self, dim, channels=2, out_dim=None, dim_mults=(1, 2, 4, 8), heads=8, dim_head=32,
+                 groups=8, sigmoid_last_channel=False):
+        self.dim = dim
+        self.channels = channels
+        self.out_dim = out_dim if out_dim is not None else channels
+        self.dim_mults = tuple(dim_mults)
+        self.heads = heads
+        self.dim_head = dim_head
+        self.groups = groups
+        self.sigmoid_last_channel = sigmoid_last_channel
+
+
+def _w2d(w):
+    """Conv3d weight [O,I,1,k,k] -> [O,I,k,k]."""
+    return w.squeeze(2) if w.dim() == 5 else w
+
+
+def _resnet_block(p, pre, x, t_emb, groups):
+    """src/unet_model.py:255-267 + Block :233-241."""
+    scale = shift = None
+    if (pre + "mlp.1.weight") in p and t_emb is not None:
+        te = F.linear(F.silu(t_emb), p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"])
+        scale, shift = te.chunk(2, dim=1)
+    h = F.conv2d(x, _w2d(p[pre + "block1.proj.weight"]), p[pre + "block1.proj.bias"], padding=1)
+    h = F.group_norm(h, groups, p[pre + "block1.norm.weight"], p[pre + "block1.norm.bias"], eps=1e-5)
+    if scale is not None:
+        h = h * (scale[:, :, None, None] + 1) + shift[:, :, None, None]
+    h = F.silu(h)
+    h = F.conv2d(h, _w2d(p[pre + "block2.proj.weight"]), p[pre + "block2.proj.bias"], padding=1)
+    h = F.group_norm(h, groups, p[pre + "block2.norm.weight"], p[pre + "block2.norm.bias"], eps=1e-5)
+    h = F.silu(h)
+    if (pre + "res_conv.weight") in p:
+        res = F.conv2d(x, _w2d(p[pre + "res_conv.weight"]), p[pre + "res_conv.bias"])
+    else:
+        res = x
+    return h + res
+
+
+def _chan_layernorm(x, gamma):
+    """src/unet_model.py:207-210: per pixel over channels, biased var, eps=1e-5, gamma only."""
+    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+    mean = torch.mean(x, dim=1, keepdim=True)
+    return (x - mean) / (var + 1e-5).sqrt() * gamma.reshape(1, -1, 1, 1)
+
+
+def _linear_attention(p, pre, x, heads, dim_head):
+    """Residual(PreNorm(SpatialLinearAttention)): src/unet_model.py:281-299, 139-145, 212-220."""
+    B, C, H, W = x.shape
+    xn = _chan_layernorm(x, p[pre + "norm.gamma"])
+    qkv = F.conv2d(xn, p[pre + "fn.to_qkv.weight"])
+    q, k, v = qkv.chunk(3, dim=1)
+    q = q.reshape(B, heads, dim_head, H * W)
+    k = k.reshape(B, heads, dim_head, H * W)
+    v = v.reshape(B, heads, dim_head, H * W)
+    q = q.softmax(dim=-2) * (dim_head ** -0.5)
+    k = k.softmax(dim=-1)
+    v = v / (H * W)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, heads * dim_head, H, W)
+    out = F.conv2d(out, p[pre + "fn.to_out.weight"], p[pre + "fn.to_out.bias"])
+    return out + x
+
+
+def _mid_attention(p, pre, x, heads, dim_head):
+    """Residual(PreNorm(EinopsToAndFrom('b c f h w','b f (h w) c', Attention))): src/unet_model.py:341-367."""
+    B, C, H, W = x.shape
+    xn = _chan_layernorm(x, p[pre + "norm.gamma"])
+    tok = xn.reshape(B, C, H * W).transpose(1, 2)  # [B, n, C]
+    qkv = F.linear(tok, p[pre + "fn.fn.to_qkv.weight"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    sh = lambda z: z.reshape(B, H * W, heads, dim_head).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = sh(q), sh(k), sh(v)
+    q = q * (dim_head ** -0.5)
+    sim = torch.einsum("bhid,bhjd->bhij", q, k)
+    sim = sim - sim.amax(dim=-1, keepdim=True).detach()
+    attn = sim.softmax(dim=-1)
+    out = torch.einsum("bhij,bhjd->bhid", attn, v)
+    out = out.permute(0, 2, 1, 3).reshape(B, H * W, heads * dim_head)
+    out = F.linear(out, p[pre + "fn.fn.to_out.weight"])
+    out = out.transpose(1, 2).reshape(B, C, H, W)
+    return out + x
+
+
+def time_embedding(p, t, dim):
+    """SinusoidalPosEmb + Linear + GELU(erf) + Linear: src/unet_model.py:147-159,464-469."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    freqs = torch.exp(torch.arange(half) * -e)
+    emb = t.to(torch.float32)[:, None] * freqs[None, :]
+    emb = torch.cat((emb.sin(), emb.cos()), dim=-1)
+    h = F.linear(emb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
+    h = F.gelu(h)
+    return F.linear(h, p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+
+
+def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg) -> torch.Tensor:
+    """x: [B,C,P,P] (NCHW) or [B,P*P,C]; t: int64 [B].  Returns [B,out_dim,P,P].
+    src/unet_model.py:542-623 (image path: no self-conditioning, no cond)."""
+    if x.dim() == 3:
+        B, N, C = x.shape
+        P = int(round(math.sqrt(N)))
+        x = x.reshape(B, P, P, C).permute(0, 3, 1, 2)
+    g = cfg.groups
+    kinit = p["init_conv.weight"].shape[-1]
+    x = F.conv2d(x, _w2d(p["init_conv.weight"]), p["init_conv.bias"], padding=kinit // 2)
+    r = x
+    te = time_embedding(p, t, cfg.dim)
+    n_res = len(cfg.dim_mults)
+    hs = []
+    for i in range(n_res):
+        pre = f"downs.{i}."
+        x = _resnet_block(p, pre + "0.", x, te, g)
+        x = _resnet_block(p, pre + "1.", x, te, g)
+        x = _linear_attention(p, pre + "2.fn.", x, cfg.heads, cfg.dim_head)
+        hs.append(x)
+        if i < n_res - 1:
+            x = F.conv2d(x, _w2d(p[pre + "3.weight"]), p[pre + "3.bias"], stride=2, padding=1)
+    x = _resnet_block(p, "mid_block1.", x, te, g)
+    x = _mid_attention(p, "mid_spatial_attn.fn.", x, cfg.heads, cfg.dim_head)
+    x = _resnet_block(p, "mid_block2.", x, te, g)
+    for i in range(n_res):
+        pre = f"ups.{i}."
+        x = torch.cat((x, hs.pop()), dim=1)
+        x = _resnet_block(p, pre + "0.", x, te, g)
+        x = _resnet_block(p, pre + "1.", x, te, g)
+        x = _linear_attention(p, pre + "2.fn.", x, cfg.heads, cfg.dim_head)
+        if i < n_res - 1:
+            x = F.conv_transpose2d(x, _w2d(p[pre + "3.weight"]), p[pre + "3.bias"], stride=2, padding=1)
+    x = torch.cat((x, r), dim=1)
+    x = _resnet_block(p, "final_conv.0.", x, None, g)
+    x = F.conv2d(x, _w2d(p["final_conv.1.weight"]), p["final_conv.1.bias"])
+    if cfg.sigmoid_last_channel:
+        x = torch.cat((x[:, :-1], torch.sigmoid(x[:, -1:])), dim=1)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# a3: training loss (src/denoising_utils.py:616-710), Darcy, mean estimation
+# ----------------------------------------------------------------------------------------------
+def q_sample(tables, x0, t, eps):
+    """x_t = sqrt(abar_t) x0 + sqrt(1-abar_t) eps  (src/denoising_utils.py:633-638)."""
+    a = tables["alphas_bar_sqrt"][t].reshape(-1, 1, 1, 1)
+    am1 = tables["one_minus_alphas_bar_sqrt"][t].reshape(-1, 1, 1, 1)
+    return x0 * a + eps * am1
+
+
+def darcy_loss_from_pred(tables, x0, x0_pred, t, c_data=1.0, c_residual=1e-3):
+    """Given the model output, the loss of src/denoising_utils.py:666-692.
+    Returns (loss, data_loss, mean|r|, residual)."""
+    B = x0.shape[0]
+    res = darcy_residual(x0_pred)
+    per = ((x0 - x0_pred) ** 2).reshape(B, -1).mean(dim=1)
+    data = (per * tables["p2_loss_weight"][t]).mean() * c_data
+    var = tables["posterior_variance_clipped"][t].reshape(B, 1, 1)
+    rl = (c_residual * 0.5 * res ** 2 / var).mean()
+    return data + rl, data, res.abs().mean(), res
+
+
+def darcy_training_loss(p, cfg, tables, x0, t, eps, c_data=1.0, c_residual=1e-3):
+    """Full model_estimation_loss with injected (t, eps).  Returns (loss, data, mean|r|, x0_pred)."""
+    xt = q_sample(tables, x0, t, eps)
+    x0_pred = unet_forward(p, xt, t, cfg)
+    loss, data, rabs, _ = darcy_loss_from_pred(tables, x0, x0_pred, t, c_data, c_residual)
+    return loss, data, rabs, x0_pred
+
+
+# ----------------------------------------------------------------------------------------------
+# a10: ancestral sampling step (src/denoising_utils.py:441-455)
+# ----------------------------------------------------------------------------------------------
+def p_sample_update(tables, x0_pred, x_t, t_scalar: int, z, surpress_noise=True):
+    c1 = tables["posterior_mean_coef1"][t_scalar]
+    c2 = tables["posterior_mean_coef2"][t_scalar]
+    mean = c1 * x0_pred + c2 * x_t
+    sigma = tables["betas"][t_scalar].sqrt()
+    mask = 0.0 if (surpress_noise and t_scalar == 0) else 1.0
+    return mean + mask * sigma * z
+
+
+# ----------------------------------------------------------------------------------------------
+# a9: mechanics residual, matrix-free (src/residuals_mechanics_K.py:166-274)
+# ----------------------------------------------------------------------------------------------
+def q4_plane_stress_stiffness(E=1.0, nu=0.3, a=1.0) -> np.ndarray:
+    """8x8 Q4 plane-stress stiffness of an a-by-a square, 2x2 Gauss, dofs [u1x,u1y,..,u4x,u4y], nodes
+    CCW from bottom-left (what solidspy.uelutil.elast_quad4 returns; src/residuals_mechanics_K.py:99-103)."""
+    C = E / (1.0 - nu ** 2) * np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, (1.0 - nu) / 2.0]])
+    coord = np.array([[0.0, 0.0], [a, 0.0], [a, a], [0.0, a]])
+    g = 1.0 / math.sqrt(3.0)
+    k = np.zeros((8, 8))
+    for r in (-g, g):
+        for s in (-g, g):
+            dN = 0.25 * np.array([[-(1 - s), (1 - s), (1 + s), -(1 + s)],
+                                  [-(1 - r), -(1 + r), (1 + r), (1 - r)]])
+            J = dN @ coord
+            dNdx = np.linalg.solve(J, dN)
+            Bm = np.zeros((3, 8))
+            Bm[0, 0::2] = dNdx[0]
+            Bm[1, 1::2] = dNdx[1]
+            Bm[2, 0::2] = dNdx[1]
+            Bm[2, 1::2] = dNdx[0]
+            k += np.linalg.det(J) * (Bm.T @ C @ Bm)
+    return k
+
+
+def synthetic_mesh_element_dofs(nel: int = 64) -> np.ndarray:
+    """int32 [nel*nel, 8]: global dofs of each element for the synthetic SolidsPy mesh of SURVEY 8(d):
+    node id = row*(nel+1)+col, element e=r*nel+c has nodes CCW [bl, br, tr, tl] with y pointing up
+    (row r+1 is *below* row r), dof = 2*node + d (all dofs free, src/residuals_mechanics_K.py:51-69)."""
+    nn = nel + 1
+    out = np.zeros((nel * nel, 8), dtype=np.int32)
+    for r in range(nel):
+        for c in range(nel):
+            bl, br = (r + 1) * nn + c, (r + 1) * nn + c + 1
+            tr, tl = r * nn + c + 1, r * nn + c
+            nodes = [bl, br, tr, tl]
+            out[r * nel + c] = [2 * n + d for n in nodes for d in (0, 1)]
+    return out
+
+
+def bilinear_resize(x: torch.Tensor, size: int) -> torch.Tensor:
+    """torchvision Resize(antialias=False) on tensors (src/residuals_mechanics_K.py:10-21)."""
+    return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
+
+
+def mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs):
+    """x0_pred [B,3,64,64] (u1,u2,rho), bcs [B,4,65,65] (bc_x, bc_y, load_x, load_y), vf [B].
+    Returns residual [B,8450], compliance [B], shift [B].  Matrix-free K(rho) u."""
+    B = x0_pred.shape[0]
+    nel = x0_pred.shape[-1]
+    nn = nel + 1
+    u = bilinear_resize(x0_pred[:, :2], nn)                      # [B,2,65,65]
+    U = u.permute(0, 2, 3, 1).reshape(B, nn * nn * 2)            # dof = 2*(r*65+c)+d
+    rho = x0_pred[:, 2].reshape(B, nel * nel)
+    D = torch.as_tensor(elem_dofs, dtype=torch.long)             # [E,8]
+    k = torch.as_tensor(kloc, dtype=x0_pred.dtype)               # [8,8]
+    ue = U[:, D]                                                 # [B,E,8]
+    fe = torch.einsum("ab,beb->bea", k, ue) * rho[:, :, None]   # [B,E,8]
+    KU = torch.zeros_like(U).index_add_(1, D.reshape(-1), fe.reshape(B, -1))
+    f = bcs[:, 2:4].permute(0, 2, 3, 1).reshape(B, -1)
+    mask = bcs[:, 0:2].permute(0, 2, 3, 1).reshape(B, -1) != 0
+    Ku_bc = torch.where(mask, U, KU)
+    residual = Ku_bc - torch.where(mask, torch.zeros_like(f), f)
+    compliance = (U * Ku_bc).sum(dim=1)
+    shift = rho.mean(dim=1) - vf
+    return residual, compliance, shift

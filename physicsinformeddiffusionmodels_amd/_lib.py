@@ -1,0 +1,114 @@
+"""ctypes binding of the C ABI declared in include/pidm.h.
+
+The product path loads `csrc/libpidm_hip.so` (hand-written gfx950 kernels) and nothing else: there is no
+CPU or eager-PyTorch fallback.  `PidmLib(path)` with an explicit path exists so the unit tests can bind
+the host-emulated build of the same sources (tests/hipemu); package code never does that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libpidm_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("dim", C.c_int), ("channels", C.c_int), ("out_dim", C.c_int), ("n_levels", C.c_int),
+                ("dim_mults", C.c_int * 8), ("heads", C.c_int), ("dim_head", C.c_int), ("groups", C.c_int),
+                ("init_kernel", C.c_int), ("image_size", C.c_int), ("sigmoid_last_channel", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("C0", C.c_int), ("C1", C.c_int),
+                ("ld0", C.c_int), ("ld1", C.c_int), ("Cout", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int), ("transposed", C.c_int), ("out_nchw", C.c_int),
+                ("ldo", C.c_int)]
+
+
+class PidmError(RuntimeError):
+    pass
+
+
+class PidmLib:
+    def __init__(self, path: str | None = None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise PidmError(
+                f"{path} not found: the gfx950 engine is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C physicsinformeddiffusionmodels_amd/csrc`). There is no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.pidm_version.restype = C.c_int
+        L.pidm_last_error.restype = C.c_char_p
+        L.pidm_backend.restype = C.c_char_p
+        i, f, sz = C.c_int, C.c_float, C.c_size_t
+        self._sig("pidm_darcy_residual_fwd", [vp, vp, f, f, vp, i, i, vp])
+        self._sig("pidm_darcy_residual_bwd", [vp, vp, f, f, vp, i, i, vp])
+        self._sig("pidm_darcy_loss_ws", [i, i], sz)
+        self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
+        self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
+        self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
+        self._sig("pidm_unet_create", [C.POINTER(UnetCfg), C.POINTER(vp)])
+        self._sig("pidm_unet_destroy", [vp], None)
+        self._sig("pidm_unet_num_params", [vp])
+        self._sig("pidm_unet_param_name", [vp, i], C.c_char_p)
+        self._sig("pidm_unet_param_numel", [vp, i], sz)
+        self._sig("pidm_unet_workspace_bytes", [vp, i, i], sz)
+        self._sig("pidm_unet_bind", [vp, C.POINTER(vp), C.POINTER(vp)])
+        self._sig("pidm_unet_forward", [vp, vp, vp, vp, i, i, i, vp, sz, vp])
+        self._sig("pidm_unet_backward", [vp, vp, vp, i, vp, sz, vp])
+        self._sig("pidm_conv_packed_weight_floats", [C.POINTER(ConvDesc)], sz)
+        self._sig("pidm_conv_pack_weights", [C.POINTER(ConvDesc), vp, vp, i, vp])
+        self._sig("pidm_conv_forward", [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])
+        self._sig("pidm_conv_wgrad_ws", [C.POINTER(ConvDesc)], sz)
+        self._sig("pidm_conv_wgrad", [C.POINTER(ConvDesc), vp, vp, vp, i, vp, vp, vp, vp])
+        if L.pidm_version() != 1:
+            raise PidmError(f"{path}: ABI version {L.pidm_version()} != 1")
+
+    def _sig(self, name, argtypes, restype=C.c_int):
+        fn = getattr(self.lib, name, None)
+        if fn is None:  # tolerated only while a symbol is under construction; exports are tested
+            return
+        fn.argtypes = argtypes
+        fn.restype = restype
+
+    @property
+    def backend(self) -> str:
+        return self.lib.pidm_backend().decode()
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            raise PidmError(f"{what}: {self.lib.pidm_last_error().decode()} (rc={rc})")
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+_default: PidmLib | None = None
+
+
+def get_lib() -> PidmLib:
+    """The product library (gfx950).  Raises if it has not been built - no fallback."""
+    global _default
+    if _default is None:
+        _default = PidmLib(DEFAULT_LIB)
+    return _default
+
+
+def ptr(t):
+    """Raw pointer of a torch tensor (or None) as c_void_p."""
+    if t is None:
+        return vp(0)
+    return vp(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    if device is not None and torch.device(device).type == "cuda":
+        return vp(torch.cuda.current_stream(device).cuda_stream)
+    return vp(0)

@@ -1,0 +1,58 @@
+// Common host/device declarations for the gfx950 engine (libpidm_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/pidm.h"
+
+namespace pidm {
+
+// thread-local error string behind pidm_last_error()
+void set_error(const char* fmt, ...);
+int fail(const char* fmt, ...);  // sets the error, returns -1
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define PIDM_CHECK_LAUNCH(what)                                                     \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) return ::pidm::fail("%s: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of one implicit-GEMM convolution launch (see k_conv.hip).  "Virtual" output pixels
+// (vy,vx) in [0,Hv)x[0,Wv) map to real output (vy*os+ooy, vx*os+oox) and read input rows
+// vy*stride + ky - pad.  A transposed 4x4/s2/p1 convolution is 4 such problems (one per output
+// parity), selected by blockIdx.z.
+// ---------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int B, Hi, Wi;     // input spatial
+  int Hv, Wv;        // virtual output grid
+  int Ho, Wo;        // real output spatial
+  int C0, C1;        // channels from src0 / src1
+  int ld0, ld1;      // channel strides of src0/src1
+  int Cin;           // C0 + C1
+  int Cout;
+  int KH, KW;        // taps actually iterated (2x2 for a parity class of the transposed conv)
+  int stride;        // input stride
+  int os;            // output stride (2 for transposed)
+  int nz;            // 1, or 4 parity classes
+  int pad_y[4], pad_x[4], ooy[4], oox[4];
+  long w_off[4];     // float offset of the packed weight slab per z
+  // output addressing: out[b*sob + oy*soy + ox*sox + c*soc]
+  long sob, soy, sox, soc;
+  int ldr;           // channel stride of the (channels-last) residual operand
+  // tiling
+  int TH, NI;        // rows per tile, images per tile: TH*NI*Wv == 128
+  int IHt, IWt;      // input halo tile extent per image
+  int tiles_m;       // number of 128-pixel tiles
+};
+
+}  // namespace pidm

@@ -1,0 +1,223 @@
+// hipemu: a CPU emulation of the small HIP subset used by physicsinformeddiffusionmodels_amd/csrc.
+//
+// TEST INFRASTRUCTURE ONLY.  The authoring container has no GPU, and a gpurun round-trip costs
+// minutes, so the unmodified gfx950 kernel sources (csrc/*.hip) are additionally compiled for the host
+// against THIS header (it shadows <hip/hip_runtime.h> via -I tests/hipemu) and executed with one fiber
+// per GPU thread: __syncthreads / wave shuffles / MFMA are emulated with the documented gfx950 lane
+// layouts (cdna_hip_programming.md section 3).  It checks index math, LDS addressing, barriers
+// placement (deadlock detection), fragment layouts and the host-side orchestration.  It proves nothing
+// about performance and it is never loaded by the product package: the product path loads
+// libpidm_hip.so only and fails loudly without it.
+#pragma once
+#include <ucontext.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_smem());
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2,
+                     hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3 { unsigned x, y, z; };
+
+typedef float float4 __attribute__((ext_vector_type(4)));
+typedef float float2 __attribute__((ext_vector_type(2)));
+typedef int int4 __attribute__((ext_vector_type(4)));
+typedef int int2 __attribute__((ext_vector_type(2)));
+typedef double double2 __attribute__((ext_vector_type(2)));
+static inline float4 make_float4(float a, float b, float c, float d) { float4 v = {a, b, c, d}; return v; }
+static inline float2 make_float2(float a, float b) { float2 v = {a, b}; return v; }
+static inline double2 make_double2(double a, double b) { double2 v = {a, b}; return v; }
+static inline int2 make_int2(int a, int b) { int2 v = {a, b}; return v; }
+
+namespace hipemu {
+enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber {
+  ucontext_t ctx;
+  char* stack;
+  int state;
+};
+struct BlockRunner {
+  std::vector<Fiber> fibers;
+  std::vector<uint64_t> xa, xb;  // cross-lane exchange slots
+  ucontext_t sched;
+  int cur = 0;
+  int nthreads = 0;
+  char* dyn = nullptr;
+  size_t dyn_cap = 0;
+  std::function<void()> body;
+};
+extern thread_local BlockRunner* g_runner;
+extern thread_local uint3 g_tid, g_bid;
+extern thread_local dim3 g_bdim, g_gdim;
+char* dyn_smem();
+void yield_state(int st);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+inline int lane_id() { return (int)(g_tid.x + g_bdim.x * (g_tid.y + g_bdim.y * g_tid.z)) & 63; }
+inline int flat_tid() { return (int)(g_tid.x + g_bdim.x * (g_tid.y + g_bdim.y * g_tid.z)); }
+inline void wave_sync() { yield_state(WAIT_WAVE); }
+inline uint64_t exchange(uint64_t v, int src_lane) {
+  BlockRunner* r = g_runner;
+  int t = flat_tid();
+  r->xa[t] = v;
+  wave_sync();
+  int s = (t & ~63) | (src_lane & 63);
+  uint64_t out = (s < r->nthreads) ? r->xa[s] : v;
+  wave_sync();
+  return out;
+}
+template <typename T>
+inline T shfl_any(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "shfl of >8 bytes");
+  uint64_t raw = 0;
+  memcpy(&raw, &v, sizeof(T));
+  raw = exchange(raw, src_lane);
+  T o;
+  memcpy(&o, &raw, sizeof(T));
+  return o;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_tid)
+#define blockIdx (hipemu::g_bid)
+#define blockDim (hipemu::g_bdim)
+#define gridDim (hipemu::g_gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::yield_state(hipemu::WAIT_BLOCK); }
+static inline void __builtin_amdgcn_s_barrier() { hipemu::yield_state(hipemu::WAIT_BLOCK); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+  int l = hipemu::lane_id();
+  return hipemu::shfl_any(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+  int l = hipemu::lane_id();
+  (void)width;
+  return hipemu::shfl_any(v, l ^ mask);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int l = hipemu::lane_id();
+  int s = l + (int)d;
+  if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l;
+  return hipemu::shfl_any(v, s);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int l = hipemu::lane_id();
+  int s = l - (int)d;
+  if (s < 0 || (s & ~(width - 1)) != (l & ~(width - 1))) s = l;
+  return hipemu::shfl_any(v, s);
+}
+
+// ---- MFMA (f32 in / f32 acc), lane layouts per cdna_hip_programming.md section 3 -----------------
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+  hipemu::BlockRunner* r = hipemu::g_runner;
+  int t = hipemu::flat_tid(), lane = t & 63, wb = t & ~63;
+  uint32_t ua, ub;
+  memcpy(&ua, &a, 4);
+  memcpy(&ub, &b, 4);
+  r->xa[t] = ua;
+  r->xb[t] = ub;
+  hipemu::wave_sync();
+  for (int reg = 0; reg < 16; ++reg) {
+    int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+    float acc = c[reg];
+    for (int k = 0; k < 2; ++k) {
+      uint32_t xa = (uint32_t)r->xa[wb + k * 32 + row], xb = (uint32_t)r->xb[wb + k * 32 + col];
+      float fa, fb;
+      memcpy(&fa, &xa, 4);
+      memcpy(&fb, &xb, 4);
+      acc = fmaf(fa, fb, acc);
+    }
+    c[reg] = acc;
+  }
+  hipemu::wave_sync();
+  return c;
+}
+static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  hipemu::BlockRunner* r = hipemu::g_runner;
+  int t = hipemu::flat_tid(), lane = t & 63, wb = t & ~63;
+  uint32_t ua, ub;
+  memcpy(&ua, &a, 4);
+  memcpy(&ub, &b, 4);
+  r->xa[t] = ua;
+  r->xb[t] = ub;
+  hipemu::wave_sync();
+  for (int reg = 0; reg < 4; ++reg) {
+    int row = (lane >> 4) * 4 + reg, col = lane & 15;
+    float acc = c[reg];
+    for (int k = 0; k < 4; ++k) {
+      uint32_t xa = (uint32_t)r->xa[wb + k * 16 + row], xb = (uint32_t)r->xb[wb + k * 16 + col];
+      float fa, fb;
+      memcpy(&fa, &xa, 4);
+      memcpy(&fb, &xb, 4);
+      acc = fmaf(fa, fb, acc);
+    }
+    c[reg] = acc;
+  }
+  hipemu::wave_sync();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+
+// ---- atomics / math ---------------------------------------------------------------------------
+static inline float atomicAdd(float* p, float v) {
+  auto* a = reinterpret_cast<std::atomic<float>*>(p);
+  float old = a->load();
+  while (!a->compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+static inline int atomicAdd(int* p, int v) { return reinterpret_cast<std::atomic<int>*>(p)->fetch_add(v); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return reinterpret_cast<std::atomic<unsigned>*>(p)->fetch_add(v); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __ldg(const float* p) { return *p; }
+
+// ---- runtime API subset ------------------------------------------------------------------------
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+
+template <typename K, typename... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
+}
+
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename K> static inline hipError_t hipFuncSetAttribute(K, hipFuncAttribute, int) { return hipSuccess; }

@@ -120,6 +120,10 @@ size_t pidm_conv_packed_weight_floats(const pidm_conv_desc* d);
 int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w_packed, int mode, void* stream);
 int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
                       const float* bias, const float* residual, float* out, void* stream);
+/* adjoint wrt the input: dx[B,Hi,Wi,Cin] (+ residual) from dy[B,Ho,Wo,Cout]; weights packed with mode 1 */
+size_t pidm_conv_dgrad_packed_weight_floats(const pidm_conv_desc* d);
+int pidm_conv_dgrad(const pidm_conv_desc* d, const float* dy, int ld_dy, const float* w_packed_dgrad,
+                    const float* residual, float* dx, int ld_dx, void* stream);
 size_t pidm_conv_wgrad_ws(const pidm_conv_desc* d);
 /* dW (reference layout) and dbias (may be NULL) from input x (src0/src1) and output-gradient dy */
 int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const float* src1, const float* dy, int ld_dy,

@@ -65,6 +65,8 @@ class PidmLib:
         self._sig("pidm_conv_packed_weight_floats", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_pack_weights", [C.POINTER(ConvDesc), vp, vp, i, vp])
         self._sig("pidm_conv_forward", [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])
+        self._sig("pidm_conv_dgrad_packed_weight_floats", [C.POINTER(ConvDesc)], sz)
+        self._sig("pidm_conv_dgrad", [C.POINTER(ConvDesc), vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_conv_wgrad_ws", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_wgrad", [C.POINTER(ConvDesc), vp, vp, vp, i, vp, vp, vp, vp])
         if L.pidm_version() != 1:

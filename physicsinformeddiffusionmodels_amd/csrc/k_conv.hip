@@ -1,0 +1,631 @@
+// Implicit-GEMM convolutions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces every `convolution` / `conv_transpose` / `addmm` ATen op of the reference UNet
+// (src/unet_model.py:163,197,227,253,275,279,453,517 and the nn.Linear layers :248,332,339,466,468):
+// 3x3 p1, 7x7 p3, 1x1, 4x4 s2 p1, ConvTranspose 4x4 s2 p1, and Linear (as a 1x1 conv on a 1x1 image).
+//
+// Data layout: activations channels-last (NHWC == the reference's [B, P*P, C] interchange layout), weights
+// re-packed once per step to [Cout_p][tap][Cin_p] (K contiguous) by `pack_kernel`.
+// GEMM view: M = output pixels, N = Cout, K = taps x Cin.   One workgroup = 4 waves = a 128-pixel x (32*NT)
+// channel tile; each wave owns one 32-pixel m-tile x NT 32x32 accumulators.  The input tile WITH ITS HALO is
+// staged once per Cin-chunk in LDS and re-used by all KHxKW taps (9x fewer global->LDS bytes for 3x3), the
+// weight slab of the tap group sits next to it.  LDS rows are KC+4 floats so the per-lane ds_read_b128 of 4
+// consecutive k (lanes = consecutive pixels / output channels) is bank-conflict free.
+// The MFMA k-slots are permuted (lane-half h supplies channels 8g+4h+s for step s): A and B use the same
+// permutation, so the sum is unchanged and each operand fetch is one 16-byte LDS read per 4 MFMAs.
+//
+// Backward: dgrad runs the SAME kernel on a flipped/transposed weight packing; wgrad is its own kernel
+// (M = Cout, N = Cin, K = pixels) with a deterministic split-K over pixel tiles.
+#include "pidm_common.h"
+
+namespace pidm {
+
+static const int kBM = 128;  // pixels per workgroup tile
+
+// ---------------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------------
+template <int KC, int NT>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, int sigmoid_last,
+                                                         const float* __restrict__ src0, const float* __restrict__ src1,
+                                                         const float* __restrict__ wp, const float* __restrict__ bias,
+                                                         const float* __restrict__ residual, float* __restrict__ out) {
+  constexpr int KCP = KC + 4;
+  constexpr int BN = 32 * NT;
+  constexpr int Q = KC / 4;  // float4 quads per chunk
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int z = blockIdx.z;
+  const int tiles_n = (g.Cout + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int n0 = tile_n * BN;
+  const int T = g.KH * g.KW;
+  const int CinP = (g.Cin + KC - 1) / KC * KC;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  float* As = smem;
+  float* Bs = smem + (size_t)npixA * KCP;
+
+  const int tpi = g.Hv / g.TH;                 // tiles per image (1 when NI > 1)
+  const int b0 = (tile_m / tpi) * g.NI;
+  const int vy0 = (tile_m % tpi) * g.TH;
+  const int iy0 = vy0 * g.stride - g.pad_y[z];
+  const int ix0 = -g.pad_x[z];
+  const float* wz = wp + g.w_off[z];
+  const bool vec_ok = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0);
+
+  // this lane's A row (pixel) inside the wave's m-tile
+  const int pm = wave * 32 + l31;
+  const int a_tx = pm % g.Wv, a_ty = (pm / g.Wv) % g.TH, a_img = pm / (g.Wv * g.TH);
+  const int abase = (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  for (int c0 = 0; c0 < CinP; c0 += KC) {
+    __syncthreads();
+    // ---- stage the input tile (with halo) for channels [c0, c0+KC) ----
+    for (int e = tid; e < npixA * Q; e += 256) {
+      const int q = e % Q, hp = e / Q;
+      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx, c = c0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < g.Cin) {
+        const size_t pix = ((size_t)b * g.Hi + iy) * g.Wi + ix;
+        if (vec_ok) {
+          v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
+                         : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
+        } else {
+          float t4[4];
+          for (int k = 0; k < 4; ++k) {
+            const int ck = c + k;
+            t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+          }
+          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(As + (size_t)hp * KCP + 4 * q) = v;
+    }
+    for (int t0 = 0; t0 < T; t0 += tgs) {
+      const int nt = (T - t0 < tgs) ? (T - t0) : tgs;
+      if (t0 > 0) __syncthreads();
+      // ---- stage the weight slab of this tap group: Bs[tl][row][KCP] ----
+      for (int e = tid; e < nt * BN * Q; e += 256) {
+        const int q = e % Q, row = (e / Q) % BN, tl = e / (Q * BN);
+        const float4 v = *reinterpret_cast<const float4*>(wz + ((size_t)(n0 + row) * T + (t0 + tl)) * CinP + c0 + 4 * q);
+        *reinterpret_cast<float4*>(Bs + ((size_t)tl * BN + row) * KCP + 4 * q) = v;
+      }
+      __syncthreads();
+      // ---- MFMA over the taps of the group ----
+      for (int tl = 0; tl < nt; ++tl) {
+        const int t = t0 + tl;
+        const int ky = t / g.KW, kx = t - ky * g.KW;
+        const float* arow = As + (size_t)(abase + ky * g.IWt + kx) * KCP + 4 * half;
+        const float* brow = Bs + ((size_t)tl * BN + l31) * KCP + 4 * half;
+#pragma unroll
+        for (int g8 = 0; g8 < KC / 8; ++g8) {
+          const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * g8);
+          float4 b4[NT];
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const float4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, residual, (sigmoid), store ----
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int c = n0 + ni * 32 + l31;
+    if (c >= g.Cout) continue;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int p = wave * 32 + row;
+      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int b = b0 + img;
+      if (b >= g.B) continue;
+      const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+      float v = acc[ni][r] + bv;
+      if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
+      if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
+      out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: reference layout -> [nz][Np][T][Kp] (zero padded)
+//   kind 0: fwd, normal conv        src [N=Cout][K=Cin][KH][KW]
+//   kind 1: fwd, transposed 4x4s2   src [K=Cin][N=Cout][4][4], 4 parity classes of 2x2 taps
+//   kind 2: dgrad of normal s1      src [K=Cout][N=Cin][KH][KW]  (flip taps)
+//   kind 3: dgrad of normal 4x4 s2  src [K=Cout][N=Cin][4][4], 4 parity classes of 2x2 taps
+//   kind 4: dgrad of transposed     src [N=Cin][K=Cout][4][4]   (stride-2 conv over dy)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int parity_tap(int par, int j) { return par == 0 ? 3 - 2 * j : 2 - 2 * j; }
+
+__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int nz, int N, int K,
+                            int Np, int Kp, int KH, int KW, int T) {
+  const size_t total = (size_t)nz * Np * T * Kp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kp);
+    const int t = (int)((idx / Kp) % T);
+    const int n = (int)((idx / ((size_t)Kp * T)) % Np);
+    const int z = (int)(idx / ((size_t)Kp * T * Np));
+    float v = 0.f;
+    if (n < N && k < K) {
+      if (kind == 0) {
+        v = src[((size_t)n * K + k) * T + t];
+      } else if (kind == 2) {
+        const int ky = KH - 1 - t / KW, kx = KW - 1 - t % KW;
+        v = src[(((size_t)k * N + n) * KH + ky) * KW + kx];
+      } else if (kind == 4) {
+        v = src[((size_t)n * K + k) * T + t];
+      } else {  // parity kinds: T == 4 (2x2), source taps 4x4
+        const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
+        v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
+      }
+    }
+    dst[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: dW[m][t][n] = sum_p dY[p][m] * X[p (+tap)][n]   (M = rows of dY's channels, N = X's channels)
+// one workgroup = 32 x 32 output block for up to `tgs` taps, over `tiles_per_split` pixel tiles;
+// the 4 waves split each 128-pixel tile 4-ways along K and are reduced through LDS at the end.
+// ---------------------------------------------------------------------------------------------------
+struct WgradGeom {
+  ConvGeom g;        // pixel tiling / halo geometry of the forward problem (Cout = channels of dY)
+  int ld_dy;         // channel stride of dY
+  int tgs, ntg;      // taps per group, number of groups
+  int nsplit, tiles_per_split;
+  int MP, NP;        // padded (to 32) rows / cols of the partial buffer
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const float* __restrict__ src0,
+                                                         const float* __restrict__ src1, const float* __restrict__ dy,
+                                                         float* __restrict__ partial) {
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int T = g.KH * g.KW;
+  const int ntn = wg.NP / 32;
+  int rest = blockIdx.y;
+  const int tg = rest % wg.ntg;
+  rest /= wg.ntg;
+  const int tn = rest % ntn, tm = rest / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int t0 = tg * wg.tgs;
+  const int nt = (T - t0 < wg.tgs) ? (T - t0) : wg.tgs;
+  const int split = blockIdx.x;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  float* Xs = smem;                         // [npixA][32]
+  float* Ys = smem + (size_t)npixA * 32;    // [128][32]
+  const int tpi = g.Hv / g.TH;
+  const bool vec_ok = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0);
+  const bool vec_dy = ((wg.ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int tile_lo = split * wg.tiles_per_split;
+  const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b0 = (tile / tpi) * g.NI;
+    const int vy0 = (tile % tpi) * g.TH;
+    const int iy0 = vy0 * g.stride - g.pad_y[0], ix0 = -g.pad_x[0];
+    __syncthreads();
+    for (int e = tid; e < npixA * 8; e += 256) {
+      const int q = e & 7, hp = e >> 3;
+      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx, c = n0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < g.Cin) {
+        const size_t pix = ((size_t)b * g.Hi + iy) * g.Wi + ix;
+        if (vec_ok) {
+          v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
+                         : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
+        } else {
+          float t4[4];
+          for (int k = 0; k < 4; ++k) {
+            const int ck = c + k;
+            t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+          }
+          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(Xs + (size_t)hp * 32 + 4 * q) = v;
+    }
+    for (int e = tid; e < kBM * 8; e += 256) {
+      const int q = e & 7, p = e >> 3;
+      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int b = b0 + img, c = m0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < g.B && c < g.Cout) {
+        const size_t pix = ((size_t)b * g.Hv + (vy0 + ty)) * g.Wv + tx;
+        if (vec_dy) {
+          v = *reinterpret_cast<const float4*>(dy + pix * wg.ld_dy + c);
+        } else {
+          float t4[4];
+          for (int k = 0; k < 4; ++k) t4[k] = (c + k < g.Cout) ? dy[pix * wg.ld_dy + c + k] : 0.f;
+          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(Ys + (size_t)p * 32 + 4 * q) = v;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < 16; ++ks) {
+      const int p = wave * 32 + 2 * ks + half;
+      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int xb = (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride;
+      const float a = Ys[p * 32 + l31];
+#pragma unroll
+      for (int tl = 0; tl < MAXT; ++tl) {
+        if (tl < nt) {
+          const int t = t0 + tl;
+          const int ky = t / g.KW, kx = t - ky * g.KW;
+          const float bv = Xs[(size_t)(xb + ky * g.IWt + kx) * 32 + l31];
+          acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tl], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- cross-wave reduction, one tap at a time through LDS (re-using the staging area) ----
+  float* red = smem;  // [4][1024]
+#pragma unroll
+  for (int tl = 0; tl < MAXT; ++tl) {
+    if (tl < nt) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        red[wave * 1024 + row * 32 + l31] = acc[tl][r];
+      }
+      __syncthreads();
+      for (int e = tid; e < 1024; e += 256) {
+        const float s = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        const int row = e >> 5, col = e & 31;
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + (t0 + tl)) * wg.NP + n0 + col] = s;
+      }
+    }
+  }
+}
+
+// dst[(m*N + n)*T + t] = sum_s partial[s][m][t][n]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dst, int nsplit, int M,
+                                    int N, int T, int MP, int NP) {
+  const size_t total = (size_t)M * N * T;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % T);
+    const int n = (int)((idx / T) % N);
+    const int m = (int)(idx / ((size_t)T * N));
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * MP + m) * T + t) * NP + n];
+    dst[idx] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums (bias gradients etc.): out[c] = sum_r x[r*ld + c], two deterministic stages
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, size_t rows, int C, int ld,
+                                                             size_t rows_per_block, float* __restrict__ partial) {
+  // block (bx, by): rows [bx*rpb, ...), columns [by*64, by*64+64); thread (r = tid/64, c = tid%64)
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  if (c < C)
+    for (size_t r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// kind: 0 normal conv (any KHxKW/stride/pad), 1 "transposed type" (4 parity classes of 2x2 taps, os=2)
+int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int ld0, int ld1, int Cout, int KH, int KW,
+              int stride, int pad, int out_nchw, int ldo, int ldr) {
+  memset(g, 0, sizeof(*g));
+  g->B = B; g->Hi = Hi; g->Wi = Wi; g->C0 = C0; g->C1 = C1; g->ld0 = ld0; g->ld1 = ld1 > 0 ? ld1 : 4;
+  g->Cin = C0 + C1; g->Cout = Cout;
+  if (kind == 0) {
+    g->KH = KH; g->KW = KW; g->stride = stride; g->os = 1; g->nz = 1;
+    g->Hv = g->Ho = (Hi + 2 * pad - KH) / stride + 1;
+    g->Wv = g->Wo = (Wi + 2 * pad - KW) / stride + 1;
+    g->pad_y[0] = g->pad_x[0] = pad;
+  } else {
+    g->KH = g->KW = 2; g->stride = 1; g->os = 2; g->nz = 4;
+    g->Hv = Hi; g->Wv = Wi; g->Ho = 2 * Hi; g->Wo = 2 * Wi;
+    for (int z = 0; z < 4; ++z) {
+      const int py = z >> 1, px = z & 1;
+      g->pad_y[z] = py == 0 ? 1 : 0; g->pad_x[z] = px == 0 ? 1 : 0;
+      g->ooy[z] = py; g->oox[z] = px;
+    }
+  }
+  if (!is_pow2(g->Wv) || g->Wv > kBM || g->Hv < 1) return fail("conv: output width %d must be a power of two <= %d", g->Wv, kBM);
+  g->TH = kBM / g->Wv < g->Hv ? kBM / g->Wv : g->Hv;
+  if (g->Hv % g->TH) return fail("conv: output height %d not divisible by tile rows %d", g->Hv, g->TH);
+  g->NI = kBM / (g->Wv * g->TH);
+  g->IHt = (g->TH - 1) * g->stride + g->KH;
+  g->IWt = (g->Wv - 1) * g->stride + g->KW;
+  const int tpi = g->Hv / g->TH;
+  g->tiles_m = (g->NI > 1) ? cdiv(B, g->NI) : B * tpi;
+  if (out_nchw) { g->sob = (long)Cout * g->Ho * g->Wo; g->soc = (long)g->Ho * g->Wo; g->soy = g->Wo; g->sox = 1; }
+  else { g->sob = (long)g->Ho * g->Wo * ldo; g->soy = (long)g->Wo * ldo; g->sox = ldo; g->soc = 1; }
+  g->ldr = ldr;
+  return 0;
+}
+
+static int pick_kc(int Cin) { return (Cin % 16 == 0) ? 16 : 8; }
+static int pick_nt(int Cout) { return Cout > 32 ? 2 : 1; }
+
+size_t packed_floats(const ConvGeom& g) {
+  const int KC = pick_kc(g.Cin), BN = 32 * pick_nt(g.Cout);
+  const size_t Np = (size_t)cdiv(g.Cout, BN) * BN, Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  return (size_t)g.nz * Np * g.KH * g.KW * Kp;
+}
+
+// w_ref -> packed. N/K are the packed problem's Cout/Cin (g.Cout / g.Cin); srcKH/srcKW the reference tap grid.
+int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, hipStream_t st) {
+  const int KC = pick_kc(g.Cin), BN = 32 * pick_nt(g.Cout);
+  const int Np = cdiv(g.Cout, BN) * BN, Kp = cdiv(g.Cin, KC) * KC, T = g.KH * g.KW;
+  const size_t total = (size_t)g.nz * Np * T * Kp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nz, g.Cout, g.Cin, Np, Kp,
+                     srcKH, srcKW, T);
+  PIDM_CHECK_LAUNCH("pack_kernel");
+  return 0;
+}
+
+template <int KC, int NT>
+static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const float* wp, const float* bias,
+                         const float* residual, float* out, int sigmoid_last, hipStream_t st) {
+  constexpr int KCP = KC + 4, BN = 32 * NT;
+  const int T = g.KH * g.KW;
+  const size_t a_bytes = (size_t)g.NI * g.IHt * g.IWt * KCP * sizeof(float);
+  const size_t b_tap = (size_t)BN * KCP * sizeof(float);
+  const size_t budget = 72 * 1024;  // keep two workgroups per CU where the halo tile allows
+  int tgs = T;
+  if (a_bytes + (size_t)tgs * b_tap > budget) {
+    tgs = a_bytes < budget ? (int)((budget - a_bytes) / b_tap) : 1;
+    if (tgs < 1) tgs = 1;
+  }
+  if (tgs > T) tgs = T;
+  const size_t lds = a_bytes + (size_t)tgs * b_tap;
+  if (lds > 160 * 1024 - 512) return fail("conv: tile needs %zu B of LDS", lds);
+  size_t off = 0;
+  const size_t Np = (size_t)cdiv(g.Cout, BN) * BN, Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  for (int z = 0; z < g.nz; ++z) { g.w_off[z] = (long)off; off += Np * T * Kp; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KC, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_done = true;
+  }
+  const int tiles_n = cdiv(g.Cout, BN);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<KC, NT>), dim3(g.tiles_m * tiles_n, 1, g.nz), dim3(256), lds, st, g,
+                     tgs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
+  PIDM_CHECK_LAUNCH("conv_igemm_kernel");
+  return 0;
+}
+
+int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
+                const float* residual, float* out, int sigmoid_last, hipStream_t st) {
+  const int KC = pick_kc(g.Cin), NT = pick_nt(g.Cout);
+  if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+  if (KC == 16 && NT == 1) return launch_conv_t<16, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+  if (KC == 8 && NT == 2) return launch_conv_t<8, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+  return launch_conv_t<8, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+}
+
+// ---- wgrad ------------------------------------------------------------------------------------------
+static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
+  wg->g = g;
+  wg->ld_dy = ld_dy;
+  const int T = g.KH * g.KW;
+  wg->tgs = T < 9 ? T : 9;
+  if (T == 16) wg->tgs = 8;
+  if (T == 49) wg->tgs = 7;
+  wg->ntg = cdiv(T, wg->tgs);
+  wg->MP = cdiv(g.Cout, 32) * 32;
+  wg->NP = cdiv(g.Cin, 32) * 32;
+  const int blocks_mn = (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
+  int nsplit = 1024 / blocks_mn;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > g.tiles_m) nsplit = g.tiles_m;
+  wg->tiles_per_split = cdiv(g.tiles_m, nsplit);
+  wg->nsplit = cdiv(g.tiles_m, wg->tiles_per_split);
+}
+
+size_t wgrad_ws_bytes(const ConvGeom& g) {
+  WgradGeom wg;
+  wgrad_plan(g, 4, &wg);
+  return (size_t)wg.nsplit * wg.MP * g.KH * g.KW * wg.NP * sizeof(float);
+}
+
+// dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
+int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
+                 void* workspace, hipStream_t st) {
+  if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
+  WgradGeom wg;
+  wgrad_plan(g, ld_dy, &wg);
+  const int T = g.KH * g.KW;
+  const size_t lds_stage = ((size_t)g.NI * g.IHt * g.IWt + kBM) * 32 * sizeof(float);
+  const size_t lds = lds_stage > 16384 ? lds_stage : 16384;
+  if (lds > 160 * 1024 - 512) return fail("wgrad: tile needs %zu B of LDS", lds);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32) * wg.ntg, 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_done = true;
+  }
+  if (wg.tgs == 1)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
+  PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
+  const size_t total = (size_t)g.Cout * g.Cin * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, dw_ref, wg.nsplit, g.Cout, g.Cin, T, wg.MP, wg.NP);
+  PIDM_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return 0;
+}
+
+size_t colsum_ws_bytes(size_t rows, int C) {
+  size_t nblk = rows / 256;
+  if (nblk < 1) nblk = 1;
+  if (nblk > 256) nblk = 256;
+  return nblk * (size_t)C * sizeof(float);
+}
+
+int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st) {
+  size_t nblk = rows / 256;
+  if (nblk < 1) nblk = 1;
+  if (nblk > 256) nblk = 256;
+  const size_t rpb = (rows + nblk - 1) / nblk;
+  nblk = (rows + rpb - 1) / rpb;
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk, cdiv(C, 64)), dim3(256), 0, st, x, rows, C, ld, rpb, partial);
+  PIDM_CHECK_LAUNCH("colsum_partial_kernel");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, (int)nblk, C, out);
+  PIDM_CHECK_LAUNCH("colsum_final_kernel");
+  return 0;
+}
+
+// geometry of the forward op described by a public pidm_conv_desc
+static int geom_fwd(const pidm_conv_desc* d, ConvGeom* g) {
+  if (d->transposed) {
+    if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1) return fail("transposed conv: only 4x4 s2 p1");
+    return make_geom(g, 1, d->B, d->Hi, d->Wi, d->C0, d->C1, d->ld0, d->ld1, d->Cout, 4, 4, 2, 1, d->out_nchw, d->ldo, d->ldo);
+  }
+  return make_geom(g, 0, d->B, d->Hi, d->Wi, d->C0, d->C1, d->ld0, d->ld1, d->Cout, d->KH, d->KW, d->stride, d->pad,
+                   d->out_nchw, d->ldo, d->ldo);
+}
+
+// geometry of the adjoint (dgrad) problem: input = dy [B,Ho,Wo,Cout] (stride ld_dy), output = dx [B,Hi,Wi,Cin] (stride ld_dx)
+int geom_dgrad(const pidm_conv_desc* d, int ld_dy, int ld_dx, ConvGeom* g, int* pack_kind) {
+  const int Cin = d->C0 + d->C1;
+  if (d->transposed) {
+    *pack_kind = 4;
+    return make_geom(g, 0, d->B, 2 * d->Hi, 2 * d->Wi, d->Cout, 0, ld_dy, 0, Cin, 4, 4, 2, 1, 0, ld_dx, ld_dx);
+  }
+  const int Ho = (d->Hi + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Wi + 2 * d->pad - d->KW) / d->stride + 1;
+  if (d->stride == 1) {
+    *pack_kind = 2;
+    return make_geom(g, 0, d->B, Ho, Wo, d->Cout, 0, ld_dy, 0, Cin, d->KH, d->KW, 1, d->KH - 1 - d->pad, 0, ld_dx, ld_dx);
+  }
+  if (d->stride == 2 && d->KH == 4 && d->KW == 4 && d->pad == 1) {
+    *pack_kind = 3;
+    return make_geom(g, 1, d->B, Ho, Wo, d->Cout, 0, ld_dy, 0, Cin, 4, 4, 2, 1, 0, ld_dx, ld_dx);
+  }
+  return fail("dgrad: unsupported conv geometry");
+}
+
+}  // namespace pidm
+
+using namespace pidm;
+
+extern "C" size_t pidm_conv_packed_weight_floats(const pidm_conv_desc* d) {
+  ConvGeom g;
+  if (geom_fwd(d, &g)) return 0;
+  return packed_floats(g);
+}
+
+extern "C" int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w_packed, int mode, void* stream) {
+  ConvGeom g;
+  if (mode == 0) {
+    if (geom_fwd(d, &g)) return -1;
+    return launch_pack(g, d->transposed ? 1 : 0, w_ref, w_packed, d->KH, d->KW, as_stream(stream));
+  }
+  int kind = 0;
+  if (geom_dgrad(d, d->Cout, d->C0 + d->C1, &g, &kind)) return -1;
+  return launch_pack(g, kind, w_ref, w_packed, d->KH, d->KW, as_stream(stream));
+}
+
+extern "C" size_t pidm_conv_dgrad_packed_weight_floats(const pidm_conv_desc* d) {
+  ConvGeom g;
+  int kind;
+  if (geom_dgrad(d, d->Cout, d->C0 + d->C1, &g, &kind)) return 0;
+  return packed_floats(g);
+}
+
+extern "C" int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
+                                 const float* bias, const float* residual, float* out, void* stream) {
+  ConvGeom g;
+  if (geom_fwd(d, &g)) return -1;
+  return launch_conv(g, src0, src1, w_packed, bias, residual, out, 0, as_stream(stream));
+}
+
+extern "C" int pidm_conv_dgrad(const pidm_conv_desc* d, const float* dy, int ld_dy, const float* w_packed_dgrad,
+                               const float* residual, float* dx, int ld_dx, void* stream) {
+  ConvGeom g;
+  int kind;
+  if (geom_dgrad(d, ld_dy, ld_dx, &g, &kind)) return -1;
+  return launch_conv(g, dy, nullptr, w_packed_dgrad, nullptr, residual, dx, 0, as_stream(stream));
+}
+
+extern "C" size_t pidm_conv_wgrad_ws(const pidm_conv_desc* d) {
+  ConvGeom g;
+  if (d->transposed) {
+    if (make_geom(&g, 0, d->B, 2 * d->Hi, 2 * d->Wi, d->Cout, 0, d->Cout, 0, d->C0 + d->C1, 4, 4, 2, 1, 0, 4, 4)) return 0;
+  } else if (geom_fwd(d, &g)) {
+    return 0;
+  }
+  return wgrad_ws_bytes(g) + colsum_ws_bytes((size_t)d->B * g.Ho * g.Wo * 4, d->Cout);
+}
+
+extern "C" int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const float* src1, const float* dy, int ld_dy,
+                               float* dw_ref, float* dbias, void* workspace, void* stream) {
+  ConvGeom g;
+  hipStream_t st = as_stream(stream);
+  int rc;
+  size_t dy_rows;
+  if (d->transposed) {
+    // swapped operands: X' = dy [B,2H,2W,Cout], dY' = x [B,H,W,Cin]; result [Cin][Cout][4][4]
+    if (d->C1) return fail("wgrad: transposed conv with two sources is not supported");
+    if (make_geom(&g, 0, d->B, 2 * d->Hi, 2 * d->Wi, d->Cout, 0, ld_dy, 0, d->C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
+    rc = launch_wgrad(g, dy, nullptr, src0, d->ld0, dw_ref, workspace, st);
+    dy_rows = (size_t)d->B * 4 * d->Hi * d->Wi;
+  } else {
+    if (geom_fwd(d, &g)) return -1;
+    rc = launch_wgrad(g, src0, src1, dy, ld_dy, dw_ref, workspace, st);
+    dy_rows = (size_t)d->B * g.Ho * g.Wo;
+  }
+  if (rc) return rc;
+  if (dbias) {
+    char* ws2 = reinterpret_cast<char*>(workspace) + wgrad_ws_bytes(g);
+    return launch_colsum(dy, dy_rows, d->Cout, ld_dy, dbias, ws2, st);
+  }
+  return 0;
+}

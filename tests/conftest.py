@@ -18,3 +18,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    """(lib, device): the host-emulated build of csrc on CPU tensors, or the real gfx950 library on cuda:0."""
+    import torch
+    if request.param == "emu":
+        from tests.emu_util import emu_lib
+        return emu_lib(), torch.device("cpu")
+    from physicsinformeddiffusionmodels_amd._lib import get_lib
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    L = get_lib()
+    assert L.backend == "hip"
+    return L, torch.device("cuda:0")

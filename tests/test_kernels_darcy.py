@@ -1,41 +1,45 @@
-"""Darcy residual / adjoint / fused loss kernels (csrc/k_darcy.hip) run through the host emulator and
-compared with the oracle.  CPU only; the same comparisons run on the real GPU in test_gpu_*.py."""
-import numpy as np
+"""Darcy residual / adjoint / fused-loss kernels (csrc/k_darcy.hip) vs the oracle.
+`backend` = host-emulated build of the same sources on CPU (default run) or the real gfx950 library
+through the C ABI (-m gpu)."""
 import pytest
 import torch
 
 from oracle import pidm_oracle as O
-from physicsinformeddiffusionmodels_amd._lib import ptr
-from tests.emu_util import emu_lib
+from physicsinformeddiffusionmodels_amd._lib import ptr, stream_ptr
 
 
 def rel(a, b):
+    a, b = a.detach().cpu(), b.detach().cpu()
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
 @pytest.mark.parametrize("P,B", [(16, 3), (64, 2)])
-def test_darcy_residual_fwd_bwd(P, B):
-    L = emu_lib()
+def test_darcy_residual_fwd_bwd(backend, P, B):
+    L, dev = backend
+    st = stream_ptr(dev)
     g = torch.Generator().manual_seed(5)
     x0 = torch.randn(B, 2, P, P, generator=g)
     x0[:, 1] = torch.exp(0.5 * x0[:, 1])
     fs = O.darcy_source_field(P).reshape(-1).contiguous()
     inv_h = float(P - 1)
-    res = torch.empty(B, P * P, 3)
-    L.check(L.pidm_darcy_residual_fwd(ptr(x0), ptr(fs), inv_h, -inv_h, ptr(res), B, P, None))
+    x0d, fsd = x0.to(dev), fs.to(dev)
+    res = torch.empty(B, P * P, 3, device=dev)
+    L.check(L.pidm_darcy_residual_fwd(ptr(x0d), ptr(fsd), inv_h, -inv_h, ptr(res), B, P, st))
     xr = x0.clone().requires_grad_(True)
     ref = O.darcy_residual(xr)
-    assert rel(res, ref.detach()) < 2e-6
+    assert rel(res, ref) < 2e-6
     gr = torch.randn(B, P * P, 3, generator=g)
     (gref,) = torch.autograd.grad(ref, xr, gr)
-    gx = torch.empty_like(x0)
-    L.check(L.pidm_darcy_residual_bwd(ptr(x0), ptr(gr), inv_h, -inv_h, ptr(gx), B, P, None))
+    grd = gr.to(dev)
+    gx = torch.empty_like(x0d)
+    L.check(L.pidm_darcy_residual_bwd(ptr(x0d), ptr(grd), inv_h, -inv_h, ptr(gx), B, P, st))
     assert rel(gx, gref) < 5e-6
 
 
 @pytest.mark.parametrize("P,B", [(16, 4), (64, 2)])
-def test_darcy_fused_loss(P, B):
-    L = emu_lib()
+def test_darcy_fused_loss(backend, P, B):
+    L, dev = backend
+    st = stream_ptr(dev)
     g = torch.Generator().manual_seed(6)
     tables = O.diffusion_tables(100)
     x0 = torch.randn(B, 2, P, P, generator=g)
@@ -46,16 +50,18 @@ def test_darcy_fused_loss(P, B):
     inv_var = (1.0 / tables["posterior_variance_clipped"][t]).contiguous()
     fs = O.darcy_source_field(P).reshape(-1).contiguous()
     inv_h = float(P - 1)
-    res = torch.empty(B, P * P, 3)
-    gpred = torch.empty_like(pred)
-    out = torch.zeros(4)
-    ws = torch.empty(L.pidm_darcy_loss_ws(B, P), dtype=torch.uint8)
-    L.check(L.pidm_darcy_loss_fwd_bwd(ptr(x0), ptr(pred), ptr(fs), ptr(p2w), ptr(inv_var), 1.0, 1e-3, inv_h, -inv_h,
-                                      ptr(res), ptr(gpred), ptr(out), ptr(ws), B, P, None))
+    x0d, predd, fsd, p2wd, ivd = (z.to(dev) for z in (x0, pred, fs, p2w, inv_var))
+    res = torch.empty(B, P * P, 3, device=dev)
+    gpred = torch.empty_like(predd)
+    out = torch.zeros(4, device=dev)
+    ws = torch.empty(L.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+    L.check(L.pidm_darcy_loss_fwd_bwd(ptr(x0d), ptr(predd), ptr(fsd), ptr(p2wd), ptr(ivd), 1.0, 1e-3, inv_h, -inv_h,
+                                      ptr(res), ptr(gpred), ptr(out), ptr(ws), B, P, st))
     pr = pred.clone().requires_grad_(True)
     loss, data, rabs, rref = O.darcy_loss_from_pred(tables, x0, pr, t, 1.0, 1e-3)
     loss.backward()
-    assert rel(res, rref.detach()) < 2e-6
+    out = out.cpu()
+    assert rel(res, rref) < 2e-6
     assert abs(out[0].item() - loss.item()) < 1e-5 * abs(loss.item())
     assert abs(out[1].item() - data.item()) < 1e-5 * abs(data.item())
     assert abs(out[2].item() - rabs.item()) < 1e-5 * abs(rabs.item())

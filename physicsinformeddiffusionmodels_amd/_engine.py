@@ -1,0 +1,212 @@
+"""Host glue between the `Unet3D` parameter container and the gfx950 UNet engine (C ABI, include/pidm.h).
+
+PyTorch is plumbing here: it owns the parameter / gradient / workspace memory and the RNG; every FLOP of the
+forward and backward pass runs in hand-written HIP kernels behind `pidm_unet_forward` / `pidm_unet_backward`.
+There is no CPU or eager fallback: tensors must live on an MI355X and `libpidm_hip.so` must be built.
+(The unit tests bind the host-emulated build of the same C sources by passing `lib=` explicitly.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ._lib import PidmError, PidmLib, UnetCfg, get_lib, ptr, stream_ptr, vp
+
+
+class UnetEngine:
+    """One native engine handle per (model, image size).  Not thread-safe (one per process per device)."""
+
+    def __init__(self, model, image_size: int, lib: PidmLib | None = None):
+        self.lib = lib or get_lib()
+        cfg = UnetCfg()
+        cfg.dim = model.dim
+        cfg.channels = model.channels
+        cfg.out_dim = model.out_dim
+        cfg.n_levels = len(model.dim_mults)
+        for i, m in enumerate(model.dim_mults):
+            cfg.dim_mults[i] = int(m)
+        cfg.heads = model.attn_heads
+        cfg.dim_head = model.attn_dim_head
+        cfg.groups = model.resnet_groups
+        cfg.init_kernel = model.init_kernel_size
+        cfg.image_size = image_size
+        cfg.sigmoid_last_channel = int(bool(model.sigmoid_last_channel))
+        self.image_size = image_size
+        self.handle = vp()
+        self.lib.check(self.lib.pidm_unet_create(C.byref(cfg), C.byref(self.handle)), "pidm_unet_create")
+        n = self.lib.pidm_unet_num_params(self.handle)
+        self.names = [self.lib.pidm_unet_param_name(self.handle, i).decode() for i in range(n)]
+        self.numels = [self.lib.pidm_unet_param_numel(self.handle, i) for i in range(n)]
+        named = dict(model.named_parameters())
+        missing = [k for k in self.names if k not in named]
+        if missing:
+            raise PidmError(f"engine parameter(s) not found in the model: {missing[:4]}")
+        for k, ne in zip(self.names, self.numels):
+            if named[k].numel() != ne:
+                raise PidmError(f"parameter {k}: numel {named[k].numel()} != engine's {ne}")
+        self.params = [named[k] for k in self.names]
+        self.flat_grad = None
+        self.grad_views = None
+        self._bound_key = None
+        self.workspace = None
+        self._ws_key = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pidm_unet_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- memory owned by torch, borrowed by the engine -------------------------------------------------
+    def _ensure_bound(self, need_grad: bool):
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise PidmError("engine parameters must be contiguous fp32 tensors on one device")
+        if need_grad and (self.flat_grad is None or self.flat_grad.device != dev):
+            # one flat gradient buffer in the engine's canonical order: p.grad become views of it (a single
+            # all-reduce payload for data parallel training, contiguous FiLM-linear gradients for the engine)
+            total = sum(self.numels)
+            self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.grad_views, off = [], 0
+            for p, ne in zip(self.params, self.numels):
+                self.grad_views.append(self.flat_grad[off:off + ne].view(p.shape))
+                off += ne
+            self._bound_key = None
+        key = (tuple(p.data_ptr() for p in self.params), need_grad and self.flat_grad.data_ptr())
+        if key != self._bound_key:
+            n = len(self.params)
+            pp = (vp * n)(*[vp(p.data_ptr()) for p in self.params])
+            if need_grad:
+                gp = (vp * n)(*[vp(g.data_ptr()) for g in self.grad_views])
+                self.lib.check(self.lib.pidm_unet_bind(self.handle, pp, gp), "pidm_unet_bind")
+            else:
+                self.lib.check(self.lib.pidm_unet_bind(self.handle, pp, None), "pidm_unet_bind")
+            self._bound_key = key
+
+    def _ensure_workspace(self, B: int, training: bool, device):
+        key = (B, training, str(device))
+        if self._ws_key != key or self.workspace is None:
+            nbytes = self.lib.pidm_unet_workspace_bytes(self.handle, B, int(training))
+            if nbytes == 0:
+                raise PidmError("pidm_unet_workspace_bytes: " + self.lib.lib.pidm_last_error().decode())
+            if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != torch.device(device):
+                self.workspace = None
+                self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self._ws_key = key
+        return self.workspace
+
+    # ---- forward / backward ------------------------------------------------------------------------------
+    def forward(self, x_nhwc: torch.Tensor, t: torch.Tensor, training: bool, repack: bool = True) -> torch.Tensor:
+        B = x_nhwc.shape[0]
+        dev = x_nhwc.device
+        self._ensure_bound(training)
+        ws = self._ensure_workspace(B, training, dev)
+        P = self.image_size
+        out = torch.empty(B, self.lib_out_dim, P, P, dtype=torch.float32, device=dev)
+        base = ws.data_ptr()
+        al = (-base) % 256
+        self.lib.check(self.lib.pidm_unet_forward(self.handle, ptr(x_nhwc), ptr(t), ptr(out), B, int(training), int(repack),
+                                                  vp(base + al), ws.numel() - al, stream_ptr(dev)), "pidm_unet_forward")
+        return out
+
+    def backward(self, grad_out: torch.Tensor, want_grad_x: bool, channels: int):
+        B = grad_out.shape[0]
+        dev = grad_out.device
+        ws = self.workspace
+        gx = torch.empty(B, self.image_size * self.image_size, channels, dtype=torch.float32, device=dev) if want_grad_x else None
+        base = ws.data_ptr()
+        al = (-base) % 256
+        self.lib.check(self.lib.pidm_unet_backward(self.handle, ptr(grad_out), ptr(gx), B, vp(base + al), ws.numel() - al,
+                                                   stream_ptr(dev)), "pidm_unet_backward")
+        return gx
+
+
+class _UnetFunction(torch.autograd.Function):
+    """autograd node whose forward/backward are single C-ABI calls.  Parameter gradients are written by the
+    engine into the flat gradient buffer and attached as `p.grad` views (accumulated if a grad already exists),
+    so `optimizer.zero_grad(); loss.backward(); clip_grad_norm_; optimizer.step()` behaves as in main.py:163-166.
+    Parameters that forward never reads keep `grad is None`, exactly like the reference."""
+
+    @staticmethod
+    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool):
+        ctx.engine = engine
+        ctx.x_requires_grad = x_nhwc.requires_grad
+        ctx.channels = x_nhwc.shape[-1]
+        ctx.training = training
+        out = engine.forward(x_nhwc, t, training=training)
+        # the engine keeps RAW pointers to its input and output until backward: keep both tensors alive
+        ctx.save_for_backward(out, x_nhwc)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.engine
+        if not ctx.training:
+            raise PidmError("backward through a forward that ran without gradient tracking")
+        gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
+        for p, g in zip(eng.params, eng.grad_views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)
+            # else: p.grad already aliases the engine buffer, which now holds this step's gradient
+        return None, gx, None, None, None
+
+
+def get_engine(model, image_size: int, lib: PidmLib | None = None) -> UnetEngine:
+    cache = model.__dict__.setdefault("_engines", {})
+    key = (image_size, id(lib))
+    eng = cache.get(key)
+    if eng is None:
+        eng = UnetEngine(model, image_size, lib)
+        eng.lib_out_dim = model.out_dim
+        cache[key] = eng
+    return eng
+
+
+def used_parameter_names(model, image_size: int = 64):
+    return list(get_engine(model, image_size).names)
+
+
+def unet_apply(model, x, time, lib: PidmLib | None = None):
+    """x: [B,P*P,C] (reference interchange layout), [B,C,P,P] or [B,C,1,P,P]; time: int64 [B].
+    Returns [B,out_dim,P,P] (or [B,out_dim,1,P,P] for 5-D input), as reference Unet3D.forward does."""
+    video = False
+    if x.dim() == 3:
+        B, N, Cc = x.shape
+        P = int(math.isqrt(N))
+        if P * P != N:
+            raise ValueError('Input [B, P*P, C] needs a square number of pixels.')
+        x_nhwc = x
+    elif x.dim() == 4:
+        B, Cc, P, P2 = x.shape
+        x_nhwc = x.permute(0, 2, 3, 1).reshape(B, P * P2, Cc)
+    elif x.dim() == 5:
+        video = True
+        B, Cc, F_, P, P2 = x.shape
+        if F_ != 1:
+            raise NotImplementedError('the gfx950 engine runs the image path (singleton frame axis) only')
+        x_nhwc = x[:, :, 0].permute(0, 2, 3, 1).reshape(B, P * P2, Cc)
+    else:
+        raise ValueError('Input must be image [BxCxPxP] or image sequence [BxCxFxPxP].')
+    if Cc != model.channels:
+        raise ValueError(f'expected {model.channels} input channels, got {Cc}')
+    if lib is None and not x.is_cuda:
+        raise PidmError("Unet3D.forward needs tensors on an MI355X (cuda device): the gfx950 engine has no CPU fallback")
+    x_nhwc = x_nhwc.contiguous().float()
+    t = time.to(device=x.device, dtype=torch.int64).contiguous()
+    if t.numel() != B:
+        raise ValueError('time must have one entry per batch element')
+    eng = get_engine(model, P, lib)
+    anchor = eng.params[0]
+    training = torch.is_grad_enabled() and (anchor.requires_grad or x_nhwc.requires_grad)
+    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training)
+    if video:
+        out = out.unsqueeze(2)
+    return out

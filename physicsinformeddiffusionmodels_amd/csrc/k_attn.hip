@@ -1,0 +1,434 @@
+// Linear attention (every UNet level) and the 64-token softmax attention of the bottleneck, fwd + bwd.
+//
+// Replaces SpatialLinearAttention.forward src/unet_model.py:281-299 and Attention.forward :341-367 (+ their
+// autograd).  qkv comes from the 1x1 to_qkv GEMM as [B][N][3*HD] channels-last (q | k | v, head-major), HD =
+// heads*32.  The contractions run on the fp32 matrix cores (32x32x2) straight from global memory: a
+// 32-wide head slice of one pixel is 128 contiguous bytes, so every lane-half fetch is a coalesced line.
+//   context[d][e] = 1/N sum_n softmax_n(k)[n][d] v[n][e]        (K = N pixels, split over 4 waves)
+//   out[n][e]     = sum_d context[d][e] * softmax_d(q)[n][d]*scale   (K = 32)
+// q/k/v are never re-materialised after softmax: the softmax is applied on the fly from per-column (k) and
+// per-pixel (q) statistics.
+#include "pidm_launch.h"
+
+namespace pidm {
+
+static const int DH = 32;  // dim_head (the 32x32 MFMA tile)
+
+// ---- k softmax statistics over pixels: kstat[b][j] = (max_n, 1/sum_n exp(k - max)) -----------------
+__global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict__ qkv, int N, int HD,
+                                                        float* __restrict__ kstat) {
+  __shared__ float sm[4][64], ssum[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  float m = -3.0e38f, s = 0.f;
+  if (j < HD) {
+    const float* base = qkv + (size_t)b * N * 3 * HD + HD + j;
+    for (int n = rl; n < N; n += 4) {
+      const float v = base[(size_t)n * 3 * HD];
+      const float mn = fmaxf(m, v);
+      s = s * expf(m - mn) + expf(v - mn);
+      m = mn;
+    }
+  }
+  sm[rl][cl] = m;
+  ssum[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && j < HD) {
+    float M = fmaxf(fmaxf(sm[0][cl], sm[1][cl]), fmaxf(sm[2][cl], sm[3][cl]));
+    float S = 0.f;
+    for (int r = 0; r < 4; ++r) S += ssum[r][cl] * expf(sm[r][cl] - M);
+    kstat[((size_t)b * HD + j) * 2] = M;
+    kstat[((size_t)b * HD + j) * 2 + 1] = 1.f / S;
+  }
+}
+
+// ---- D[b][h][i][j] = alpha * sum_n A(n,i) * Bm(n,j)  (32x32 per (b,h), K = N) ----------------------
+// MODE 0 (forward context): A = softmax_n(k)[n][h*32+i] from kstat,  Bm = v[n][h*32+j]
+// MODE 1 (backward dctx):   A = softmax_d(q)[n][h*32+i]*scale from qstat, Bm = dA[n][h*32+j]; also writes
+//                           rowdot[b][h][i] = sum_j D[i][j] * ctx[b][h][i][j]
+template <int MODE>
+__global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict__ qkv, const float* __restrict__ stat,
+                                                         const float* __restrict__ dA, const float* __restrict__ ctx,
+                                                         float* __restrict__ D, float* __restrict__ rowdot, int N, int heads,
+                                                         float alpha, float scale) {
+  __shared__ float red[4][1024];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* q0 = qkv + (size_t)b * N * 3 * HD;
+  float cm = 0.f, cis = 0.f;
+  if (MODE == 0) {
+    cm = stat[((size_t)b * HD + h * DH + l31) * 2];
+    cis = stat[((size_t)b * HD + h * DH + l31) * 2 + 1];
+  }
+  const int per = (N + 3) / 4;
+  const int n_lo = wave * per, n_hi = (n_lo + per < N) ? n_lo + per : N;
+  for (int n0 = n_lo; n0 < n_hi; n0 += 2) {
+    const int n = n0 + half;
+    float a = 0.f, bv = 0.f;
+    if (n < n_hi) {
+      const float* row = q0 + (size_t)n * 3 * HD;
+      if (MODE == 0) {
+        a = expf(row[HD + h * DH + l31] - cm) * cis;
+        bv = row[2 * HD + h * DH + l31];
+      } else {
+        const float* qs = stat + (((size_t)b * N + n) * heads + h) * 2;
+        a = expf(row[h * DH + l31] - qs[0]) * qs[1] * scale;
+        bv = dA[((size_t)b * N + n) * HD + h * DH + l31];
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+  }
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    red[wave][row * 32 + l31] = acc[r];
+  }
+  __syncthreads();
+  float* out = D + (size_t)bh * 1024;
+  for (int e = tid; e < 1024; e += 256) {
+    const float v = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * alpha;
+    out[e] = v;
+    if (MODE == 1) red[0][e] = v * ctx[(size_t)bh * 1024 + e];
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    if (tid < 32) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += red[0][tid * 32 + j];
+      rowdot[(size_t)bh * 32 + tid] = s;
+    }
+  }
+}
+
+// ---- out[n][h*32+e] = sum_d ctx[d][e] * softmax_d(q[n][h*32+:])[d] * scale ; qstat = (max, 1/sum) -------
+// one wave = 32 pixels, loops over heads.  lane (pixel l31, half) owns d in [16*half, 16*half+16).
+__global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                     float* __restrict__ out, float* __restrict__ qstat, int N, int heads,
+                                                     size_t npix, float scale) {
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const size_t p = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;   // global pixel index (b*N + n)
+  const bool valid = p < npix;
+  const size_t b = valid ? p / N : 0;
+  for (int h = 0; h < heads; ++h) {
+    float qv[16];
+    float m = -3.0e38f;
+    if (valid) {
+      const float* qp = qkv + p * 3 * HD + h * DH + 16 * half;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(qp + 4 * k);
+        qv[4 * k] = v.x; qv[4 * k + 1] = v.y; qv[4 * k + 2] = v.z; qv[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m = fmaxf(m, qv[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) qv[k] = 0.f;
+      m = 0.f;
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      qv[k] = expf(qv[k] - m);
+      s += qv[k];
+    }
+    s += __shfl_xor(s, 32);
+    const float inv = 1.f / s;
+    if (valid && half == 0) {
+      qstat[(p * heads + h) * 2] = m;
+      qstat[(p * heads + h) * 2 + 1] = inv;
+    }
+    const float* cb = ctx + (b * heads + h) * 1024;   // [d][e]; rows of *other* batches are never mixed:
+    // a wave's 32 pixels may straddle two images only when N < 32; handle by per-lane b below
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (N % 32 == 0) {
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float a = qv[s2] * inv * scale;
+        const float bv = cb[(16 * half + s2) * 32 + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+      }
+      // all 32 rows belong to image b of lane... rows = pixels of this wave: same image since N % 32 == 0
+      const size_t pw = ((size_t)blockIdx.x * 4 + wave) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (pw + row < npix) out[(pw + row) * HD + h * DH + l31] = acc[r];
+      }
+    } else {
+      // small images (N < 32 or ragged): the B operand differs per row -> plain FMA path, lane = pixel
+      // each lane-half computes e in [16*half, 16*half+16) for its own pixel from the full q row
+      float qfull[32];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float mine = qv[k] * inv * scale;
+        const float other = __shfl_xor(mine, 32);
+        qfull[k] = half ? other : mine;        // static indices keep the array in registers
+        qfull[16 + k] = half ? mine : other;
+      }
+      if (valid) {
+        for (int e = 16 * half; e < 16 * half + 16; ++e) {
+          float o = 0.f;
+#pragma unroll
+          for (int d = 0; d < 32; ++d) o = fmaf(cb[d * 32 + e], qfull[d], o);
+          out[p * HD + h * DH + e] = o;
+        }
+      }
+    }
+  }
+}
+
+// ---- backward, per pixel: dq, dk, dv into dqkv[B][N][3*HD] ------------------------------------------------
+// dq' = dA ctx^T ; dq = scale*qs*(dq' - sum_d qs dq')        qs = softmax_d(q)
+// dP  = (1/N) v dctx^T ; dk = P*(dP - rowdot)                 P  = softmax_n(k)
+// dv  = (1/N) P dctx
+// generic (non-MFMA) formulation: one thread per (pixel, head); the three 32x32 mat-vecs read ctx/dctx from LDS.
+__global__ void __launch_bounds__(256) la_bwd_pix_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                         const float* __restrict__ qstat, const float* __restrict__ ctx,
+                                                         const float* __restrict__ dctx, const float* __restrict__ rowdot,
+                                                         const float* __restrict__ dA, float* __restrict__ dqkv, int N,
+                                                         int heads, float scale) {
+  // block = (b, h, 256-pixel slab)
+  __shared__ float sc[32][33], sd[32][33], srd[32], skm[32], skis[32];
+  const int HD = heads * DH;
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 1024; e += 256) {
+    sc[e >> 5][e & 31] = ctx[(size_t)bh * 1024 + e];
+    sd[e >> 5][e & 31] = dctx[(size_t)bh * 1024 + e];
+  }
+  if (tid < 32) {
+    srd[tid] = rowdot[(size_t)bh * 32 + tid];
+    skm[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2];
+    skis[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2 + 1];
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= N) return;
+  const size_t p = (size_t)b * N + n;
+  const float* row = qkv + p * 3 * HD + h * DH;
+  float q[32], da[32], tmp[32];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * k);
+    q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
+    const float4 w = *reinterpret_cast<const float4*>(dA + p * HD + h * DH + 4 * k);
+    da[4 * k] = w.x; da[4 * k + 1] = w.y; da[4 * k + 2] = w.z; da[4 * k + 3] = w.w;
+  }
+  const float qm = qstat[(p * heads + h) * 2], qis = qstat[(p * heads + h) * 2 + 1];
+  // dq
+  float dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) {
+    float dqp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) dqp = fmaf(sc[d][e], da[e], dqp);
+    const float qs = expf(q[d] - qm) * qis;
+    q[d] = qs;
+    tmp[d] = dqp;
+    dot = fmaf(qs, dqp, dot);
+  }
+  float* orow = dqkv + p * 3 * HD + h * DH;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float4 o;
+    o.x = scale * q[4 * k] * (tmp[4 * k] - dot);
+    o.y = scale * q[4 * k + 1] * (tmp[4 * k + 1] - dot);
+    o.z = scale * q[4 * k + 2] * (tmp[4 * k + 2] - dot);
+    o.w = scale * q[4 * k + 3] * (tmp[4 * k + 3] - dot);
+    *reinterpret_cast<float4*>(orow + 4 * k) = o;
+  }
+  // dk: needs v and P
+  float v[32], P[32];
+  const float invN = 1.f / (float)N;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float4 kk = *reinterpret_cast<const float4*>(row + HD + 4 * k);
+    const float4 vv = *reinterpret_cast<const float4*>(row + 2 * HD + 4 * k);
+    P[4 * k] = expf(kk.x - skm[4 * k]) * skis[4 * k];
+    P[4 * k + 1] = expf(kk.y - skm[4 * k + 1]) * skis[4 * k + 1];
+    P[4 * k + 2] = expf(kk.z - skm[4 * k + 2]) * skis[4 * k + 2];
+    P[4 * k + 3] = expf(kk.w - skm[4 * k + 3]) * skis[4 * k + 3];
+    v[4 * k] = vv.x; v[4 * k + 1] = vv.y; v[4 * k + 2] = vv.z; v[4 * k + 3] = vv.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int d = 4 * k + u;
+      float dP = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dP = fmaf(sd[d][e], v[e], dP);
+      o[u] = P[d] * (dP * invN - srd[d]);
+    }
+    *reinterpret_cast<float4*>(orow + HD + 4 * k) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // dv
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = 4 * k + u;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) s = fmaf(P[d], sd[d][e], s);
+      o[u] = s * invN;
+    }
+    *reinterpret_cast<float4*>(orow + 2 * HD + 4 * k) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bottleneck softmax attention over N <= 64 tokens, one workgroup per (b, h)
+// ---------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(256) mid_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                       float* __restrict__ out,   // FWD: O [B][N][HD] ; BWD: dqkv [B][N][3HD]
+                                                       int N, int heads, float scale) {
+  // dynamic LDS carve: q,k,v,(dO) as [N][33]; S,(dS) as [N][N+1]
+  HIP_DYNAMIC_SHARED(float, smem)
+  float (*sq)[33] = reinterpret_cast<float (*)[33]>(smem);
+  float (*sk)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)N * 33);
+  float (*sv)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)2 * N * 33);
+  float (*sdo)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)3 * N * 33);
+  float* sS_ = smem + (size_t)4 * N * 33;
+  float* sdS_ = sS_ + (size_t)N * (N + 1);
+  const int LS = N + 1;
+#define sS(i, j) sS_[(i) * LS + (j)]
+#define sdS(i, j) sdS_[(i) * LS + (j)]
+  const int HD = heads * DH;
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  for (int e = tid; e < N * 32; e += 256) {
+    const int n = e >> 5, d = e & 31;
+    const float* row = qkv + ((size_t)b * N + n) * 3 * HD + h * DH + d;
+    sq[n][d] = row[0] * scale;
+    sk[n][d] = row[HD];
+    sv[n][d] = row[2 * HD];
+    if (BWD) sdo[n][d] = dO[((size_t)b * N + n) * HD + h * DH + d];
+  }
+  __syncthreads();
+  for (int e = tid; e < N * N; e += 256) {
+    const int i = e / N, j = e % N;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s = fmaf(sq[i][d], sk[j][d], s);
+    sS(i, j) = s;
+  }
+  __syncthreads();
+  if (tid < N) {
+    float m = -3.0e38f;
+    for (int j = 0; j < N; ++j) m = fmaxf(m, sS(tid, j));
+    float s = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float ex = expf(sS(tid, j) - m);
+      sS(tid, j) = ex;
+      s += ex;
+    }
+    const float inv = 1.f / s;
+    for (int j = 0; j < N; ++j) sS(tid, j) *= inv;
+  }
+  __syncthreads();
+  if (!BWD) {
+    for (int e = tid; e < N * 32; e += 256) {
+      const int i = e >> 5, d = e & 31;
+      float o = 0.f;
+      for (int j = 0; j < N; ++j) o = fmaf(sS(i, j), sv[j][d], o);
+      out[((size_t)b * N + i) * HD + h * DH + d] = o;
+    }
+    return;
+  }
+  // dV[j][d] = sum_i P[i][j] dO[i][d]
+  for (int e = tid; e < N * 32; e += 256) {
+    const int j = e >> 5, d = e & 31;
+    float o = 0.f;
+    for (int i = 0; i < N; ++i) o = fmaf(sS(i, j), sdo[i][d], o);
+    out[((size_t)b * N + j) * 3 * HD + 2 * HD + h * DH + d] = o;
+  }
+  __syncthreads();
+  // dP[i][j] = sum_d dO[i][d] v[j][d]; dS = P*(dP - sum_j dP*P)   (overwrite sv rows are still needed: keep)
+  for (int e = tid; e < N * N; e += 256) {
+    const int i = e / N, j = e % N;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s = fmaf(sdo[i][d], sv[j][d], s);
+    sdS(i, j) = s;
+  }
+  __syncthreads();
+  if (tid < N) {
+    float dot = 0.f;
+    for (int j = 0; j < N; ++j) dot = fmaf(sdS(tid, j), sS(tid, j), dot);
+    for (int j = 0; j < N; ++j) sdS(tid, j) = sS(tid, j) * (sdS(tid, j) - dot);
+  }
+  __syncthreads();
+  // dq[i][d] = scale * sum_j dS[i][j] k[j][d] ; dk[j][d] = sum_i dS[i][j] * (scale*q[i][d]) (sq already holds scale*q)
+  for (int e = tid; e < N * 32; e += 256) {
+    const int i = e >> 5, d = e & 31;
+    float a = 0.f, c = 0.f;
+    for (int j = 0; j < N; ++j) {
+      a = fmaf(sdS(i, j), sk[j][d], a);
+      c = fmaf(sdS(j, i), sq[j][d], c);
+    }
+    out[((size_t)b * N + i) * 3 * HD + h * DH + d] = a * scale;
+    out[((size_t)b * N + i) * 3 * HD + HD + h * DH + d] = c;
+  }
+}
+
+#undef sS
+#undef sdS
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
+                      hipStream_t st) {
+  const int HD = heads * DH;
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B), dim3(256), 0, st, qkv, N, HD, kstat);
+  PIDM_CHECK_LAUNCH("la_kstats_kernel");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads), dim3(256), 0, st, qkv, kstat, nullptr, nullptr, ctx,
+                     nullptr, N, heads, 1.f / (float)N, scale);
+  PIDM_CHECK_LAUNCH("la_context");
+  const size_t npix = (size_t)B * N;
+  hipLaunchKernelGGL(la_out_kernel, dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn, qstat, N, heads, npix,
+                     scale);
+  PIDM_CHECK_LAUNCH("la_out_kernel");
+  return 0;
+}
+
+int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
+                       float* rowdot, float* dqkv, int B, int N, int heads, hipStream_t st) {
+  const float scale = 0.17677669529663687f;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<1>), dim3(B * heads), dim3(256), 0, st, qkv, qstat, dA, ctx, dctx, rowdot, N,
+                     heads, 1.f, scale);
+  PIDM_CHECK_LAUNCH("la_dctx");
+  hipLaunchKernelGGL(la_bwd_pix_kernel, dim3(cdiv(N, 256), B * heads), dim3(256), 0, st, qkv, kstat, qstat, ctx, dctx, rowdot, dA,
+                     dqkv, N, heads, scale);
+  PIDM_CHECK_LAUNCH("la_bwd_pix_kernel");
+  return 0;
+}
+
+int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st) {
+  if (N > 64) return fail("mid attention: %d tokens > 64", N);
+  const float scale = 0.17677669529663687f;
+  const size_t lds = ((size_t)4 * N * 33 + (size_t)2 * N * (N + 1)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  if (bwd)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(mid_attn_kernel<true>), dim3(B * heads), dim3(256), lds, st, qkv, dO, out, N, heads, scale);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(mid_attn_kernel<false>), dim3(B * heads), dim3(256), lds, st, qkv, dO, out, N, heads, scale);
+  PIDM_CHECK_LAUNCH("mid_attn_kernel");
+  return 0;
+}
+
+}  // namespace pidm

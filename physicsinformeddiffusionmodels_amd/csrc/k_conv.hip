@@ -16,7 +16,7 @@
 //
 // Backward: dgrad runs the SAME kernel on a flipped/transposed weight packing; wgrad is its own kernel
 // (M = Cout, N = Cin, K = pixels) with a deterministic split-K over pixel tiles.
-#include "pidm_common.h"
+#include "pidm_launch.h"
 
 namespace pidm {
 
@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
   // this lane's A row (pixel) inside the wave's m-tile
   const int pm = wave * 32 + l31;
   const int a_tx = pm % g.Wv, a_ty = (pm / g.Wv) % g.TH, a_img = pm / (g.Wv * g.TH);
-  const int abase = (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride;
+  // (g.NI may be smaller than 128/(Wv*TH) when the halo tile of tiny strided images would not fit in LDS:
+  //  rows of the missing images read tile pixel 0 and are discarded in the epilogue)
+  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
       const int p = wave * 32 + row;
       const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
       const int b = b0 + img;
-      if (b >= g.B) continue;
+      if (b >= g.B || img >= g.NI) continue;
       const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
       float v = acc[ni][r] + bv;
       if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
@@ -153,29 +155,29 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int parity_tap(int par, int j) { return par == 0 ? 3 - 2 * j : 2 - 2 * j; }
 
+// iterates over the SOURCE-valid elements (n < N, k < K) only; padding is zero-filled once by the caller.
+// (n_off, k_off) place a source tensor inside a larger packed matrix (concatenated time-MLP linears).
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int nz, int N, int K,
-                            int Np, int Kp, int KH, int KW, int T) {
-  const size_t total = (size_t)nz * Np * T * Kp;
+                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off) {
+  const size_t total = (size_t)nz * N * T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % Kp);
-    const int t = (int)((idx / Kp) % T);
-    const int n = (int)((idx / ((size_t)Kp * T)) % Np);
-    const int z = (int)(idx / ((size_t)Kp * T * Np));
-    float v = 0.f;
-    if (n < N && k < K) {
-      if (kind == 0) {
-        v = src[((size_t)n * K + k) * T + t];
-      } else if (kind == 2) {
-        const int ky = KH - 1 - t / KW, kx = KW - 1 - t % KW;
-        v = src[(((size_t)k * N + n) * KH + ky) * KW + kx];
-      } else if (kind == 4) {
-        v = src[((size_t)n * K + k) * T + t];
-      } else {  // parity kinds: T == 4 (2x2), source taps 4x4
-        const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
-        v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
-      }
+    const int k = (int)(idx % K);
+    const int t = (int)((idx / K) % T);
+    const int n = (int)((idx / ((size_t)K * T)) % N);
+    const int z = (int)(idx / ((size_t)K * T * N));
+    float v;
+    if (kind == 0) {
+      v = src[((size_t)n * K + k) * T + t];
+    } else if (kind == 2) {
+      const int ky = KH - 1 - t / KW, kx = KW - 1 - t % KW;
+      v = src[(((size_t)k * N + n) * KH + ky) * KW + kx];
+    } else if (kind == 4) {
+      v = src[((size_t)n * K + k) * T + t];
+    } else {  // parity kinds: T == 4 (2x2), source taps 4x4
+      const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
+      v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
     }
-    dst[idx] = v;
+    dst[(((size_t)z * Np + n_off + n) * T + t) * Kp + k_off + k] = v;
   }
 }
 
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
       const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
       const int b = b0 + img, c = m0 + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < g.B && c < g.Cout) {
+      if (b < g.B && img < g.NI && c < g.Cout) {
         const size_t pix = ((size_t)b * g.Hv + (vy0 + ty)) * g.Wv + tx;
         if (vec_dy) {
           v = *reinterpret_cast<const float4*>(dy + pix * wg.ld_dy + c);
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
     for (int ks = 0; ks < 16; ++ks) {
       const int p = wave * 32 + 2 * ks + half;
       const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
-      const int xb = (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride;
+      const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
       const float a = Ys[p * 32 + l31];
 #pragma unroll
       for (int tl = 0; tl < MAXT; ++tl) {
@@ -375,6 +377,8 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
   g->NI = kBM / (g->Wv * g->TH);
   g->IHt = (g->TH - 1) * g->stride + g->KH;
   g->IWt = (g->Wv - 1) * g->stride + g->KW;
+  // tiny strided images: the halo blow-up (e.g. 36 input pixels per 2x2 output) must still fit in LDS
+  while (g->NI > 1 && g->NI * g->IHt * g->IWt > 768) g->NI >>= 1;
   const int tpi = g->Hv / g->TH;
   g->tiles_m = (g->NI > 1) ? cdiv(B, g->NI) : B * tpi;
   if (out_nchw) { g->sob = (long)Cout * g->Ho * g->Wo; g->soc = (long)g->Ho * g->Wo; g->soy = g->Wo; g->sox = 1; }
@@ -392,15 +396,19 @@ size_t packed_floats(const ConvGeom& g) {
   return (size_t)g.nz * Np * g.KH * g.KW * Kp;
 }
 
-// w_ref -> packed. N/K are the packed problem's Cout/Cin (g.Cout / g.Cin); srcKH/srcKW the reference tap grid.
-int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, hipStream_t st) {
+// w_ref -> packed.  The packed matrix is sized by g (g.Cout rows, g.Cin columns); the source tensor covers rows
+// [n_off, n_off+n_src) and columns [k_off, k_off+k_src) of it (n_src/k_src <= 0: the whole matrix).
+// Padding must have been zero-filled by the caller.
+int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
+                int n_src, int k_src, hipStream_t st) {
   const int KC = pick_kc(g.Cin), BN = 32 * pick_nt(g.Cout);
   const int Np = cdiv(g.Cout, BN) * BN, Kp = cdiv(g.Cin, KC) * KC, T = g.KH * g.KW;
-  const size_t total = (size_t)g.nz * Np * T * Kp;
+  const int N = n_src > 0 ? n_src : g.Cout, K = k_src > 0 ? k_src : g.Cin;
+  const size_t total = (size_t)g.nz * N * T * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nz, g.Cout, g.Cin, Np, Kp,
-                     srcKH, srcKW, T);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nz, N, K, Np, Kp, srcKH, srcKW, T,
+                     n_off, k_off);
   PIDM_CHECK_LAUNCH("pack_kernel");
   return 0;
 }
@@ -564,13 +572,16 @@ extern "C" size_t pidm_conv_packed_weight_floats(const pidm_conv_desc* d) {
 
 extern "C" int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w_packed, int mode, void* stream) {
   ConvGeom g;
+  int kind = 0;
   if (mode == 0) {
     if (geom_fwd(d, &g)) return -1;
-    return launch_pack(g, d->transposed ? 1 : 0, w_ref, w_packed, d->KH, d->KW, as_stream(stream));
+    kind = d->transposed ? 1 : 0;
+  } else if (geom_dgrad(d, d->Cout, d->C0 + d->C1, &g, &kind)) {
+    return -1;
   }
-  int kind = 0;
-  if (geom_dgrad(d, d->Cout, d->C0 + d->C1, &g, &kind)) return -1;
-  return launch_pack(g, kind, w_ref, w_packed, d->KH, d->KW, as_stream(stream));
+  if (hipMemsetAsync(w_packed, 0, packed_floats(g) * sizeof(float), as_stream(stream)) != hipSuccess)
+    return fail("pack: memset failed");
+  return launch_pack(g, kind, w_ref, w_packed, d->KH, d->KW, 0, 0, 0, 0, as_stream(stream));
 }
 
 extern "C" size_t pidm_conv_dgrad_packed_weight_floats(const pidm_conv_desc* d) {

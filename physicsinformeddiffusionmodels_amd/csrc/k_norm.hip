@@ -1,0 +1,631 @@
+// GroupNorm(+FiLM+SiLU), channel LayerNorm, and small elementwise kernels (forward and backward), gfx950.
+//
+// Replaces: nn.GroupNorm + scale/shift + SiLU of Block.forward src/unet_model.py:233-241, the channel
+// LayerNorm src/unet_model.py:207-210, GELU/SiLU of the time MLP :246-249,464-469, SinusoidalPosEmb :152-159,
+// and the autograd of all of them.  All tensors channels-last [B][HW][C]; all of this is HBM-bound:
+// every kernel reads/writes full 16-byte vectors along C and reduces with wave shuffles + a fixed-order LDS
+// tree (no atomics -> deterministic).
+#include "pidm_launch.h"
+
+namespace pidm {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm statistics: partial (sum, sumsq) per (b, chunk, g) in double, then mean / rstd
+// thread e -> (pixel, group): group = tid % G is fixed because G | 256
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_partial_kernel(const float* __restrict__ x, int HW, int C, int G, int ppb,
+                                                               double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int g = tid % G, pl = tid / G, ppi = 256 / G;
+  const int p0 = chunk * ppb;
+  const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
+  float s = 0.f, ss = 0.f;
+  for (int p = p0 + pl; p < p1; p += ppi) {
+    const float* row = x + ((size_t)b * HW + p) * C + g * cpg;
+    if ((cpg & 3) == 0) {
+      for (int k = 0; k < cpg; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + k);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (int k = 0; k < cpg; ++k) {
+        const float v = row[k];
+        s += v;
+        ss += v * v;
+      }
+    }
+  }
+  double ds = s, dss = ss;
+  // lanes with equal (lane % G) hold the same group: xor-reduce over offsets G, 2G, ... < 64
+  for (int off = G; off < 64; off <<= 1) {
+    ds += __shfl_xor(ds, off);
+    dss += __shfl_xor(dss, off);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < G) {
+    red[wave][lane][0] = ds;
+    red[wave][lane][1] = dss;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, c = 0.0;
+    // when G > 64 is excluded by the host (G <= 64): every wave has all groups
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][tid][0];
+      c += red[w][tid][1];
+    }
+    double* o = partial + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+    o[0] = a;
+    o[1] = c;
+  }
+}
+
+__global__ void gn_stats_final_kernel(const double* __restrict__ partial, int nchunk, int G, int B, double count, float eps,
+                                      float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * G) return;
+  const int b = i / G, g = i % G;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const double* p = partial + (((size_t)b * nchunk + c) * G + g) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = SiLU( ((x-mean)*rstd*gamma + beta) * (1 + scale) + shift ) [+ res]
+// scale[b][c] = ss[b*ldss + c] + ssb[c], shift[b][c] = ss[b*ldss + C + c] + ssb[C + c]   (ss may be null)
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ss, const float* __restrict__ ssb, int ldss,
+                                                       const float* __restrict__ res, float* __restrict__ y, int B, int HW,
+                                                       int C, int G) {
+  const int cpg = C / G;
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const int c0 = (int)(i % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = *reinterpret_cast<const float4*>(res + i);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k, g = c / cpg;
+      const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+      float v = (xv[k] - mean) * rstd * gamma[c] + beta[c];
+      if (ss) {
+        const float sc = ss[(size_t)b * ldss + c] + ssb[c], sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
+        v = v * (sc + 1.f) + sh;
+      }
+      o[k] = v * sigmoidf_(v) + rv[k];
+    }
+    *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dv = dy * silu'(v) recomputed from x
+__device__ __forceinline__ void gn_recompute(float xv, float dyv, float mean, float rstd, float gm, float bt, float sc1,
+                                             float sh, float* xhat, float* dv) {
+  const float xh = (xv - mean) * rstd;
+  const float v = (xh * gm + bt) * sc1 + sh;
+  const float sg = sigmoidf_(v);
+  *xhat = xh;
+  *dv = dyv * (sg * (1.f + v * (1.f - sg)));
+}
+
+// per (b, chunk, c): S1 = sum dv, S2 = sum dv*xhat  (double partials).  Requires 256 % C == 0 or C % 256 == 0.
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ ss,
+                                                            const float* __restrict__ ssb, int ldss, int HW, int C, int G,
+                                                            int ppb, double* __restrict__ partial) {
+  __shared__ double red[256][2];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int p0 = chunk * ppb;
+  const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
+  const int nrep = C > 256 ? C / 256 : 1;
+  const int cw = C > 256 ? 256 : C;  // channels covered by one pass of the block
+  const int rl = tid / cw, nrl = 256 / cw;
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int c = rep * 256 + tid % cw;
+    const int g = c / cpg;
+    const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+    const float gm = gamma[c], bt = beta[c];
+    float sc1 = 1.f, sh = 0.f;
+    if (ss) {
+      sc1 = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
+      sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = p0 + rl; p < p1; p += nrl) {
+      const size_t idx = ((size_t)b * HW + p) * C + c;
+      float xh, dv;
+      gn_recompute(x[idx], dy[idx], mean, rstd, gm, bt, sc1, sh, &xh, &dv);
+      s1 += dv;
+      s2 += dv * xh;
+    }
+    __syncthreads();
+    red[tid][0] = s1;
+    red[tid][1] = s2;
+    __syncthreads();
+    if (tid < cw) {
+      double a = 0.0, d = 0.0;
+      for (int r = 0; r < nrl; ++r) {
+        a += red[r * cw + tid][0];
+        d += red[r * cw + tid][1];
+      }
+      double* o = partial + (((size_t)b * gridDim.x + chunk) * C + c) * 2;
+      o[0] = a;
+      o[1] = d;
+    }
+  }
+}
+
+// per sample b: totals over chunks, dscale/dshift, per-(b,c) dgamma/dbeta contributions, group coefficients c1,c2
+__global__ void __launch_bounds__(256) gn_bwd_final_kernel(const double* __restrict__ partial, int nchunk,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ ss, const float* __restrict__ ssb, int ldss,
+                                                           float* __restrict__ dss, int HW, int C, int G,
+                                                           float* __restrict__ dgb,   // [B][2][C]: (s1*S2, s1*S1)
+                                                           float* __restrict__ coef)  // [B][G][2]: (c1, c2)
+{
+  __shared__ double ga[1024], gb[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int c = tid; c < C; c += 256) {
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
+      S1 += p[0];
+      S2 += p[1];
+    }
+    const double gm = gamma[c], bt = beta[c];
+    double sc1 = 1.0;
+    if (ss) {
+      sc1 = 1.0 + ((double)ss[(size_t)b * ldss + c] + (double)ssb[c]);
+      dss[(size_t)b * ldss + c] = (float)(gm * S2 + bt * S1);      // d scale
+      dss[(size_t)b * ldss + C + c] = (float)S1;                    // d shift
+    }
+    dgb[((size_t)b * 2 + 0) * C + c] = (float)(sc1 * S2);
+    dgb[((size_t)b * 2 + 1) * C + c] = (float)(sc1 * S1);
+    ga[c] = gm * sc1 * S1;
+    gb[c] = gm * sc1 * S2;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, d = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      a += ga[tid * cpg + k];
+      d += gb[tid * cpg + k];
+    }
+    const double n = (double)cpg * HW;
+    coef[((size_t)b * G + tid) * 2] = (float)(a / n);
+    coef[((size_t)b * G + tid) * 2 + 1] = (float)(d / n);
+  }
+}
+
+// dgamma[c] = sum_b dgb[b][0][c], dbeta[c] = sum_b dgb[b][1][c]
+__global__ void gn_param_grad_kernel(const float* __restrict__ dgb, int B, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, d = 0.f;
+  for (int b = 0; b < B; ++b) {
+    a += dgb[((size_t)b * 2 + 0) * C + c];
+    d += dgb[((size_t)b * 2 + 1) * C + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = d;
+}
+
+// dx = rstd * (dv * sc1 * gamma - c1 - xhat * c2)
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss,
+                                                           const float* __restrict__ ssb, int ldss,
+                                                           const float* __restrict__ coef, float* __restrict__ dx, int B,
+                                                           int HW, int C, int G) {
+  const int cpg = C / G;
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const int c0 = (int)(i % C);
+    const int b = (int)(i / ((size_t)HW * C));
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    const float4 dv4 = *reinterpret_cast<const float4*>(dy + i);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k, g = c / cpg;
+      const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+      const float gm = gamma[c], bt = beta[c];
+      float sc1 = 1.f, sh = 0.f;
+      if (ss) {
+        sc1 = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
+        sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
+      }
+      float xh, dv;
+      gn_recompute(xv[k], dv4[k], mean, rstd, gm, bt, sc1, sh, &xh, &dv);
+      o[k] = rstd * (dv * sc1 * gm - coef[((size_t)b * G + g) * 2] - xh * coef[((size_t)b * G + g) * 2 + 1]);
+    }
+    *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// channel LayerNorm (per pixel over C, biased variance, eps, gamma only).  TPP lanes per pixel, each lane
+// owns up to 4 float4 quads.  Requires C % 4 == 0, C/4 a power of two (<= 256).
+// ---------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ dy,    // BWD: grad wrt LN output
+                                                        const float* __restrict__ res,   // BWD: added to dx (residual path)
+                                                        float* __restrict__ out,         // FWD: y ; BWD: dx
+                                                        float* __restrict__ dgamma_partial,  // BWD: [gridDim.x][C]
+                                                        size_t npix, int C, float eps) {
+  __shared__ float dgs[256][16];
+  const int C4 = C / 4;
+  const int TPP = C4 < 64 ? C4 : 64;
+  const int NQ = C4 / TPP;  // quads per lane (1..4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane / TPP, ql = lane % TPP, ppw = 64 / TPP;
+  float dg[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dg[k] = 0.f;
+  const size_t wave_global = (size_t)blockIdx.x * 4 + wave, nwaves = (size_t)gridDim.x * 4;
+  for (size_t pbase = wave_global * ppw; pbase < npix; pbase += nwaves * ppw) {
+    const size_t p = pbase + sub;
+    const bool valid = p < npix;
+    float4 xv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < NQ && valid) xv[j] = *reinterpret_cast<const float4*>(x + p * C + (size_t)(ql + j * TPP) * 4);
+      s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+    }
+    for (int off = 1; off < TPP; off <<= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < NQ) {
+        const float a = xv[j].x - mean, b2 = xv[j].y - mean, c2 = xv[j].z - mean, d2 = xv[j].w - mean;
+        v += (a * a + b2 * b2) + (c2 * c2 + d2 * d2);
+      }
+    }
+    for (int off = 1; off < TPP; off <<= 1) v += __shfl_xor(v, off);
+    const float rstd = 1.f / sqrtf(v / (float)C + eps);
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < NQ && valid) {
+          const int c = (ql + j * TPP) * 4;
+          const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+          float4 o;
+          o.x = (xv[j].x - mean) * rstd * gm.x;
+          o.y = (xv[j].y - mean) * rstd * gm.y;
+          o.z = (xv[j].z - mean) * rstd * gm.z;
+          o.w = (xv[j].w - mean) * rstd * gm.w;
+          *reinterpret_cast<float4*>(out + p * C + c) = o;
+        }
+      }
+    } else {
+      float4 gv[4], xh[4];
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[j] = gv[j];
+        if (j < NQ && valid) {
+          const int c = (ql + j * TPP) * 4;
+          const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+          const float4 d = *reinterpret_cast<const float4*>(dy + p * C + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            xh[j][k] = (xv[j][k] - mean) * rstd;
+            gv[j][k] = d[k] * gm[k];
+            dg[j * 4 + k] += d[k] * xh[j][k];
+            m1 += gv[j][k];
+            m2 += gv[j][k] * xh[j][k];
+          }
+        }
+      }
+      for (int off = 1; off < TPP; off <<= 1) {
+        m1 += __shfl_xor(m1, off);
+        m2 += __shfl_xor(m2, off);
+      }
+      m1 /= (float)C;
+      m2 /= (float)C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < NQ && valid) {
+          const int c = (ql + j * TPP) * 4;
+          float4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = rstd * (gv[j][k] - m1 - xh[j][k] * m2);
+          if (res) {
+            const float4 r = *reinterpret_cast<const float4*>(res + p * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += r[k];
+          }
+          *reinterpret_cast<float4*>(out + p * C + c) = o;
+        }
+      }
+    }
+  }
+  if (BWD) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dgs[tid][k] = dg[k];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
+      float a = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int sb = 0; sb < ppw; ++sb) a += dgs[w * 64 + sb * TPP + qlane][j * 4 + k];
+      dgamma_partial[(size_t)blockIdx.x * C + c] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ---------------------------------------------------------------------------------------------------
+// act: 0 SiLU, 1 GELU(erf)
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = act == 0 ? v * sigmoidf_(v) : 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  }
+}
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, size_t n,
+                               int act) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    float d;
+    if (act == 0) {
+      const float sg = sigmoidf_(v);
+      d = sg * (1.f + v * (1.f - sg));
+    } else {
+      const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+      d = cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+    }
+    dx[i] = dy[i] * d;
+  }
+}
+
+// emb[b][i] = sin(t_b * w_i), emb[b][half+i] = cos(t_b * w_i), w_i = exp(-i * ln(1e4)/(half-1))
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ emb, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float e = (float)(9.210340371976184 / (double)(half - 1));  // ln(10000)/(half-1)
+  const float w = expf((float)k * -e);
+  const float arg = (float)t[b] * w;
+  emb[(size_t)b * dim + k] = sinf(arg);
+  emb[(size_t)b * dim + half + k] = cosf(arg);
+}
+
+// dst[r*ldd + c] = a[r*lda + c] (+ b[r*ldb + c]) for c < cols (cols % 4 == 0, all ld % 4 == 0)
+__global__ void copy_add_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ a, int lda,
+                                const float* __restrict__ b, int ldb, size_t rows, int cols) {
+  const int c4 = cols / 4;
+  const size_t total = rows * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / c4;
+    const int c = (int)(i % c4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(a + r * lda + c);
+    if (b) {
+      const float4 w = *reinterpret_cast<const float4*>(b + r * ldb + c);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+
+// NCHW [B][C][HW] -> channels-last [B][HW][C]; optional sigmoid-backward on the last channel:
+// g_last *= y_last * (1 - y_last)  (y = the forward NCHW output)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW,
+                                    const float* __restrict__ y_for_sigmoid_bwd) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
+    float v = src[(b * C + c) * HW + p];
+    if (y_for_sigmoid_bwd && c == C - 1) {
+      const float y = y_for_sigmoid_bwd[(b * C + c) * HW + p];
+      v *= y * (1.f - y);
+    }
+    dst[i] = v;
+  }
+}
+
+// x_t (channels-last) = a[b] * x0 (NCHW) + am1[b] * eps (NCHW)
+__global__ void qsample_kernel(const float* __restrict__ x0, const float* __restrict__ eps, const float* __restrict__ a,
+                               const float* __restrict__ am1, float* __restrict__ xt, int B, int C, int HW) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
+    const size_t s = (b * C + c) * HW + p;
+    xt[i] = x0[s] * a[b] + eps[s] * am1[b];
+  }
+}
+
+__global__ void psample_kernel(const float* __restrict__ x0p, const float* __restrict__ xt, const float* __restrict__ z,
+                               float c1, float c2, float sigma, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float mean = c1 * x0p[i] + c2 * xt[i];
+    out[i] = z ? mean + sigma * z[i] : mean;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static int ew_blocks(size_t n_threads) {
+  size_t b = (n_threads + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int gn_chunks(int HW, int B) {
+  // enough blocks to fill the chip, at least 64 pixels per block
+  int nchunk = (1024 + B - 1) / B;
+  if (nchunk > HW / 64) nchunk = HW / 64;
+  if (nchunk < 1) nchunk = 1;
+  return nchunk;
+}
+
+size_t gn_ws_bytes(int B, int HW, int C, int G) {
+  const int nchunk = gn_chunks(HW, B);
+  const size_t part = (size_t)B * nchunk * (C > G ? C : G) * 2 * sizeof(double);
+  return part + (size_t)B * 2 * C * sizeof(float) + (size_t)B * G * 2 * sizeof(float) + 256;
+}
+
+int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st) {
+  if (G > 64 || (256 % G) || (C % G)) return fail("groupnorm: groups=%d must divide 256 and C=%d", G, C);
+  const int nchunk = gn_chunks(HW, B);
+  const int ppb = cdiv(HW, nchunk);
+  double* partial = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, HW, C, G, ppb, partial);
+  PIDM_CHECK_LAUNCH("gn_stats_partial_kernel");
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(B * G, 256)), dim3(256), 0, st, partial, nchunk, G, B,
+                     (double)HW * (C / G), 1e-5f, stats);
+  PIDM_CHECK_LAUNCH("gn_stats_final_kernel");
+  return 0;
+}
+
+int launch_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
+                    const float* ssb, int ldss, const float* res, float* y, int B, int HW, int C, int G, hipStream_t st) {
+  if (C % 4) return fail("groupnorm: C=%d must be a multiple of 4", C);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks((size_t)B * HW * C / 4)), dim3(256), 0, st, x, stats, gamma, beta, ss,
+                     ssb, ldss, res, y, B, HW, C, G);
+  PIDM_CHECK_LAUNCH("gn_apply_kernel");
+  return 0;
+}
+
+// dx, dgamma, dbeta and (if ss) dss[b][off..off+2C) from dy
+int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
+                  const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
+                  void* ws, hipStream_t st) {
+  if (!((256 % C == 0) || (C % 256 == 0)) || C > 1024 * 4) return fail("groupnorm bwd: unsupported C=%d", C);
+  if (C > 1024) return fail("groupnorm bwd: C=%d > 1024", C);
+  const int nchunk = gn_chunks(HW, B);
+  const int ppb = cdiv(HW, nchunk);
+  char* w = reinterpret_cast<char*>(ws);
+  double* partial = reinterpret_cast<double*>(w);
+  w += (size_t)B * nchunk * C * 2 * sizeof(double);
+  float* dgb = reinterpret_cast<float*>(w);
+  w += (size_t)B * 2 * C * sizeof(float);
+  float* coef = reinterpret_cast<float*>(w);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, HW, C,
+                     G, ppb, partial);
+  PIDM_CHECK_LAUNCH("gn_bwd_reduce_kernel");
+  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, gamma, beta, ss, ssb, ldss, dss, HW, C, G,
+                     dgb, coef);
+  PIDM_CHECK_LAUNCH("gn_bwd_final_kernel");
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, B, C, dgamma, dbeta);
+  PIDM_CHECK_LAUNCH("gn_param_grad_kernel");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * C / 4)), dim3(256), 0, st, x, dy, stats, gamma, beta,
+                     ss, ssb, ldss, coef, dx, B, HW, C, G);
+  PIDM_CHECK_LAUNCH("gn_bwd_apply_kernel");
+  return 0;
+}
+
+static int ln_blocks(size_t npix, int C) {
+  const int C4 = C / 4, TPP = C4 < 64 ? C4 : 64, ppw = 64 / TPP;
+  size_t b = (npix + (size_t)4 * ppw - 1) / ((size_t)4 * ppw);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+static bool ln_ok(int C) {
+  const int C4 = C / 4;
+  return (C % 4 == 0) && C4 >= 1 && C4 <= 256 && ((C4 & (C4 - 1)) == 0);
+}
+
+int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st) {
+  if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
+                     nullptr, y, nullptr, npix, C, 1e-5f);
+  PIDM_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+size_t layernorm_bwd_ws_bytes(int C) { return (size_t)1024 * C * sizeof(float); }
+
+// dx = LN_bwd(dy) + res ; dgamma = sum_pix dy * xhat
+int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
+                         size_t npix, int C, void* ws, hipStream_t st) {
+  if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
+  const int nb = ln_blocks(npix, C);
+  float* partial = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, npix, C,
+                     1e-5f);
+  PIDM_CHECK_LAUNCH("layernorm_bwd");
+  // fixed-order sum of the per-block partials
+  char* ws2 = reinterpret_cast<char*>(ws) + (size_t)nb * C * sizeof(float);
+  return launch_colsum(partial, (size_t)nb, C, C, dgamma, ws2, st);
+}
+
+int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st) {
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, x, y, n, act);
+  PIDM_CHECK_LAUNCH("act_fwd_kernel");
+  return 0;
+}
+int launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, x, dy, dx, n, act);
+  PIDM_CHECK_LAUNCH("act_bwd_kernel");
+  return 0;
+}
+int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st) {
+  if (dim < 4 || (dim & 1)) return fail("sinusoidal embedding: dim=%d must be even and >= 4", dim);
+  hipLaunchKernelGGL(sinusoid_kernel, dim3(cdiv(B * dim / 2, 256)), dim3(256), 0, st, t, emb, B, dim);
+  PIDM_CHECK_LAUNCH("sinusoid_kernel");
+  return 0;
+}
+int launch_copy_add(float* dst, int ldd, const float* a, int lda, const float* b, int ldb, size_t rows, int cols, hipStream_t st) {
+  if ((cols | ldd | lda | (b ? ldb : 0)) & 3) return fail("copy_add: widths must be multiples of 4");
+  hipLaunchKernelGGL(copy_add_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(256), 0, st, dst, ldd, a, lda, b, ldb, rows, cols);
+  PIDM_CHECK_LAUNCH("copy_add_kernel");
+  return 0;
+}
+int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, const float* y_sig, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((size_t)B * C * HW)), dim3(256), 0, st, src, dst, B, C, HW, y_sig);
+  PIDM_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+  return 0;
+}
+
+}  // namespace pidm
+
+using namespace pidm;
+
+extern "C" int pidm_qsample_nhwc(const float* x0, const float* eps, const float* a_t, const float* am1_t, float* xt_nhwc,
+                                 int B, int C, int HW, void* stream) {
+  hipLaunchKernelGGL(qsample_kernel, dim3(ew_blocks((size_t)B * C * HW)), dim3(256), 0, as_stream(stream), x0, eps, a_t,
+                     am1_t, xt_nhwc, B, C, HW);
+  PIDM_CHECK_LAUNCH("qsample_kernel");
+  return 0;
+}
+
+extern "C" int pidm_psample_update(const float* x0_pred, const float* x_t, const float* z, float c1, float c2, float sigma,
+                                   float* x_prev, size_t n, void* stream) {
+  hipLaunchKernelGGL(psample_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x0_pred, x_t, z, c1, c2, sigma,
+                     x_prev, n);
+  PIDM_CHECK_LAUNCH("psample_kernel");
+  return 0;
+}

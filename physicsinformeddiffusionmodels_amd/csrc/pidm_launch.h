@@ -1,0 +1,43 @@
+// Host-side launcher declarations shared between the kernel translation units and the UNet engine.
+#pragma once
+#include "pidm_common.h"
+
+namespace pidm {
+// k_conv.hip
+int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int ld0, int ld1, int Cout, int KH, int KW,
+              int stride, int pad, int out_nchw, int ldo, int ldr);
+int geom_dgrad(const pidm_conv_desc* d, int ld_dy, int ld_dx, ConvGeom* g, int* pack_kind);
+size_t packed_floats(const ConvGeom& g);
+int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
+                int n_src, int k_src, hipStream_t st);
+int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
+                const float* residual, float* out, int sigmoid_last, hipStream_t st);
+size_t wgrad_ws_bytes(const ConvGeom& g);
+int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
+                 void* workspace, hipStream_t st);
+size_t colsum_ws_bytes(size_t rows, int C);
+int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st);
+// k_norm.hip
+size_t gn_ws_bytes(int B, int HW, int C, int G);
+int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st);
+int launch_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
+                    const float* ssb, int ldss, const float* res, float* y, int B, int HW, int C, int G, hipStream_t st);
+int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
+                  const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
+                  void* ws, hipStream_t st);
+int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st);
+size_t layernorm_bwd_ws_bytes(int C);
+int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
+                         size_t npix, int C, void* ws, hipStream_t st);
+int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);
+int launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
+int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st);
+int launch_copy_add(float* dst, int ldd, const float* a, int lda, const float* b, int ldb, size_t rows, int cols, hipStream_t st);
+int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, const float* y_sig, hipStream_t st);
+// k_attn.hip
+int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
+                      hipStream_t st);
+int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
+                       float* rowdot, float* dqkv, int B, int N, int heads, hipStream_t st);
+int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st);
+}  // namespace pidm

@@ -1,0 +1,832 @@
+// Host orchestration of the denoiser UNet forward / backward on gfx950.
+//
+// Replaces Unet3D.forward (reference src/unet_model.py:542-623) and everything `loss.backward()` replays
+// through it (main.py:164).  The layer graph is SURVEY Appendix A; every op is one of the hand-written
+// kernels in k_conv / k_norm / k_attn.  No autograd, no tracing compiler: forward records raw pointers of the
+// tensors the backward needs ("tape" region of the caller-provided workspace), backward walks the graph in
+// reverse.  All launches go to the caller's stream; no allocation, no synchronisation.
+//
+// Workspace layout:  [ packed weights (fwd + dgrad packings, persistent across the step) | tape | temporaries ]
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pidm_launch.h"
+
+namespace pidm {
+
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0, hwm = 0, cap = 0;
+  bool dry = false;
+  float* alloc(size_t nfloats) {
+    off = align_up(off, 256);
+    char* p = base + off;
+    off += nfloats * sizeof(float);
+    if (off > hwm) hwm = off;
+    return reinterpret_cast<float*>(p);
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+  bool overflow() const { return !dry && hwm > cap; }
+};
+
+struct ConvLayer {
+  int w = -1, b = -1;  // parameter indices (b = -1: no bias)
+  int C0 = 0, C1 = 0, Cout = 0, K = 1, stride = 1, pad = 0, transposed = 0, H = 1;
+  size_t off_f = 0, off_d = 0;  // float offsets into the packed-weight region
+  bool dgrad = true;
+};
+
+struct ResBlock {
+  ConvLayer c1, c2, cr;
+  bool has_mlp = false, has_res = false;
+  int C0 = 0, C1 = 0, Co = 0, H = 0;
+  int gn1w = -1, gn1b = -1, gn2w = -1, gn2b = -1, mlpw = -1, mlpb = -1;
+  int ss_off = 0;
+  // tape
+  const float *x0 = nullptr, *x1 = nullptr;
+  float *a = nullptr, *st1 = nullptr, *bact = nullptr, *c = nullptr, *st2 = nullptr;
+};
+
+struct AttnBlock {
+  bool mid = false;
+  int C = 0, H = 0, gamma = -1;
+  ConvLayer qkv, out;
+  const float* x = nullptr;
+  float *xn = nullptr, *qkvb = nullptr, *kstat = nullptr, *qstat = nullptr, *ctx = nullptr, *attn = nullptr;
+};
+
+}  // namespace pidm
+
+using namespace pidm;
+
+struct pidm_unet {
+  pidm_unet_cfg cfg;
+  std::vector<std::string> names;
+  std::vector<size_t> numels;
+  std::map<std::string, int> index;
+  std::vector<const float*> P;
+  std::vector<float*> G;
+  bool have_grads = false;
+
+  int tdim = 0, ss_total = 0, n_lv = 0, heads = 8, groups = 8;
+  std::vector<int> dims;  // [init_dim, dim*m0, dim*m1, ...]
+  ConvLayer init_conv, lin1, lin2, lincat, final_conv;
+  std::vector<ResBlock> rb;       // order: downs (2 per level), mid1, mid2, ups (2 per level), final
+  std::vector<AttnBlock> attn;    // order: downs (1 per level), mid, ups (1 per level)
+  std::vector<ConvLayer> down, up;
+  size_t packed_floats_total = 0;
+  const void* packed_zeroed_for = nullptr;
+
+  // tape of the latest forward
+  int tape_B = 0;
+  const float* x_in = nullptr;
+  float *emb = nullptr, *h1 = nullptr, *h1g = nullptr, *temb = nullptr, *st = nullptr, *ss = nullptr, *h0 = nullptr;
+  float* xfinal = nullptr;
+  const float* out_nchw = nullptr;
+  std::vector<const float*> skip;     // per level
+  std::vector<const float*> down_in;  // input of each downsample
+  std::vector<const float*> up_in;    // input of each upsample
+  std::map<int, std::pair<size_t, size_t>> ws_cache[2];  // B -> (tape bytes, tmp bytes) for inference/training
+};
+
+namespace pidm {
+
+struct Run {
+  pidm_unet* U;
+  int B;
+  bool train, dry;
+  hipStream_t st;
+  float* wpack;
+  Arena tape, tmp;
+  float* scratch = nullptr;  // shared scratch for wgrad partials / norm reductions
+  size_t scratch_floats = 0;
+};
+
+#define RUN(call)                 \
+  do {                            \
+    if (!r.dry) {                 \
+      int rc__ = (call);          \
+      if (rc__) return rc__;      \
+    }                             \
+  } while (0)
+
+static int add_param(pidm_unet* U, const std::string& name, size_t numel) {
+  U->index[name] = (int)U->names.size();
+  U->names.push_back(name);
+  U->numels.push_back(numel);
+  return (int)U->names.size() - 1;
+}
+
+static pidm_conv_desc desc_of(const ConvLayer& L, int B) {
+  pidm_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.Hi = L.H; d.Wi = L.H; d.C0 = L.C0; d.C1 = L.C1; d.ld0 = L.C0; d.ld1 = L.C1; d.Cout = L.Cout;
+  d.KH = d.KW = L.K; d.stride = L.stride; d.pad = L.pad; d.transposed = L.transposed; d.out_nchw = 0; d.ldo = L.Cout;
+  return d;
+}
+
+static int geom_fwd_layer(const ConvLayer& L, int B, int out_nchw, ConvGeom* g) {
+  if (L.transposed) return make_geom(g, 1, B, L.H, L.H, L.C0, L.C1, L.C0, L.C1, L.Cout, 4, 4, 2, 1, out_nchw, L.Cout, L.Cout);
+  return make_geom(g, 0, B, L.H, L.H, L.C0, L.C1, L.C0, L.C1, L.Cout, L.K, L.K, L.stride, L.pad, out_nchw, L.Cout, L.Cout);
+}
+
+static int out_h(const ConvLayer& L) { return L.transposed ? 2 * L.H : (L.H + 2 * L.pad - L.K) / L.stride + 1; }
+
+static void conv_param(pidm_unet* U, ConvLayer& L, const std::string& pre, bool bias) {
+  const int Cin = L.C0 + L.C1;
+  L.w = add_param(U, pre + ".weight", (size_t)L.Cout * Cin * L.K * L.K);
+  L.b = bias ? add_param(U, pre + ".bias", (size_t)L.Cout) : -1;
+}
+
+static int reserve_packed(pidm_unet* U, ConvLayer& L) {
+  ConvGeom g;
+  if (geom_fwd_layer(L, 1, 0, &g)) return -1;
+  L.off_f = U->packed_floats_total;
+  U->packed_floats_total += align_up(packed_floats(g), 64);
+  if (L.dgrad) {
+    pidm_conv_desc d = desc_of(L, 1);
+    int kind;
+    if (geom_dgrad(&d, L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
+    L.off_d = U->packed_floats_total;
+    U->packed_floats_total += align_up(packed_floats(g), 64);
+  }
+  return 0;
+}
+
+static void make_resblock(pidm_unet* U, ResBlock& m, const std::string& pre, int C0, int C1, int Co, int H, bool mlp) {
+  m.C0 = C0; m.C1 = C1; m.Co = Co; m.H = H; m.has_mlp = mlp; m.has_res = (C0 + C1 != Co);
+  if (mlp) {
+    m.mlpw = U->index.at(pre + "mlp.1.weight");
+    m.mlpb = U->index.at(pre + "mlp.1.bias");
+  }
+  m.c1.C0 = C0; m.c1.C1 = C1; m.c1.Cout = Co; m.c1.K = 3; m.c1.pad = 1; m.c1.H = H;
+  conv_param(U, m.c1, pre + "block1.proj", true);
+  m.gn1w = add_param(U, pre + "block1.norm.weight", Co);
+  m.gn1b = add_param(U, pre + "block1.norm.bias", Co);
+  m.c2.C0 = Co; m.c2.Cout = Co; m.c2.K = 3; m.c2.pad = 1; m.c2.H = H;
+  conv_param(U, m.c2, pre + "block2.proj", true);
+  m.gn2w = add_param(U, pre + "block2.norm.weight", Co);
+  m.gn2b = add_param(U, pre + "block2.norm.bias", Co);
+  if (m.has_res) {
+    m.cr.C0 = C0; m.cr.C1 = C1; m.cr.Cout = Co; m.cr.K = 1; m.cr.H = H;
+    conv_param(U, m.cr, pre + "res_conv", true);
+  }
+}
+
+static void make_attn(pidm_unet* U, AttnBlock& a, const std::string& pre, int C, int H, bool mid) {
+  a.mid = mid; a.C = C; a.H = H;
+  const int HD = U->heads * 32;
+  const std::string f = mid ? pre + "fn.fn.fn." : pre + "fn.fn.";
+  a.qkv.C0 = C; a.qkv.Cout = 3 * HD; a.qkv.K = 1; a.qkv.H = H;
+  conv_param(U, a.qkv, f + "to_qkv", false);
+  a.out.C0 = HD; a.out.Cout = C; a.out.K = 1; a.out.H = H;
+  conv_param(U, a.out, f + "to_out", !mid);
+  a.gamma = add_param(U, pre + "fn.norm.gamma", C);
+}
+
+}  // namespace pidm
+
+extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
+  if (!cfg || !out) return fail("unet_create: null argument");
+  if (cfg->dim_head != 32) return fail("unet_create: dim_head must be 32 (got %d)", cfg->dim_head);
+  if (cfg->n_levels < 1 || cfg->n_levels > 8) return fail("unet_create: bad n_levels");
+  if (cfg->dim % 8 || cfg->dim < 8) return fail("unet_create: dim must be a multiple of 8");
+  const int P = cfg->image_size;
+  if (P <= 0 || (P & (P - 1)) || (P >> (cfg->n_levels - 1)) < 1 || P > 128) return fail("unet_create: image_size %d must be a power of two <= 128", P);
+  pidm_unet* U = new pidm_unet();
+  U->cfg = *cfg;
+  U->n_lv = cfg->n_levels;
+  U->heads = cfg->heads;
+  U->groups = cfg->groups;
+  U->tdim = 4 * cfg->dim;
+  const int dim = cfg->dim, n = U->n_lv, td = U->tdim;
+  U->dims.push_back(dim);
+  for (int i = 0; i < n; ++i) U->dims.push_back(dim * cfg->dim_mults[i]);
+  std::vector<int> res(n);
+  for (int i = 0; i < n; ++i) res[i] = P >> i;
+
+  // ---- canonical parameter order: the 18 FiLM linears first (weights, then biases) so that their gradients
+  //      are one contiguous [sum 2*Cout][tdim] matrix when the caller lays grads out in this order ----
+  std::vector<std::pair<std::string, int>> film;  // (prefix, Cout)
+  for (int i = 0; i < n; ++i) {
+    film.push_back({"downs." + std::to_string(i) + ".0.", U->dims[i + 1]});
+    film.push_back({"downs." + std::to_string(i) + ".1.", U->dims[i + 1]});
+  }
+  film.push_back({"mid_block1.", U->dims[n]});
+  film.push_back({"mid_block2.", U->dims[n]});
+  for (int j = 0; j < n; ++j) {
+    const int din = U->dims[n - 1 - j];
+    film.push_back({"ups." + std::to_string(j) + ".0.", din});
+    film.push_back({"ups." + std::to_string(j) + ".1.", din});
+  }
+  std::map<std::string, int> ss_off;
+  int off = 0;
+  for (auto& f : film) {
+    add_param(U, f.first + "mlp.1.weight", (size_t)2 * f.second * td);
+    ss_off[f.first] = off;
+    off += 2 * f.second;
+  }
+  U->ss_total = off;
+  for (auto& f : film) add_param(U, f.first + "mlp.1.bias", (size_t)2 * f.second);
+
+  U->init_conv.C0 = cfg->channels; U->init_conv.Cout = dim; U->init_conv.K = cfg->init_kernel;
+  U->init_conv.pad = cfg->init_kernel / 2; U->init_conv.H = P; U->init_conv.dgrad = true;
+  conv_param(U, U->init_conv, "init_conv", true);
+  U->lin1.C0 = dim; U->lin1.Cout = td; conv_param(U, U->lin1, "time_mlp.1", true);
+  U->lin2.C0 = td; U->lin2.Cout = td; conv_param(U, U->lin2, "time_mlp.3", true);
+  U->lincat.C0 = td; U->lincat.Cout = U->ss_total;  // virtual layer: weights gathered from the FiLM linears
+
+  U->rb.resize(4 * n + 3);
+  U->attn.resize(2 * n + 1);
+  U->down.resize(n);
+  U->up.resize(n);
+  int irb = 0, iat = 0;
+  for (int i = 0; i < n; ++i) {
+    const std::string pre = "downs." + std::to_string(i) + ".";
+    const int din = U->dims[i], dout = U->dims[i + 1];
+    make_resblock(U, U->rb[irb], pre + "0.", din, 0, dout, res[i], true); U->rb[irb++].ss_off = ss_off[pre + "0."];
+    make_resblock(U, U->rb[irb], pre + "1.", dout, 0, dout, res[i], true); U->rb[irb++].ss_off = ss_off[pre + "1."];
+    make_attn(U, U->attn[iat++], pre + "2.", dout, res[i], false);
+    if (i < n - 1) {
+      ConvLayer& d = U->down[i];
+      d.C0 = dout; d.Cout = dout; d.K = 4; d.stride = 2; d.pad = 1; d.H = res[i];
+      conv_param(U, d, pre + "3", true);
+    }
+  }
+  make_resblock(U, U->rb[irb], "mid_block1.", U->dims[n], 0, U->dims[n], res[n - 1], true); U->rb[irb++].ss_off = ss_off["mid_block1."];
+  make_attn(U, U->attn[iat++], "mid_spatial_attn.", U->dims[n], res[n - 1], true);
+  make_resblock(U, U->rb[irb], "mid_block2.", U->dims[n], 0, U->dims[n], res[n - 1], true); U->rb[irb++].ss_off = ss_off["mid_block2."];
+  for (int j = 0; j < n; ++j) {
+    const std::string pre = "ups." + std::to_string(j) + ".";
+    const int lvl = n - 1 - j;
+    const int din = U->dims[lvl], dout = U->dims[lvl + 1];
+    make_resblock(U, U->rb[irb], pre + "0.", dout, dout, din, res[lvl], true); U->rb[irb++].ss_off = ss_off[pre + "0."];
+    make_resblock(U, U->rb[irb], pre + "1.", din, 0, din, res[lvl], true); U->rb[irb++].ss_off = ss_off[pre + "1."];
+    make_attn(U, U->attn[iat++], pre + "2.", din, res[lvl], false);
+    if (j < n - 1) {
+      ConvLayer& u = U->up[j];
+      u.C0 = din; u.Cout = din; u.K = 4; u.stride = 2; u.pad = 1; u.transposed = 1; u.H = res[lvl];
+      conv_param(U, u, pre + "3", true);
+    }
+  }
+  make_resblock(U, U->rb[irb], "final_conv.0.", dim, dim, dim, P, false); irb++;
+  U->final_conv.C0 = dim; U->final_conv.Cout = cfg->out_dim; U->final_conv.K = 1; U->final_conv.H = P;
+  conv_param(U, U->final_conv, "final_conv.1", true);
+
+  // ---- packed-weight region ----
+  int rc = 0;
+  rc |= reserve_packed(U, U->init_conv);
+  rc |= reserve_packed(U, U->lin1);
+  rc |= reserve_packed(U, U->lin2);
+  rc |= reserve_packed(U, U->lincat);
+  for (auto& m : U->rb) {
+    rc |= reserve_packed(U, m.c1);
+    rc |= reserve_packed(U, m.c2);
+    if (m.has_res) rc |= reserve_packed(U, m.cr);
+  }
+  for (auto& a : U->attn) {
+    rc |= reserve_packed(U, a.qkv);
+    rc |= reserve_packed(U, a.out);
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    rc |= reserve_packed(U, U->down[i]);
+    rc |= reserve_packed(U, U->up[i]);
+  }
+  rc |= reserve_packed(U, U->final_conv);
+  if (rc) {
+    delete U;
+    return -1;
+  }
+  U->P.assign(U->names.size(), nullptr);
+  U->G.assign(U->names.size(), nullptr);
+  U->skip.assign(n, nullptr);
+  U->down_in.assign(n, nullptr);
+  U->up_in.assign(n, nullptr);
+  *out = U;
+  return 0;
+}
+
+extern "C" void pidm_unet_destroy(pidm_unet* h) { delete h; }
+extern "C" int pidm_unet_num_params(const pidm_unet* h) { return (int)h->names.size(); }
+extern "C" const char* pidm_unet_param_name(const pidm_unet* h, int i) {
+  return (i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : "";
+}
+extern "C" size_t pidm_unet_param_numel(const pidm_unet* h, int i) {
+  return (i >= 0 && i < (int)h->numels.size()) ? h->numels[i] : 0;
+}
+
+extern "C" int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, void* const* grad_ptrs_host) {
+  if (!h || !param_ptrs_host) return fail("unet_bind: null argument");
+  for (size_t i = 0; i < h->names.size(); ++i) {
+    if (!param_ptrs_host[i]) return fail("unet_bind: parameter %s is null", h->names[i].c_str());
+    h->P[i] = reinterpret_cast<const float*>(param_ptrs_host[i]);
+    h->G[i] = grad_ptrs_host ? reinterpret_cast<float*>(grad_ptrs_host[i]) : nullptr;
+  }
+  h->have_grads = grad_ptrs_host != nullptr;
+  if (h->have_grads) {
+    // the FiLM linear gradients must be contiguous (see pidm_unet_create)
+    const int nf = 4 * h->n_lv + 2;
+    for (int i = 1; i < nf; ++i) {
+      if (h->G[i] != h->G[i - 1] + h->numels[i - 1]) return fail("unet_bind: gradients of the %d FiLM linear weights must be contiguous in canonical order", nf);
+      if (h->G[nf + i] != h->G[nf + i - 1] + h->numels[nf + i - 1]) return fail("unet_bind: gradients of the FiLM linear biases must be contiguous");
+    }
+  }
+  return 0;
+}
+
+namespace pidm {
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing (once per step)
+// ------------------------------------------------------------------------------------------------------
+static int pack_layer(Run& r, const ConvLayer& L) {
+  pidm_unet* U = r.U;
+  ConvGeom g;
+  if (geom_fwd_layer(L, 1, 0, &g)) return -1;
+  RUN(launch_pack(g, L.transposed ? 1 : 0, U->P[L.w], r.wpack + L.off_f, L.K, L.K, 0, 0, 0, 0, r.st));
+  if (L.dgrad) {
+    pidm_conv_desc d = desc_of(L, 1);
+    int kind;
+    if (geom_dgrad(&d, L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
+    RUN(launch_pack(g, kind, U->P[L.w], r.wpack + L.off_d, L.K, L.K, 0, 0, 0, 0, r.st));
+  }
+  return 0;
+}
+
+static int pack_all(Run& r) {
+  pidm_unet* U = r.U;
+  if (!r.dry && U->packed_zeroed_for != r.wpack) {
+    if (hipMemsetAsync(r.wpack, 0, U->packed_floats_total * sizeof(float), r.st) != hipSuccess) return fail("memset failed");
+    U->packed_zeroed_for = r.wpack;
+  }
+  int rc = 0;
+  rc |= pack_layer(r, U->init_conv);
+  rc |= pack_layer(r, U->lin1);
+  rc |= pack_layer(r, U->lin2);
+  // concatenated FiLM linear: forward rows [ss_off, ss_off+2C), dgrad columns likewise
+  {
+    ConvGeom gf, gd;
+    if (geom_fwd_layer(U->lincat, 1, 0, &gf)) return -1;
+    pidm_conv_desc d = desc_of(U->lincat, 1);
+    int kind;
+    if (geom_dgrad(&d, U->lincat.Cout, U->lincat.C0, &gd, &kind)) return -1;
+    for (auto& m : U->rb) {
+      if (!m.has_mlp) continue;
+      RUN(launch_pack(gf, 0, U->P[m.mlpw], r.wpack + U->lincat.off_f, 1, 1, m.ss_off, 0, 2 * m.Co, U->tdim, r.st));
+      RUN(launch_pack(gd, kind, U->P[m.mlpw], r.wpack + U->lincat.off_d, 1, 1, 0, m.ss_off, U->tdim, 2 * m.Co, r.st));
+    }
+  }
+  for (auto& m : U->rb) {
+    rc |= pack_layer(r, m.c1);
+    rc |= pack_layer(r, m.c2);
+    if (m.has_res) rc |= pack_layer(r, m.cr);
+  }
+  for (auto& a : U->attn) {
+    rc |= pack_layer(r, a.qkv);
+    rc |= pack_layer(r, a.out);
+  }
+  for (int i = 0; i < U->n_lv - 1; ++i) {
+    rc |= pack_layer(r, U->down[i]);
+    rc |= pack_layer(r, U->up[i]);
+  }
+  rc |= pack_layer(r, U->final_conv);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward building blocks
+// ------------------------------------------------------------------------------------------------------
+static float* act_alloc(Run& r, size_t n) { return r.train ? r.tape.alloc(n) : r.tmp.alloc(n); }
+
+static int conv_fwd(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* residual, float* out,
+                    int out_nchw = 0, int sigmoid_last = 0) {
+  ConvGeom g;
+  if (geom_fwd_layer(L, r.B, out_nchw, &g)) return -1;
+  RUN(launch_conv(g, x0, x1, r.wpack + L.off_f, L.b >= 0 ? r.U->P[L.b] : nullptr, residual, out, sigmoid_last, r.st));
+  return 0;
+}
+
+static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, float** out_p) {
+  pidm_unet* U = r.U;
+  const int B = r.B, HW = m.H * m.H, Co = m.Co, G = U->groups;
+  const size_t n = (size_t)B * HW * Co;
+  float* out = act_alloc(r, n);
+  const size_t mk = r.tmp.mark();
+  m.x0 = x0; m.x1 = x1;
+  m.a = act_alloc(r, n);
+  if (conv_fwd(r, m.c1, x0, x1, nullptr, m.a)) return -1;
+  m.st1 = act_alloc(r, (size_t)B * G * 2);
+  RUN(launch_gn_stats(m.a, B, HW, Co, G, m.st1, r.scratch, r.st));
+  m.bact = act_alloc(r, n);
+  const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
+  const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
+  RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.st));
+  m.c = act_alloc(r, n);
+  if (conv_fwd(r, m.c2, m.bact, nullptr, nullptr, m.c)) return -1;
+  m.st2 = act_alloc(r, (size_t)B * G * 2);
+  RUN(launch_gn_stats(m.c, B, HW, Co, G, m.st2, r.scratch, r.st));
+  if (m.has_res) {
+    float* d = r.tmp.alloc(n);
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.st));
+    if (conv_fwd(r, m.cr, x0, x1, d, out)) return -1;
+  } else {
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.st));
+  }
+  if (!r.train) r.tmp.release(mk);
+  else r.tmp.release(mk);
+  *out_p = out;
+  return 0;
+}
+
+static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
+  pidm_unet* U = r.U;
+  const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
+  const size_t npix = (size_t)B * N;
+  float* out = act_alloc(r, npix * C);
+  const size_t mk = r.tmp.mark();
+  a.x = x;
+  a.xn = act_alloc(r, npix * C);
+  RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
+  a.qkvb = act_alloc(r, npix * 3 * HD);
+  if (conv_fwd(r, a.qkv, a.xn, nullptr, nullptr, a.qkvb)) return -1;
+  a.attn = act_alloc(r, npix * HD);
+  if (a.mid) {
+    RUN(launch_mid_attn(a.qkvb, nullptr, a.attn, B, N, heads, false, r.st));
+  } else {
+    a.kstat = act_alloc(r, (size_t)B * HD * 2);
+    a.ctx = act_alloc(r, (size_t)B * heads * 1024);
+    a.qstat = act_alloc(r, npix * heads * 2);
+    RUN(launch_la_forward(a.qkvb, a.kstat, a.ctx, a.attn, a.qstat, B, N, heads, r.st));
+  }
+  if (conv_fwd(r, a.out, a.attn, nullptr, x, out)) return -1;
+  r.tmp.release(mk);
+  *out_p = out;
+  return 0;
+}
+
+static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* out_nchw) {
+  pidm_unet* U = r.U;
+  const int B = r.B, P = U->cfg.image_size, dim = U->cfg.dim, n = U->n_lv, td = U->tdim;
+  U->tape_B = B;
+  U->x_in = x_nhwc;
+  U->out_nchw = out_nchw;
+  // time path: emb -> lin1 -> GELU -> lin2 -> SiLU -> concatenated FiLM linears (bias added by the consumers)
+  U->emb = act_alloc(r, (size_t)B * dim);
+  RUN(launch_sinusoid(t, U->emb, B, dim, r.st));
+  U->h1 = act_alloc(r, (size_t)B * td);
+  if (conv_fwd(r, U->lin1, U->emb, nullptr, nullptr, U->h1)) return -1;
+  U->h1g = act_alloc(r, (size_t)B * td);
+  RUN(launch_act_fwd(U->h1, U->h1g, (size_t)B * td, 1, r.st));
+  U->temb = act_alloc(r, (size_t)B * td);
+  if (conv_fwd(r, U->lin2, U->h1g, nullptr, nullptr, U->temb)) return -1;
+  U->st = act_alloc(r, (size_t)B * td);
+  RUN(launch_act_fwd(U->temb, U->st, (size_t)B * td, 0, r.st));
+  U->ss = act_alloc(r, (size_t)B * U->ss_total);
+  if (conv_fwd(r, U->lincat, U->st, nullptr, nullptr, U->ss)) return -1;
+
+  U->h0 = act_alloc(r, (size_t)B * P * P * dim);
+  if (conv_fwd(r, U->init_conv, x_nhwc, nullptr, nullptr, U->h0)) return -1;
+  float* x = U->h0;
+  int irb = 0, iat = 0;
+  for (int i = 0; i < n; ++i) {
+    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+    if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
+    U->skip[i] = x;
+    if (i < n - 1) {
+      U->down_in[i] = x;
+      const int Ho = out_h(U->down[i]);
+      float* y = act_alloc(r, (size_t)B * Ho * Ho * U->down[i].Cout);
+      if (conv_fwd(r, U->down[i], x, nullptr, nullptr, y)) return -1;
+      x = y;
+    }
+  }
+  if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+  if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
+  if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+  for (int j = 0; j < n; ++j) {
+    const float* sk = U->skip[n - 1 - j];
+    if (resblock_fwd(r, U->rb[irb++], x, sk, &x)) return -1;
+    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+    if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
+    if (j < n - 1) {
+      U->up_in[j] = x;
+      const int Ho = out_h(U->up[j]);
+      float* y = act_alloc(r, (size_t)B * Ho * Ho * U->up[j].Cout);
+      if (conv_fwd(r, U->up[j], x, nullptr, nullptr, y)) return -1;
+      x = y;
+    }
+  }
+  if (resblock_fwd(r, U->rb[irb++], x, U->h0, &x)) return -1;
+  U->xfinal = x;
+  if (conv_fwd(r, U->final_conv, x, nullptr, nullptr, out_nchw, 1, U->cfg.sigmoid_last_channel)) return -1;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward building blocks
+// ------------------------------------------------------------------------------------------------------
+static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* dy) {
+  pidm_unet* U = r.U;
+  if (!U->have_grads && !r.dry) return 0;
+  ConvGeom g;
+  const int Ho = out_h(L);
+  if (L.transposed) {
+    if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
+    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], r.scratch, r.st));
+  } else {
+    if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
+    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], r.scratch, r.st));
+  }
+  if (L.b >= 0) RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], r.scratch, r.st));
+  return 0;
+}
+
+static int conv_dgrad(Run& r, const ConvLayer& L, const float* dy, const float* residual, float* dx) {
+  pidm_conv_desc d = desc_of(L, r.B);
+  ConvGeom g;
+  int kind;
+  if (geom_dgrad(&d, L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
+  RUN(launch_conv(g, dy, nullptr, r.wpack + L.off_d, nullptr, residual, dx, 0, r.st));
+  return 0;
+}
+
+// g_out [B,HW,Co] -> g_x [B,HW,C0+C1]
+static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, float* dss) {
+  pidm_unet* U = r.U;
+  const int B = r.B, HW = m.H * m.H, Co = m.Co, G = U->groups;
+  const size_t n = (size_t)B * HW * Co;
+  const size_t mk = r.tmp.mark();
+  float* g_c = r.tmp.alloc(n);
+  RUN(launch_gn_bwd(m.c, g_out, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, g_c, U->G[m.gn2w],
+                    U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st));
+  if (conv_wgrad(r, m.c2, m.bact, nullptr, g_c)) return -1;
+  float* g_b = r.tmp.alloc(n);
+  if (conv_dgrad(r, m.c2, g_c, nullptr, g_b)) return -1;
+  float* g_a = g_c;  // g_c is dead after the two uses above
+  const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
+  const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
+  RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
+                    g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st));
+  if (conv_wgrad(r, m.c1, m.x0, m.x1, g_a)) return -1;
+  if (m.has_res) {
+    if (conv_wgrad(r, m.cr, m.x0, m.x1, g_out)) return -1;
+    if (conv_dgrad(r, m.cr, g_out, nullptr, g_x)) return -1;
+    if (conv_dgrad(r, m.c1, g_a, g_x, g_x)) return -1;
+  } else {
+    if (conv_dgrad(r, m.c1, g_a, g_out, g_x)) return -1;
+  }
+  r.tmp.release(mk);
+  return 0;
+}
+
+// g_out [B,N,C] -> g_x [B,N,C]
+static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
+  pidm_unet* U = r.U;
+  const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
+  const size_t npix = (size_t)B * N;
+  const size_t mk = r.tmp.mark();
+  if (conv_wgrad(r, a.out, a.attn, nullptr, g_out)) return -1;
+  float* g_attn = r.tmp.alloc(npix * HD);
+  if (conv_dgrad(r, a.out, g_out, nullptr, g_attn)) return -1;
+  float* g_qkv = r.tmp.alloc(npix * 3 * HD);
+  if (a.mid) {
+    RUN(launch_mid_attn(a.qkvb, g_attn, g_qkv, B, N, heads, true, r.st));
+  } else {
+    float* dctx = r.tmp.alloc((size_t)B * heads * 1024);
+    float* rowdot = r.tmp.alloc((size_t)B * heads * 32);
+    RUN(launch_la_backward(a.qkvb, a.kstat, a.qstat, a.ctx, g_attn, dctx, rowdot, g_qkv, B, N, heads, r.st));
+  }
+  if (conv_wgrad(r, a.qkv, a.xn, nullptr, g_qkv)) return -1;
+  float* g_xn = g_attn;  // reuse (npix*HD >= npix*C is not guaranteed) -> allocate when C > HD
+  if (C > HD) g_xn = r.tmp.alloc(npix * C);
+  if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
+  RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, r.scratch, r.st));
+  r.tmp.release(mk);
+  return 0;
+}
+
+static size_t scratch_floats_needed(pidm_unet* U, int B) {
+  size_t mx = 1 << 16;
+  auto upd = [&](size_t bytes) { if (bytes / 4 + 64 > mx) mx = bytes / 4 + 64; };
+  auto conv_ws = [&](const ConvLayer& L) {
+    ConvGeom g;
+    if (L.transposed) {
+      if (make_geom(&g, 0, B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return;
+    } else if (geom_fwd_layer(L, B, 0, &g)) {
+      return;
+    }
+    upd(wgrad_ws_bytes(g));
+    const int Ho = out_h(L);
+    upd(colsum_ws_bytes((size_t)B * Ho * Ho, L.Cout));
+  };
+  conv_ws(U->init_conv); conv_ws(U->lin1); conv_ws(U->lin2); conv_ws(U->lincat); conv_ws(U->final_conv);
+  for (auto& m : U->rb) {
+    conv_ws(m.c1); conv_ws(m.c2);
+    if (m.has_res) conv_ws(m.cr);
+    upd(gn_ws_bytes(B, m.H * m.H, m.Co, U->groups));
+  }
+  for (auto& a : U->attn) {
+    conv_ws(a.qkv); conv_ws(a.out);
+    upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
+  }
+  for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }
+  return mx;
+}
+
+static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc) {
+  pidm_unet* U = r.U;
+  const int B = r.B, P = U->cfg.image_size, dim = U->cfg.dim, n = U->n_lv, td = U->tdim, od = U->cfg.out_dim;
+  const size_t HW = (size_t)P * P;
+  float* dss = r.tmp.alloc((size_t)B * U->ss_total);
+  float* g_o = r.tmp.alloc((size_t)B * HW * od);
+  RUN(launch_nchw_to_nhwc(grad_out_nchw, g_o, B, od, (int)HW, U->cfg.sigmoid_last_channel ? U->out_nchw : nullptr, r.st));
+  // final 1x1 conv (the NHWC gradient has channel stride od, which may not be a multiple of 4: scalar staging)
+  {
+    const ConvLayer& L = U->final_conv;
+    if (U->have_grads || r.dry) {
+      ConvGeom g;
+      if (geom_fwd_layer(L, B, 0, &g)) return -1;
+      RUN(launch_wgrad(g, U->xfinal, nullptr, g_o, od, U->G[L.w], r.scratch, r.st));
+      RUN(launch_colsum(g_o, (size_t)B * HW, od, od, U->G[L.b], r.scratch, r.st));
+    }
+  }
+  float* g_x = r.tmp.alloc((size_t)B * HW * dim);
+  if (conv_dgrad(r, U->final_conv, g_o, nullptr, g_x)) return -1;
+  int irb = (int)U->rb.size() - 1, iat = (int)U->attn.size() - 1;
+  // final resblock: input cat(x, h0)
+  float* g_cat = r.tmp.alloc((size_t)B * HW * 2 * dim);
+  if (resblock_bwd(r, U->rb[irb--], g_x, g_cat, dss)) return -1;
+  float* g_r = r.tmp.alloc((size_t)B * HW * dim);
+  g_x = r.tmp.alloc((size_t)B * HW * dim);
+  RUN(launch_copy_add(g_x, dim, g_cat, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
+  RUN(launch_copy_add(g_r, dim, g_cat + dim, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
+  std::vector<float*> g_skip(n, nullptr);
+  for (int j = n - 1; j >= 0; --j) {
+    const int lvl = n - 1 - j;
+    const int din = U->dims[lvl], dout = U->dims[lvl + 1], H = P >> lvl;
+    const size_t npix = (size_t)B * H * H;
+    if (j < n - 1) {
+      const ConvLayer& L = U->up[j];
+      if (conv_wgrad(r, L, U->up_in[j], nullptr, g_x)) return -1;
+      float* g = r.tmp.alloc(npix * din);
+      if (conv_dgrad(r, L, g_x, nullptr, g)) return -1;
+      g_x = g;
+    }
+    float* g1 = r.tmp.alloc(npix * din);
+    if (attn_bwd(r, U->attn[iat--], g_x, g1)) return -1;
+    float* g2 = r.tmp.alloc(npix * din);
+    if (resblock_bwd(r, U->rb[irb--], g1, g2, dss)) return -1;
+    float* gc = r.tmp.alloc(npix * 2 * dout);
+    if (resblock_bwd(r, U->rb[irb--], g2, gc, dss)) return -1;
+    g_x = r.tmp.alloc(npix * dout);
+    g_skip[lvl] = r.tmp.alloc(npix * dout);
+    RUN(launch_copy_add(g_x, dout, gc, 2 * dout, nullptr, 0, npix, dout, r.st));
+    RUN(launch_copy_add(g_skip[lvl], dout, gc + dout, 2 * dout, nullptr, 0, npix, dout, r.st));
+  }
+  {
+    const int C = U->dims[n], H = P >> (n - 1);
+    const size_t nn = (size_t)B * H * H * C;
+    float* g1 = r.tmp.alloc(nn);
+    if (resblock_bwd(r, U->rb[irb--], g_x, g1, dss)) return -1;
+    float* g2 = r.tmp.alloc(nn);
+    if (attn_bwd(r, U->attn[iat--], g1, g2)) return -1;
+    float* g3 = r.tmp.alloc(nn);
+    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss)) return -1;
+    g_x = g3;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const int din = U->dims[i], dout = U->dims[i + 1], H = P >> i;
+    const size_t npix = (size_t)B * H * H;
+    float* g_la = r.tmp.alloc(npix * dout);
+    if (i < n - 1) {
+      const ConvLayer& L = U->down[i];
+      if (conv_wgrad(r, L, U->down_in[i], nullptr, g_x)) return -1;
+      if (conv_dgrad(r, L, g_x, g_skip[i], g_la)) return -1;
+    } else {
+      RUN(launch_copy_add(g_la, dout, g_x, dout, g_skip[i], dout, npix, dout, r.st));
+    }
+    float* g1 = r.tmp.alloc(npix * dout);
+    if (attn_bwd(r, U->attn[iat--], g_la, g1)) return -1;
+    float* g2 = r.tmp.alloc(npix * dout);
+    if (resblock_bwd(r, U->rb[irb--], g1, g2, dss)) return -1;
+    float* g3 = r.tmp.alloc(npix * din);
+    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss)) return -1;
+    g_x = g3;
+  }
+  // h0 feeds both the first resblock and the final concat
+  float* g_h0 = r.tmp.alloc((size_t)B * HW * dim);
+  RUN(launch_copy_add(g_h0, dim, g_x, dim, g_r, dim, (size_t)B * HW, dim, r.st));
+  if (conv_wgrad(r, U->init_conv, U->x_in, nullptr, g_h0)) return -1;
+  if (grad_x_nhwc) {
+    if (conv_dgrad(r, U->init_conv, g_h0, nullptr, grad_x_nhwc)) return -1;
+  }
+  // ---- time path ----
+  if (U->have_grads || r.dry) {
+    const int nf = 4 * n + 2;
+    ConvGeom g;
+    if (geom_fwd_layer(U->lincat, B, 0, &g)) return -1;
+    RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], r.scratch, r.st));           // all FiLM weights at once
+    RUN(launch_colsum(dss, (size_t)B, U->ss_total, U->ss_total, U->G[nf], r.scratch, r.st));     // all FiLM biases at once
+    float* d_st = r.tmp.alloc((size_t)B * td);
+    if (conv_dgrad(r, U->lincat, dss, nullptr, d_st)) return -1;
+    float* d_temb = r.tmp.alloc((size_t)B * td);
+    RUN(launch_act_bwd(U->temb, d_st, d_temb, (size_t)B * td, 0, r.st));
+    if (conv_wgrad(r, U->lin2, U->h1g, nullptr, d_temb)) return -1;
+    float* d_h1g = r.tmp.alloc((size_t)B * td);
+    if (conv_dgrad(r, U->lin2, d_temb, nullptr, d_h1g)) return -1;
+    float* d_h1 = r.tmp.alloc((size_t)B * td);
+    RUN(launch_act_bwd(U->h1, d_h1g, d_h1, (size_t)B * td, 1, r.st));
+    if (conv_wgrad(r, U->lin1, U->emb, nullptr, d_h1)) return -1;
+  }
+  return 0;
+}
+
+static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, size_t* tmp_bytes) {
+  auto& cache = U->ws_cache[training ? 1 : 0];
+  auto it = cache.find(B);
+  if (it != cache.end()) {
+    *tape_bytes = it->second.first;
+    *tmp_bytes = it->second.second;
+    return 0;
+  }
+  Run r;
+  r.U = U; r.B = B; r.train = training != 0; r.dry = true; r.st = nullptr; r.wpack = nullptr;
+  r.tape.dry = r.tmp.dry = true;
+  // state touched by a dry run is restored afterwards
+  pidm_unet saved_ptrs = *U;
+  r.scratch_floats = scratch_floats_needed(U, B);
+  r.scratch = r.tmp.alloc(r.scratch_floats);
+  int rc = forward_impl(r, nullptr, nullptr, nullptr);
+  if (!rc && training) {
+    r.tmp.release(align_up(r.scratch_floats * sizeof(float), 256));
+    rc = backward_impl(r, nullptr, reinterpret_cast<float*>(16));
+  }
+  const size_t tb = r.tape.hwm, mb = r.tmp.hwm;
+  auto keep_cache0 = U->ws_cache[0];
+  auto keep_cache1 = U->ws_cache[1];
+  *U = saved_ptrs;
+  U->ws_cache[0] = keep_cache0;
+  U->ws_cache[1] = keep_cache1;
+  if (rc) return rc;
+  cache[B] = {tb + 4096, mb + 4096};
+  *tape_bytes = tb + 4096;
+  *tmp_bytes = mb + 4096;
+  return 0;
+}
+
+static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, size_t workspace_bytes, void* stream) {
+  size_t tape_b, tmp_b;
+  if (plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b)) return -1;
+  const size_t packed_b = align_up(h->packed_floats_total * sizeof(float), 4096);
+  if (workspace_bytes < packed_b + tape_b + tmp_b)
+    return fail("unet: workspace too small (%zu < %zu bytes)", workspace_bytes, packed_b + tape_b + tmp_b);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail("unet: workspace must be 256-byte aligned");
+  char* w = reinterpret_cast<char*>(workspace);
+  r.U = h; r.B = B; r.train = train; r.dry = false; r.st = as_stream(stream);
+  r.wpack = reinterpret_cast<float*>(w);
+  r.tape.base = w + packed_b; r.tape.cap = tape_b;
+  r.tmp.base = w + packed_b + tape_b; r.tmp.cap = tmp_b;
+  r.scratch_floats = scratch_floats_needed(h, B);
+  r.scratch = r.tmp.alloc(r.scratch_floats);
+  return 0;
+}
+
+}  // namespace pidm
+
+extern "C" size_t pidm_unet_workspace_bytes(const pidm_unet* h, int B, int training) {
+  size_t tape_b, tmp_b;
+  if (plan_sizes(const_cast<pidm_unet*>(h), B, training, &tape_b, &tmp_b)) return 0;
+  return align_up(h->packed_floats_total * sizeof(float), 4096) + tape_b + tmp_b + 256;
+}
+
+extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B,
+                                 int save_for_backward, int repack_weights, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (!h || !x_nhwc || !t || !out_nchw || !workspace) return fail("unet_forward: null argument");
+  if (B <= 0) return fail("unet_forward: B must be positive");
+  for (size_t i = 0; i < h->P.size(); ++i)
+    if (!h->P[i]) return fail("unet_forward: parameters not bound (pidm_unet_bind)");
+  Run r;
+  if (setup_run(r, h, B, save_for_backward != 0, workspace, workspace_bytes, stream)) return -1;
+  if (repack_weights || h->packed_zeroed_for != r.wpack) {
+    if (pack_all(r)) return -1;
+  }
+  if (forward_impl(r, x_nhwc, t, out_nchw)) return -1;
+  if (r.tape.overflow() || r.tmp.overflow()) return fail("unet_forward: internal arena overflow");
+  return 0;
+}
+
+extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, float* grad_x_nhwc, int B, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!h || !grad_out_nchw || !workspace) return fail("unet_backward: null argument");
+  if (h->tape_B != B) return fail("unet_backward: no matching forward (tape holds B=%d)", h->tape_B);
+  if (!h->have_grads) return fail("unet_backward: gradient buffers not bound");
+  Run r;
+  if (setup_run(r, h, B, true, workspace, workspace_bytes, stream)) return -1;
+  if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
+  if (r.tmp.overflow()) return fail("unet_backward: internal arena overflow");
+  return 0;
+}

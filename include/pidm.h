@@ -29,6 +29,11 @@ const char* pidm_last_error(void);
 /* "hip" for the product library, "hipemu" for the host-emulated test build (tests/hipemu). */
 const char* pidm_backend(void);
 
+/* bench-only: per-launch timing of the dominant kernels with HIP events recorded on the launch stream.
+ * class 0 = implicit-GEMM conv forward/dgrad (work = algorithmic FLOPs), class 1 = conv wgrad (FLOPs). */
+int pidm_prof_enable(int on);
+int pidm_prof_collect(double* ms4, long long* launches4, double* work4);
+
 /* ---------------------------------------------------------------------------------------------
  * Darcy PDE residual                    replaces ResidualsDarcy.compute_residual's stencil part
  *   src/residuals_darcy.py:137-183 + StencilGradientComputation.forward src/grad_utils.py:64-146

@@ -52,6 +52,7 @@ class UnetEngine:
         self._bound_key = None
         self.workspace = None
         self._ws_key = None
+        self.tape_generation = 0
 
     def __del__(self):
         try:
@@ -137,6 +138,9 @@ class _UnetFunction(torch.autograd.Function):
         ctx.x_requires_grad = x_nhwc.requires_grad
         ctx.channels = x_nhwc.shape[-1]
         ctx.training = training
+        if training:
+            engine.tape_generation += 1
+        ctx.generation = engine.tape_generation
         out = engine.forward(x_nhwc, t, training=training)
         # the engine keeps RAW pointers to its input and output until backward: keep both tensors alive
         ctx.save_for_backward(out, x_nhwc)
@@ -147,6 +151,10 @@ class _UnetFunction(torch.autograd.Function):
         eng = ctx.engine
         if not ctx.training:
             raise PidmError("backward through a forward that ran without gradient tracking")
+        if ctx.generation != eng.tape_generation:
+            raise PidmError("the engine's activation tape was overwritten by a later training-mode forward of the same "
+                            "model (two differentiable UNet calls per step, e.g. x0_estimation='sample', need a second "
+                            "tape: not supported yet)")
         gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
         for p, g in zip(eng.params, eng.grad_views):
             if not p.requires_grad:

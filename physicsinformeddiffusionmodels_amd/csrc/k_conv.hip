@@ -439,8 +439,11 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
     attr_done = true;
   }
   const int tiles_n = cdiv(g.Cout, BN);
+  const bool prof = prof_enabled();
+  if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * g.nz * (double)g.Cout * g.Cin * T, st);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<KC, NT>), dim3(g.tiles_m * tiles_n, 1, g.nz), dim3(256), lds, st, g,
                      tgs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
+  if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_igemm_kernel");
   return 0;
 }
@@ -497,10 +500,13 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr_done = true;
   }
+  const bool prof = prof_enabled();
+  if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
   if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
+  if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
   const size_t total = (size_t)g.Cout * g.Cin * T;
   int blocks = (int)((total + 255) / 256);

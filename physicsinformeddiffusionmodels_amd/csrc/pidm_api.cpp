@@ -32,3 +32,42 @@ extern "C" const char* pidm_backend(void) {
   return "hip";
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline figures)
+// ---------------------------------------------------------------------------------------------------------
+#include <vector>
+namespace pidm {
+struct ProfRec { hipEvent_t a, b; int cls; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+bool prof_enabled() { return g_prof_on; }
+void prof_begin_launch(int cls, double work, hipStream_t st) {
+  ProfRec r;
+  r.cls = cls; r.work = work;
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+}
+void prof_end_launch(hipStream_t st) { (void)hipEventRecord(g_prof.back().b, st); }
+}  // namespace pidm
+
+extern "C" int pidm_prof_enable(int on) {
+  pidm::g_prof_on = on != 0;
+  return 0;
+}
+// sums since the last collect: ms[c], launches[c], work[c] (flops or bytes as declared by the launcher), c < 4
+extern "C" int pidm_prof_collect(double* ms, long long* launches, double* work) {
+  for (int c = 0; c < 4; ++c) { ms[c] = 0.0; launches[c] = 0; work[c] = 0.0; }
+  for (auto& r : pidm::g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    if (r.cls >= 0 && r.cls < 4) { ms[r.cls] += t; launches[r.cls] += 1; work[r.cls] += r.work; }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  pidm::g_prof.clear();
+  return 0;
+}

@@ -13,6 +13,11 @@ namespace pidm {
 void set_error(const char* fmt, ...);
 int fail(const char* fmt, ...);  // sets the error, returns -1
 
+// bench-only per-launch timing (pidm_api.cpp).  classes: 0 conv fwd/dgrad (flops), 1 conv wgrad (flops)
+bool prof_enabled();
+void prof_begin_launch(int cls, double work, hipStream_t st);
+void prof_end_launch(hipStream_t st);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define PIDM_CHECK_LAUNCH(what)                                                     \

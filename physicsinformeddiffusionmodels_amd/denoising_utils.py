@@ -1,0 +1,407 @@
+"""Diffusion process: host-side mirror of reference `src/denoising_utils.py` (DenoisingDiffusion, EMA,
+save_model/load_model, extract and the helpers main.py / sample.py star-import).
+
+`DenoisingDiffusion.model_estimation_loss` / `p_sample` / `p_sample_loop` keep the reference signatures and
+return structures.  For the Darcy mean-estimation configuration (the `north_star` hot path) the step is three
+native calls: fused q-sample (csrc/k_norm.hip), UNet forward (csrc/unet_engine.hip), fused residual + loss +
+d loss/d x0_pred (csrc/k_darcy.hip); `loss.backward()` then runs the native UNet backward.  Other
+configurations compose the same native pieces through autograd with the reference's op sequence.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path  # noqa: F401  (re-exported: main.py uses `Path` from the star-import)
+
+import numpy as np  # noqa: F401  (re-exported)
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import yaml
+
+from ._lib import get_lib, ptr, stream_ptr
+from .residuals_darcy import ResidualsDarcy
+from .unet_model import (default, exists, generalized_b_xy_c_to_image, generalized_image_to_b_xy_c,  # noqa: F401
+                         noop)
+
+device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+def fix_seeds(seed=42):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    np.random.seed(seed)
+
+
+def image_to_b_xy_c(tensor):
+    """[B,C,X,Y] -> [B,X*Y,C] (a strided view, like the reference's permute+view; src/denoising_utils.py:36-42)."""
+    assert tensor.dim() == 4, 'Input tensor must have shape [batch, channels, x, y].'
+    b, c, px, py = tensor.shape
+    return tensor.permute(0, 2, 3, 1).reshape(b, px * py, c)
+
+
+def b_xy_c_to_image(tensor, pixels_x=None, pixels_y=None):
+    assert tensor.dim() == 3, 'Input tensor must have shape [batch, x*y, channels].'
+    b, n, c = tensor.shape
+    if pixels_x is None and pixels_y is None:
+        assert np.sqrt(n) % 1 == 0, 'Number of pixels must be a perfect square.'
+        pixels_x = pixels_y = int(np.sqrt(n))
+    else:
+        assert pixels_x * pixels_y == n, 'Number of given pixels must match dim 1 of input tensor.'
+    return tensor.reshape(b, pixels_x, pixels_y, c).permute(0, 3, 1, 2)
+
+
+def right_pad_dims_to(x, t):
+    padding_dims = x.ndim - t.ndim
+    if padding_dims <= 0:
+        return t
+    return t.view(*t.shape, *((1,) * padding_dims))
+
+
+def extract(input, t, x):
+    """gather(table, t) reshaped to [B,1,...] (src/denoising_utils.py:302-306)."""
+    out = torch.gather(input, 0, t.to(input.device))
+    return out.reshape(t.shape[0], *([1] * (len(x.shape) - 1)))
+
+
+class EMA(object):
+    """Shadow-weight EMA with the reference's swap-in/swap-out protocol (src/denoising_utils.py:163-205)."""
+
+    def __init__(self, mu=0.999):
+        self.mu = mu
+        self.shadow = {}
+        self.backup = {}
+
+    def register(self, module):
+        for name, param in module.named_parameters():
+            if param.requires_grad:
+                self.shadow[name] = param.data.clone()
+
+    def update(self, module):
+        for name, param in module.named_parameters():
+            if param.requires_grad:
+                self.shadow[name].data = (1. - self.mu) * param.data + self.mu * self.shadow[name].data
+
+    def ema(self, module, backup=True):
+        for name, param in module.named_parameters():
+            if param.requires_grad:
+                assert name in self.shadow
+                if backup:
+                    self.backup[name] = param.data.clone()
+                param.data.copy_(self.shadow[name].data)
+
+    def restore(self, module):
+        for name, param in module.named_parameters():
+            if param.requires_grad:
+                assert name in self.backup
+                param.data.copy_(self.backup[name])
+        self.backup = {}
+
+    def state_dict(self):
+        return self.shadow
+
+    def load_state_dict(self, state_dict):
+        self.shadow = state_dict
+
+
+def image_array_to_gif(image_array, output_file, frame_duration=0.05, normalization_mode='final_pred', given_min_max=None):
+    raise NotImplementedError('GIF export needs imageio, which is outside the accelerated path (main.py: create_gif=False)')
+
+
+def save_model(config, model, train_iterations, output_save_dir):
+    """{dir}/model/model.yaml + checkpoint_{it}.pt = {'model': state_dict} (src/denoising_utils.py:273-287)."""
+    os.makedirs(Path(output_save_dir, 'model/'), exist_ok=True)
+    with open(output_save_dir + '/model/model.yaml', 'w') as f:
+        yaml.dump(dict(config), f, default_flow_style=False)
+    with open(output_save_dir + '/model/checkpoint_' + str(train_iterations) + '.pt', 'wb') as f:
+        torch.save(dict(model=model.state_dict()), f)
+    print(f'\ncheckpoint saved to {output_save_dir}/.')
+
+
+def load_model(path, model, strict=True):
+    with open(path, 'rb') as f:
+        loaded_obj = torch.load(f, map_location='cpu')
+    try:
+        model.load_state_dict(loaded_obj['model'], strict=strict)
+    except RuntimeError:
+        print('Failed loading state dict.')
+    print('\nCheckpoint loaded from {}'.format(path))
+    return model
+
+
+class _DarcyPidmLossFn(torch.autograd.Function):
+    """loss = c_data*mean_b(w_t*mse) + mean(c_r*0.5*r^2/var_t) in one kernel, together with d loss/d x0_pred
+    (src/denoising_utils.py:666-692).  Returns (loss, scalars[4], residual)."""
+
+    @staticmethod
+    def forward(ctx, x0_pred, x0, f_s, p2w, inv_var, c_data, c_residual, inv_h0, inv_h1, lib):
+        pred = x0_pred.contiguous()
+        B, C, P, _ = pred.shape
+        dev = pred.device
+        res = torch.empty(B, P * P, 3, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(pred)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_darcy_loss_fwd_bwd(ptr(x0), ptr(pred), ptr(f_s), ptr(p2w), ptr(inv_var), float(c_data),
+                                              float(c_residual), inv_h0, inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
+                                              B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd')
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(out, res)
+        return out[0].clone(), out, res
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out, _g_res):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss, None, None, None, None, None, None, None, None, None
+
+
+class DenoisingDiffusion(nn.Module):
+    """Drop-in for reference DenoisingDiffusion (src/denoising_utils.py:308-788)."""
+
+    def __init__(self, n_steps, device, residual_grad_guidance=False, lib=None):
+        super().__init__()
+        self.n_steps = n_steps
+        self.device = device
+        self.diff_dict = self.create_diff_dict()
+        self.residual_grad_guidance = residual_grad_guidance
+        self._lib = lib
+
+    @property
+    def lib(self):
+        if self._lib is None:
+            self._lib = get_lib()
+        return self._lib
+
+    # ---- schedule (fp32 op order of src/denoising_utils.py:315-370 preserved: the tables are bit-exact) ----
+    def make_beta_schedule(self, schedule='linear', n_timesteps=1000, start=1e-5, end=1e-2):
+        if schedule == 'linear':
+            return torch.linspace(start, end, n_timesteps)
+        if schedule == 'quad':
+            return torch.linspace(start ** 0.5, end ** 0.5, n_timesteps) ** 2
+        if schedule == 'sigmoid':
+            return torch.sigmoid(torch.linspace(-6, 6, n_timesteps)) * (end - start) + start
+        if schedule == 'cosine':
+            s = 0.008
+            x = torch.linspace(0, n_timesteps, n_timesteps + 1)
+            ac = torch.cos(((x / n_timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+            ac = ac / ac[0]
+            return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+        raise ValueError(schedule)
+
+    def create_diff_dict(self):
+        b = self.make_beta_schedule(schedule='cosine', n_timesteps=self.n_steps, start=1e-5, end=1e-2)
+        d = {'betas': b}
+        d['alphas'] = 1. - b
+        d['sqrt_recip_alphas'] = torch.sqrt(1. / d['alphas'])
+        ap = torch.cumprod(d['alphas'], 0)
+        d['alphas_prod'] = ap
+        d['alphas_prod_p'] = torch.cat([torch.ones(1), ap[:-1]], 0)
+        d['alphas_bar_sqrt'] = torch.sqrt(ap)
+        d['sqrt_recip_alphas_cumprod'] = torch.sqrt(1. / ap)
+        d['sqrt_recipm1_alphas_cumprod'] = torch.sqrt(1. / ap - 1)
+        d['one_minus_alphas_bar_log'] = torch.log(1 - ap)
+        d['one_minus_alphas_bar_sqrt'] = torch.sqrt(1 - ap)
+        app = F.pad(ap[:-1], (1, 0), value=1.)
+        d['alphas_prod_prev'] = app
+        d['posterior_mean_coef1'] = b * torch.sqrt(app) / (1. - ap)
+        d['posterior_mean_coef2'] = (1. - app) * torch.sqrt(d['alphas']) / (1. - ap)
+        d['noise_mean_coeff'] = torch.sqrt(1. / d['alphas']) * (1. - d['alphas']) / torch.sqrt(1. - ap)
+        pv = b * (1. - app) / (1. - ap)
+        d['posterior_variance'] = pv
+        pvc = pv.clone()
+        pvc[0] = pv[1]
+        d['posterior_variance_clipped'] = pvc
+        d['posterior_log_variance_clipped'] = torch.log(pvc)
+        snr = ap / (1. - ap)
+        d['p2_loss_weight'] = torch.minimum(snr, torch.ones_like(snr) * 5.0)
+        self._host_tables = {k: v.clone() for k, v in d.items()}  # python-float access without device syncs
+        return {k: v.to(self.device) for k, v in d.items()}
+
+    def q_sample(self, x_0, t, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        return extract(alphas_bar_sqrt, t, x_0) * x_0 + extract(one_minus_alphas_bar_sqrt, t, x_0) * noise
+
+    def gaussian_log_likelihood(self, x, means, variance):
+        return -0.5 * ((x - means) ** 2) / variance
+
+    def predict_noise_from_mean(self, x_t, t, mean_t):
+        return (extract(self.diff_dict['sqrt_recip_alphas'], t, mean_t) * x_t - mean_t) / \
+            extract(self.diff_dict['noise_mean_coeff'], t, mean_t)
+
+    # ---- training loss (src/denoising_utils.py:616-710) ---------------------------------------------------------
+    def _darcy_fast_path_ok(self, residual_func, c_ineq, lambda_opt, x):
+        return (isinstance(residual_func, ResidualsDarcy) and not residual_func.use_ddim_x0 and c_ineq <= 0.
+                and lambda_opt <= 0. and x.dtype == torch.float32 and (x.is_cuda or self._lib is not None))
+
+    def model_estimation_loss(self, input, residual_func=None, c_data=1., c_residual=0., c_ineq=0., lambda_opt=0.):
+        batch_size = len(input)
+        t = torch.randint(0, self.n_steps, size=(batch_size,), device=input.device)   # RNG draw #1 (:625)
+        if residual_func.gov_eqs == 'darcy':
+            x_0 = input
+            conditioning = bcs = None
+        elif residual_func.gov_eqs == 'mechanics':
+            conditioning, x_0, bcs = torch.tensor_split(input, (3, 6), dim=1)
+        else:
+            raise ValueError('Unknown governing equations.')
+        e = torch.randn_like(x_0)                                                       # RNG draw #2 (:636)
+
+        if self._darcy_fast_path_ok(residual_func, c_ineq, lambda_opt, x_0):
+            return self._darcy_step(x_0, e, t, residual_func, c_data, c_residual)
+
+        a = extract(self.diff_dict['alphas_bar_sqrt'], t, x_0)
+        am1 = extract(self.diff_dict['one_minus_alphas_bar_sqrt'], t, x_0)
+        x = x_0 * a + e * am1
+        if residual_func.gov_eqs == 'mechanics':
+            x = torch.cat((x, conditioning), dim=1)
+        model_input = (image_to_b_xy_c(x), t)
+        return_inequality = c_ineq > 0.
+        return_optimizer = lambda_opt > 0. or residual_func.gov_eqs == 'mechanics'
+        if residual_func.gov_eqs == 'darcy':
+            residual_input = (model_input,)
+        else:
+            vf = conditioning[:, 0, 0, 0]
+            residual_input = (model_input, bcs, vf, x_0)
+        out_dict = residual_func.compute_residual(residual_input, reduce='per-batch', return_model_out=True,
+                                                  return_optimizer=return_optimizer, return_inequality=return_inequality,
+                                                  ddim_func=self.ddim_sample_x0)
+        residual, output = out_dict['residual'], out_dict['model_out']
+        if output.dim() == 3:
+            output = b_xy_c_to_image(output)
+        loss = ((x_0 - output) ** 2).reshape(batch_size, -1).mean(dim=1)
+        loss = (loss * extract(self.diff_dict['p2_loss_weight'], t, loss)).mean()
+        data_loss = c_data * loss
+        data_loss_track = data_loss.item()
+        loss = data_loss
+        var = extract(self.diff_dict['posterior_variance_clipped'], t, residual)
+        residual_loss_track = residual.abs().mean().item()
+        loss = loss + (c_residual * 0.5 * residual ** 2 / var).mean()
+        ineq_loss_track = 0.
+        if return_inequality:
+            # NOTE the reference broadcasts [B] against [B,1] -> [B,B] here (src/denoising_utils.py:697); reproduced
+            ineq = out_dict['inequality']
+            ineq_loss_track = ineq.mean().item()
+            loss = loss + (c_ineq * 0.5 * ineq ** 2 / var).mean()
+        opt_loss_track = 0.
+        if return_optimizer:
+            opt_loss_track = out_dict['optimizer'].mean().item()
+            loss = loss + (lambda_opt * out_dict['optimizer']).mean()
+        return loss, data_loss_track, residual_loss_track, ineq_loss_track, opt_loss_track
+
+    def _darcy_step(self, x_0, e, t, residual_func, c_data, c_residual):
+        """Native hot path: q-sample -> UNet -> fused residual+loss(+grad).  One host sync for the 2 floats the
+        reference API returns (it forces two .item() calls, src/denoising_utils.py:681,688)."""
+        lib = residual_func.lib
+        B, C, P, _ = x_0.shape
+        dev = x_0.device
+        dd = self.diff_dict
+        x_0 = x_0.contiguous()
+        a = dd['alphas_bar_sqrt'][t].contiguous()
+        am1 = dd['one_minus_alphas_bar_sqrt'][t].contiguous()
+        xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
+        lib.check(lib.pidm_qsample_nhwc(ptr(x_0), ptr(e.contiguous()), ptr(a), ptr(am1), ptr(xt), B, C, P * P,
+                                        stream_ptr(dev)), 'pidm_qsample_nhwc')
+        x0_pred = residual_func.model(xt, t)
+        p2w = dd['p2_loss_weight'][t].contiguous()
+        inv_var = (1.0 / dd['posterior_variance_clipped'][t]).contiguous()
+        if residual_func._f_s_flat.device != dev:
+            residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
+        loss, scalars, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, residual_func._f_s_flat, p2w, inv_var, c_data, c_residual,
+                                                     residual_func.inv_h0, residual_func.inv_h1, lib)
+        s = scalars.tolist()  # single D2H sync
+        return loss, s[1], s[2], 0., 0.
+
+    # ---- sampling (src/denoising_utils.py:388-545) ---------------------------------------------------------------
+    def p_sample(self, x, conditioning_input, t, save_output=False, surpress_noise=False, use_dynamic_threshold=False,
+                 residual_func=None, eval_residuals=False, return_optimizer=False, return_inequality=False,
+                 residual_correction=False, correction_mode='none'):
+        if residual_correction:
+            raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3')
+        if use_dynamic_threshold:
+            raise NotImplementedError('dynamic thresholding is off in main.py/sample.py and not on the accelerated path')
+        x_init = x.detach()
+        if conditioning_input is not None:
+            conditioning, bcs, solution = conditioning_input
+            x = torch.cat((x, conditioning), dim=1)
+        batch_size = len(x)
+        t_int = int(t)
+        tt = torch.full((batch_size,), t_int, device=x.device, dtype=torch.long)
+        model_input = (image_to_b_xy_c(x), tt)
+        if residual_func.gov_eqs == 'darcy':
+            residual_input = (model_input,)
+            sample = True
+        else:
+            vf = conditioning[:, 0, 0, 0]
+            residual_input = (model_input, bcs, vf, solution)
+            sample = t_int == 0
+        # the reference builds (and discards) an autograd graph here (:492-493); nothing downstream needs it
+        with torch.no_grad():
+            out_dict = residual_func.compute_residual(residual_input, reduce='per-batch', return_model_out=True,
+                                                      return_optimizer=return_optimizer, return_inequality=return_inequality,
+                                                      sample=sample, ddim_func=self.ddim_sample_x0)
+            model_out, residual = out_dict['model_out'], out_dict['residual']
+            if model_out.dim() == 3:
+                model_out = generalized_b_xy_c_to_image(model_out)
+            model_intermediate = model_out.clone() if save_output else None
+            ht = self._host_tables
+            c1, c2 = float(ht['posterior_mean_coef1'][t_int]), float(ht['posterior_mean_coef2'][t_int])
+            sigma = float(ht['betas'][t_int].sqrt())
+            z = torch.randn_like(x_init)
+            if surpress_noise and t_int == 0:
+                sigma = 0.0
+            lib = self.lib
+            x0p = model_out.contiguous()
+            xi = x_init.contiguous()
+            out = torch.empty_like(xi)
+            lib.check(lib.pidm_psample_update(ptr(x0p), ptr(xi), ptr(z), c1, c2, sigma, ptr(out), xi.numel(),
+                                              stream_ptr(xi.device)), 'pidm_psample_update')
+        if t_int == 0 and eval_residuals:
+            aux_out = {'residual': residual}
+            if return_optimizer:
+                aux_out['optimized_quant'] = out_dict['optimizer']
+            if return_inequality:
+                aux_out['inequality_quant'] = out_dict['inequality']
+            if residual_func.gov_eqs == 'mechanics' and residual_func.topopt_eval:
+                for k in ('rel_CE_error_full_batch', 'vf_error_full_batch', 'fm_error_full_batch'):
+                    aux_out[k] = out_dict[k]
+            return (out, model_intermediate), aux_out
+        return (out, model_intermediate), None
+
+    def p_sample_loop(self, conditioning_input, shape, save_output=False, surpress_noise=True, use_dynamic_threshold=False,
+                      residual_func=None, eval_residuals=False, return_optimizer=False, return_inequality=False,
+                      M_correction=0, N_correction=0, correction_mode='none', keep_history=True):
+        """`keep_history=False` (extension) skips the two blocking D2H copies per step the reference performs
+        (src/denoising_utils.py:531-532) and returns only the final state in the lists."""
+        if M_correction or N_correction:
+            raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3')
+        cur_x = torch.randn(shape, device=self.diff_dict['alphas'].device)
+        x_seq = [cur_x.detach().cpu()] if keep_history else []
+        interm_imgs = [torch.zeros(shape)] if (save_output and keep_history) else []
+        output = None
+        for i in reversed(range(self.n_steps)):
+            output = self.p_sample(cur_x.detach(), conditioning_input, i, save_output, surpress_noise, use_dynamic_threshold,
+                                   residual_func=residual_func, eval_residuals=eval_residuals,
+                                   return_optimizer=return_optimizer, return_inequality=return_inequality)
+            cur_x, interm_img = output[0]
+            if keep_history:
+                x_seq.append(cur_x.detach().cpu())
+                interm_imgs.append(interm_img.detach().cpu())
+        if not keep_history:
+            x_seq.append(cur_x.detach())
+            if save_output:
+                interm_imgs.append(interm_img.detach())
+        if eval_residuals:
+            return (x_seq, interm_imgs), output[1]
+        return x_seq, interm_imgs
+
+    def ddim_sample_x0(self, xt, t, model, shape, reduced_n_steps, ddim_sampling_eta, gov_eqs=None, self_cond=None):
+        """Sample estimation with ddim_steps = 0 (the manuscript's setting, model.yaml:7): the reference evaluates
+        the model at (x_t, t) and again at (x_t, 0) - its loop never updates `model_input`
+        (src/denoising_utils.py:741-753) - and returns (second output, first output)."""
+        if reduced_n_steps != 0:
+            raise NotImplementedError('ddim_steps > 0 is not on the accelerated path (model.yaml: ddim_steps 0)')
+        batch = shape[0]
+        if len(t) == 1:
+            t = torch.ones(batch, device=xt.device, dtype=torch.long) * t
+        model_out = model(xt, t)
+        x0_pred = model(xt, torch.zeros_like(t))
+        return x0_pred, model_out

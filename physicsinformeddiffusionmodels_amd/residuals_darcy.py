@@ -1,0 +1,144 @@
+"""Darcy-flow residual callback: host-side mirror of reference `src/residuals_darcy.py::ResidualsDarcy`.
+
+Same constructor, same attributes (`gov_eqs`, `model`, `f_s`, `trapezoidal_weights`, ...) and the same
+`compute_residual(...) -> dict` contract, but the 200 ATen ops of the reference's stencil engine
+(src/grad_utils.py:64-146, called six times from src/residuals_darcy.py:139-145) are ONE hand-written gfx950
+kernel and its adjoint (csrc/k_darcy.hip) reached through the C ABI.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import PidmError, get_lib, ptr, stream_ptr
+from .unet_model import generalized_b_xy_c_to_image, generalized_image_to_b_xy_c
+
+
+class _DarcyResidualFn(torch.autograd.Function):
+    """residual [B,P*P,3] = R(x0_pred [B,2,P,P]); backward = transposed-stencil gather kernel."""
+
+    @staticmethod
+    def forward(ctx, x0_pred, f_s, inv_h0, inv_h1, lib):
+        x = x0_pred.contiguous().float()
+        B, C, P, _ = x.shape
+        res = torch.empty(B, P * P, 3, dtype=torch.float32, device=x.device)
+        lib.check(lib.pidm_darcy_residual_fwd(ptr(x), ptr(f_s), inv_h0, inv_h1, ptr(res), B, P, stream_ptr(x.device)),
+                  "pidm_darcy_residual_fwd")
+        ctx.save_for_backward(x)
+        ctx.meta = (inv_h0, inv_h1, lib)
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_res):
+        (x,) = ctx.saved_tensors
+        inv_h0, inv_h1, lib = ctx.meta
+        B, C, P, _ = x.shape
+        g = grad_res.contiguous().float()
+        gx = torch.empty_like(x)
+        lib.check(lib.pidm_darcy_residual_bwd(ptr(x), ptr(g), inv_h0, inv_h1, ptr(gx), B, P, stream_ptr(x.device)),
+                  "pidm_darcy_residual_bwd")
+        return gx, None, None, None, None
+
+
+class ResidualsDarcy:
+    """Drop-in for reference ResidualsDarcy (src/residuals_darcy.py:5-207)."""
+
+    def __init__(self, model, fd_acc, pixels_per_dim, pixels_at_boundary, reverse_d1, device='cpu', bcs='none',
+                 domain_length=1., residual_grad_guidance=False, use_ddim_x0=False, ddim_steps=0, lib=None):
+        if fd_acc != 2:
+            raise NotImplementedError('the gfx950 stencil kernel implements fd_acc=2 (model.yaml:13)')
+        if bcs == 'periodic':
+            raise NotImplementedError("periodic stencils are not on the accelerated path (reference default bcs='none')")
+        if residual_grad_guidance:
+            raise NotImplementedError('residual gradient guidance is SURVEY 8(f) rank 3 (off by default, model.yaml:8)')
+        self.gov_eqs = 'darcy'
+        self.model = model
+        self.pixels_at_boundary = pixels_at_boundary
+        self.periodic = False
+        self.input_dim = 2
+        d0 = domain_length / (pixels_per_dim - 1) if pixels_at_boundary else domain_length / pixels_per_dim
+        d1 = -d0 if reverse_d1 else d0
+        self.reverse_d1 = reverse_d1
+        self.d0, self.d1 = d0, d1
+        self.inv_h0, self.inv_h1 = 1.0 / d0, 1.0 / d1
+        self.pixels_per_dim = pixels_per_dim
+        self.device = device
+        self._lib = lib
+        # stationary source field on pixel centres (src/residuals_darcy.py:41-53,95-104)
+        P = pixels_per_dim
+        ps = 1.0 / P
+        x = torch.linspace(ps / 2, 1.0 - ps / 2, steps=P)
+        X, Y = torch.meshgrid(x, x, indexing='ij')
+        self.f_s = generalized_image_to_b_xy_c(self.create_f_s(X, Y, 0.125, 10.0).unsqueeze(0)).to(device)  # [1,P*P]
+        self._f_s_flat = self.f_s.reshape(-1).contiguous().float()
+        self.use_trapezoid = bool(pixels_at_boundary)
+        if self.use_trapezoid:
+            self.trapezoidal_weights = self.create_trapezoidal_weights()
+        self.residual_grad_guidance = residual_grad_guidance
+        self.use_ddim_x0 = use_ddim_x0
+        self.ddim_steps = ddim_steps
+
+    @property
+    def lib(self):
+        if self._lib is None:
+            self._lib = get_lib()
+        return self._lib
+
+    def create_trapezoidal_weights(self):
+        P = self.pixels_per_dim
+        w = torch.full((1, P, P), 4.0)
+        w[..., 0, :] = 2.0
+        w[..., -1, :] = 2.0
+        w[..., :, 0] = 2.0
+        w[..., :, -1] = 2.0
+        w[..., 0, 0] = w[..., 0, -1] = w[..., -1, 0] = w[..., -1, -1] = 1.0
+        w *= (1. / P) ** 2 / 4.
+        return generalized_image_to_b_xy_c(w).to(self.device)
+
+    def create_f_s(self, x, y, w=0.125, r=10.):
+        lo_x, hi_x = (x - 0.5 * w).abs() <= 0.5 * w, (x - 1 + 0.5 * w).abs() <= 0.5 * w
+        lo_y, hi_y = (y - 0.5 * w).abs() <= 0.5 * w, (y - 1 + 0.5 * w).abs() <= 0.5 * w
+        out = torch.zeros_like(x)
+        out[lo_x & lo_y] = r
+        out[hi_x & hi_y] = -r
+        return out
+
+    def residual_of(self, x0_pred):
+        """[B,2,P,P] -> [B,P*P,3] through the gfx950 kernel (differentiable)."""
+        if x0_pred.dim() != 4 or x0_pred.shape[1] != 2:
+            raise AssertionError('Model output must be a tensor shaped as an image [B,2,P,P].')
+        if self._lib is None and not x0_pred.is_cuda:
+            raise PidmError('ResidualsDarcy needs tensors on an MI355X: the gfx950 kernels have no CPU fallback')
+        if self._f_s_flat.device != x0_pred.device:
+            self._f_s_flat = self._f_s_flat.to(x0_pred.device)
+        return _DarcyResidualFn.apply(x0_pred, self._f_s_flat, self.inv_h0, self.inv_h1, self.lib)
+
+    def compute_residual(self, input, reduce='none', return_model_out=False, return_optimizer=False,
+                         return_inequality=False, sample=False, ddim_func=None, pass_through=False):
+        if pass_through:
+            assert isinstance(input, torch.Tensor), 'Input is assumed to directly be given output.'
+            x0_pred = input
+            model_out = x0_pred
+        else:
+            assert len(input[0]) == 2 and isinstance(input[0], tuple), \
+                'Input[0] must be a tuple consisting of noisy signal and time.'
+            noisy_in, time = input[0]
+            if self.use_ddim_x0:
+                x0_pred, model_out = ddim_func(noisy_in, time, self.model, noisy_in.shape, self.ddim_steps, 0.)
+            else:
+                x0_pred = self.model(noisy_in, time)
+                model_out = x0_pred
+        output = {'residual': self.residual_of(x0_pred)}
+        if return_model_out:
+            output['model_out'] = model_out
+        if reduce == 'full':
+            return {k: v.mean() for k, v in output.items()}
+        elif reduce == 'per-batch':
+            return {k: v.mean(dim=tuple(range(1, v.ndim))) if v.ndim > 1 and (k != 'model_out' and k != 'residual') else v
+                    for k, v in output.items()}
+        elif reduce == 'none':
+            return output
+        raise ValueError('Unknown reduction method.')
+
+    def residual_correction(self, x0_pred_in):
+        raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3 (N_correction/M_correction '
+                                  'default 0 in model.yaml:10-11)')

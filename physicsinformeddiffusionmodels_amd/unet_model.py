@@ -255,7 +255,7 @@ class Unet3D(nn.Module):
                                       nn.Conv2d(init_dim, init_dim, 3, padding=1))
         self.combine_conv = nn.Conv2d(init_dim * 2, init_dim, 1)
         self.sigmoid_last_channel = sigmoid_last_channel
-        self._engine = None
+        self._pidm_lib = None  # tests may bind the host-emulated build of csrc here; None = libpidm_hip.so
 
     # ---- engine plumbing ------------------------------------------------------------------------
     def used_parameter_names(self):
@@ -269,7 +269,7 @@ class Unet3D(nn.Module):
             raise NotImplementedError('gradient-guidance / self-conditioning branch is not on the accelerated '
                                       'path (SURVEY 8(f) rank 3)')
         from ._engine import unet_apply
-        return unet_apply(self, x, time)
+        return unet_apply(self, x, time, lib=self._pidm_lib)
 
     def forward_with_guidance_scale(self, *args, **kwargs):
         guidance_scale = kwargs.pop('guidance_scale', 3.)

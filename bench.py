@@ -52,7 +52,8 @@ def cpu_baseline(batch=8, steps=2):
     from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch
     torch.manual_seed(0)
     m = Unet3D(dim=32, channels=2)
-    p = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and v.requires_grad) for k, v in m.state_dict().items()}
+    trainable = {k for k, v in m.named_parameters() if v.requires_grad}
+    p = {k: v.detach().clone().requires_grad_(k in trainable) for k, v in m.state_dict().items()}
     used = None
     cfg = O.UnetCfg(dim=32, channels=2)
     tables = O.diffusion_tables(100)

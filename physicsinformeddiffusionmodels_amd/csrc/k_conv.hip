@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 
   // this lane's A row (pixel) inside the wave's m-tile
   const int pm = wave * 32 + l31;
-  const int a_tx = pm % g.Wv, a_ty = (pm / g.Wv) % g.TH, a_img = pm / (g.Wv * g.TH);
+  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
   // (g.NI may be smaller than 128/(Wv*TH) when the halo tile of tiny strided images would not fit in LDS:
   //  rows of the missing images read tile pixel 0 and are discarded in the epilogue)
   const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
@@ -67,29 +67,41 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
   for (int i = 0; i < NT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // per-tap halo offsets (pixels), computed once: no integer divisions in the MFMA loop
+  __shared__ int tap_off[64];
+  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
+
+  const int rows = g.NI * g.IHt;   // halo rows of the tile
+  const int rowf4 = g.IWt * Q;     // 16-byte quads per halo row
   for (int c0 = 0; c0 < CinP; c0 += KC) {
     __syncthreads();
-    // ---- stage the input tile (with halo) for channels [c0, c0+KC) ----
-    for (int e = tid; e < npixA * Q; e += 256) {
-      const int q = e % Q, hp = e / Q;
-      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
-      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx, c = c0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < g.Cin) {
-        const size_t pix = ((size_t)b * g.Hi + iy) * g.Wi + ix;
-        if (vec_ok) {
-          v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
-                         : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
-        } else {
-          float t4[4];
-          for (int k = 0; k < 4; ++k) {
-            const int ck = c + k;
-            t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+    // ---- stage the input tile (with halo) for channels [c0, c0+KC): one wave per halo row ----
+    for (int rrow = wave; rrow < rows; rrow += 4) {
+      const int img = rrow / g.IHt, hy = rrow - img * g.IHt;
+      const int b = b0 + img, iy = iy0 + hy;
+      const bool rowvalid = (b < g.B) && (iy >= 0) && (iy < g.Hi);
+      const size_t rowpix = ((size_t)b * g.Hi + iy) * g.Wi;
+      float* arow_s = As + (size_t)rrow * g.IWt * KCP;
+      for (int e = lane; e < rowf4; e += 64) {
+        const int hx = e / Q, q = e % Q;
+        const int ix = ix0 + hx, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowvalid && ix >= 0 && ix < g.Wi && c < g.Cin) {
+          const size_t pix = rowpix + ix;
+          if (vec_ok) {
+            v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
+                           : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
+          } else {
+            float t4[4];
+            for (int k = 0; k < 4; ++k) {
+              const int ck = c + k;
+              t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+            }
+            v = make_float4(t4[0], t4[1], t4[2], t4[3]);
           }
-          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
+        *reinterpret_cast<float4*>(arow_s + (size_t)hx * KCP + 4 * q) = v;
       }
-      *reinterpret_cast<float4*>(As + (size_t)hp * KCP + 4 * q) = v;
     }
     for (int t0 = 0; t0 < T; t0 += tgs) {
       const int nt = (T - t0 < tgs) ? (T - t0) : tgs;
@@ -103,9 +115,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
       __syncthreads();
       // ---- MFMA over the taps of the group ----
       for (int tl = 0; tl < nt; ++tl) {
-        const int t = t0 + tl;
-        const int ky = t / g.KW, kx = t - ky * g.KW;
-        const float* arow = As + (size_t)(abase + ky * g.IWt + kx) * KCP + 4 * half;
+        const float* arow = As + (size_t)(abase + tap_off[t0 + tl]) * KCP + 4 * half;
         const float* brow = Bs + ((size_t)tl * BN + l31) * KCP + 4 * half;
 #pragma unroll
         for (int g8 = 0; g8 < KC / 8; ++g8) {
@@ -133,7 +143,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int p = wave * 32 + row;
-      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
       const int b = b0 + img;
       if (b >= g.B || img >= g.NI) continue;
       const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
@@ -197,7 +207,7 @@ struct WgradGeom {
 template <int MAXT>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                          const float* __restrict__ src1, const float* __restrict__ dy,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, float* __restrict__ bias_partial) {
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -222,7 +232,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // bias gradient = column sums of dY: done by the (tn == 0, tg == 0) blocks from the tile already in LDS
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0) && (tg == 0);
+  float bacc = 0.f;
 
+  __shared__ int tap_off[64];
+  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
+  const int rows = g.NI * g.IHt, rowf4 = g.IWt * 8;
   const int tile_lo = split * wg.tiles_per_split;
   const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
@@ -230,30 +246,36 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
     const int vy0 = (tile % tpi) * g.TH;
     const int iy0 = vy0 * g.stride - g.pad_y[0], ix0 = -g.pad_x[0];
     __syncthreads();
-    for (int e = tid; e < npixA * 8; e += 256) {
-      const int q = e & 7, hp = e >> 3;
-      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
-      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx, c = n0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < g.Cin) {
-        const size_t pix = ((size_t)b * g.Hi + iy) * g.Wi + ix;
-        if (vec_ok) {
-          v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
-                         : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
-        } else {
-          float t4[4];
-          for (int k = 0; k < 4; ++k) {
-            const int ck = c + k;
-            t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+    for (int rrow = wave; rrow < rows; rrow += 4) {
+      const int img = rrow / g.IHt, hy = rrow - img * g.IHt;
+      const int b = b0 + img, iy = iy0 + hy;
+      const bool rowvalid = (b < g.B) && (iy >= 0) && (iy < g.Hi);
+      const size_t rowpix = ((size_t)b * g.Hi + iy) * g.Wi;
+      float* xrow_s = Xs + (size_t)rrow * g.IWt * 32;
+      for (int e = lane; e < rowf4; e += 64) {
+        const int hx = e >> 3, q = e & 7;
+        const int ix = ix0 + hx, c = n0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowvalid && ix >= 0 && ix < g.Wi && c < g.Cin) {
+          const size_t pix = rowpix + ix;
+          if (vec_ok) {
+            v = (c < g.C0) ? *reinterpret_cast<const float4*>(src0 + pix * g.ld0 + c)
+                           : *reinterpret_cast<const float4*>(src1 + pix * g.ld1 + (c - g.C0));
+          } else {
+            float t4[4];
+            for (int k = 0; k < 4; ++k) {
+              const int ck = c + k;
+              t4[k] = (ck < g.Cin) ? ((ck < g.C0) ? src0[pix * g.ld0 + ck] : src1[pix * g.ld1 + (ck - g.C0)]) : 0.f;
+            }
+            v = make_float4(t4[0], t4[1], t4[2], t4[3]);
           }
-          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
+        *reinterpret_cast<float4*>(xrow_s + (size_t)hx * 32 + 4 * q) = v;
       }
-      *reinterpret_cast<float4*>(Xs + (size_t)hp * 32 + 4 * q) = v;
     }
     for (int e = tid; e < kBM * 8; e += 256) {
       const int q = e & 7, p = e >> 3;
-      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
       const int b = b0 + img, c = m0 + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (b < g.B && img < g.NI && c < g.Cout) {
@@ -269,17 +291,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
       *reinterpret_cast<float4*>(Ys + (size_t)p * 32 + 4 * q) = v;
     }
     __syncthreads();
+    if (do_bias) {
+      const int o = tid & 31, part = tid >> 5;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
+    }
     for (int ks = 0; ks < 16; ++ks) {
       const int p = wave * 32 + 2 * ks + half;
-      const int tx = p % g.Wv, ty = (p / g.Wv) % g.TH, img = p / (g.Wv * g.TH);
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
       const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
       const float a = Ys[p * 32 + l31];
 #pragma unroll
       for (int tl = 0; tl < MAXT; ++tl) {
         if (tl < nt) {
-          const int t = t0 + tl;
-          const int ky = t / g.KW, kx = t - ky * g.KW;
-          const float bv = Xs[(size_t)(xb + ky * g.IWt + kx) * 32 + l31];
+          const float bv = Xs[(size_t)(xb + tap_off[t0 + tl]) * 32 + l31];
           acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tl], 0, 0, 0);
         }
       }
@@ -304,19 +329,50 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
       }
     }
   }
+  if (do_bias) {
+    __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[k * 32 + tid];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
 }
 
-// dst[(m*N + n)*T + t] = sum_s partial[s][m][t][n]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dst, int nsplit, int M,
-                                    int N, int T, int MP, int NP) {
-  const size_t total = (size_t)M * N * T;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(idx % T);
-    const int n = (int)((idx / T) % N);
-    const int m = (int)(idx / ((size_t)T * N));
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * MP + m) * T + t) * NP + n];
-    dst[idx] = s;
+// dst[(m*N + n)*T + t] = sum_s partial[s][m][t][n]  and  dbias[m] = sum_s bias_partial[s][m].
+// One block = 32 consecutive outputs (n fastest: coalesced reads of the partials) x 8 split lanes.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dst,
+                                                           const float* __restrict__ bias_partial, float* __restrict__ dbias,
+                                                           int nsplit, int M, int N, int T, int MP, int NP) {
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, ol = tid & 31, sl = tid >> 5;
+  const long nw = (long)M * T * N;
+  const long o = (long)blockIdx.x * 32 + ol;
+  float s = 0.f;
+  long dsti = -1;
+  float* dptr = nullptr;
+  if (o < nw) {
+    const int n = (int)(o % N), t = (int)((o / N) % T), m = (int)(o / ((long)N * T));
+    const float* p = partial + ((size_t)m * T + t) * NP + n;
+    const size_t sstride = (size_t)MP * T * NP;
+    for (int sp = sl; sp < nsplit; sp += 8) s += p[(size_t)sp * sstride];
+    dptr = dst;
+    dsti = ((long)m * N + n) * T + t;
+  } else if (dbias && o < nw + M) {
+    const int m = (int)(o - nw);
+    for (int sp = sl; sp < nsplit; sp += 8) s += bias_partial[(size_t)sp * MP + m];
+    dptr = dbias;
+    dsti = m;
+  }
+  red[sl][ol] = s;
+  __syncthreads();
+  if (sl == 0 && dptr) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][ol];
+    dptr[dsti] = a;
   }
 }
 
@@ -375,6 +431,9 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
   g->TH = kBM / g->Wv < g->Hv ? kBM / g->Wv : g->Hv;
   if (g->Hv % g->TH) return fail("conv: output height %d not divisible by tile rows %d", g->Hv, g->TH);
   g->NI = kBM / (g->Wv * g->TH);
+  for (g->wsh = 0; (1 << g->wsh) < g->Wv; ++g->wsh) {}
+  for (g->tsh = 0; (1 << g->tsh) < g->TH; ++g->tsh) {}
+  if ((1 << g->tsh) != g->TH) return fail("conv: tile rows %d must be a power of two", g->TH);
   g->IHt = (g->TH - 1) * g->stride + g->KH;
   g->IWt = (g->Wv - 1) * g->stride + g->KW;
   // tiny strided images: the halo blow-up (e.g. 36 input pixels per 2x2 output) must still fit in LDS
@@ -469,7 +528,7 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->MP = cdiv(g.Cout, 32) * 32;
   wg->NP = cdiv(g.Cin, 32) * 32;
   const int blocks_mn = (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
-  int nsplit = 1024 / blocks_mn;
+  int nsplit = 768 / blocks_mn;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > g.tiles_m) nsplit = g.tiles_m;
   wg->tiles_per_split = cdiv(g.tiles_m, nsplit);
@@ -479,12 +538,13 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
 size_t wgrad_ws_bytes(const ConvGeom& g) {
   WgradGeom wg;
   wgrad_plan(g, 4, &wg);
-  return (size_t)wg.nsplit * wg.MP * g.KH * g.KW * wg.NP * sizeof(float);
+  return (size_t)wg.nsplit * wg.MP * g.KH * g.KW * wg.NP * sizeof(float) + (size_t)wg.nsplit * wg.MP * sizeof(float) + 256;
 }
 
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
+// dbias (may be null) = column sums of dy, fused into the same two launches
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 void* workspace, hipStream_t st) {
+                 float* dbias, void* workspace, hipStream_t st) {
   if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
@@ -493,6 +553,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   const size_t lds = lds_stage > 16384 ? lds_stage : 16384;
   if (lds > 160 * 1024 - 512) return fail("wgrad: tile needs %zu B of LDS", lds);
   float* partial = reinterpret_cast<float*>(workspace);
+  float* bias_partial = dbias ? partial + (size_t)wg.nsplit * wg.MP * T * wg.NP : nullptr;
   const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32) * wg.ntg, 1);
   static bool attr_done = false;
   if (!attr_done) {
@@ -503,15 +564,15 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   const bool prof = prof_enabled();
   if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
   if (wg.tgs == 1)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
-  const size_t total = (size_t)g.Cout * g.Cin * T;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, dw_ref, wg.nsplit, g.Cout, g.Cin, T, wg.MP, wg.NP);
+  const size_t total = (size_t)g.Cout * g.Cin * T + (dbias ? g.Cout : 0);
+  const int blocks = (int)((total + 31) / 32);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, dw_ref, bias_partial, dbias, wg.nsplit, g.Cout,
+                     g.Cin, T, wg.MP, wg.NP);
   PIDM_CHECK_LAUNCH("wgrad_reduce_kernel");
   return 0;
 }
@@ -632,12 +693,11 @@ extern "C" int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const
     // swapped operands: X' = dy [B,2H,2W,Cout], dY' = x [B,H,W,Cin]; result [Cin][Cout][4][4]
     if (d->C1) return fail("wgrad: transposed conv with two sources is not supported");
     if (make_geom(&g, 0, d->B, 2 * d->Hi, 2 * d->Wi, d->Cout, 0, ld_dy, 0, d->C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
-    rc = launch_wgrad(g, dy, nullptr, src0, d->ld0, dw_ref, workspace, st);
+    rc = launch_wgrad(g, dy, nullptr, src0, d->ld0, dw_ref, nullptr, workspace, st);
     dy_rows = (size_t)d->B * 4 * d->Hi * d->Wi;
   } else {
     if (geom_fwd(d, &g)) return -1;
-    rc = launch_wgrad(g, src0, src1, dy, ld_dy, dw_ref, workspace, st);
-    dy_rows = (size_t)d->B * g.Ho * g.Wo;
+    return launch_wgrad(g, src0, src1, dy, ld_dy, dw_ref, dbias, workspace, st);
   }
   if (rc) return rc;
   if (dbias) {

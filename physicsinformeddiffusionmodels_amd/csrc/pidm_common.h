@@ -57,6 +57,7 @@ struct ConvGeom {
   int ldr;           // channel stride of the (channels-last) residual operand
   // tiling
   int TH, NI;        // rows per tile, images per tile: TH*NI*Wv == 128
+  int wsh, tsh;      // log2(Wv), log2(TH): pixel p of a tile -> tx = p & (Wv-1), ty = (p >> wsh) & (TH-1), img = p >> (wsh+tsh)
   int IHt, IWt;      // input halo tile extent per image
   int tiles_m;       // number of 128-pixel tiles
 };

@@ -14,7 +14,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
                 const float* residual, float* out, int sigmoid_last, hipStream_t st);
 size_t wgrad_ws_bytes(const ConvGeom& g);
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 void* workspace, hipStream_t st);
+                 float* dbias, void* workspace, hipStream_t st);
 size_t colsum_ws_bytes(size_t rows, int C);
 int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st);
 // k_norm.hip

@@ -535,12 +535,12 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
   const int Ho = out_h(L);
   if (L.transposed) {
     if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
-    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], r.scratch, r.st));
+    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, r.scratch, r.st));
+    if (L.b >= 0) RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], r.scratch, r.st));
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
-    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], r.scratch, r.st));
+    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, r.scratch, r.st));
   }
-  if (L.b >= 0) RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], r.scratch, r.st));
   return 0;
 }
 
@@ -649,8 +649,7 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (U->have_grads || r.dry) {
       ConvGeom g;
       if (geom_fwd_layer(L, B, 0, &g)) return -1;
-      RUN(launch_wgrad(g, U->xfinal, nullptr, g_o, od, U->G[L.w], r.scratch, r.st));
-      RUN(launch_colsum(g_o, (size_t)B * HW, od, od, U->G[L.b], r.scratch, r.st));
+      RUN(launch_wgrad(g, U->xfinal, nullptr, g_o, od, U->G[L.w], U->G[L.b], r.scratch, r.st));
     }
   }
   float* g_x = r.tmp.alloc((size_t)B * HW * dim);
@@ -728,8 +727,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     const int nf = 4 * n + 2;
     ConvGeom g;
     if (geom_fwd_layer(U->lincat, B, 0, &g)) return -1;
-    RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], r.scratch, r.st));           // all FiLM weights at once
-    RUN(launch_colsum(dss, (size_t)B, U->ss_total, U->ss_total, U->G[nf], r.scratch, r.st));     // all FiLM biases at once
+    // all FiLM weights and biases at once (contiguous in the flat gradient buffer)
+    RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], U->G[nf], r.scratch, r.st));
     float* d_st = r.tmp.alloc((size_t)B * td);
     if (conv_dgrad(r, U->lincat, dss, nullptr, d_st)) return -1;
     float* d_temb = r.tmp.alloc((size_t)B * td);

@@ -156,6 +156,145 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// software-pipelined variant (the hot one): all taps of a Cin-chunk in one LDS slab (T <= 9), Cin % KC == 0,
+// 16-byte aligned sources.  Per thread the (halo pixel, quad) -> (global offset, LDS offset) decode is done ONCE
+// in the prologue; per chunk the thread issues its <= AMAX + BMAX global loads for chunk i+1 into registers right
+// after the barrier that publishes chunk i, so HBM/L2 latency hides under the 9*KC/2*NT MFMAs of chunk i.
+// ---------------------------------------------------------------------------------------------------
+template <int KC, int NT, int AMAX, int BMAX>
+__global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
+                                                              const float* __restrict__ src1, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ residual, float* __restrict__ out) {
+  constexpr int KCP = KC + 4;
+  constexpr int BN = 32 * NT;
+  constexpr int Q = KC / 4;
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ int tap_off[16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int z = blockIdx.z;
+  const int tiles_n = (g.Cout + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int n0 = tile_n * BN;
+  const int T = g.KH * g.KW;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  float* As = smem;
+  float* Bs = smem + (size_t)npixA * KCP;
+  const int tpi = g.Hv / g.TH;
+  const int b0 = (tile_m / tpi) * g.NI;
+  const int vy0 = (tile_m % tpi) * g.TH;
+  const int iy0 = vy0 * g.stride - g.pad_y[z];
+  const int ix0 = -g.pad_x[z];
+  const float* wz = wp + g.w_off[z];
+  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
+
+  const int pm = wave * 32 + l31;
+  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
+
+  // ---- prologue: decode this thread's staging slots once (q = tid % Q is the same for every slot) ----
+  const int nA = npixA * Q, nB = T * BN * Q;
+  const int aq = tid % Q;
+  int a_pix[AMAX];    // global pixel index, -1: zero fill
+  int a_lds[AMAX];    // float offset in As, -1: slot unused
+#pragma unroll
+  for (int k = 0; k < AMAX; ++k) {
+    const int e = tid + k * 256;
+    a_pix[k] = -1;
+    a_lds[k] = -1;
+    if (e < nA) {
+      const int hp = e / Q;
+      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
+      a_lds[k] = hp * KCP + 4 * aq;
+      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
+    }
+  }
+  const int CinP = g.Cin;  // Cin % KC == 0 for this kernel
+  // B slot k of this thread: e = tid + 256k -> (q = e % Q, row = (e / Q) % BN, tl = e / (Q*BN)); all powers of two
+  const int bq = tid % Q, brow0 = (tid / Q) % BN;
+  f32x4 ra[AMAX], rb[BMAX];  // native vectors: stay in VGPRs across the loop back-edge
+
+#define PIDM_PREFETCH(c0_)                                                                                         \
+  {                                                                                                                \
+    const int c0__ = (c0_);                                                                                        \
+    const float* sp__ = (c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0);                                       \
+    const int ld__ = (c0__ < g.C0) ? g.ld0 : g.ld1;                                                                \
+    _Pragma("unroll") for (int k = 0; k < AMAX; ++k) {                                                             \
+      ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
+      if (a_pix[k] >= 0) ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (size_t)a_pix[k] * ld__ + 4 * aq);        \
+    }                                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) {                                                             \
+      const int e = tid + k * 256;                                                                                 \
+      const int row = (brow0 + (k * 256 / Q)) % BN, tl = (e < nB) ? e / (Q * BN) : 0;                              \
+      rb[k] = *reinterpret_cast<const f32x4*>(wz +  ((size_t)(n0 + row) * T + tl) * CinP + c0__ + 4 * bq);        \
+    }                                                                                                              \
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  PIDM_PREFETCH(0)
+  for (int c0 = 0; c0 < CinP; c0 += KC) {
+    __syncthreads();          // previous chunk's LDS reads are done
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k)
+      if (a_lds[k] >= 0) *reinterpret_cast<f32x4*>(As + a_lds[k]) = ra[k];
+#pragma unroll
+    for (int k = 0; k < BMAX; ++k) {
+      const int e = tid + k * 256;
+      if (e < nB) {
+        const int row = (brow0 + (k * 256 / Q)) % BN, tl = e / (Q * BN);
+        *reinterpret_cast<f32x4*>(Bs + ((size_t)tl * BN + row) * KCP + 4 * bq) = rb[k];
+      }
+    }
+    __syncthreads();          // chunk c0 visible
+    if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
+    for (int t = 0; t < T; ++t) {
+      const float* arow = As + (size_t)(abase + tap_off[t]) * KCP + 4 * half;
+      const float* brow = Bs + ((size_t)t * BN + l31) * KCP + 4 * half;
+#pragma unroll
+      for (int g8 = 0; g8 < KC / 8; ++g8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * g8);
+        float4 b4[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const float4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef PIDM_PREFETCH
+
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int c = n0 + ni * 32 + l31;
+    if (c >= g.Cout) continue;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int p = wave * 32 + row;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int b = b0 + img;
+      if (b >= g.B || img >= g.NI) continue;
+      const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+      float v = acc[ni][r] + bv;
+      if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
+      if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
+      out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: reference layout -> [nz][Np][T][Kp] (zero padded)
 //   kind 0: fwd, normal conv        src [N=Cout][K=Cin][KH][KW]
 //   kind 1: fwd, transposed 4x4s2   src [K=Cin][N=Cout][4][4], 4 parity classes of 2x2 taps
@@ -341,6 +480,150 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
   }
 }
 
+// software-pipelined wgrad (3x3 / 1x1, 16-byte aligned operands): the (halo pixel, quad) decode is done once, the
+// next pixel tile is prefetched into registers while the 16 x nt MFMAs per wave of the current one run.
+template <int MAXT>
+__global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
+                                                              const float* __restrict__ src1, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, float* __restrict__ bias_partial) {
+  constexpr int XMAX = 9, YMAX = 4;
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ int tap_off[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int T = g.KH * g.KW;
+  const int ntn = wg.NP / 32;
+  int rest = blockIdx.y;
+  const int tg = rest % wg.ntg;
+  rest /= wg.ntg;
+  const int tn = rest % ntn, tm = rest / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int t0 = tg * wg.tgs;
+  const int nt = (T - t0 < wg.tgs) ? (T - t0) : wg.tgs;
+  const int split = blockIdx.x;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  float* Xs = smem;
+  float* Ys = smem + (size_t)npixA * 32;
+  const int tpi = g.Hv / g.TH;
+  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
+
+  // ---- prologue: per-thread staging slots.  quad q = tid & 7 is the same for every slot ----
+  const int q = tid & 7;
+  const int cx = n0 + 4 * q;                       // X channel of this thread
+  const bool cx_ok = cx < g.Cin;
+  const float* xsrc = (cx < g.C0) ? src0 + cx : src1 + (cx - g.C0);
+  const int xld = (cx < g.C0) ? g.ld0 : g.ld1;
+  const int cy = m0 + 4 * q;
+  const bool cy_ok = cy < g.Cout;
+  int x_dec[XMAX];   // packed (img << 20 | hy << 10 | hx), -1: slot unused
+#pragma unroll
+  for (int k = 0; k < XMAX; ++k) {
+    const int hp = (tid + k * 256) >> 3;
+    x_dec[k] = -1;
+    if (hp < npixA && cx_ok) {
+      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      x_dec[k] = (img << 20) | (hy << 10) | hx;
+    }
+  }
+  f32x4 rx[XMAX], ry[YMAX];
+
+#define PIDM_WG_PREFETCH(tile_)                                                                                   \
+  {                                                                                                               \
+    const int tile__ = (tile_);                                                                                   \
+    const int b0__ = (tile__ / tpi) * g.NI, vy0__ = (tile__ % tpi) * g.TH;                                        \
+    const int iy0__ = vy0__ * g.stride - g.pad_y[0], ix0__ = -g.pad_x[0];                                         \
+    _Pragma("unroll") for (int k = 0; k < XMAX; ++k) {                                                            \
+      rx[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                          \
+      if (x_dec[k] >= 0) {                                                                                        \
+        const int b = b0__ + (x_dec[k] >> 20), iy = iy0__ + ((x_dec[k] >> 10) & 1023), ix = ix0__ + (x_dec[k] & 1023); \
+        if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                               \
+          rx[k] = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * g.Hi + iy) * g.Wi + ix) * xld);            \
+      }                                                                                                           \
+    }                                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < YMAX; ++k) {                                                            \
+      const int p = (tid + k * 256) >> 3;                                                                         \
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);                  \
+      const int b = b0__ + img;                                                                                   \
+      ry[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                          \
+      if (cy_ok && b < g.B && img < g.NI)                                                                         \
+        ry[k] = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * g.Hv + (vy0__ + ty)) * g.Wv + tx) * wg.ld_dy + cy); \
+    }                                                                                                             \
+  }
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0) && (tg == 0);
+  float bacc = 0.f;
+
+  const int tile_lo = split * wg.tiles_per_split;
+  const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
+  if (tile_lo < tile_hi) PIDM_WG_PREFETCH(tile_lo)
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XMAX; ++k) {
+      const int hp = (tid + k * 256) >> 3;
+      if (hp < npixA) *reinterpret_cast<f32x4*>(Xs + (size_t)hp * 32 + 4 * q) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < YMAX; ++k) {
+      const int p = (tid + k * 256) >> 3;
+      *reinterpret_cast<f32x4*>(Ys + (size_t)p * 32 + 4 * q) = ry[k];
+    }
+    __syncthreads();
+    if (tile + 1 < tile_hi) PIDM_WG_PREFETCH(tile + 1)
+    if (do_bias) {
+      const int o = tid & 31, part = tid >> 5;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
+    }
+    for (int ks = 0; ks < 16; ++ks) {
+      const int p = wave * 32 + 2 * ks + half;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
+      const float a = Ys[p * 32 + l31];
+#pragma unroll
+      for (int tl = 0; tl < MAXT; ++tl) {
+        if (tl < nt) {
+          const float bv = Xs[(size_t)(xb + tap_off[t0 + tl]) * 32 + l31];
+          acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tl], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef PIDM_WG_PREFETCH
+  float* red = smem;  // [4][1024]
+#pragma unroll
+  for (int tl = 0; tl < MAXT; ++tl) {
+    if (tl < nt) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        red[wave * 1024 + row * 32 + l31] = acc[tl][r];
+      }
+      __syncthreads();
+      for (int e = tid; e < 1024; e += 256) {
+        const float sv = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        const int row = e >> 5, col = e & 31;
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + (t0 + tl)) * wg.NP + n0 + col] = sv;
+      }
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[k * 32 + tid];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
 // dst[(m*N + n)*T + t] = sum_s partial[s][m][t][n]  and  dbias[m] = sum_s bias_partial[s][m].
 // One block = 32 consecutive outputs (n fastest: coalesced reads of the partials) x 8 split lanes.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dst,
@@ -447,11 +730,17 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
 }
 
 static int pick_kc(int Cin) { return (Cin % 16 == 0) ? 16 : 8; }
-static int pick_nt(int Cout) { return Cout > 32 ? 2 : 1; }
+// n-tiles per workgroup: 64 output channels per workgroup unless that leaves the chip under-filled
+static int pick_nt(int Cout, int tiles_m) {
+  if (Cout <= 32) return 1;
+  return (tiles_m * cdiv(Cout, 64) >= 384) ? 2 : 1;
+}
+// packed weights always pad Cout to a multiple of 64 so that either tile width can read them
+static int packed_np(int Cout) { return cdiv(Cout, 64) * 64; }
 
 size_t packed_floats(const ConvGeom& g) {
-  const int KC = pick_kc(g.Cin), BN = 32 * pick_nt(g.Cout);
-  const size_t Np = (size_t)cdiv(g.Cout, BN) * BN, Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  const int KC = pick_kc(g.Cin);
+  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Cin, KC) * KC;
   return (size_t)g.nz * Np * g.KH * g.KW * Kp;
 }
 
@@ -460,8 +749,8 @@ size_t packed_floats(const ConvGeom& g) {
 // Padding must have been zero-filled by the caller.
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
                 int n_src, int k_src, hipStream_t st) {
-  const int KC = pick_kc(g.Cin), BN = 32 * pick_nt(g.Cout);
-  const int Np = cdiv(g.Cout, BN) * BN, Kp = cdiv(g.Cin, KC) * KC, T = g.KH * g.KW;
+  const int KC = pick_kc(g.Cin);
+  const int Np = packed_np(g.Cout), Kp = cdiv(g.Cin, KC) * KC, T = g.KH * g.KW;
   const int N = n_src > 0 ? n_src : g.Cout, K = k_src > 0 ? k_src : g.Cin;
   const size_t total = (size_t)g.nz * N * T * K;
   int blocks = (int)((total + 255) / 256);
@@ -475,10 +764,36 @@ int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed
 template <int KC, int NT>
 static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const float* wp, const float* bias,
                          const float* residual, float* out, int sigmoid_last, hipStream_t st) {
-  constexpr int KCP = KC + 4, BN = 32 * NT;
+  constexpr int KCP = KC + 4, BN = 32 * NT, Q = KC / 4;
+  constexpr int AMAX = 5, BMAX = (9 * BN * Q + 255) / 256;
   const int T = g.KH * g.KW;
   const size_t a_bytes = (size_t)g.NI * g.IHt * g.IWt * KCP * sizeof(float);
   const size_t b_tap = (size_t)BN * KCP * sizeof(float);
+  size_t off = 0;
+  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  for (int z = 0; z < g.nz; ++z) { g.w_off[z] = (long)off; off += Np * T * Kp; }
+  const int tiles_n = cdiv(g.Cout, BN);
+  const bool prof = prof_enabled();
+  const double flops = 2.0 * g.B * g.Hv * g.Wv * g.nz * (double)g.Cout * g.Cin * T;
+  // ---- pipelined kernel when the whole tap set fits one slab and the sources are chunk-aligned ----
+  const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % KC == 0) && (g.C0 % KC == 0);
+  const int nA = g.NI * g.IHt * g.IWt * Q;
+  const size_t lds_pipe = a_bytes + (size_t)T * b_tap;
+  if (aligned && T <= 9 && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
+    static bool attr_pipe = false;
+    if (!attr_pipe) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_pipe = true;
+    }
+    if (prof) prof_begin_launch(0, flops, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAX>), dim3(g.tiles_m * tiles_n, 1, g.nz), dim3(256),
+                       lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
+    if (prof) prof_end_launch(st);
+    PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
+    return 0;
+  }
+  // ---- generic kernel (tap groups, ragged channels, scalar staging) ----
   const size_t budget = 72 * 1024;  // keep two workgroups per CU where the halo tile allows
   int tgs = T;
   if (a_bytes + (size_t)tgs * b_tap > budget) {
@@ -488,18 +803,13 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   if (tgs > T) tgs = T;
   const size_t lds = a_bytes + (size_t)tgs * b_tap;
   if (lds > 160 * 1024 - 512) return fail("conv: tile needs %zu B of LDS", lds);
-  size_t off = 0;
-  const size_t Np = (size_t)cdiv(g.Cout, BN) * BN, Kp = (size_t)cdiv(g.Cin, KC) * KC;
-  for (int z = 0; z < g.nz; ++z) { g.w_off[z] = (long)off; off += Np * T * Kp; }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KC, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr_done = true;
   }
-  const int tiles_n = cdiv(g.Cout, BN);
-  const bool prof = prof_enabled();
-  if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * g.nz * (double)g.Cout * g.Cin * T, st);
+  if (prof) prof_begin_launch(0, flops, st);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<KC, NT>), dim3(g.tiles_m * tiles_n, 1, g.nz), dim3(256), lds, st, g,
                      tgs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
   if (prof) prof_end_launch(st);
@@ -509,7 +819,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
 
 int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
                 const float* residual, float* out, int sigmoid_last, hipStream_t st) {
-  const int KC = pick_kc(g.Cin), NT = pick_nt(g.Cout);
+  const int KC = pick_kc(g.Cin), NT = pick_nt(g.Cout, g.tiles_m * g.nz);
   if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 16 && NT == 1) return launch_conv_t<16, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 8 && NT == 2) return launch_conv_t<8, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
@@ -563,7 +873,20 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   }
   const bool prof = prof_enabled();
   if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
-  if (wg.tgs == 1)
+  const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
+                       ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
+  if (aligned && T <= 9 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
+    static bool attr_p = false;
+    if (!attr_p) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_p = true;
+    }
+    if (wg.tgs == 1)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  } else if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // in the prologue; per chunk the thread issues its <= AMAX + BMAX global loads for chunk i+1 into registers right
 // after the barrier that publishes chunk i, so HBM/L2 latency hides under the 9*KC/2*NT MFMAs of chunk i.
 // ---------------------------------------------------------------------------------------------------
-template <int KC, int NT, int AMAX, int BMAX>
+template <int KC, int NT, int AMAX, int BMAX, int KH, int KW>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
                                                               const float* __restrict__ bias,
@@ -170,7 +170,6 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   constexpr int BN = 32 * NT;
   constexpr int Q = KC / 4;
   HIP_DYNAMIC_SHARED(float, smem)
-  __shared__ int tap_off[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -178,7 +177,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int tiles_n = (g.Cout + BN - 1) / BN;
   const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
   const int n0 = tile_n * BN;
-  const int T = g.KH * g.KW;
+  constexpr int T = KH * KW;
   const int npixA = g.NI * g.IHt * g.IWt;
   float* As = smem;
   float* Bs = smem + (size_t)npixA * KCP;
@@ -188,7 +187,6 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int iy0 = vy0 * g.stride - g.pad_y[z];
   const int ix0 = -g.pad_x[z];
   const float* wz = wp + g.w_off[z];
-  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
 
   const int pm = wave * 32 + l31;
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
@@ -254,19 +252,27 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     }
     __syncthreads();          // chunk c0 visible
     if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
-    for (int t = 0; t < T; ++t) {
-      const float* arow = As + (size_t)(abase + tap_off[t]) * KCP + 4 * half;
-      const float* brow = Bs + ((size_t)t * BN + l31) * KCP + 4 * half;
+    // taps fully unrolled (compile-time KHxKW): tap offsets are scalar adds, and the compiler can hoist the
+    // ds_read_b128 of the next tap above the MFMAs of the current one
+    const float* abase_p = As + (size_t)abase * KCP + 4 * half;
+    const float* bbase_p = Bs + (size_t)l31 * KCP + 4 * half;
 #pragma unroll
-      for (int g8 = 0; g8 < KC / 8; ++g8) {
-        const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * g8);
-        float4 b4[NT];
+    for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const float4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
+      for (int kx = 0; kx < KW; ++kx) {
+        const float* arow = abase_p + (size_t)(ky * g.IWt + kx) * KCP;
+        const float* brow = bbase_p + (size_t)((ky * KW + kx) * BN) * KCP;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int g8 = 0; g8 < KC / 8; ++g8) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
+          f32x4 b4[NT];
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
+          for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
+          }
         }
       }
     }
@@ -482,30 +488,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
 
 // software-pipelined wgrad (3x3 / 1x1, 16-byte aligned operands): the (halo pixel, quad) decode is done once, the
 // next pixel tile is prefetched into registers while the 16 x nt MFMAs per wave of the current one run.
-template <int MAXT>
+template <int KH, int KW>
 __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ dy,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial) {
-  constexpr int XMAX = 9, YMAX = 4;
+  constexpr int XMAX = 9, YMAX = 4, MAXT = KH * KW;
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smem)
-  __shared__ int tap_off[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int T = g.KH * g.KW;
+  constexpr int T = KH * KW;
   const int ntn = wg.NP / 32;
-  int rest = blockIdx.y;
-  const int tg = rest % wg.ntg;
-  rest /= wg.ntg;
-  const int tn = rest % ntn, tm = rest / ntn;
+  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;   // one tap group (all KHxKW taps)
   const int m0 = tm * 32, n0 = tn * 32;
-  const int t0 = tg * wg.tgs;
-  const int nt = (T - t0 < wg.tgs) ? (T - t0) : wg.tgs;
   const int split = blockIdx.x;
   const int npixA = g.NI * g.IHt * g.IWt;
   float* Xs = smem;
   float* Ys = smem + (size_t)npixA * 32;
   const int tpi = g.Hv / g.TH;
-  if (tid < T) tap_off[tid] = (tid / g.KW) * g.IWt + (tid % g.KW);
 
   // ---- prologue: per-thread staging slots.  quad q = tid & 7 is the same for every slot ----
   const int q = tid & 7;
@@ -554,7 +553,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const bool do_bias = (bias_partial != nullptr) && (tn == 0) && (tg == 0);
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0);
   float bacc = 0.f;
 
   const int tile_lo = split * wg.tiles_per_split;
@@ -584,11 +583,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
       const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
       const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
       const float a = Ys[p * 32 + l31];
+      const float* xrow = Xs + (size_t)xb * 32 + l31;
 #pragma unroll
-      for (int tl = 0; tl < MAXT; ++tl) {
-        if (tl < nt) {
-          const float bv = Xs[(size_t)(xb + tap_off[t0 + tl]) * 32 + l31];
-          acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tl], 0, 0, 0);
+      for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const float bv = xrow[(ky * g.IWt + kx) * 32];
+          acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
         }
       }
     }
@@ -597,7 +598,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   float* red = smem;  // [4][1024]
 #pragma unroll
   for (int tl = 0; tl < MAXT; ++tl) {
-    if (tl < nt) {
+    {
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
       for (int e = tid; e < 1024; e += 256) {
         const float sv = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
         const int row = e >> 5, col = e & 31;
-        partial[(((size_t)split * wg.MP + (m0 + row)) * T + (t0 + tl)) * wg.NP + n0 + col] = sv;
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + tl) * wg.NP + n0 + col] = sv;
       }
     }
   }
@@ -765,7 +766,7 @@ template <int KC, int NT>
 static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const float* wp, const float* bias,
                          const float* residual, float* out, int sigmoid_last, hipStream_t st) {
   constexpr int KCP = KC + 4, BN = 32 * NT, Q = KC / 4;
-  constexpr int AMAX = 5, BMAX = (9 * BN * Q + 255) / 256;
+  constexpr int AMAX = 5;
   const int T = g.KH * g.KW;
   const size_t a_bytes = (size_t)g.NI * g.IHt * g.IWt * KCP * sizeof(float);
   const size_t b_tap = (size_t)BN * KCP * sizeof(float);
@@ -779,16 +780,26 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % KC == 0) && (g.C0 % KC == 0);
   const int nA = g.NI * g.IHt * g.IWt * Q;
   const size_t lds_pipe = a_bytes + (size_t)T * b_tap;
-  if (aligned && T <= 9 && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
-    static bool attr_pipe = false;
-    if (!attr_pipe) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAX>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_pipe = true;
-    }
+  const bool khw_ok = (g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1) || (g.KH == 2 && g.KW == 2);
+  if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAX>), dim3(g.tiles_m * tiles_n, 1, g.nz), dim3(256),
-                       lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
+    const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
+#define PIDM_LAUNCH_PIPE(KH_, KW_)                                                                                         \
+  {                                                                                                                        \
+    constexpr int BMAXk = (KH_ * KW_ * BN * Q + 255) / 256;                                                                \
+    static bool attr_pipe = false;                                                                                         \
+    if (!attr_pipe) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
+      attr_pipe = true;                                                                                                    \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_>), grid, dim3(256), lds_pipe,  \
+                       st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                           \
+  }
+    if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3)
+    else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2)
+    else PIDM_LAUNCH_PIPE(1, 1)
+#undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
     PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
     return 0;
@@ -875,17 +886,18 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
                        ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
-  if (aligned && T <= 9 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
+  const bool khw_ok = ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1;
+  if (aligned && khw_ok && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
     static bool attr_p = false;
     if (!attr_p) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_p = true;
     }
-    if (wg.tgs == 1)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    if (g.KH == 1)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1, 1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<3, 3>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else

@@ -15,15 +15,18 @@ namespace pidm {
 static const int DH = 32;  // dim_head (the 32x32 MFMA tile)
 
 // ---- k softmax statistics over pixels: kstat[b][j] = (max_n, 1/sum_n exp(k - max)) -----------------
-__global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict__ qkv, int N, int HD,
-                                                        float* __restrict__ kstat) {
+// stage 1: online (max, sum) over one segment of pixels per block; stage 2 merges the segments.
+__global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict__ qkv, int N, int HD, int nseg,
+                                                        float* __restrict__ kpart) {
   __shared__ float sm[4][64], ssum[4][64];
-  const int b = blockIdx.y, tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int b = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
   const int j = blockIdx.x * 64 + cl;
+  const int per = (N + nseg - 1) / nseg;
+  const int n_lo = seg * per, n_hi = (n_lo + per < N) ? n_lo + per : N;
   float m = -3.0e38f, s = 0.f;
   if (j < HD) {
     const float* base = qkv + (size_t)b * N * 3 * HD + HD + j;
-    for (int n = rl; n < N; n += 4) {
+    for (int n = n_lo + rl; n < n_hi; n += 4) {
       const float v = base[(size_t)n * 3 * HD];
       const float mn = fmaxf(m, v);
       s = s * expf(m - mn) + expf(v - mn);
@@ -37,9 +40,23 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
     float M = fmaxf(fmaxf(sm[0][cl], sm[1][cl]), fmaxf(sm[2][cl], sm[3][cl]));
     float S = 0.f;
     for (int r = 0; r < 4; ++r) S += ssum[r][cl] * expf(sm[r][cl] - M);
-    kstat[((size_t)b * HD + j) * 2] = M;
-    kstat[((size_t)b * HD + j) * 2 + 1] = 1.f / S;
+    kpart[(((size_t)b * nseg + seg) * HD + j) * 2] = M;
+    kpart[(((size_t)b * nseg + seg) * HD + j) * 2 + 1] = S;
   }
+}
+__global__ void la_kstats_final_kernel(const float* __restrict__ kpart, int B, int HD, int nseg, float* __restrict__ kstat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HD) return;
+  const int b = i / HD, j = i % HD;
+  float M = -3.0e38f;
+  for (int sg = 0; sg < nseg; ++sg) M = fmaxf(M, kpart[(((size_t)b * nseg + sg) * HD + j) * 2]);
+  float S = 0.f;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const float* p = kpart + (((size_t)b * nseg + sg) * HD + j) * 2;
+    S += p[1] * expf(p[0] - M);
+  }
+  kstat[(size_t)i * 2] = M;
+  kstat[(size_t)i * 2 + 1] = 1.f / S;
 }
 
 // ---- D[b][h][i][j] = alpha * sum_n A(n,i) * Bm(n,j)  (32x32 per (b,h), K = N) ----------------------
@@ -49,10 +66,10 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
 template <int MODE>
 __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict__ qkv, const float* __restrict__ stat,
                                                          const float* __restrict__ dA, const float* __restrict__ ctx,
-                                                         float* __restrict__ D, float* __restrict__ rowdot, int N, int heads,
-                                                         float alpha, float scale) {
+                                                         float* __restrict__ Dpart, int N, int heads, float scale) {
   __shared__ float red[4][1024];
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+  const int ns = blockIdx.y, NS = gridDim.y;
   const int HD = heads * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   f32x16 acc;
@@ -63,8 +80,10 @@ __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict
     cm = stat[((size_t)b * HD + h * DH + l31) * 2];
     cis = stat[((size_t)b * HD + h * DH + l31) * 2 + 1];
   }
-  const int per = (N + 3) / 4;
-  const int n_lo = wave * per, n_hi = (n_lo + per < N) ? n_lo + per : N;
+  const int per_blk = (N + NS - 1) / NS;
+  const int blk_lo = ns * per_blk, blk_hi = (blk_lo + per_blk < N) ? blk_lo + per_blk : N;
+  const int per = (blk_hi - blk_lo + 3) / 4;
+  const int n_lo = blk_lo + wave * per, n_hi = (n_lo + per < blk_hi) ? n_lo + per : blk_hi;
   for (int n0 = n_lo; n0 < n_hi; n0 += 2) {
     const int n = n0 + half;
     float a = 0.f, bv = 0.f;
@@ -86,18 +105,30 @@ __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict
     red[wave][row * 32 + l31] = acc[r];
   }
   __syncthreads();
-  float* out = D + (size_t)bh * 1024;
+  float* out = Dpart + ((size_t)bh * NS + ns) * 1024;
+  for (int e = tid; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// D[bh] = alpha * sum_ns Dpart[bh][ns]; MODE 1 additionally rowdot[bh][i] = sum_j D[i][j] * ctx[bh][i][j]
+template <int MODE>
+__global__ void __launch_bounds__(256) la_nreduce_final_kernel(const float* __restrict__ Dpart, const float* __restrict__ ctx,
+                                                               float* __restrict__ D, float* __restrict__ rowdot, int NS,
+                                                               float alpha) {
+  __shared__ float prod[1024];
+  const int bh = blockIdx.x, tid = threadIdx.x;
   for (int e = tid; e < 1024; e += 256) {
-    const float v = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * alpha;
-    out[e] = v;
-    if (MODE == 1) red[0][e] = v * ctx[(size_t)bh * 1024 + e];
+    float v = 0.f;
+    for (int k = 0; k < NS; ++k) v += Dpart[((size_t)bh * NS + k) * 1024 + e];
+    v *= alpha;
+    D[(size_t)bh * 1024 + e] = v;
+    if (MODE == 1) prod[e] = v * ctx[(size_t)bh * 1024 + e];
   }
   if (MODE == 1) {
     __syncthreads();
     if (tid < 32) {
-      float s = 0.f;
-      for (int j = 0; j < 32; ++j) s += red[0][tid * 32 + j];
-      rowdot[(size_t)bh * 32 + tid] = s;
+      float sacc = 0.f;
+      for (int j = 0; j < 32; ++j) sacc += prod[tid * 32 + j];
+      rowdot[(size_t)bh * 32 + tid] = sacc;
     }
   }
 }
@@ -285,6 +316,79 @@ __global__ void __launch_bounds__(256) la_bwd_pix_kernel(const float* __restrict
   }
 }
 
+// ---- backward per pixel on the matrix cores (N % 128 == 0): one wave = 32 pixels, loops over heads ----------
+// three 32x32x32 GEMMs per (32 pixels, head): dq' = dA ctx^T, dP = v dctx^T, dv = P dctx; the softmax Jacobians are
+// applied in the MFMA C layout (row = pixel, col = channel), where the d-reduction of the q-softmax is a 32-lane
+// butterfly and the k-softmax term needs only per-column constants.
+__global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                              const float* __restrict__ qstat, const float* __restrict__ ctx,
+                                                              const float* __restrict__ dctx, const float* __restrict__ rowdot,
+                                                              const float* __restrict__ dA, float* __restrict__ dqkv, int N,
+                                                              int heads, float scale) {
+  __shared__ float sc[32][33], sd[32][33], srd[32], skm[32], skis[32];
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const size_t pblk = (size_t)blockIdx.x * 128;          // first pixel (b*N + n) of the block; one image per block
+  const int b = (int)(pblk / N);
+  const size_t pw = pblk + wave * 32;                     // first pixel of this wave
+  const size_t pa = pw + l31;                             // this lane's A-layout pixel
+  const float invN = 1.f / (float)N;
+  for (int h = 0; h < heads; ++h) {
+    const int bh = b * heads + h;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      sc[e >> 5][e & 31] = ctx[(size_t)bh * 1024 + e];
+      sd[e >> 5][e & 31] = dctx[(size_t)bh * 1024 + e];
+    }
+    if (tid < 32) {
+      srd[tid] = rowdot[(size_t)bh * 32 + tid];
+      skm[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2];
+      skis[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2 + 1];
+    }
+    __syncthreads();
+    // A-layout operands: 16 contiguous channels [16*half, 16*half+16) of this lane's pixel
+    const float* rowA = qkv + pa * 3 * HD + h * DH + 16 * half;
+    f32x4 a_dA[4], a_v[4], a_k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a_dA[j] = *reinterpret_cast<const f32x4*>(dA + pa * HD + h * DH + 16 * half + 4 * j);
+      a_k[j] = *reinterpret_cast<const f32x4*>(rowA + HD + 4 * j);
+      a_v[j] = *reinterpret_cast<const f32x4*>(rowA + 2 * HD + 4 * j);
+    }
+    f32x16 acc1, acc2, acc3;
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int s = 4 * j + c, kk = 16 * half + s;
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dA[j][c], sc[l31][kk], acc1, 0, 0, 0);   // dq'[n][d] += dA[n][e] ctx[d][e]
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31][kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
+        const float pA = expf(a_k[j][c] - skm[kk]) * skis[kk];
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk][l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
+      }
+    }
+    // epilogues in the C layout: row r -> pixel pw + prow, column l31 -> channel
+    const float km = skm[l31], kis = skis[l31], rd = srd[l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int prow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const size_t p = pw + prow;
+      const float* rowC = qkv + p * 3 * HD + h * DH + l31;
+      const float qm = qstat[(p * heads + h) * 2], qis = qstat[(p * heads + h) * 2 + 1];
+      const float qs = expf(rowC[0] - qm) * qis;
+      float dot = qs * acc1[r];
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) dot += __shfl_xor(dot, off);
+      float* o = dqkv + p * 3 * HD + h * DH + l31;
+      o[0] = scale * qs * (acc1[r] - dot);
+      const float P = expf(rowC[HD] - km) * kis;
+      o[HD] = P * (acc2[r] * invN - rd);
+      o[2 * HD] = acc3[r] * invN;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // bottleneck softmax attention over N <= 64 tokens, one workgroup per (b, h)
 // ---------------------------------------------------------------------------------------------------
@@ -385,15 +489,41 @@ __global__ void __launch_bounds__(256) mid_attn_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+static int la_nsplit(int N) {
+  int ns = N / 512;
+  if (ns < 1) ns = 1;
+  if (ns > 8) ns = 8;
+  return ns;
+}
+static int la_kseg(int N) {
+  int s = N / 256;
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  return s;
+}
+// floats of scratch needed by launch_la_forward / launch_la_backward
+size_t la_scratch_floats(int B, int N, int heads) {
+  const size_t a = (size_t)B * la_kseg(N) * heads * DH * 2, b = (size_t)B * heads * la_nsplit(N) * 1024;
+  return a + b + 64;
+}
+
 int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
-                      hipStream_t st) {
+                      float* scratch, hipStream_t st) {
   const int HD = heads * DH;
   const float scale = 0.17677669529663687f;  // 32^-0.5
-  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B), dim3(256), 0, st, qkv, N, HD, kstat);
+  const int nseg = la_kseg(N), NS = la_nsplit(N);
+  float* kpart = scratch;
+  float* dpart = scratch + (size_t)B * nseg * HD * 2;
+  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart);
   PIDM_CHECK_LAUNCH("la_kstats_kernel");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads), dim3(256), 0, st, qkv, kstat, nullptr, nullptr, ctx,
-                     nullptr, N, heads, 1.f / (float)N, scale);
+  hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
+  PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads, NS), dim3(256), 0, st, qkv, kstat, nullptr, nullptr,
+                     dpart, N, heads, scale);
   PIDM_CHECK_LAUNCH("la_context");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
+                     1.f / (float)N);
+  PIDM_CHECK_LAUNCH("la_context_final");
   const size_t npix = (size_t)B * N;
   hipLaunchKernelGGL(la_out_kernel, dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn, qstat, N, heads, npix,
                      scale);
@@ -402,13 +532,22 @@ int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, f
 }
 
 int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
-                       float* rowdot, float* dqkv, int B, int N, int heads, hipStream_t st) {
+                       float* rowdot, float* dqkv, int B, int N, int heads, float* scratch, hipStream_t st) {
   const float scale = 0.17677669529663687f;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<1>), dim3(B * heads), dim3(256), 0, st, qkv, qstat, dA, ctx, dctx, rowdot, N,
-                     heads, 1.f, scale);
+  const int NS = la_nsplit(N);
+  float* dpart = scratch;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<1>), dim3(B * heads, NS), dim3(256), 0, st, qkv, qstat, dA, ctx, dpart, N, heads,
+                     scale);
   PIDM_CHECK_LAUNCH("la_dctx");
-  hipLaunchKernelGGL(la_bwd_pix_kernel, dim3(cdiv(N, 256), B * heads), dim3(256), 0, st, qkv, kstat, qstat, ctx, dctx, rowdot, dA,
-                     dqkv, N, heads, scale);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<1>), dim3(B * heads), dim3(256), 0, st, dpart, ctx, dctx, rowdot, NS, 1.f);
+  PIDM_CHECK_LAUNCH("la_dctx_final");
+  if (N % 128 == 0) {
+    hipLaunchKernelGGL(la_bwd_pix_mfma_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), 0, st, qkv, kstat, qstat, ctx,
+                       dctx, rowdot, dA, dqkv, N, heads, scale);
+  } else {
+    hipLaunchKernelGGL(la_bwd_pix_kernel, dim3(cdiv(N, 256), B * heads), dim3(256), 0, st, qkv, kstat, qstat, ctx, dctx, rowdot,
+                       dA, dqkv, N, heads, scale);
+  }
   PIDM_CHECK_LAUNCH("la_bwd_pix_kernel");
   return 0;
 }

@@ -336,6 +336,38 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
   }
 }
 
+// all weight tensors of the model in ONE launch: a device-side descriptor table, each block owns 2048 elements
+__global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restrict__ table, int ndesc) {
+  int lo = 0, hi = ndesc - 1;
+  const unsigned bid = blockIdx.x;
+  while (lo < hi) {  // last descriptor with blk0 <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = table[lo];
+  const size_t total = (size_t)d.nz * d.N * d.T * d.K;
+  const size_t base = (size_t)(bid - d.blk0) * 2048;
+  for (int it = 0; it < 8; ++it) {
+    const size_t idx = base + it * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int k = (int)(idx % d.K);
+    const int t = (int)((idx / d.K) % d.T);
+    const int n = (int)((idx / ((size_t)d.K * d.T)) % d.N);
+    const int z = (int)(idx / ((size_t)d.K * d.T * d.N));
+    float v;
+    if (d.kind == 0 || d.kind == 4) {
+      v = d.src[((size_t)n * d.K + k) * d.T + t];
+    } else if (d.kind == 2) {
+      const int ky = d.KH - 1 - t / d.KW, kx = d.KW - 1 - t % d.KW;
+      v = d.src[(((size_t)k * d.N + n) * d.KH + ky) * d.KW + kx];
+    } else {
+      const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
+      v = d.src[(((size_t)k * d.N + n) * 4 + ky) * 4 + kx];
+    }
+    d.dst[(((size_t)z * d.Np + d.n_off + n) * d.T + t) * d.Kp + d.k_off + k] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wgrad: dW[m][t][n] = sum_p dY[p][m] * X[p (+tap)][n]   (M = rows of dY's channels, N = X's channels)
 // one workgroup = 32 x 32 output block for up to `tgs` taps, over `tiles_per_split` pixel tiles;
@@ -762,6 +794,24 @@ int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed
   return 0;
 }
 
+// fill a descriptor for the multi-tensor pack (same arguments as launch_pack); returns its block count
+unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off,
+                        int k_off, int n_src, int k_src, PackDesc* d) {
+  const int KC = pick_kc(g.Cin);
+  d->src = w_ref; d->dst = w_packed; d->kind = kind; d->nz = g.nz;
+  d->N = n_src > 0 ? n_src : g.Cout; d->K = k_src > 0 ? k_src : g.Cin;
+  d->Np = packed_np(g.Cout); d->Kp = cdiv(g.Cin, KC) * KC; d->KH = srcKH; d->KW = srcKW; d->T = g.KH * g.KW;
+  d->n_off = n_off; d->k_off = k_off;
+  const size_t total = (size_t)d->nz * d->N * d->T * d->K;
+  d->nblk = (unsigned)((total + 2047) / 2048);
+  return d->nblk;
+}
+int launch_pack_multi(const PackDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc);
+  PIDM_CHECK_LAUNCH("pack_multi_kernel");
+  return 0;
+}
+
 template <int KC, int NT>
 static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const float* wp, const float* bias,
                          const float* residual, float* out, int sigmoid_last, hipStream_t st) {
@@ -849,10 +899,18 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->MP = cdiv(g.Cout, 32) * 32;
   wg->NP = cdiv(g.Cin, 32) * 32;
   const int blocks_mn = (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
-  int nsplit = 768 / blocks_mn;
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > g.tiles_m) nsplit = g.tiles_m;
-  wg->tiles_per_split = cdiv(g.tiles_m, nsplit);
+  // one workgroup per CU is resident (144 accumulator registers): pick tiles-per-split so that the number of
+  // workgroup "rounds" over the 256 CUs times the per-workgroup work (+ ~1.5 tile-equivalents of prologue and
+  // cross-wave reduction) is minimal
+  int best_tps = g.tiles_m;
+  double best_cost = 1e30;
+  for (int tps = 1; tps <= g.tiles_m; ++tps) {
+    const long wgs = (long)blocks_mn * cdiv(g.tiles_m, tps);
+    if (wgs > 4096 && tps < g.tiles_m) continue;
+    const double cost = (double)((wgs + 255) / 256) * (tps + 1.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_tps = tps; }
+  }
+  wg->tiles_per_split = best_tps;
   wg->nsplit = cdiv(g.tiles_m, wg->tiles_per_split);
 }
 

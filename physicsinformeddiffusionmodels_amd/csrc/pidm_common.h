@@ -62,4 +62,12 @@ struct ConvGeom {
   int tiles_m;       // number of 128-pixel tiles
 };
 
+// one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)
+struct PackDesc {
+  const float* src;
+  float* dst;
+  int kind, nz, N, K, Np, Kp, KH, KW, T, n_off, k_off;
+  unsigned blk0, nblk;
+};
+
 }  // namespace pidm

@@ -10,6 +10,9 @@ int geom_dgrad(const pidm_conv_desc* d, int ld_dy, int ld_dx, ConvGeom* g, int* 
 size_t packed_floats(const ConvGeom& g);
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
                 int n_src, int k_src, hipStream_t st);
+unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off,
+                        int k_off, int n_src, int k_src, PackDesc* d);
+int launch_pack_multi(const PackDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st);
 int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
                 const float* residual, float* out, int sigmoid_last, hipStream_t st);
 size_t wgrad_ws_bytes(const ConvGeom& g);
@@ -35,9 +38,10 @@ int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st
 int launch_copy_add(float* dst, int ldd, const float* a, int lda, const float* b, int ldb, size_t rows, int cols, hipStream_t st);
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, const float* y_sig, hipStream_t st);
 // k_attn.hip
+size_t la_scratch_floats(int B, int N, int heads);
 int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
-                      hipStream_t st);
+                      float* scratch, hipStream_t st);
 int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
-                       float* rowdot, float* dqkv, int B, int N, int heads, hipStream_t st);
+                       float* rowdot, float* dqkv, int B, int N, int heads, float* scratch, hipStream_t st);
 int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st);
 }  // namespace pidm

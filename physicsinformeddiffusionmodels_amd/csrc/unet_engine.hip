@@ -78,6 +78,9 @@ struct pidm_unet {
   std::vector<ConvLayer> down, up;
   size_t packed_floats_total = 0;
   const void* packed_zeroed_for = nullptr;
+  std::vector<PackDesc> pack_table;   // host copy of the device-side descriptor table (lives after the packed weights)
+  unsigned pack_blocks = 0;
+  bool pack_table_valid = false;
 
   // tape of the latest forward
   int tape_B = 0;
@@ -92,6 +95,8 @@ struct pidm_unet {
 };
 
 namespace pidm {
+
+static const size_t kMaxPackDesc = 1024;
 
 struct Run {
   pidm_unet* U;
@@ -325,6 +330,7 @@ extern "C" int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, 
     h->G[i] = grad_ptrs_host ? reinterpret_cast<float*>(grad_ptrs_host[i]) : nullptr;
   }
   h->have_grads = grad_ptrs_host != nullptr;
+  h->pack_table_valid = false;   // parameter pointers may have changed
   if (h->have_grads) {
     // the FiLM linear gradients must be contiguous (see pidm_unet_create)
     const int nf = 4 * h->n_lv + 2;
@@ -341,26 +347,40 @@ namespace pidm {
 // ------------------------------------------------------------------------------------------------------
 // weight packing (once per step)
 // ------------------------------------------------------------------------------------------------------
+static void push_desc(Run& r, const ConvGeom& g, int kind, const float* src, float* dst, int K, int n_off, int k_off, int n_src,
+                      int k_src) {
+  PackDesc d;
+  make_pack_desc(g, kind, src, dst, K, K, n_off, k_off, n_src, k_src, &d);
+  d.blk0 = r.U->pack_blocks;
+  r.U->pack_blocks += d.nblk;
+  r.U->pack_table.push_back(d);
+}
+
 static int pack_layer(Run& r, const ConvLayer& L) {
   pidm_unet* U = r.U;
   ConvGeom g;
   if (geom_fwd_layer(L, 1, 0, &g)) return -1;
-  RUN(launch_pack(g, L.transposed ? 1 : 0, U->P[L.w], r.wpack + L.off_f, L.K, L.K, 0, 0, 0, 0, r.st));
+  push_desc(r, g, L.transposed ? 1 : 0, U->P[L.w], r.wpack + L.off_f, L.K, 0, 0, 0, 0);
   if (L.dgrad) {
     pidm_conv_desc d = desc_of(L, 1);
     int kind;
     if (geom_dgrad(&d, L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
-    RUN(launch_pack(g, kind, U->P[L.w], r.wpack + L.off_d, L.K, L.K, 0, 0, 0, 0, r.st));
+    push_desc(r, g, kind, U->P[L.w], r.wpack + L.off_d, L.K, 0, 0, 0, 0);
   }
   return 0;
 }
 
 static int pack_all(Run& r) {
   pidm_unet* U = r.U;
-  if (!r.dry && U->packed_zeroed_for != r.wpack) {
-    if (hipMemsetAsync(r.wpack, 0, U->packed_floats_total * sizeof(float), r.st) != hipSuccess) return fail("memset failed");
-    U->packed_zeroed_for = r.wpack;
+  PackDesc* table_dev = reinterpret_cast<PackDesc*>(r.wpack + U->packed_floats_total);
+  if (U->packed_zeroed_for == r.wpack && U->pack_table_valid) {
+    // same workspace, same parameter pointers: the descriptor table on the device is still valid
+    return launch_pack_multi(table_dev, (int)U->pack_table.size(), U->pack_blocks, r.st);
   }
+  if (hipMemsetAsync(r.wpack, 0, U->packed_floats_total * sizeof(float), r.st) != hipSuccess) return fail("memset failed");
+  U->packed_zeroed_for = r.wpack;
+  U->pack_table.clear();
+  U->pack_blocks = 0;
   int rc = 0;
   rc |= pack_layer(r, U->init_conv);
   rc |= pack_layer(r, U->lin1);
@@ -374,8 +394,8 @@ static int pack_all(Run& r) {
     if (geom_dgrad(&d, U->lincat.Cout, U->lincat.C0, &gd, &kind)) return -1;
     for (auto& m : U->rb) {
       if (!m.has_mlp) continue;
-      RUN(launch_pack(gf, 0, U->P[m.mlpw], r.wpack + U->lincat.off_f, 1, 1, m.ss_off, 0, 2 * m.Co, U->tdim, r.st));
-      RUN(launch_pack(gd, kind, U->P[m.mlpw], r.wpack + U->lincat.off_d, 1, 1, 0, m.ss_off, U->tdim, 2 * m.Co, r.st));
+      push_desc(r, gf, 0, U->P[m.mlpw], r.wpack + U->lincat.off_f, 1, m.ss_off, 0, 2 * m.Co, U->tdim);
+      push_desc(r, gd, kind, U->P[m.mlpw], r.wpack + U->lincat.off_d, 1, 0, m.ss_off, U->tdim, 2 * m.Co);
     }
   }
   for (auto& m : U->rb) {
@@ -392,7 +412,12 @@ static int pack_all(Run& r) {
     rc |= pack_layer(r, U->up[i]);
   }
   rc |= pack_layer(r, U->final_conv);
-  return rc;
+  if (rc) return rc;
+  if (U->pack_table.size() > kMaxPackDesc) return fail("pack: descriptor table overflow");
+  if (hipMemcpyAsync(table_dev, U->pack_table.data(), U->pack_table.size() * sizeof(PackDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
+    return fail("pack: descriptor upload failed");
+  U->pack_table_valid = true;
+  return launch_pack_multi(table_dev, (int)U->pack_table.size(), U->pack_blocks, r.st);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -458,7 +483,7 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
     a.kstat = act_alloc(r, (size_t)B * HD * 2);
     a.ctx = act_alloc(r, (size_t)B * heads * 1024);
     a.qstat = act_alloc(r, npix * heads * 2);
-    RUN(launch_la_forward(a.qkvb, a.kstat, a.ctx, a.attn, a.qstat, B, N, heads, r.st));
+    RUN(launch_la_forward(a.qkvb, a.kstat, a.ctx, a.attn, a.qstat, B, N, heads, r.scratch, r.st));
   }
   if (conv_fwd(r, a.out, a.attn, nullptr, x, out)) return -1;
   r.tmp.release(mk);
@@ -597,7 +622,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   } else {
     float* dctx = r.tmp.alloc((size_t)B * heads * 1024);
     float* rowdot = r.tmp.alloc((size_t)B * heads * 32);
-    RUN(launch_la_backward(a.qkvb, a.kstat, a.qstat, a.ctx, g_attn, dctx, rowdot, g_qkv, B, N, heads, r.st));
+    RUN(launch_la_backward(a.qkvb, a.kstat, a.qstat, a.ctx, g_attn, dctx, rowdot, g_qkv, B, N, heads, r.scratch, r.st));
   }
   if (conv_wgrad(r, a.qkv, a.xn, nullptr, g_qkv)) return -1;
   float* g_xn = g_attn;  // reuse (npix*HD >= npix*C is not guaranteed) -> allocate when C > HD
@@ -631,6 +656,7 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
   for (auto& a : U->attn) {
     conv_ws(a.qkv); conv_ws(a.out);
     upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
+    upd(la_scratch_floats(B, a.H * a.H, U->heads) * sizeof(float));
   }
   for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }
   return mx;
@@ -779,7 +805,7 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
 static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, size_t workspace_bytes, void* stream) {
   size_t tape_b, tmp_b;
   if (plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b)) return -1;
-  const size_t packed_b = align_up(h->packed_floats_total * sizeof(float), 4096);
+  const size_t packed_b = align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096);
   if (workspace_bytes < packed_b + tape_b + tmp_b)
     return fail("unet: workspace too small (%zu < %zu bytes)", workspace_bytes, packed_b + tape_b + tmp_b);
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail("unet: workspace must be 256-byte aligned");
@@ -798,7 +824,7 @@ static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, s
 extern "C" size_t pidm_unet_workspace_bytes(const pidm_unet* h, int B, int training) {
   size_t tape_b, tmp_b;
   if (plan_sizes(const_cast<pidm_unet*>(h), B, training, &tape_b, &tmp_b)) return 0;
-  return align_up(h->packed_floats_total * sizeof(float), 4096) + tape_b + tmp_b + 256;
+  return align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096) + tape_b + tmp_b + 256;
 }
 
 extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B,
@@ -810,7 +836,7 @@ extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_
     if (!h->P[i]) return fail("unet_forward: parameters not bound (pidm_unet_bind)");
   Run r;
   if (setup_run(r, h, B, save_for_backward != 0, workspace, workspace_bytes, stream)) return -1;
-  if (repack_weights || h->packed_zeroed_for != r.wpack) {
+  if (repack_weights || h->packed_zeroed_for != r.wpack || !h->pack_table_valid) {
     if (pack_all(r)) return -1;
   }
   if (forward_impl(r, x_nhwc, t, out_nchw)) return -1;

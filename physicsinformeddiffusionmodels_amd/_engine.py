@@ -53,6 +53,7 @@ class UnetEngine:
         self.workspace = None
         self._ws_key = None
         self.tape_generation = 0
+        self.tape_busy = False   # a training-mode forward whose backward has not run yet owns the tape
 
     def __del__(self):
         try:
@@ -140,6 +141,7 @@ class _UnetFunction(torch.autograd.Function):
         ctx.training = training
         if training:
             engine.tape_generation += 1
+            engine.tape_busy = True
         ctx.generation = engine.tape_generation
         out = engine.forward(x_nhwc, t, training=training)
         # the engine keeps RAW pointers to its input and output until backward: keep both tensors alive
@@ -156,6 +158,7 @@ class _UnetFunction(torch.autograd.Function):
                             "model (two differentiable UNet calls per step, e.g. x0_estimation='sample', need a second "
                             "tape: not supported yet)")
         gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
+        eng.tape_busy = False
         for p, g in zip(eng.params, eng.grad_views):
             if not p.requires_grad:
                 continue
@@ -167,9 +170,9 @@ class _UnetFunction(torch.autograd.Function):
         return None, gx, None, None, None
 
 
-def get_engine(model, image_size: int, lib: PidmLib | None = None) -> UnetEngine:
+def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0) -> UnetEngine:
     cache = model.__dict__.setdefault("_engines", {})
-    key = (image_size, id(lib))
+    key = (image_size, id(lib), slot)
     eng = cache.get(key)
     if eng is None:
         eng = UnetEngine(model, image_size, lib)
@@ -214,6 +217,14 @@ def unet_apply(model, x, time, lib: PidmLib | None = None):
     eng = get_engine(model, P, lib)
     anchor = eng.params[0]
     training = torch.is_grad_enabled() and (anchor.requires_grad or x_nhwc.requires_grad)
+    if training and eng.tape_busy and getattr(model, "_pidm_multi_tape", False):
+        # a second differentiable UNet call inside one step (x0_estimation: 'sample' evaluates the model at (x_t, t)
+        # and at (x_t, 0), src/denoising_utils.py:741-753): give it its own engine slot = own activation tape and own
+        # gradient buffer; the two backward passes then add up in p.grad.
+        slot = 1
+        while get_engine(model, P, lib, slot).tape_busy:
+            slot += 1
+        eng = get_engine(model, P, lib, slot)
     out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training)
     if video:
         out = out.unsqueeze(2)

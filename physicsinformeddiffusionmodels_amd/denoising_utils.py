@@ -402,6 +402,10 @@ class DenoisingDiffusion(nn.Module):
         batch = shape[0]
         if len(t) == 1:
             t = torch.ones(batch, device=xt.device, dtype=torch.long) * t
-        model_out = model(xt, t)
-        x0_pred = model(xt, torch.zeros_like(t))
+        model._pidm_multi_tape = True          # two live activation tapes (see _engine.unet_apply)
+        try:
+            model_out = model(xt, t)
+            x0_pred = model(xt, torch.zeros_like(t))
+        finally:
+            model._pidm_multi_tape = False
         return x0_pred, model_out

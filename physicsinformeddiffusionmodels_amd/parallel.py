@@ -15,7 +15,8 @@ import torch.distributed as dist
 
 def flat_gradient_buffers(model):
     """The engine-owned flat gradient buffer(s) of a Unet3D (one per engine instance / image size)."""
-    return [e.flat_grad for e in model.__dict__.get("_engines", {}).values() if e.flat_grad is not None]
+    # slot 0 owns the buffer p.grad aliases; further slots (second activation tape) are added INTO it by backward
+    return [e.flat_grad for k, e in model.__dict__.get("_engines", {}).items() if e.flat_grad is not None and k[2] == 0]
 
 
 def allreduce_gradients(model, world_size: int | None = None, group=None):

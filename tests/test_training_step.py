@@ -107,3 +107,37 @@ def test_second_training_forward_invalidates_tape(backend):
     _ = m(x, t)
     with pytest.raises(RuntimeError):
         out1.sum().backward()
+
+
+def test_sample_estimation_two_tapes(backend):
+    """x0_estimation='sample' (ddim_steps=0): two differentiable UNet calls per step; gradients of both add up."""
+    L, dev = backend
+    m, diff, res, dev = setup(backend, 8, 16, 100)
+    res.use_ddim_x0 = True
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 2, 16, 16, generator=g)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(2, 2, 16, 16, generator=g)
+    t = torch.tensor([7, 60])
+    with patched_rng(randint=lambda *a, **k: t.to(dev), randn_like=lambda *a, **k: eps.to(dev)):
+        loss, data_l, res_l, _, _ = diff.model_estimation_loss(x0.to(dev), residual_func=res, c_data=1., c_residual=1e-3)
+    loss.backward()
+    # oracle: data loss on model(x_t, t), residual on model(x_t, 0)  (SURVEY 3.3)
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    cfg = O.UnetCfg(dim=8, channels=2)
+    tables = O.diffusion_tables(100)
+    xt = O.q_sample(tables, x0, t, eps)
+    out1 = O.unet_forward(p, xt, t, cfg)
+    out2 = O.unet_forward(p, xt, torch.zeros_like(t), cfg)
+    r = O.darcy_residual(out2)
+    per = ((x0 - out1) ** 2).reshape(2, -1).mean(dim=1)
+    ref = (per * tables["p2_loss_weight"][t]).mean() + (1e-3 * 0.5 * r ** 2 / tables["posterior_variance_clipped"][t].reshape(2, 1, 1)).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    for k, prm in m.named_parameters():
+        if p[k].grad is None:
+            assert prm.grad is None
+            continue
+        a, b = prm.grad.cpu().norm().item(), p[k].grad.norm().item()
+        assert abs(a - b) <= 2e-3 * b + 5e-6 * gmax, (k, a, b)

@@ -69,6 +69,22 @@ int pidm_psample_update(const float* x0_pred, const float* x_t, const float* z, 
                         float* x_prev, size_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mechanics residual r = K(rho) u - f, matrix-free      replaces ResidualsMechanics.compute_residual
+ *   src/residuals_mechanics_K.py:198-274 (dense 8450x8450 index_put assembly + einsum) and resize_image :10-21
+ * x0_pred [B,3,nel,nel] NCHW (u1,u2,rho); bcs [B,4,nel+1,nel+1] (bc_x, bc_y, load_x, load_y); vf [B]
+ * mesh: kloc [E,8,8] (kloc_stride 64) or one 8x8 (stride 0); elem_dofs int32 [E,8]; dof_elems int32 [ndof,4,2]
+ * outputs: residual [B,ndof]; model_out [B,3,nel+1,nel+1] (u bilinearly resized, rho zero padded);
+ * comp_shift [B,2] = (compliance u^T K u, mean(rho) - vf).  The adjoint takes gradients of all four.
+ * ------------------------------------------------------------------------------------------- */
+int pidm_bilinear_resize(const float* in, float* out, int BC, int Hi, int Ho, void* stream);
+int pidm_mech_residual_fwd(const float* x0_pred, const float* bcs, const float* vf, const float* kloc, int kloc_stride,
+                           const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* residual, float* model_out,
+                           float* comp_shift, int B, void* stream);
+int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, const float* kloc, int kloc_stride,
+                           const int32_t* elem_dofs, const int32_t* dof_elems, int nel, const float* g_residual,
+                           const float* g_model_out, const float* g_comp_shift, float* g_x0_pred, int B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * UNet engine                           replaces Unet3D.forward src/unet_model.py:542-623 + autograd
  * ------------------------------------------------------------------------------------------- */
 typedef struct pidm_unet pidm_unet;

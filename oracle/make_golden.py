@@ -15,14 +15,22 @@ import sys
 os.environ.setdefault("MPLBACKEND", "Agg")
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "shims"))
+# The reference's `src` is a namespace package (no __init__.py); this repo's drop-in `src/` is a regular package
+# and would shadow it from ANY position on sys.path - so the repo root is NOT put on the path here and the oracle
+# helper is loaded by file name.
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
 sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "shims"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from oracle.pidm_oracle import fill_state_dict  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("pidm_oracle", os.path.join(HERE, "pidm_oracle.py"))
+_oracle = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_oracle)
+fill_state_dict = _oracle.fill_state_dict
 
 # --- genuine reference imports -------------------------------------------------------------------
 from src.unet_model import Unet3D  # noqa: E402
@@ -30,6 +38,8 @@ from src.denoising_utils import DenoisingDiffusion  # noqa: E402
 from src.residuals_darcy import ResidualsDarcy  # noqa: E402
 from src.grad_utils import GradientsHelper  # noqa: E402
 import src.denoising_utils as du  # noqa: E402
+
+assert du.__file__.startswith("/root/reference/"), "golden vectors must come from the genuine reference: " + du.__file__
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -185,7 +195,104 @@ def g8(tag, dim, P, B, n_steps=5):
     print(tag, "x_final abs mean", float(np.abs(d["x_seq"][-1]).mean()))
 
 
+# G9: mechanics residual / compliance / volume shift on a synthetic mesh (reference with dense K) ------------------
+def write_synthetic_mesh(folder, nel=64):
+    """SolidsPy text files for the nel x nel unit-square mesh of SURVEY 8(d): node id = row*(nel+1)+col,
+    coords (x=col, y=nel-row), all dofs free, element nodes CCW [bl, br, tr, tl]."""
+    nn = nel + 1
+    os.makedirs(folder, exist_ok=True)
+    nodes = np.zeros((nn * nn, 5))
+    for r in range(nn):
+        for c in range(nn):
+            nodes[r * nn + c] = [r * nn + c, c, nel - r, 0, 0]
+    eles = np.zeros((nel * nel, 7), dtype=int)
+    for r in range(nel):
+        for c in range(nel):
+            eles[r * nel + c] = [r * nel + c, 1, 0, (r + 1) * nn + c, (r + 1) * nn + c + 1, r * nn + c + 1, r * nn + c]
+    np.savetxt(folder + "nodes.txt", nodes, fmt="%d %.6f %.6f %d %d")
+    np.savetxt(folder + "eles.txt", eles, fmt="%d")
+    np.savetxt(folder + "mater.txt", np.array([[1.0, 0.3]]))
+    np.savetxt(folder + "loads.txt", np.array([[32 * nn + 64, 0.0, -1.0]]))
+
+
+def g9():
+    import tempfile
+    from src.residuals_mechanics_K import ResidualsMechanics
+    folder = tempfile.mkdtemp() + "/"
+    write_synthetic_mesh(folder)
+    res = ResidualsMechanics(model=None, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder=folder, device="cpu",
+                             topopt_eval=False)
+    B = 2
+    x0 = seeded((B, 3, 64, 64), 51, 0.1)
+    x0[:, 2] = torch.sigmoid(seeded((B, 64, 64), 52))
+    bcs = torch.zeros(B, 4, 65, 65)
+    bcs[:, 0, :, 0] = 1.0      # clamp x-displacement on the left edge
+    bcs[:, 1, :, 0] = 1.0      # clamp y-displacement on the left edge
+    bcs[0, 3, 32, 64] = -1.0   # point load
+    bcs[1, 2, 10, 64] = 0.5
+    vf = torch.tensor([0.3, 0.45])
+    x0.requires_grad_(True)
+    out = res.compute_residual((x0, bcs, vf), reduce="none", return_model_out=True, return_optimizer=True,
+                               return_inequality=True, pass_through=True)
+    wr = seeded(tuple(out["residual"].shape), 53)
+    wm = seeded(tuple(out["model_out"].shape), 54)
+    scal = (out["residual"] * wr).sum() + (out["model_out"] * wm).sum() + 0.7 * out["optimizer"].sum() + 1.3 * (out["inequality"] ** 2).sum()
+    (g,) = torch.autograd.grad(scal, x0)
+    np.savez_compressed(os.path.join(OUT, "g9_mechanics.npz"), x0=npy(x0), bcs=npy(bcs), vf=npy(vf), residual=npy(out["residual"]),
+                        model_out=npy(out["model_out"]), compliance=npy(out["optimizer"]), shift=npy(out["inequality"]),
+                        wr=npy(wr), wm=npy(wm), grad_x0=npy(g), kloc0=npy(res.stiffs.tot_local_stiffness[0]),
+                        elem_dofs=npy(res.stiffs.glob_assembler_idcs[:, :8, 1]).astype(np.int32))
+    print("g9 mechanics: |r| mean", float(out["residual"].abs().mean()), "compliance", npy(out["optimizer"]))
+
+
+# G10: full mechanics model_estimation_loss (tiny UNet, synthetic mesh, c_ineq > 0, lambda > 0) ----------------------
+def g10():
+    import tempfile
+    from src.residuals_mechanics_K import ResidualsMechanics
+    folder = tempfile.mkdtemp() + "/"
+    write_synthetic_mesh(folder)
+    torch.manual_seed(0)
+    m = Unet3D(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(100, "cpu")
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder=folder, device="cpu",
+                             topopt_eval=False)
+    B = 2
+    inp = torch.zeros(B, 10, 65, 65)
+    inp[:, 0] = torch.tensor([0.3, 0.45]).view(B, 1, 1)
+    inp[:, 1:3] = seeded((B, 2, 65, 65), 61)
+    inp[:, 3:5] = seeded((B, 2, 65, 65), 62, 0.1)
+    inp[:, 5, :64, :64] = torch.sigmoid(seeded((B, 64, 64), 63))
+    inp[:, 6, :, 0] = 1.0
+    inp[:, 7, :, 0] = 1.0
+    inp[0, 9, 32, 64] = -1.0
+    inp[1, 8, 10, 64] = 0.5
+    eps = seeded((B, 3, 65, 65), 64)
+    t = torch.tensor([4, 71], dtype=torch.long)
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda *a, **k: eps.clone()
+    try:
+        loss, data_l, res_l, ineq_l, opt_l = diff.model_estimation_loss(inp, residual_func=res, c_data=1.0, c_residual=1e-3,
+                                                                        c_ineq=0.5, lambda_opt=0.01)
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    loss.backward()
+    names, norms = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "g10_mech_loss_dim8.npz"), inp=npy(inp), eps=npy(eps), t=npy(t), loss=np.array(loss.item()),
+                        data_loss=np.array(data_l), residual_abs_mean=np.array(res_l), ineq=np.array(ineq_l), opt=np.array(opt_l),
+                        grad_names=np.array(names), grad_norms=np.array(norms))
+    print("g10 mech loss", loss.item(), data_l, res_l, ineq_l, opt_l, len(names))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10"):
+        {"g9": g9, "g10": g10}[sys.argv[1]]()
+        sys.exit(0)
     g1()
     g2_g3()
     unet_case("g5_unet_dim8_p16", dim=8, P=16, B=2, tvals=[3, 50])
@@ -194,4 +301,6 @@ if __name__ == "__main__":
     g7("g7_loss_dim8_p16", dim=8, P=16, B=3, tvals=[0, 37, 99])
     g7("g7b_loss_dim32_p64", dim=32, P=64, B=2, tvals=[5, 60])
     g8("g8_sampler_dim8_p16", dim=8, P=16, B=2, n_steps=5)
+    g9()
+    g10()
     print("golden vectors written to", OUT)

@@ -397,6 +397,12 @@ def bilinear_resize(x: torch.Tensor, size: int) -> torch.Tensor:
     return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
 
 
+def mechanics_model_out(x0_pred):
+    """(u resized to 65x65, rho zero-padded to 65x65): src/residuals_mechanics_K.py:245-255."""
+    nn = x0_pred.shape[-1] + 1
+    return torch.cat((bilinear_resize(x0_pred[:, :2], nn), F.pad(x0_pred[:, 2], (0, 1, 0, 1)).unsqueeze(1)), dim=1)
+
+
 def mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs):
     """x0_pred [B,3,64,64] (u1,u2,rho), bcs [B,4,65,65] (bc_x, bc_y, load_x, load_y), vf [B].
     Returns residual [B,8450], compliance [B], shift [B].  Matrix-free K(rho) u."""
@@ -409,7 +415,7 @@ def mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs):
     D = torch.as_tensor(elem_dofs, dtype=torch.long)             # [E,8]
     k = torch.as_tensor(kloc, dtype=x0_pred.dtype)               # [8,8]
     ue = U[:, D]                                                 # [B,E,8]
-    fe = torch.einsum("ab,beb->bea", k, ue) * rho[:, :, None]   # [B,E,8]
+    fe = torch.einsum("ac,nec->nea", k, ue) * rho[:, :, None]   # [B,E,8]
     KU = torch.zeros_like(U).index_add_(1, D.reshape(-1), fe.reshape(B, -1))
     f = bcs[:, 2:4].permute(0, 2, 3, 1).reshape(B, -1)
     mask = bcs[:, 0:2].permute(0, 2, 3, 1).reshape(B, -1) != 0

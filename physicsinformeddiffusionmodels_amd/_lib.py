@@ -55,6 +55,9 @@ class PidmLib:
         self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
         self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
         self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
+        self._sig("pidm_bilinear_resize", [vp, vp, i, i, i, vp])
+        self._sig("pidm_mech_residual_fwd", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, vp])
+        self._sig("pidm_mech_residual_bwd", [vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, i, vp])
         self._sig("pidm_unet_create", [C.POINTER(UnetCfg), C.POINTER(vp)])
         self._sig("pidm_unet_destroy", [vp], None)
         self._sig("pidm_unet_num_params", [vp])

@@ -141,3 +141,43 @@ def test_sample_estimation_two_tapes(backend):
             continue
         a, b = prm.grad.cpu().norm().item(), p[k].grad.norm().item()
         assert abs(a - b) <= 2e-3 * b + 5e-6 * gmax, (k, a, b)
+
+
+def run_mech_loss_case(backend):
+    """Full mechanics model_estimation_loss (UNet 10->3 channels with sigmoid head, matrix-free K u residual, compliance,
+    volume-shift with the reference's [B,B] broadcast) vs the reference run with the dense stiffness matrix."""
+    from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
+    L, dev = backend
+    lib = L if dev.type == "cpu" else None
+    g = np.load(os.path.join(G, "g10_mech_loss_dim8.npz"))
+    m = Unet3D(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = lib
+    diff = DenoisingDiffusion(100, dev, lib=lib)
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder="/nonexistent/", device=dev,
+                             topopt_eval=False, lib=lib)
+    inp, eps, t = (torch.from_numpy(g[k]).to(dev) for k in ("inp", "eps", "t"))
+    with patched_rng(randint=lambda *a, **k: t.clone(), randn_like=lambda *a, **k: eps.clone()):
+        loss, data_l, res_l, ineq_l, opt_l = diff.model_estimation_loss(inp, residual_func=res, c_data=1., c_residual=1e-3,
+                                                                        c_ineq=0.5, lambda_opt=0.01)
+    for got, key in ((loss.item(), "loss"), (data_l, "data_loss"), (res_l, "residual_abs_mean"), (ineq_l, "ineq"), (opt_l, "opt")):
+        assert abs(got - float(g[key])) < 2e-4 * abs(float(g[key])), (key, got, float(g[key]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    names = [str(s) for s in g["grad_names"]]
+    assert sorted(k for k, p in params.items() if p.grad is not None) == sorted(names)
+    gmax = float(np.max(g["grad_norms"]))
+    bad = []
+    for k, ref in zip(names, g["grad_norms"]):
+        got = params[k].grad.double().norm().item()
+        if not abs(got - ref) <= 2e-3 * ref + 5e-6 * gmax:
+            bad.append((k, got, float(ref)))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.slow
+def test_mechanics_loss_dim8(backend):
+    if backend[1].type == "cpu" and not os.environ.get("PIDM_SLOW"):
+        pytest.skip("emulated 64x64 mechanics step takes minutes; set PIDM_SLOW=1 (always runs on the GPU)")
+    run_mech_loss_case(backend)

@@ -178,6 +178,4 @@ def run_mech_loss_case(backend):
 
 @pytest.mark.slow
 def test_mechanics_loss_dim8(backend):
-    if backend[1].type == "cpu" and not os.environ.get("PIDM_SLOW"):
-        pytest.skip("emulated 64x64 mechanics step takes minutes; set PIDM_SLOW=1 (always runs on the GPU)")
     run_mech_loss_case(backend)

@@ -524,7 +524,12 @@ template <int KH, int KW>
 __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ dy,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial) {
-  constexpr int XMAX = 9, YMAX = 4, MAXT = KH * KW;
+  constexpr int XMAX = 9, YMAX = 4, T_ = KH * KW;
+  // T_ >= 4: TAP-SPLIT - wave w owns taps {w, w+4, w+8} and walks the whole 128-pixel tile (<= 3 accumulators per
+  // wave: three workgroups per CU, no cross-wave reduction).  T_ == 1 (1x1 conv): K-SPLIT - the 4 waves split the
+  // pixel tile and are reduced through LDS at the end.
+  constexpr bool TAPSPLIT = false;  // measured on MI355X: K-split 53 TF vs tap-split 48 TF for 3x3 (kept for reference)
+  constexpr int MAXT = TAPSPLIT ? (T_ + 3) / 4 : T_;
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -610,26 +615,65 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
 #pragma unroll
       for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
     }
-    for (int ks = 0; ks < 16; ++ks) {
-      const int p = wave * 32 + 2 * ks + half;
-      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-      const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
-      const float a = Ys[p * 32 + l31];
-      const float* xrow = Xs + (size_t)xb * 32 + l31;
+    if (TAPSPLIT) {
+      // this wave's tap offsets (floats) inside the halo tile
+      int toff[MAXT];
 #pragma unroll
-      for (int ky = 0; ky < KH; ++ky) {
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = wave + 4 * i;
+        toff[i] = (t < T_) ? ((t / KW) * g.IWt + (t % KW)) * 32 : 0;
+      }
+#pragma unroll 4
+      for (int ks = 0; ks < 64; ++ks) {
+        const int p = 2 * ks + half;
+        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+        const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
+        const float a = Ys[p * 32 + l31];
+        const float* xrow = Xs + (size_t)xb * 32 + l31;
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-          const float bv = xrow[(ky * g.IWt + kx) * 32];
-          acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
+        for (int i = 0; i < MAXT; ++i) {
+          if (wave + 4 * i < T_) {
+            const float bv = xrow[toff[i]];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      for (int ks = 0; ks < 16; ++ks) {
+        const int p = wave * 32 + 2 * ks + half;
+        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+        const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
+        const float a = Ys[p * 32 + l31];
+        const float* xrow = Xs + (size_t)xb * 32 + l31;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) {
+            const float bv = xrow[(ky * g.IWt + kx) * 32];
+            acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
+          }
         }
       }
     }
   }
 #undef PIDM_WG_PREFETCH
   float* red = smem;  // [4][1024]
+  if (TAPSPLIT) {
+    // every wave owns complete sums for its taps: write them straight to the split-K partial buffer
 #pragma unroll
-  for (int tl = 0; tl < MAXT; ++tl) {
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + 4 * i;
+      if (t < T_) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          partial[(((size_t)split * wg.MP + (m0 + row)) * T + t) * wg.NP + n0 + l31] = acc[i][r];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int tl = 0; tl < (TAPSPLIT ? 0 : MAXT); ++tl) {
     {
       __syncthreads();
 #pragma unroll
@@ -647,6 +691,119 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   }
   if (do_bias) {
     __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[k * 32 + tid];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
+// wgrad for convolutions with very few input channels (the 7x7 init conv: Cin = 2 or 10): the GEMM N dimension is
+// the flattened (tap, channel) index - 98 columns for 7x7x2 instead of 49 taps x a 32-channel tile that is 94 % padding.
+// Wave w owns n-tiles {w, w+4, ...} (<= MAXN) and walks the whole 128-pixel tile; lane j of an n-tile reads
+// X[halo(p) + tap_j][c_j] straight from the LDS halo tile.
+template <int MAXN>
+__global__ void __launch_bounds__(256) conv_wgrad_smallc_kernel(WgradGeom wg, const float* __restrict__ src0,
+                                                                const float* __restrict__ dy, float* __restrict__ partial,
+                                                                float* __restrict__ bias_partial) {
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int T = g.KH * g.KW, Cin = g.Cin, NJ = T * Cin;
+  const int m0 = blockIdx.y * 32;
+  const int split = blockIdx.x;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  float* Xs = smem;                                   // [npixA][Cin]
+  float* Ys = smem + (((size_t)npixA * Cin + 3) & ~(size_t)3);   // [128][32]
+  const int tpi = g.Hv / g.TH;
+  // per-lane column -> offset inside the halo tile (floats), -1 = padding column
+  int joff[MAXN], jt[MAXN], jc[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) {
+    const int j = (wave + 4 * i) * 32 + l31;
+    joff[i] = -1; jt[i] = 0; jc[i] = 0;
+    if (j < NJ) {
+      const int t = j / Cin, c = j - t * Cin;
+      jt[i] = t; jc[i] = c;
+      joff[i] = ((t / g.KW) * g.IWt + (t % g.KW)) * Cin + c;
+    }
+  }
+  f32x16 acc[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const bool do_bias = bias_partial != nullptr;
+  float bacc = 0.f;
+  const bool vec_dy = ((wg.ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
+  const int tile_lo = split * wg.tiles_per_split;
+  const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b0 = (tile / tpi) * g.NI, vy0 = (tile % tpi) * g.TH;
+    const int iy0 = vy0 * g.stride - g.pad_y[0], ix0 = -g.pad_x[0];
+    __syncthreads();
+    for (int e = tid; e < npixA * Cin; e += 256) {
+      const int c = e % Cin, hp = e / Cin;
+      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
+      float v = 0.f;
+      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) v = src0[(((size_t)b * g.Hi + iy) * g.Wi + ix) * g.ld0 + c];
+      Xs[e] = v;
+    }
+    for (int e = tid; e < kBM * 8; e += 256) {
+      const int q = e & 7, p = e >> 3;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int b = b0 + img, c = m0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < g.B && img < g.NI && c < g.Cout) {
+        const size_t pix = ((size_t)b * g.Hv + (vy0 + ty)) * g.Wv + tx;
+        if (vec_dy) {
+          v = *reinterpret_cast<const float4*>(dy + pix * wg.ld_dy + c);
+        } else {
+          float t4[4];
+          for (int k = 0; k < 4; ++k) t4[k] = (c + k < g.Cout) ? dy[pix * wg.ld_dy + c + k] : 0.f;
+          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(Ys + (size_t)p * 32 + 4 * q) = v;
+    }
+    __syncthreads();
+    if (do_bias) {
+      const int o = tid & 31, part = tid >> 5;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
+    }
+#pragma unroll 2
+    for (int ks = 0; ks < 64; ++ks) {
+      const int p = 2 * ks + half;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int xb = (img < g.NI) ? ((img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride) * Cin : 0;
+      const float a = Ys[p * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MAXN; ++i) {
+        if ((wave + 4 * i) * 32 < NJ) {
+          const float bv = (joff[i] >= 0) ? Xs[xb + joff[i]] : 0.f;
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // results: column j = (t, c) of this lane, rows = 32 output channels
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) {
+    if (joff[i] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + jt[i]) * wg.NP + jc[i]] = acc[i][r];
+      }
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = Ys;
     red[tid] = bacc;
     __syncthreads();
     if (tid < 32) {
@@ -888,6 +1045,11 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
 }
 
 // ---- wgrad ------------------------------------------------------------------------------------------
+static bool wgrad_smallc(const ConvGeom& g) {
+  const int T = g.KH * g.KW;
+  return g.C1 == 0 && g.Cin <= 16 && T > 1 && T * g.Cin <= 16 * 32;
+}
+
 static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->g = g;
   wg->ld_dy = ld_dy;
@@ -895,19 +1057,20 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->tgs = T < 9 ? T : 9;
   if (T == 16) wg->tgs = 8;
   if (T == 49) wg->tgs = 7;
+  if (wgrad_smallc(g)) wg->tgs = T;   // (tap, channel) flattened: one block covers all taps
   wg->ntg = cdiv(T, wg->tgs);
   wg->MP = cdiv(g.Cout, 32) * 32;
   wg->NP = cdiv(g.Cin, 32) * 32;
-  const int blocks_mn = (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
-  // one workgroup per CU is resident (144 accumulator registers): pick tiles-per-split so that the number of
-  // workgroup "rounds" over the 256 CUs times the per-workgroup work (+ ~1.5 tile-equivalents of prologue and
-  // cross-wave reduction) is minimal
+  const int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
+  // two workgroups per CU are resident: pick tiles-per-split so that the number of workgroup "rounds" over the
+  // 512 slots times the per-workgroup work (+ ~1 tile-equivalent of prologue / epilogue) is minimal
   int best_tps = g.tiles_m;
   double best_cost = 1e30;
   for (int tps = 1; tps <= g.tiles_m; ++tps) {
     const long wgs = (long)blocks_mn * cdiv(g.tiles_m, tps);
     if (wgs > 4096 && tps < g.tiles_m) continue;
-    const double cost = (double)((wgs + 255) / 256) * (tps + 1.5);
+    const double cost = (T == 9) ? (double)((wgs + 255) / 256) * (tps + 1.5)    // 3x3: 144 accumulators, 1 workgroup per CU
+                                 : (double)((wgs + 511) / 512) * (tps + 1.0);   // 1x1: two workgroups per CU
     if (cost < best_cost - 1e-9) { best_cost = cost; best_tps = tps; }
   }
   wg->tiles_per_split = best_tps;
@@ -944,8 +1107,23 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
                        ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
-  const bool khw_ok = ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1;
-  if (aligned && khw_ok && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
+  if (wgrad_smallc(g)) {
+    // few input channels, many taps (init conv): (tap, channel) flattened into the GEMM N dimension
+    const int NJ = T * g.Cin, ntl = cdiv(NJ, 32), maxn = cdiv(ntl, 4);
+    const size_t lds2 = ((((size_t)g.NI * g.IHt * g.IWt * g.Cin + 3) & ~(size_t)3) + kBM * 32) * sizeof(float);
+    const dim3 grid2(wg.nsplit, wg.MP / 32, 1);
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_smallc_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_smallc_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_s = true;
+    }
+    if (lds2 > 96 * 1024) return fail("wgrad(small-C): tile needs %zu B of LDS", lds2);
+    if (maxn <= 1)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<1>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<4>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
+  } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
     static bool attr_p = false;
     if (!attr_p) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

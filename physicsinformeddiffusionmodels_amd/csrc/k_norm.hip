@@ -216,18 +216,25 @@ __global__ void __launch_bounds__(256) gn_bwd_final_kernel(const double* __restr
   }
 }
 
-// dgamma[c] = sum_b dgb[b][0][c], dbeta[c] = sum_b dgb[b][1][c]
-__global__ void gn_param_grad_kernel(const float* __restrict__ dgb, int B, int C, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma[c] = sum_b dgb[b][0][c], dbeta[c] = sum_b dgb[b][1][c]: one wave per channel, lanes stride over the batch
+__global__ void __launch_bounds__(256) gn_param_grad_kernel(const float* __restrict__ dgb, int B, int C, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   float a = 0.f, d = 0.f;
-  for (int b = 0; b < B; ++b) {
-    a += dgb[((size_t)b * 2 + 0) * C + c];
-    d += dgb[((size_t)b * 2 + 1) * C + c];
+  if (c < C) {
+    for (int b = lane; b < B; b += 64) {
+      a += dgb[((size_t)b * 2 + 0) * C + c];
+      d += dgb[((size_t)b * 2 + 1) * C + c];
+    }
   }
-  dgamma[c] = a;
-  dbeta[c] = d;
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off);
+    d += __shfl_down(d, off);
+  }
+  if (lane == 0 && c < C) {
+    dgamma[c] = a;
+    dbeta[c] = d;
+  }
 }
 
 // dx = rstd * (dv * sc1 * gamma - c1 - xhat * c2)
@@ -538,7 +545,7 @@ int launch_gn_bwd(const float* x, const float* dy, const float* stats, const flo
   hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, gamma, beta, ss, ssb, ldss, dss, HW, C, G,
                      dgb, coef);
   PIDM_CHECK_LAUNCH("gn_bwd_final_kernel");
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, B, C, dgamma, dbeta);
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dgb, B, C, dgamma, dbeta);
   PIDM_CHECK_LAUNCH("gn_param_grad_kernel");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * C / 4)), dim3(256), 0, st, x, dy, stats, gamma, beta,
                      ss, ssb, ldss, coef, dx, B, HW, C, G);

@@ -162,81 +162,72 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // after the barrier that publishes chunk i, so HBM/L2 latency hides under the 9*KC/2*NT MFMAs of chunk i.
 // ---------------------------------------------------------------------------------------------------
 template <int KC, int NT, int AMAX, int BMAX, int KH, int KW>
-__global__ void __launch_bounds__(256, (NT == 1 ? 3 : 2)) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
+__global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ residual, float* __restrict__ out) {
-  // PERSISTENT: gridDim.x workgroups walk the work items (z, m-tile, n-tile) with stride gridDim.x; the stages
-  // (work item, Cin-chunk) form one flat software pipeline, so the first chunk of the NEXT tile is already in
-  // flight while the last chunk of the current tile is on the matrix cores and its epilogue is being stored.
   constexpr int KCP = KC + 4;
   constexpr int BN = 32 * NT;
   constexpr int Q = KC / 4;
-  constexpr int T = KH * KW;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
+  const int z = blockIdx.z;
   const int tiles_n = (g.Cout + BN - 1) / BN;
-  const int nwork = g.tiles_m * tiles_n * g.nz;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int n0 = tile_n * BN;
+  constexpr int T = KH * KW;
   const int npixA = g.NI * g.IHt * g.IWt;
   float* As = smem;
   float* Bs = smem + (size_t)npixA * KCP;
   const int tpi = g.Hv / g.TH;
+  const int b0 = (tile_m / tpi) * g.NI;
+  const int vy0 = (tile_m % tpi) * g.TH;
+  const int iy0 = vy0 * g.stride - g.pad_y[z];
+  const int ix0 = -g.pad_x[z];
+  const float* wz = wp + g.w_off[z];
 
   const int pm = wave * 32 + l31;
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
   const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
 
-  // ---- prologue: tile-relative decode of this thread's staging slots (q = tid % Q is the same for every slot) ----
+  // ---- prologue: decode this thread's staging slots once (q = tid % Q is the same for every slot) ----
   const int nA = npixA * Q, nB = T * BN * Q;
   const int aq = tid % Q;
-  int a_rel[AMAX];    // packed (img << 20 | hy << 10 | hx), -1: slot unused
-  int a_lds[AMAX];    // float offset in As
+  int a_pix[AMAX];    // global pixel index, -1: zero fill
+  int a_lds[AMAX];    // float offset in As, -1: slot unused
 #pragma unroll
   for (int k = 0; k < AMAX; ++k) {
     const int e = tid + k * 256;
-    a_rel[k] = -1;
-    a_lds[k] = 0;
+    a_pix[k] = -1;
+    a_lds[k] = -1;
     if (e < nA) {
       const int hp = e / Q;
       const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
-      a_rel[k] = (img << 20) | (hy << 10) | hx;
+      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
       a_lds[k] = hp * KCP + 4 * aq;
+      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
     }
   }
   const int CinP = g.Cin;  // Cin % KC == 0 for this kernel
+  // B slot k of this thread: e = tid + 256k -> (q = e % Q, row = (e / Q) % BN, tl = e / (Q*BN)); all powers of two
   const int bq = tid % Q, brow0 = (tid / Q) % BN;
   f32x4 ra[AMAX], rb[BMAX];  // native vectors: stay in VGPRs across the loop back-edge
 
-  // work item w -> (z, tile_m, tile_n); n fastest so that neighbouring workgroups share the input tile in L2
-#define PIDM_DECODE(w_, z_, b0_, vy0_, n0_)              \
-  const int z_ = (w_) / (g.tiles_m * tiles_n);            \
-  const int tm__##z_ = ((w_) / tiles_n) % g.tiles_m;      \
-  const int n0_ = ((w_) % tiles_n) * BN;                  \
-  const int b0_ = (tm__##z_ / tpi) * g.NI;                \
-  const int vy0_ = (tm__##z_ % tpi) * g.TH;
-
-#define PIDM_PREFETCH(w_, c0_)                                                                                     \
+#define PIDM_PREFETCH(c0_)                                                                                         \
   {                                                                                                                \
-    PIDM_DECODE(w_, pz, pb0, pvy0, pn0)                                                                            \
-    const int piy0 = pvy0 * g.stride - g.pad_y[pz], pix0 = -g.pad_x[pz];                                           \
     const int c0__ = (c0_);                                                                                        \
     const float* sp__ = (c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0);                                       \
     const int ld__ = (c0__ < g.C0) ? g.ld0 : g.ld1;                                                                \
     _Pragma("unroll") for (int k = 0; k < AMAX; ++k) {                                                             \
-      ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                           \
-      if (a_rel[k] >= 0) {                                                                                         \
-        const int b = pb0 + (a_rel[k] >> 20), iy = piy0 + ((a_rel[k] >> 10) & 1023), ix = pix0 + (a_rel[k] & 1023); \
-        if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                               \
-          ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (((size_t)b * g.Hi + iy) * g.Wi + ix) * ld__ + 4 * aq);  \
-      }                                                                                                            \
+      ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
+      if (a_pix[k] >= 0) ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (size_t)a_pix[k] * ld__ + 4 * aq);        \
     }                                                                                                              \
-    const float* wz__ = wp + g.w_off[pz];                                                                          \
     _Pragma("unroll") for (int k = 0; k < BMAX; ++k) {                                                             \
       const int e = tid + k * 256;                                                                                 \
       const int row = (brow0 + (k * 256 / Q)) % BN, tl = (e < nB) ? e / (Q * BN) : 0;                              \
-      rb[k] = *reinterpret_cast<const f32x4*>(wz__ + ((size_t)(pn0 + row) * T + tl) * CinP + c0__ + 4 * bq);      \
+      rb[k] = *reinterpret_cast<const f32x4*>(wz +  ((size_t)(n0 + row) * T + tl) * CinP + c0__ + 4 * bq);        \
     }                                                                                                              \
   }
 
@@ -245,79 +236,68 @@ __global__ void __launch_bounds__(256, (NT == 1 ? 3 : 2)) conv_igemm_pipe_kernel
   for (int i = 0; i < NT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  int w = blockIdx.x;
-  if (w < nwork) PIDM_PREFETCH(w, 0)
-  for (; w < nwork; w += gridDim.x) {
-    for (int c0 = 0; c0 < CinP; c0 += KC) {
-      __syncthreads();          // previous stage's LDS reads are done
+  PIDM_PREFETCH(0)
+  for (int c0 = 0; c0 < CinP; c0 += KC) {
+    __syncthreads();          // previous chunk's LDS reads are done
 #pragma unroll
-      for (int k = 0; k < AMAX; ++k)
-        if (a_rel[k] >= 0) *reinterpret_cast<f32x4*>(As + a_lds[k]) = ra[k];
+    for (int k = 0; k < AMAX; ++k)
+      if (a_lds[k] >= 0) *reinterpret_cast<f32x4*>(As + a_lds[k]) = ra[k];
 #pragma unroll
-      for (int k = 0; k < BMAX; ++k) {
-        const int e = tid + k * 256;
-        if (e < nB) {
-          const int row = (brow0 + (k * 256 / Q)) % BN, tl = e / (Q * BN);
-          *reinterpret_cast<f32x4*>(Bs + ((size_t)tl * BN + row) * KCP + 4 * bq) = rb[k];
-        }
+    for (int k = 0; k < BMAX; ++k) {
+      const int e = tid + k * 256;
+      if (e < nB) {
+        const int row = (brow0 + (k * 256 / Q)) % BN, tl = e / (Q * BN);
+        *reinterpret_cast<f32x4*>(Bs + ((size_t)tl * BN + row) * KCP + 4 * bq) = rb[k];
       }
-      __syncthreads();          // stage visible
-      {
-        // the next stage: next chunk of this work item, or chunk 0 of this workgroup's next work item
-        const bool same = c0 + KC < CinP;
-        const int nw = same ? w : w + (int)gridDim.x;
-        const int nc0 = same ? c0 + KC : 0;
-        if (nw < nwork) PIDM_PREFETCH(nw, nc0)
-      }
-      // taps fully unrolled (compile-time KHxKW): tap offsets are scalar adds, and the compiler can hoist the
-      // ds_read_b128 of the next tap above the MFMAs of the current one
-      const float* abase_p = As + (size_t)abase * KCP + 4 * half;
-      const float* bbase_p = Bs + (size_t)l31 * KCP + 4 * half;
+    }
+    __syncthreads();          // chunk c0 visible
+    if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
+    // taps fully unrolled (compile-time KHxKW): tap offsets are scalar adds, and the compiler can hoist the
+    // ds_read_b128 of the next tap above the MFMAs of the current one
+    const float* abase_p = As + (size_t)abase * KCP + 4 * half;
+    const float* bbase_p = Bs + (size_t)l31 * KCP + 4 * half;
 #pragma unroll
-      for (int ky = 0; ky < KH; ++ky) {
+    for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-          const float* arow = abase_p + (size_t)(ky * g.IWt + kx) * KCP;
-          const float* brow = bbase_p + (size_t)((ky * KW + kx) * BN) * KCP;
+      for (int kx = 0; kx < KW; ++kx) {
+        const float* arow = abase_p + (size_t)(ky * g.IWt + kx) * KCP;
+        const float* brow = bbase_p + (size_t)((ky * KW + kx) * BN) * KCP;
 #pragma unroll
-          for (int g8 = 0; g8 < KC / 8; ++g8) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
-            f32x4 b4[NT];
+        for (int g8 = 0; g8 < KC / 8; ++g8) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
+          f32x4 b4[NT];
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
+          for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < 4; ++s) {
 #pragma unroll
-              for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
-            }
+            for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
           }
         }
       }
     }
-    // ---- epilogue of work item w (the next item's first chunk is already in flight) ----
-    PIDM_DECODE(w, z, b0, vy0, n0)
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      const int c = n0 + ni * 32 + l31;
-      const float bv = (bias && c < g.Cout) ? bias[c] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int p = wave * 32 + row;
-        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-        const int b = b0 + img;
-        float v = acc[ni][r] + bv;
-        acc[ni][r] = 0.f;
-        if (c >= g.Cout || b >= g.B || img >= g.NI) continue;
-        const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
-        if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
-        if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
-        out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
-      }
-    }
   }
 #undef PIDM_PREFETCH
-#undef PIDM_DECODE
+
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int c = n0 + ni * 32 + l31;
+    if (c >= g.Cout) continue;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int p = wave * 32 + row;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int b = b0 + img;
+      if (b >= g.B || img >= g.NI) continue;
+      const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+      float v = acc[ni][r] + bv;
+      if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
+      if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
+      out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1010,20 +990,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   const bool khw_ok = (g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1) || (g.KH == 2 && g.KW == 2);
   if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
-    // persistent grid: k workgroups per CU (k <= 3, limited by LDS), k chosen for the best balance of work items
-    const int nwork = g.tiles_m * tiles_n * g.nz;
-    int kmax = (int)((150 * 1024) / (lds_pipe + 1024));
-    if (kmax > 3) kmax = 3;
-    if (kmax < 1) kmax = 1;
-    int best_k = 1;
-    double best_waste = 1e30;
-    for (int k = kmax; k >= 1; --k) {
-      const long slots = 256L * k;
-      const double waste = (double)(((nwork + slots - 1) / slots) * slots) / (double)nwork;
-      if (waste < best_waste - 1e-9) { best_waste = waste; best_k = k; }
-    }
-    const int nwg = nwork < 256 * best_k ? nwork : 256 * best_k;
-    const dim3 grid(nwg, 1, 1);
+    const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
 #define PIDM_LAUNCH_PIPE(KH_, KW_)                                                                                         \
   {                                                                                                                        \
     constexpr int BMAXk = (KH_ * KW_ * BN * Q + 255) / 256;                                                                \

@@ -204,7 +204,8 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     a_lds[k] = -1;
     if (e < nA) {
       const int hp = e / Q;
-      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;      // halo row index, column
+      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
       const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
       a_lds[k] = hp * KCP + 4 * aq;
       if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
@@ -213,6 +214,15 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int CinP = g.Cin;  // Cin % KC == 0 for this kernel
   // B slot k of this thread: e = tid + 256k -> (q = e % Q, row = (e / Q) % BN, tl = e / (Q*BN)); all powers of two
   const int bq = tid % Q, brow0 = (tid / Q) % BN;
+  int b_g[BMAX], b_l[BMAX];  // per-slot global (floats, relative to the n-tile's first row) and LDS offsets
+#pragma unroll
+  for (int k = 0; k < BMAX; ++k) {
+    const int e = tid + k * 256;
+    const int row = (brow0 + (k * 256 / Q)) % BN, tl = (e < nB) ? e / (Q * BN) : 0;
+    b_g[k] = (row * T + tl) * CinP + 4 * bq;
+    b_l[k] = (e < nB) ? (tl * BN + row) * KCP + 4 * bq : -1;
+  }
+  const float* wn = wz + (size_t)n0 * T * CinP;
   f32x4 ra[AMAX], rb[BMAX];  // native vectors: stay in VGPRs across the loop back-edge
 
 #define PIDM_PREFETCH(c0_)                                                                                         \
@@ -224,11 +234,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
       if (a_pix[k] >= 0) ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (size_t)a_pix[k] * ld__ + 4 * aq);        \
     }                                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) {                                                             \
-      const int e = tid + k * 256;                                                                                 \
-      const int row = (brow0 + (k * 256 / Q)) % BN, tl = (e < nB) ? e / (Q * BN) : 0;                              \
-      rb[k] = *reinterpret_cast<const f32x4*>(wz +  ((size_t)(n0 + row) * T + tl) * CinP + c0__ + 4 * bq);        \
-    }                                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) rb[k] = *reinterpret_cast<const f32x4*>(wn + b_g[k] + c0__);   \
   }
 
   f32x16 acc[NT];
@@ -243,13 +249,8 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     for (int k = 0; k < AMAX; ++k)
       if (a_lds[k] >= 0) *reinterpret_cast<f32x4*>(As + a_lds[k]) = ra[k];
 #pragma unroll
-    for (int k = 0; k < BMAX; ++k) {
-      const int e = tid + k * 256;
-      if (e < nB) {
-        const int row = (brow0 + (k * 256 / Q)) % BN, tl = e / (Q * BN);
-        *reinterpret_cast<f32x4*>(Bs + ((size_t)tl * BN + row) * KCP + 4 * bq) = rb[k];
-      }
-    }
+    for (int k = 0; k < BMAX; ++k)
+      if (b_l[k] >= 0) *reinterpret_cast<f32x4*>(Bs + b_l[k]) = rb[k];
     __syncthreads();          // chunk c0 visible
     if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
     // taps fully unrolled (compile-time KHxKW): tap offsets are scalar adds, and the compiler can hoist the
@@ -279,6 +280,37 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   }
 #undef PIDM_PREFETCH
 
+  if (g.Wv >= 32) {
+    // the wave's 32 pixels are consecutive in x inside one image row: one 64-bit base per (wave, n-tile), then
+    // row * (os*sox) steps with compile-time row constants (no per-row index math)
+    const int p0 = wave * 32;
+    const int tx0 = p0 & (g.Wv - 1), ty = (p0 >> g.wsh) & (g.TH - 1), img = p0 >> (g.wsh + g.tsh);
+    const int b = b0 + img;
+    if (b < g.B && img < g.NI) {
+      const int oy = (vy0 + ty) * g.os + g.ooy[z];
+      const long rstep = (long)g.os * g.sox, rrstep = (long)g.os * g.ldr;
+      const long opix = (long)b * g.sob + (long)oy * g.soy + (long)(tx0 * g.os + g.oox[z]) * g.sox + 4 * half * rstep;
+      const long rpix = (((long)b * g.Ho + oy) * g.Wo + (tx0 * g.os + g.oox[z])) * g.ldr + 4 * half * rrstep;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        const int c = n0 + ni * 32 + l31;
+        if (c >= g.Cout) continue;
+        const float bv = bias ? bias[c] : 0.f;
+        float* op = out + opix + (long)c * g.soc;
+        const float* rp = residual ? residual + rpix + c : nullptr;
+        const bool sig = sigmoid_last && c == g.Cout - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = (r & 3) + 8 * (r >> 2);   // compile-time part of the row index
+          float v = acc[ni][r] + bv;
+          if (rp) v += rp[rowc * rrstep];
+          if (sig) v = 1.f / (1.f + expf(-v));
+          op[rowc * rstep] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     const int c = n0 + ni * 32 + l31;
@@ -909,6 +941,8 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
   if ((1 << g->tsh) != g->TH) return fail("conv: tile rows %d must be a power of two", g->TH);
   g->IHt = (g->TH - 1) * g->stride + g->KH;
   g->IWt = (g->Wv - 1) * g->stride + g->KW;
+  g->mIWt = g->IWt > 1 ? (unsigned)((0x100000000ULL + g->IWt - 1) / g->IWt) : 0;
+  g->mIHt = g->IHt > 1 ? (unsigned)((0x100000000ULL + g->IHt - 1) / g->IHt) : 0;
   // tiny strided images: the halo blow-up (e.g. 36 input pixels per 2x2 output) must still fit in LDS
   while (g->NI > 1 && g->NI * g->IHt * g->IWt > 768) g->NI >>= 1;
   const int tpi = g->Hv / g->TH;

@@ -26,6 +26,9 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
     if (e__ != hipSuccess) return ::pidm::fail("%s: %s", what, hipGetErrorString(e__)); \
   } while (0)
 
+// exact n / d for small operands via one mulhi (d == 1 handled by the caller's magic == 0 convention)
+__device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -59,6 +62,7 @@ struct ConvGeom {
   int TH, NI;        // rows per tile, images per tile: TH*NI*Wv == 128
   int wsh, tsh;      // log2(Wv), log2(TH): pixel p of a tile -> tx = p & (Wv-1), ty = (p >> wsh) & (TH-1), img = p >> (wsh+tsh)
   int IHt, IWt;      // input halo tile extent per image
+  unsigned mIWt, mIHt;  // ceil(2^32 / IWt), ceil(2^32 / IHt): n / d == __umulhi(n, m) for n*d < 2^32 (d > 1)
   int tiles_m;       // number of 128-pixel tiles
 };
 

@@ -89,6 +89,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    # PIDM_BENCH_SHARE_GPU=1 (debug only): all ranks share cuda:0 and talk over gloo - exercises the N>1 code path on
+    # a single-GPU box; real runs use one GPU per rank over RCCL (backend "nccl").
+    share = os.environ.get("PIDM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -96,7 +101,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from physicsinformeddiffusionmodels_amd._lib import get_lib
     from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch

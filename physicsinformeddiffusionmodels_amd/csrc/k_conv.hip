@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
     const int hp = (tid + k * 256) >> 3;
     x_dec[k] = -1;
     if (hp < npixA && cx_ok) {
-      const int hx = hp % g.IWt, hy = (hp / g.IWt) % g.IHt, img = hp / (g.IWt * g.IHt);
+      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;
+      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
       x_dec[k] = (img << 20) | (hy << 10) | hx;
     }
   }
@@ -667,6 +668,27 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
           if (wave + 4 * i < T_) {
             const float bv = xrow[toff[i]];
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    } else if (g.Wv >= 32) {
+      // the wave's 32 pixels are consecutive in x inside one image row: pointer bumps instead of per-step decode
+      const int p0 = wave * 32;
+      const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
+      const int xb0 = (img0 < g.NI) ? (img0 * g.IHt + ty0 * g.stride) * g.IWt + tx0 * g.stride : 0;
+      const float* ap = Ys + (size_t)(p0 + half) * 32 + l31;
+      const float* xp = Xs + (size_t)(xb0 + half * g.stride) * 32 + l31;
+      const int xstep = 2 * g.stride * 32;
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const float a = ap[ks * 64];
+        const float* xrow = xp + (size_t)ks * xstep;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) {
+            const float bv = xrow[(ky * g.IWt + kx) * 32];
+            acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
           }
         }
       }

@@ -16,6 +16,8 @@
 //
 // Backward: dgrad runs the SAME kernel on a flipped/transposed weight packing; wgrad is its own kernel
 // (M = Cout, N = Cin, K = pixels) with a deterministic split-K over pixel tiles.
+#include <stdlib.h>
+
 #include "pidm_launch.h"
 
 namespace pidm {
@@ -253,30 +255,43 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       if (b_l[k] >= 0) *reinterpret_cast<f32x4*>(Bs + b_l[k]) = rb[k];
     __syncthreads();          // chunk c0 visible
     if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
-    // taps fully unrolled (compile-time KHxKW): tap offsets are scalar adds, and the compiler can hoist the
-    // ds_read_b128 of the next tap above the MFMAs of the current one
+    // taps fully unrolled (compile-time KHxKW).  The LDS fragments of tap t+1 are fetched into a second register set
+    // BEFORE the MFMAs of tap t are issued, so the ~128-cycle ds_read latency hides under 8*NT*KC/8 MFMAs instead of
+    // stalling the matrix pipe once per tap.
     const float* abase_p = As + (size_t)abase * KCP + 4 * half;
     const float* bbase_p = Bs + (size_t)l31 * KCP + 4 * half;
+    f32x4 fa[2][KC / 8], fb[2][KC / 8][NT];
+#define PIDM_LOAD_FRAGS(set_, t_)                                                                                  \
+  {                                                                                                                \
+    const float* arow = abase_p + (size_t)(((t_) / KW) * g.IWt + ((t_) % KW)) * KCP;                               \
+    const float* brow = bbase_p + (size_t)((t_)*BN) * KCP;                                                         \
+    _Pragma("unroll") for (int g8 = 0; g8 < KC / 8; ++g8) {                                                        \
+      fa[set_][g8] = *reinterpret_cast<const f32x4*>(arow + 8 * g8);                                               \
+      _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                                                            \
+          fb[set_][g8][ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);               \
+    }                                                                                                              \
+  }
+    PIDM_LOAD_FRAGS(0, 0)
+    __builtin_amdgcn_sched_group_barrier(0x100, (1 + NT) * (KC / 8), 0);   // tap 0's reads form their own group
 #pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
+    for (int t = 0; t < T; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < T) PIDM_LOAD_FRAGS(cur ^ 1, t + 1)
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
-        const float* arow = abase_p + (size_t)(ky * g.IWt + kx) * KCP;
-        const float* brow = bbase_p + (size_t)((ky * KW + kx) * BN) * KCP;
+      for (int g8 = 0; g8 < KC / 8; ++g8) {
 #pragma unroll
-        for (int g8 = 0; g8 < KC / 8; ++g8) {
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
-          f32x4 b4[NT];
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni) b4[ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[ni][s], acc[ni], 0, 0, 0);
-          }
+          for (int ni = 0; ni < NT; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][s], fb[cur][g8][ni][s], acc[ni], 0, 0, 0);
         }
       }
+      // pin the order hipcc otherwise undoes (it sinks the next tap's ds_reads below this tap's MFMAs):
+      // first the (1 + NT) * KC/8 LDS reads of tap t+1, then the 4 * NT * KC/8 MFMAs of tap t
+      if (t + 1 < T) __builtin_amdgcn_sched_group_barrier(0x100, (1 + NT) * (KC / 8), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * (KC / 8), 0);
     }
+#undef PIDM_LOAD_FRAGS
   }
 #undef PIDM_PREFETCH
 
@@ -975,7 +990,16 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
   return 0;
 }
 
-static int pick_kc(int Cin) { return (Cin % 16 == 0) ? 16 : 8; }
+static int pick_kc(int Cin) {
+  // PIDM_KC=8 forces the 8-channel chunk (experiments); default: 16 when the channel count allows it
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("PIDM_KC");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 8) return 8;
+  return (Cin % 16 == 0) ? 16 : 8;
+}
 // n-tiles per workgroup: 64 output channels per workgroup unless that leaves the chip under-filled
 static int pick_nt(int Cout, int tiles_m) {
   if (Cout <= 32) return 1;

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // in the prologue; per chunk the thread issues its <= AMAX + BMAX global loads for chunk i+1 into registers right
 // after the barrier that publishes chunk i, so HBM/L2 latency hides under the 9*KC/2*NT MFMAs of chunk i.
 // ---------------------------------------------------------------------------------------------------
-template <int KC, int NT, int AMAX, int BMAX, int KH, int KW>
+template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
                                                               const float* __restrict__ bias,
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   // ---- prologue: decode this thread's staging slots once (q = tid % Q is the same for every slot) ----
   const int nA = npixA * Q, nB = T * BN * Q;
   const int aq = tid % Q;
-  int a_pix[AMAX];    // global pixel index, -1: zero fill
+  int a_pix[AMAX];    // global pixel index, -1: zero fill (PHASED: packed tile-relative (img<<20 | hy<<10 | hx))
   int a_lds[AMAX];    // float offset in As, -1: slot unused
 #pragma unroll
   for (int k = 0; k < AMAX; ++k) {
@@ -210,10 +210,14 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
       const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
       a_lds[k] = hp * KCP + 4 * aq;
-      if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
+      if (PHASED) {
+        a_pix[k] = (img << 20) | (hy << 10) | hx;   // the source pixel depends on the K-phase: resolved per prefetch
+      } else if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) {
+        a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
+      }
     }
   }
-  const int CinP = g.Cin;  // Cin % KC == 0 for this kernel
+  const int CinP = g.Kw;  // packed weight row length (nph * Cin); Cin % KC == 0 for this kernel
   // B slot k of this thread: e = tid + 256k -> (q = e % Q, row = (e / Q) % BN, tl = e / (Q*BN)); all powers of two
   const int bq = tid % Q, brow0 = (tid / Q) % BN;
   int b_g[BMAX], b_l[BMAX];  // per-slot global (floats, relative to the n-tile's first row) and LDS offsets
@@ -229,14 +233,26 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 
 #define PIDM_PREFETCH(c0_)                                                                                         \
   {                                                                                                                \
-    const int c0__ = (c0_);                                                                                        \
+    const int kk__ = (c0_);                 /* position along the packed K axis */                                 \
+    const int ph__ = PHASED ? kk__ / g.Cin : 0;                                                                    \
+    const int c0__ = PHASED ? kk__ - ph__ * g.Cin : kk__;                                                          \
     const float* sp__ = (c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0);                                       \
     const int ld__ = (c0__ < g.C0) ? g.ld0 : g.ld1;                                                                \
     _Pragma("unroll") for (int k = 0; k < AMAX; ++k) {                                                             \
-      ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
-      if (a_pix[k] >= 0) ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (size_t)a_pix[k] * ld__ + 4 * aq);        \
+      ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                           \
+      if (PHASED) {                                                                                                \
+        if (a_lds[k] >= 0) {                                                                                       \
+          const int b = b0 + (a_pix[k] >> 20);                                                                     \
+          const int iy = (vy0 - g.ph_pad_y[ph__] + ((a_pix[k] >> 10) & 1023)) * g.in_step + g.ph_oy[ph__];         \
+          const int ix = ((a_pix[k] & 1023) - g.ph_pad_x[ph__]) * g.in_step + g.ph_ox[ph__];                       \
+          if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                             \
+            ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (((size_t)b * g.Hi + iy) * g.Wi + ix) * ld__ + 4 * aq); \
+        }                                                                                                          \
+      } else if (a_pix[k] >= 0) {                                                                                  \
+        ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (size_t)a_pix[k] * ld__ + 4 * aq);                          \
+      }                                                                                                            \
     }                                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) rb[k] = *reinterpret_cast<const f32x4*>(wn + b_g[k] + c0__);   \
+    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) rb[k] = *reinterpret_cast<const f32x4*>(wn + b_g[k] + kk__);   \
   }
 
   f32x16 acc[NT];
@@ -368,6 +384,15 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
     const int n = (int)((idx / ((size_t)K * T)) % N);
     const int z = (int)(idx / ((size_t)K * T * N));
     float v;
+    if (kind == 5 || kind == 6) {
+      // phased 4x4s2 (z = phase (py,px)): tap j of phase parity p is source tap (p == 0 ? 1 + 2j : 2j); one packed matrix
+      const int py = z >> 1, px = z & 1, jy = t >> 1, jx = t & 1;
+      const int ky = py == 0 ? 1 + 2 * jy : 2 * jy, kx = px == 0 ? 1 + 2 * jx : 2 * jx;
+      v = (kind == 5) ? src[(((size_t)n * K + k) * 4 + ky) * 4 + kx]     // strided conv  W[n][k][ky][kx]
+                      : src[(((size_t)n * K + k) * 4 + ky) * 4 + kx];    // dgrad of convT Wt[n][k][ky][kx]
+      dst[(((size_t)(n_off + n)) * T + t) * Kp + k_off + z * K + k] = v;
+      continue;
+    }
     if (kind == 0) {
       v = src[((size_t)n * K + k) * T + t];
     } else if (kind == 2) {
@@ -402,6 +427,13 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
     const int n = (int)((idx / ((size_t)d.K * d.T)) % d.N);
     const int z = (int)(idx / ((size_t)d.K * d.T * d.N));
     float v;
+    if (d.kind == 5 || d.kind == 6) {
+      const int py = z >> 1, px = z & 1, jy = t >> 1, jx = t & 1;
+      const int ky = py == 0 ? 1 + 2 * jy : 2 * jy, kx = px == 0 ? 1 + 2 * jx : 2 * jx;
+      v = d.src[(((size_t)n * d.K + k) * 4 + ky) * 4 + kx];
+      d.dst[(((size_t)(d.n_off + n)) * d.T + t) * d.Kp + d.k_off + z * d.K + k] = v;
+      continue;
+    }
     if (d.kind == 0 || d.kind == 4) {
       v = d.src[((size_t)n * d.K + k) * d.T + t];
     } else if (d.kind == 2) {
@@ -567,7 +599,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
 
 // software-pipelined wgrad (3x3 / 1x1, 16-byte aligned operands): the (halo pixel, quad) decode is done once, the
 // next pixel tile is prefetched into registers while the 16 x nt MFMAs per wave of the current one run.
-template <int KH, int KW>
+template <int KH, int KW, bool PHASED>
 __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ dy,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial) {
@@ -580,7 +612,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  constexpr int T = KH * KW;
+  constexpr int T = PHASED ? 16 : KH * KW;   // taps of the partial-buffer layout (4x4 source taps when phased)
+  const int ph = PHASED ? blockIdx.z : 0;
   const int ntn = wg.NP / 32;
   const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;   // one tap group (all KHxKW taps)
   const int m0 = tm * 32, n0 = tn * 32;
@@ -615,11 +648,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   {                                                                                                               \
     const int tile__ = (tile_);                                                                                   \
     const int b0__ = (tile__ / tpi) * g.NI, vy0__ = (tile__ % tpi) * g.TH;                                        \
-    const int iy0__ = vy0__ * g.stride - g.pad_y[0], ix0__ = -g.pad_x[0];                                         \
+    const int iy0__ = PHASED ? vy0__ - g.ph_pad_y[ph] : vy0__ * g.stride - g.pad_y[0];                            \
+    const int ix0__ = PHASED ? -g.ph_pad_x[ph] : -g.pad_x[0];                                                      \
     _Pragma("unroll") for (int k = 0; k < XMAX; ++k) {                                                            \
       rx[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                          \
       if (x_dec[k] >= 0) {                                                                                        \
-        const int b = b0__ + (x_dec[k] >> 20), iy = iy0__ + ((x_dec[k] >> 10) & 1023), ix = ix0__ + (x_dec[k] & 1023); \
+        const int b = b0__ + (x_dec[k] >> 20);                                                                    \
+        int iy = iy0__ + ((x_dec[k] >> 10) & 1023), ix = ix0__ + (x_dec[k] & 1023);                                \
+        if (PHASED) { iy = iy * g.in_step + g.ph_oy[ph]; ix = ix * g.in_step + g.ph_ox[ph]; }                      \
         if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                               \
           rx[k] = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * g.Hi + iy) * g.Wi + ix) * xld);            \
       }                                                                                                           \
@@ -638,7 +674,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const bool do_bias = (bias_partial != nullptr) && (tn == 0);
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0) && (ph == 0);
   float bacc = 0.f;
 
   const int tile_lo = split * wg.tiles_per_split;
@@ -754,7 +790,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
       for (int e = tid; e < 1024; e += 256) {
         const float sv = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
         const int row = e >> 5, col = e & 31;
-        partial[(((size_t)split * wg.MP + (m0 + row)) * T + tl) * wg.NP + n0 + col] = sv;
+        int tdst = tl;
+        if (PHASED) {   // local tap (jy, jx) of phase (py, px) -> source tap (ky, kx) of the 4x4 kernel
+          const int py = ph >> 1, px = ph & 1, jy = tl >> 1, jx = tl & 1;
+          tdst = (py == 0 ? 1 + 2 * jy : 2 * jy) * 4 + (px == 0 ? 1 + 2 * jx : 2 * jx);
+        }
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + tdst) * wg.NP + n0 + col] = sv;
       }
     }
   }
@@ -955,7 +996,20 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
   memset(g, 0, sizeof(*g));
   g->B = B; g->Hi = Hi; g->Wi = Wi; g->C0 = C0; g->C1 = C1; g->ld0 = ld0; g->ld1 = ld1 > 0 ? ld1 : 4;
   g->Cin = C0 + C1; g->Cout = Cout;
-  if (kind == 0) {
+  g->nph = 1; g->in_step = 1; g->Kw = g->Cin;
+  if (kind == 0 && KH == 4 && KW == 4 && stride == 2 && pad == 1 && (Hi % 2 == 0) && (Wi % 2 == 0) && (C0 % 8 == 0) &&
+      (C1 % 8 == 0) && (ld0 % 4 == 0) && (C1 == 0 || ld1 % 4 == 0)) {
+    // phased form of the 4x4/s2/p1 convolution: input row 2y + ky - 1 = 2*sy + py with (py = 0: sy = y + j, ky = 1 + 2j)
+    // and (py = 1: sy = y + j - 1, ky = 2j), j in {0,1}; likewise in x.  K = 4 phases x Cin, taps 2x2, stride 1.
+    g->KH = g->KW = 2; g->stride = 1; g->os = 1; g->nz = 1;
+    g->nph = 4; g->in_step = 2; g->Kw = 4 * g->Cin;
+    g->Hv = g->Ho = Hi / 2; g->Wv = g->Wo = Wi / 2;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      g->ph_oy[ph] = py; g->ph_ox[ph] = px;
+      g->ph_pad_y[ph] = py; g->ph_pad_x[ph] = px;   // py = 0 -> pad 0, py = 1 -> pad 1
+    }
+  } else if (kind == 0) {
     g->KH = KH; g->KW = KW; g->stride = stride; g->os = 1; g->nz = 1;
     g->Hv = g->Ho = (Hi + 2 * pad - KH) / stride + 1;
     g->Wv = g->Wo = (Wi + 2 * pad - KW) / stride + 1;
@@ -1010,7 +1064,7 @@ static int packed_np(int Cout) { return cdiv(Cout, 64) * 64; }
 
 size_t packed_floats(const ConvGeom& g) {
   const int KC = pick_kc(g.Cin);
-  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Kw, KC) * KC;
   return (size_t)g.nz * Np * g.KH * g.KW * Kp;
 }
 
@@ -1020,13 +1074,14 @@ size_t packed_floats(const ConvGeom& g) {
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
                 int n_src, int k_src, hipStream_t st) {
   const int KC = pick_kc(g.Cin);
-  const int Np = packed_np(g.Cout), Kp = cdiv(g.Cin, KC) * KC, T = g.KH * g.KW;
+  const int Np = packed_np(g.Cout), Kp = cdiv(g.Kw, KC) * KC, T = g.KH * g.KW;
   const int N = n_src > 0 ? n_src : g.Cout, K = k_src > 0 ? k_src : g.Cin;
-  const size_t total = (size_t)g.nz * N * T * K;
+  if (g.nph > 1) kind = (kind == 4) ? 6 : 5;   // phased 4x4s2: forward of a strided conv (5) / dgrad of a transposed conv (6)
+  const size_t total = (size_t)g.nz * N * T * K * g.nph;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nz, N, K, Np, Kp, srcKH, srcKW, T,
-                     n_off, k_off);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nph > 1 ? 4 : g.nz, N, K, Np, Kp, srcKH,
+                     srcKW, T, n_off, k_off);
   PIDM_CHECK_LAUNCH("pack_kernel");
   return 0;
 }
@@ -1037,8 +1092,9 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   const int KC = pick_kc(g.Cin);
   d->src = w_ref; d->dst = w_packed; d->kind = kind; d->nz = g.nz;
   d->N = n_src > 0 ? n_src : g.Cout; d->K = k_src > 0 ? k_src : g.Cin;
-  d->Np = packed_np(g.Cout); d->Kp = cdiv(g.Cin, KC) * KC; d->KH = srcKH; d->KW = srcKW; d->T = g.KH * g.KW;
+  d->Np = packed_np(g.Cout); d->Kp = cdiv(g.Kw, KC) * KC; d->KH = srcKH; d->KW = srcKW; d->T = g.KH * g.KW;
   d->n_off = n_off; d->k_off = k_off;
+  if (g.nph > 1) { d->kind = (kind == 4) ? 6 : 5; d->nz = 4; }   // nz doubles as the phase count for kinds 5/6
   const size_t total = (size_t)d->nz * d->N * d->T * d->K;
   d->nblk = (unsigned)((total + 2047) / 2048);
   return d->nblk;
@@ -1058,39 +1114,42 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   const size_t a_bytes = (size_t)g.NI * g.IHt * g.IWt * KCP * sizeof(float);
   const size_t b_tap = (size_t)BN * KCP * sizeof(float);
   size_t off = 0;
-  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Cin, KC) * KC;
+  const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Kw, KC) * KC;
   for (int z = 0; z < g.nz; ++z) { g.w_off[z] = (long)off; off += Np * T * Kp; }
   const int tiles_n = cdiv(g.Cout, BN);
   const bool prof = prof_enabled();
-  const double flops = 2.0 * g.B * g.Hv * g.Wv * g.nz * (double)g.Cout * g.Cin * T;
+  const double flops = 2.0 * g.B * g.Hv * g.Wv * g.nz * (double)g.Cout * g.Kw * T;
   // ---- pipelined kernel when the whole tap set fits one slab and the sources are chunk-aligned ----
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % KC == 0) && (g.C0 % KC == 0);
   const int nA = g.NI * g.IHt * g.IWt * Q;
   const size_t lds_pipe = a_bytes + (size_t)T * b_tap;
+  if (g.nph > 1 && !aligned) return fail("conv: phased 4x4/s2 path needs 16-byte aligned channel counts");
   const bool khw_ok = (g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1) || (g.KH == 2 && g.KW == 2);
   if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
     const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
-#define PIDM_LAUNCH_PIPE(KH_, KW_)                                                                                         \
+#define PIDM_LAUNCH_PIPE(KH_, KW_, PH_)                                                                                    \
   {                                                                                                                        \
     constexpr int BMAXk = (KH_ * KW_ * BN * Q + 255) / 256;                                                                \
     static bool attr_pipe = false;                                                                                         \
     if (!attr_pipe) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_>),     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
       attr_pipe = true;                                                                                                    \
     }                                                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_>), grid, dim3(256), lds_pipe,  \
-                       st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_>), grid, dim3(256),       \
+                       lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
-    if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3)
-    else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2)
-    else PIDM_LAUNCH_PIPE(1, 1)
+    if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3, false)
+    else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true)
+    else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false)
+    else PIDM_LAUNCH_PIPE(1, 1, false)
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
     PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
     return 0;
   }
+  if (g.nph > 1) return fail("conv: phased 4x4/s2 geometry is not eligible for the pipelined kernel (tile too large)");
   // ---- generic kernel (tap groups, ragged channels, scalar staging) ----
   const size_t budget = 72 * 1024;  // keep two workgroups per CU where the halo tile allows
   int tgs = T;
@@ -1127,8 +1186,10 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
 // ---- wgrad ------------------------------------------------------------------------------------------
 static bool wgrad_smallc(const ConvGeom& g) {
   const int T = g.KH * g.KW;
-  return g.C1 == 0 && g.Cin <= 16 && T > 1 && T * g.Cin <= 16 * 32;
+  return g.nph == 1 && g.C1 == 0 && g.Cin <= 16 && T > 1 && T * g.Cin <= 16 * 32;
 }
+
+static int wgrad_taps(const ConvGeom& g) { return g.nph > 1 ? 16 : g.KH * g.KW; }   // taps of the weight tensor
 
 static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->g = g;
@@ -1141,7 +1202,7 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->ntg = cdiv(T, wg->tgs);
   wg->MP = cdiv(g.Cout, 32) * 32;
   wg->NP = cdiv(g.Cin, 32) * 32;
-  const int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg;
+  const int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg * g.nph;
   // two workgroups per CU are resident: pick tiles-per-split so that the number of workgroup "rounds" over the
   // 512 slots times the per-workgroup work (+ ~1 tile-equivalent of prologue / epilogue) is minimal
   int best_tps = g.tiles_m;
@@ -1160,7 +1221,7 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
 size_t wgrad_ws_bytes(const ConvGeom& g) {
   WgradGeom wg;
   wgrad_plan(g, 4, &wg);
-  return (size_t)wg.nsplit * wg.MP * g.KH * g.KW * wg.NP * sizeof(float) + (size_t)wg.nsplit * wg.MP * sizeof(float) + 256;
+  return (size_t)wg.nsplit * wg.MP * wgrad_taps(g) * wg.NP * sizeof(float) + (size_t)wg.nsplit * wg.MP * sizeof(float) + 256;
 }
 
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
@@ -1170,7 +1231,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
-  const int T = g.KH * g.KW;
+  const int T = wgrad_taps(g);
   const size_t lds_stage = ((size_t)g.NI * g.IHt * g.IWt + kBM) * 32 * sizeof(float);
   const size_t lds = lds_stage > 16384 ? lds_stage : 16384;
   if (lds > 160 * 1024 - 512) return fail("wgrad: tile needs %zu B of LDS", lds);
@@ -1203,17 +1264,26 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<1>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<4>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
+  } else if (g.nph > 1) {
+    if (!aligned || g.NI * g.IHt * g.IWt * 8 > 9 * 256) return fail("wgrad: phased 4x4/s2 geometry not eligible for the pipelined kernel");
+    static bool attr_ph = false;
+    if (!attr_ph) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_ph = true;
+    }
+    const dim3 gridp(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<2, 2, true>), gridp, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
     static bool attr_p = false;
     if (!attr_p) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<3, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_p = true;
     }
     if (g.KH == 1)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1, 1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1, 1, false>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<3, 3>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<3, 3, false>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else

@@ -53,6 +53,11 @@ struct ConvGeom {
   int stride;        // input stride
   int os;            // output stride (2 for transposed)
   int nz;            // 1, or 4 parity classes
+  // a 4x4 / stride-2 / pad-1 convolution runs as 4 K-phases of 2x2 stride-1 convolutions over the parity sub-images of
+  // the input (space-to-depth without moving data): phase ph reads source pixel ((sy)*in_step + ph_oy, (sx)*in_step + ph_ox)
+  int nph, in_step;  // 1,1 for ordinary convolutions; 4,2 for the phased 4x4s2
+  int Kw;            // K columns of one packed weight row = nph * Cin
+  int ph_oy[4], ph_ox[4], ph_pad_y[4], ph_pad_x[4];
   int pad_y[4], pad_x[4], ooy[4], oox[4];
   long w_off[4];     // float offset of the packed weight slab per z
   // output addressing: out[b*sob + oy*soy + ox*sox + c*soc]

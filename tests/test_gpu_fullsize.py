@@ -1,0 +1,125 @@
+"""Full-size (BASELINE.json configs) checks on the real GPU through size-independent properties: analytic residuals,
+adjoint (dot-product) identity, batch independence, run-to-run determinism, shard/average equivalence."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _darcy_setup(dim=32, P=64):
+    from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion
+    from physicsinformeddiffusionmodels_amd.residuals_darcy import ResidualsDarcy
+    from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+    dev = _dev()
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2).to(dev)
+    diff = DenoisingDiffusion(100, dev)
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True, device=dev)
+    return m, diff, res, dev
+
+
+def test_darcy_residual_analytic_quadratic_b256():
+    """p = x0^2 + 2 x1^2 (exactly differentiated by the acc-2 stencils, edges included), K = const:
+    eq = -K (2 + 4) - f_s everywhere; boundary rows carry -/+ dp/dx."""
+    m, diff, res, dev = _darcy_setup()
+    B, P = 256, 64
+    xs = torch.linspace(0, 1, P, dtype=torch.float64)
+    X0, X1 = torch.meshgrid(xs, xs, indexing="ij")
+    x1c = 1.0 - X1   # reverse_d1: axis 1 runs with spacing -1/63
+    p = (X0 ** 2 + 2 * x1c ** 2)
+    K = 1.7
+    x0 = torch.stack([p, torch.full_like(p, K)]).float().unsqueeze(0).repeat(B, 1, 1, 1).to(dev)
+    r = res.compute_residual(x0, pass_through=True)["residual"].double().cpu().reshape(B, P, P, 3)
+    fs = res.f_s.double().cpu().reshape(P, P)
+    eq_ref = -K * 6.0 - fs
+    assert (r[..., 0] - eq_ref).abs().max() < 2e-2          # fp32 cancellation at h^-2 = 3969: abs error, values ~10
+    assert (r[3:-3, :, :, 0] - r[0, :, :, 0]).abs().max() == 0.0   # every sample identical (no cross-sample coupling)
+    bc0 = r[0, :, :, 1]
+    assert bc0[1:-1].abs().max() == 0.0
+    assert (bc0[0] - (-2 * X0[0])).abs().max() < 1e-3 and (bc0[-1] - (2 * X0[-1])).abs().max() < 1e-3
+
+
+def test_darcy_adjoint_dot_product_b256():
+    """<J v, w> == <v, J^T w> with J the Jacobian of the residual (directional derivative by central difference in fp64
+    on the host oracle is not needed: J v is obtained from the linearity in p for fixed K)."""
+    m, diff, res, dev = _darcy_setup()
+    B, P = 256, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 2, P, P, generator=g).to(dev)
+    v = torch.zeros_like(x)
+    v[:, 0] = torch.randn(B, P, P, generator=g).to(dev)      # perturb p only: residual is linear in p
+    w = torch.randn(B, P * P, 3, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True)
+    r0 = res.compute_residual(xr, pass_through=True)["residual"]
+    (jtw,) = torch.autograd.grad(r0, xr, w)
+    with torch.no_grad():
+        r1 = res.compute_residual(x + v, pass_through=True)["residual"]
+    lhs = ((r1 - r0.detach()).double() * w.double()).sum().item()
+    rhs = (v.double() * jtw.double()).sum().item()
+    assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs))
+
+
+def test_unet_batch_independence_and_determinism_b64():
+    m, diff, res, dev = _darcy_setup()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(64, 4096, 2, generator=g).to(dev)
+    t = torch.randint(0, 100, (64,), generator=g).to(dev)
+    with torch.no_grad():
+        full = m(x, t)
+        sub = m(x[5:9].contiguous(), t[5:9].contiguous())
+        again = m(x, t)
+    assert torch.equal(full, again)                               # bit-exact run to run
+    assert (full[5:9] - sub).abs().max().item() <= 1e-5 * full.abs().max().item()   # samples do not interact
+
+
+def test_training_step_determinism_and_shard_average_b64():
+    """Two identical steps give bit-identical gradients (no atomics); the gradient of the batch-mean loss equals the
+    average of the gradients of the two half-batch mean losses (what the data-parallel all-reduce computes)."""
+    m, diff, res, dev = _darcy_setup()
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(64, 2, 64, 64, generator=g).to(dev)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(64, 2, 64, 64, generator=g).to(dev)
+    t = torch.randint(0, 100, (64,), generator=g).to(dev)
+
+    def grads(lo, hi):
+        orig = torch.randint, torch.randn_like
+        torch.randint = lambda *a, **k: t[lo:hi].clone()
+        torch.randn_like = lambda *a, **k: eps[lo:hi].clone()
+        try:
+            loss, *_ = diff.model_estimation_loss(x0[lo:hi].contiguous(), residual_func=res, c_data=1., c_residual=1e-3)
+        finally:
+            torch.randint, torch.randn_like = orig
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        eng = next(iter(m.__dict__["_engines"].values()))
+        return loss.item(), eng.flat_grad.clone()
+
+    l1, g1 = grads(0, 64)
+    l2, g2 = grads(0, 64)
+    assert l1 == l2 and torch.equal(g1, g2)
+    la, ga = grads(0, 32)
+    lb, gb = grads(32, 64)
+    avg = 0.5 * (ga + gb)
+    assert abs(0.5 * (la + lb) - l1) < 1e-5 * abs(l1)
+    scale = g1.abs().max().item()
+    assert (avg - g1).abs().max().item() < 2e-4 * scale
+
+
+def test_sampling_b1024_two_steps_finite_and_deterministic():
+    m, diff, res, dev = _darcy_setup()
+    torch.manual_seed(11)
+    x = torch.randn(1024, 2, 64, 64, device=dev)
+    outs = []
+    for rep in range(2):
+        torch.manual_seed(12)
+        (nx, _), _ = diff.p_sample(x, None, 57, save_output=False, surpress_noise=True, residual_func=res)
+        outs.append(nx)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (configs[1] = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--calib-copy", action="store_true",
+                    help="also run one 1 GiB device copy (known byte count for the PMC traffic passes, tools/pmc_traffic.sh)")
     return ap.parse_args()
 
 
@@ -80,6 +82,18 @@ def cpu_baseline(batch=8, steps=2):
     return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed steps (1 warm-up) of the oracle's Darcy 64x64 training step (UNet dim=32 fwd+bwd, "
                       f"residual, loss, clip, Adam) at batch {batch}, {dt:.2f} s/step"}
+
+
+def pmc_traffic(batch):
+    """HBM bytes per launch of the conv class from the committed PMC passes (tools/pmc_traffic.sh -> profiles/): the
+    counters need rocprofv3 around the process, so they cannot be read live; null when no pass exists for this batch."""
+    import json as _json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_b{batch}.json")
+    try:
+        with open(path) as f:
+            return round(float(_json.load(f)["conv"]["hbm_bytes_per_launch"]), 0)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -140,6 +154,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.calib_copy:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        del src, dst
     for _ in range(args.warmup):
         step()
     fence()
@@ -174,7 +193,7 @@ def main():
         step_flops = B * FLOPS_PER_SAMPLE_FWD_BWD
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
             "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 MFMA implicit GEMM: fwd, dgrad, wgrad)",
             "launches_per_step": conv_n // nprof, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "kernel_ms_per_step": round(conv_ms / nprof, 3),

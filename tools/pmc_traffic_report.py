@@ -1,0 +1,45 @@
+"""Fold the two rocprofv3 --pmc passes of tools/pmc_traffic.sh into HBM bytes per launch per kernel class.
+
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE/WRITE_SIZE are reported in KiB; the factor 2 is the gfx950
+correction of MI355X_MICROARCH.md §HBM).  The calibration rows (a 1 GiB torch copy: 2^30 B read, 2^30 B written) are
+printed next to the result so the correction can be judged on this very run."""
+import collections, csv, glob, json, sys
+
+d, batch = sys.argv[1], int(sys.argv[2])
+CLASSES = [("conv_igemm", "conv"), ("conv_wgrad", "conv"), ("wgrad_reduce", "conv_aux"), ("pack_", "conv_aux"),
+           ("colsum", "conv_aux"), ("gn_", "norm"), ("layernorm", "norm"), ("la_", "attn"), ("mid_attn", "attn"),
+           ("darcy", "darcy"), ("qsample", "darcy")]
+
+
+def cls(name):
+    for pat, c in CLASSES:
+        if pat in name:
+            return c
+    return "calib_copy" if ("elementwise" in name or "copy" in name.lower()) and "pidm" not in name else "other"
+
+
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+big = collections.defaultdict(dict)
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{d}/{counter}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            c = cls(r["Kernel_Name"])
+            v = float(r["Counter_Value"])
+            tot[c][counter] += v
+            cnt[c][counter] += 1
+            if c == "calib_copy":
+                big[counter][r["Dispatch_Id"]] = max(big[counter].get(r["Dispatch_Id"], 0.0), v)
+res = {"batch": batch, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; 2 steps (1 warm-up + 1 timed)"}
+for c in tot:
+    n = max(cnt[c]["FETCH_SIZE"], cnt[c]["WRITE_SIZE"], 1)
+    fk, wk = tot[c]["FETCH_SIZE"], tot[c]["WRITE_SIZE"]
+    res[c] = {"launches": n, "fetch_KiB": fk, "write_KiB": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024 / n,
+              "hbm_bytes_per_step": (2 * fk + wk) * 1024 / 2}
+cal = {k: max(v.values()) if v else None for k, v in big.items()}
+res["calibration_1GiB_copy"] = {"FETCH_SIZE_KiB_max_dispatch": cal.get("FETCH_SIZE"), "WRITE_SIZE_KiB_max_dispatch": cal.get("WRITE_SIZE"),
+                                "expected_KiB_each": 2 ** 20}
+json.dump(res, open(f"{d}/traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))

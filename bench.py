@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (configs[1] = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused flat clip+Adam kernel (same math)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="also run one 1 GiB device copy (known byte count for the PMC traffic passes, tools/pmc_traffic.sh)")
     return ap.parse_args()
@@ -134,7 +136,11 @@ def main():
     diffusion = DenoisingDiffusion(100, dev)
     residuals = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=64, pixels_at_boundary=True, reverse_d1=True,
                                device=dev, bcs='none', domain_length=1.)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1.e-4)
+    if args.torch_optimizer:
+        optimizer = torch.optim.Adam(model.parameters(), lr=1.e-4)
+    else:
+        from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
+        optimizer = FusedClipAdam(model, lr=1.e-4, max_norm=1., image_size=64)   # clip_grad_norm_(1.) + Adam, 2 launches
     batch = synthetic_darcy_batch(B, 64, seed=100 + rank, device=dev)   # resident in HBM; each rank its own shard
     torch.manual_seed(1234 + rank)
 
@@ -145,7 +151,8 @@ def main():
         loss.backward()
         if world > 1:
             allreduce_gradients(model, world)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
+        if args.torch_optimizer:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
         optimizer.step()
         return loss
 
@@ -215,6 +222,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Darcy 64x64 2-ch (K,p), PIDM loss on (c_residual=1e-3), Unet3D dim=32, 100 diffusion "
                                    "steps, loss+backward+clip+Adam (main.py:157-166)", "per_gpu_batch": B,
+                       "optimizer": "torch clip_grad_norm_+Adam" if args.torch_optimizer else "fused flat clip+Adam (k_optim.hip)",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

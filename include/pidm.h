@@ -69,6 +69,17 @@ int pidm_psample_update(const float* x0_pred, const float* x_t, const float* z, 
                         float* x_prev, size_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused global-norm clip + Adam over flat fp32 buffers    replaces main.py:165-166
+ *   torch.nn.utils.clip_grad_norm_(model.parameters(), 1.) ; optimizer.step()   (torch.optim.Adam, no weight decay/amsgrad)
+ * param/grad/exp_avg/exp_avg_sq: n floats each, 16-byte aligned; `step` is the 1-based update count (bias correction);
+ * max_norm <= 0 disables clipping; total_norm_out (device float, may be NULL) receives the pre-clip global L2 norm.
+ * workspace: pidm_clip_adam_ws_bytes() bytes.  Deterministic (fixed-order sums). */
+size_t pidm_clip_adam_ws_bytes(void);
+int pidm_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                        double beta2, double eps, long long step, double max_norm, float* total_norm_out, void* workspace,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Mechanics residual r = K(rho) u - f, matrix-free      replaces ResidualsMechanics.compute_residual
  *   src/residuals_mechanics_K.py:198-274 (dense 8450x8450 index_put assembly + einsum) and resize_image :10-21
  * x0_pred [B,3,nel,nel] NCHW (u1,u2,rho); bcs [B,4,nel+1,nel+1] (bc_x, bc_y, load_x, load_y); vf [B]

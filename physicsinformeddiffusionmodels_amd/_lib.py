@@ -55,6 +55,9 @@ class PidmLib:
         self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
         self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
         self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
+        self._sig("pidm_clip_adam_ws_bytes", [], sz)
+        self._sig("pidm_clip_adam_step", [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
+                                          C.c_double, vp, vp, vp])
         self._sig("pidm_bilinear_resize", [vp, vp, i, i, i, vp])
         self._sig("pidm_mech_residual_fwd", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_mech_residual_bwd", [vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, i, vp])

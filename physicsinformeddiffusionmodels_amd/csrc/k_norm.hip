@@ -65,52 +65,105 @@ __global__ void __launch_bounds__(256) gn_stats_partial_kernel(const float* __re
   }
 }
 
-__global__ void gn_stats_final_kernel(const double* __restrict__ partial, int nchunk, int G, int B, double count, float eps,
-                                      float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * G) return;
-  const int b = i / G, g = i % G;
-  double s = 0.0, ss = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
-    const double* p = partial + (((size_t)b * nchunk + c) * G + g) * 2;
-    s += p[0];
-    ss += p[1];
+// Lane geometry of the streaming GroupNorm kernels: a block owns sample b = blockIdx.y and a pixel chunk; thread ->
+// (channel quad q, pixel lane pl).  QC = C/4 quads per pixel; QC <= 256 must divide 256 (pixel lanes = 256/QC), larger
+// QC must be a multiple of 256 (the block loops over `nrep` quad slabs).  Per-channel constants live in registers, so
+// the pixel loop is pure 16-byte streaming.
+struct GnLanes {
+  int qw, ppi, nrep;
+};
+__device__ __forceinline__ GnLanes gn_lanes(int C) {
+  const int QC = C >> 2;
+  GnLanes l;
+  l.qw = QC > 256 ? 256 : QC;
+  l.ppi = 256 / l.qw;
+  l.nrep = QC > 256 ? QC / 256 : 1;
+  return l;
+}
+
+// group statistics from the per-chunk partial sums (every block of a sample repeats this tiny reduction instead of a
+// separate "final" launch); block x == 0 also publishes (mean, rstd) for the backward pass
+__device__ __forceinline__ void gn_finalize_stats(const double* __restrict__ partial, int nchunk, int G, int b, double count,
+                                                  float eps, float* __restrict__ stats_out, float (*s_stat)[2]) {
+  const int tid = threadIdx.x;
+  if (tid < G) {
+    double s = 0.0, ss = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+      const double* p = partial + (((size_t)b * nchunk + c) * G + tid) * 2;
+      s += p[0];
+      ss += p[1];
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+    s_stat[tid][0] = mf;
+    s_stat[tid][1] = rf;
+    if (blockIdx.x == 0 && stats_out) {
+      stats_out[((size_t)b * G + tid) * 2] = mf;
+      stats_out[((size_t)b * G + tid) * 2 + 1] = rf;
+    }
   }
-  const double mean = s / count;
-  double var = ss / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  __syncthreads();
 }
 
 // y = SiLU( ((x-mean)*rstd*gamma + beta) * (1 + scale) + shift ) [+ res]
 // scale[b][c] = ss[b*ldss + c] + ssb[c], shift[b][c] = ss[b*ldss + C + c] + ssb[C + c]   (ss may be null)
-__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+// `partial` != null: statistics are finalised here from the stats_partial sums and written to `stats`;
+// `partial` == null: `stats` is read.
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, int nchunk,
+                                                       double count, float eps, float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, const float* __restrict__ ssb, int ldss,
-                                                       const float* __restrict__ res, float* __restrict__ y, int B, int HW,
-                                                       int C, int G) {
+                                                       const float* __restrict__ res, float* __restrict__ y, int HW, int C, int G,
+                                                       int ppb) {
+  __shared__ float s_stat[64][2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (partial) {
+    gn_finalize_stats(partial, nchunk, G, b, count, eps, stats, s_stat);
+  } else {
+    if (tid < G) {
+      s_stat[tid][0] = stats[((size_t)b * G + tid) * 2];
+      s_stat[tid][1] = stats[((size_t)b * G + tid) * 2 + 1];
+    }
+    __syncthreads();
+  }
   const int cpg = C / G;
-  const size_t total = (size_t)B * HW * C;
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
-    const int c0 = (int)(i % C);
-    const int b = (int)(i / ((size_t)HW * C));
-    const float4 xv = *reinterpret_cast<const float4*>(x + i);
-    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (res) rv = *reinterpret_cast<const float4*>(res + i);
-    float o[4];
+  const GnLanes L = gn_lanes(C);
+  const int pl = tid / L.qw;
+  const int p0 = blockIdx.x * ppb;
+  const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
+  for (int rep = 0; rep < L.nrep; ++rep) {
+    const int c0 = 4 * (rep * 256 + tid % L.qw);
+    float mean[4], a[4], bt[4], sc1[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k, g = c / cpg;
-      const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-      float v = (xv[k] - mean) * rstd * gamma[c] + beta[c];
+      mean[k] = s_stat[g][0];
+      a[k] = s_stat[g][1] * gamma[c];
+      bt[k] = beta[c];
+      sc1[k] = 1.f;
+      sh[k] = 0.f;
       if (ss) {
-        const float sc = ss[(size_t)b * ldss + c] + ssb[c], sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
-        v = v * (sc + 1.f) + sh;
+        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
+        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
       }
-      o[k] = v * sigmoidf_(v) + rv[k];
     }
-    *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+    const size_t base = (size_t)b * HW * C + c0;
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += L.ppi) {
+      const size_t i = base + (size_t)p * C;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = ((xv[k] - mean[k]) * a[k] + bt[k]) * sc1[k] + sh[k];
+        o[k] = v * sigmoidf_(v) + rv[k];
+      }
+      *reinterpret_cast<f32x4*>(y + i) = o;
+    }
   }
 }
 
@@ -124,95 +177,71 @@ __device__ __forceinline__ void gn_recompute(float xv, float dyv, float mean, fl
   *dv = dyv * (sg * (1.f + v * (1.f - sg)));
 }
 
-// per (b, chunk, c): S1 = sum dv, S2 = sum dv*xhat  (double partials).  Requires 256 % C == 0 or C % 256 == 0.
+// per (b, chunk, c): S1 = sum dv, S2 = sum dv*xhat  (double partials)
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ ss,
                                                             const float* __restrict__ ssb, int ldss, int HW, int C, int G,
                                                             int ppb, double* __restrict__ partial) {
-  __shared__ double red[256][2];
+  __shared__ float red[256][8];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
+  const GnLanes L = gn_lanes(C);
+  const int pl = tid / L.qw, ql = tid % L.qw;
   const int p0 = chunk * ppb;
   const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
-  const int nrep = C > 256 ? C / 256 : 1;
-  const int cw = C > 256 ? 256 : C;  // channels covered by one pass of the block
-  const int rl = tid / cw, nrl = 256 / cw;
-  for (int rep = 0; rep < nrep; ++rep) {
-    const int c = rep * 256 + tid % cw;
-    const int g = c / cpg;
-    const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-    const float gm = gamma[c], bt = beta[c];
-    float sc1 = 1.f, sh = 0.f;
-    if (ss) {
-      sc1 = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
-      sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
-    }
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = p0 + rl; p < p1; p += nrl) {
-      const size_t idx = ((size_t)b * HW + p) * C + c;
-      float xh, dv;
-      gn_recompute(x[idx], dy[idx], mean, rstd, gm, bt, sc1, sh, &xh, &dv);
-      s1 += dv;
-      s2 += dv * xh;
-    }
-    __syncthreads();
-    red[tid][0] = s1;
-    red[tid][1] = s2;
-    __syncthreads();
-    if (tid < cw) {
-      double a = 0.0, d = 0.0;
-      for (int r = 0; r < nrl; ++r) {
-        a += red[r * cw + tid][0];
-        d += red[r * cw + tid][1];
+  for (int rep = 0; rep < L.nrep; ++rep) {
+    const int c0 = 4 * (rep * 256 + ql);
+    float mean[4], rstd[4], gm[4], bt[4], sc1[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k, g = c / cpg;
+      mean[k] = stats[((size_t)b * G + g) * 2];
+      rstd[k] = stats[((size_t)b * G + g) * 2 + 1];
+      gm[k] = gamma[c];
+      bt[k] = beta[c];
+      sc1[k] = 1.f;
+      sh[k] = 0.f;
+      if (ss) {
+        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
+        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
       }
-      double* o = partial + (((size_t)b * gridDim.x + chunk) * C + c) * 2;
-      o[0] = a;
-      o[1] = d;
     }
-  }
-}
-
-// per sample b: totals over chunks, dscale/dshift, per-(b,c) dgamma/dbeta contributions, group coefficients c1,c2
-__global__ void __launch_bounds__(256) gn_bwd_final_kernel(const double* __restrict__ partial, int nchunk,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ ss, const float* __restrict__ ssb, int ldss,
-                                                           float* __restrict__ dss, int HW, int C, int G,
-                                                           float* __restrict__ dgb,   // [B][2][C]: (s1*S2, s1*S1)
-                                                           float* __restrict__ coef)  // [B][G][2]: (c1, c2)
-{
-  __shared__ double ga[1024], gb[1024];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int cpg = C / G;
-  for (int c = tid; c < C; c += 256) {
-    double S1 = 0.0, S2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
-      S1 += p[0];
-      S2 += p[1];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t base = (size_t)b * HW * C + c0;
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += L.ppi) {
+      const size_t i = base + (size_t)p * C;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+      const f32x4 dv4 = *reinterpret_cast<const f32x4*>(dy + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xh, dv;
+        gn_recompute(xv[k], dv4[k], mean[k], rstd[k], gm[k], bt[k], sc1[k], sh[k], &xh, &dv);
+        s1[k] += dv;
+        s2[k] += dv * xh;
+      }
     }
-    const double gm = gamma[c], bt = beta[c];
-    double sc1 = 1.0;
-    if (ss) {
-      sc1 = 1.0 + ((double)ss[(size_t)b * ldss + c] + (double)ssb[c]);
-      dss[(size_t)b * ldss + c] = (float)(gm * S2 + bt * S1);      // d scale
-      dss[(size_t)b * ldss + C + c] = (float)S1;                    // d shift
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[tid][k] = s1[k];
+      red[tid][4 + k] = s2[k];
     }
-    dgb[((size_t)b * 2 + 0) * C + c] = (float)(sc1 * S2);
-    dgb[((size_t)b * 2 + 1) * C + c] = (float)(sc1 * S1);
-    ga[c] = gm * sc1 * S1;
-    gb[c] = gm * sc1 * S2;
-  }
-  __syncthreads();
-  if (tid < G) {
-    double a = 0.0, d = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-      a += ga[tid * cpg + k];
-      d += gb[tid * cpg + k];
+    __syncthreads();
+    if (tid < L.qw) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = 0.0, d = 0.0;
+        for (int r = 0; r < L.ppi; ++r) {
+          a += red[r * L.qw + tid][k];
+          d += red[r * L.qw + tid][4 + k];
+        }
+        double* o = partial + (((size_t)b * gridDim.x + chunk) * C + c0 + k) * 2;
+        o[0] = a;
+        o[1] = d;
+      }
     }
-    const double n = (double)cpg * HW;
-    coef[((size_t)b * G + tid) * 2] = (float)(a / n);
-    coef[((size_t)b * G + tid) * 2 + 1] = (float)(d / n);
   }
 }
 
@@ -237,36 +266,91 @@ __global__ void __launch_bounds__(256) gn_param_grad_kernel(const float* __restr
   }
 }
 
-// dx = rstd * (dv * sc1 * gamma - c1 - xhat * c2)
+// dx = rstd * (dv * sc1 * gamma - c1 - xhat * c2).  Every block first totals the chunk partials of its sample (what a
+// separate "final" launch used to do): S1_c, S2_c -> group coefficients (c1, c2) in LDS; block x == 0 also writes the
+// FiLM gradients dss[b][..] and the per-sample (dgamma, dbeta) contributions dgb[b][2][C].
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
                                                            const float* __restrict__ ssb, int ldss,
-                                                           const float* __restrict__ coef, float* __restrict__ dx, int B,
-                                                           int HW, int C, int G) {
+                                                           const double* __restrict__ partial, int nchunk, float* __restrict__ dss,
+                                                           float* __restrict__ dgb, float* __restrict__ dx, int HW, int C, int G,
+                                                           int ppb) {
+  __shared__ double ga[1024], gb[1024];
+  __shared__ float s_coef[64][2];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
-  const size_t total = (size_t)B * HW * C;
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
-    const int c0 = (int)(i % C);
-    const int b = (int)(i / ((size_t)HW * C));
-    const float4 xv = *reinterpret_cast<const float4*>(x + i);
-    const float4 dv4 = *reinterpret_cast<const float4*>(dy + i);
-    float o[4];
+  for (int c = tid; c < C; c += 256) {
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
+      S1 += p[0];
+      S2 += p[1];
+    }
+    const double gm = gamma[c], bt = beta[c];
+    double sc1 = 1.0;
+    if (ss) sc1 = 1.0 + ((double)ss[(size_t)b * ldss + c] + (double)ssb[c]);
+    if (blockIdx.x == 0) {
+      if (ss) {
+        dss[(size_t)b * ldss + c] = (float)(gm * S2 + bt * S1);      // d scale
+        dss[(size_t)b * ldss + C + c] = (float)S1;                    // d shift
+      }
+      dgb[((size_t)b * 2 + 0) * C + c] = (float)(sc1 * S2);
+      dgb[((size_t)b * 2 + 1) * C + c] = (float)(sc1 * S1);
+    }
+    ga[c] = gm * sc1 * S1;
+    gb[c] = gm * sc1 * S2;
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, d = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      a += ga[tid * cpg + k];
+      d += gb[tid * cpg + k];
+    }
+    const double n = (double)cpg * HW;
+    s_coef[tid][0] = (float)(a / n);
+    s_coef[tid][1] = (float)(d / n);
+  }
+  __syncthreads();
+  const GnLanes L = gn_lanes(C);
+  const int pl = tid / L.qw;
+  const int p0 = blockIdx.x * ppb;
+  const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
+  for (int rep = 0; rep < L.nrep; ++rep) {
+    const int c0 = 4 * (rep * 256 + tid % L.qw);
+    float mean[4], rstd[4], gm[4], bt[4], sc1[4], sh[4], k1[4], k2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k, g = c / cpg;
-      const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-      const float gm = gamma[c], bt = beta[c];
-      float sc1 = 1.f, sh = 0.f;
+      mean[k] = stats[((size_t)b * G + g) * 2];
+      rstd[k] = stats[((size_t)b * G + g) * 2 + 1];
+      gm[k] = gamma[c];
+      bt[k] = beta[c];
+      sc1[k] = 1.f;
+      sh[k] = 0.f;
       if (ss) {
-        sc1 = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
-        sh = ss[(size_t)b * ldss + C + c] + ssb[C + c];
+        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
+        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
       }
-      float xh, dv;
-      gn_recompute(xv[k], dv4[k], mean, rstd, gm, bt, sc1, sh, &xh, &dv);
-      o[k] = rstd * (dv * sc1 * gm - coef[((size_t)b * G + g) * 2] - xh * coef[((size_t)b * G + g) * 2 + 1]);
+      k1[k] = s_coef[g][0];
+      k2[k] = s_coef[g][1];
     }
-    *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    const size_t base = (size_t)b * HW * C + c0;
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += L.ppi) {
+      const size_t i = base + (size_t)p * C;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+      const f32x4 dv4 = *reinterpret_cast<const f32x4*>(dy + i);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float xh, dv;
+        gn_recompute(xv[k], dv4[k], mean[k], rstd[k], gm[k], bt[k], sc1[k], sh[k], &xh, &dv);
+        o[k] = rstd[k] * (dv * sc1[k] * gm[k] - k1[k] - xh * k2[k]);
+      }
+      *reinterpret_cast<f32x4*>(dx + i) = o;
+    }
   }
 }
 
@@ -500,27 +584,37 @@ static int gn_chunks(int HW, int B) {
 size_t gn_ws_bytes(int B, int HW, int C, int G) {
   const int nchunk = gn_chunks(HW, B);
   const size_t part = (size_t)B * nchunk * (C > G ? C : G) * 2 * sizeof(double);
-  return part + (size_t)B * 2 * C * sizeof(float) + (size_t)B * G * 2 * sizeof(float) + 256;
+  return part + (size_t)B * 2 * C * sizeof(float) + 256;
 }
 
-int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st) {
+static int gn_check(int C, int G) {
   if (G > 64 || (256 % G) || (C % G)) return fail("groupnorm: groups=%d must divide 256 and C=%d", G, C);
+  const int QC = C / 4;
+  if ((C % 4) || C > 4096 || !((QC <= 256 && 256 % QC == 0) || (QC % 256 == 0)))
+    return fail("groupnorm: unsupported channel count C=%d (C/4 must divide 256 or be a multiple of 256, C <= 4096)", C);
+  return 0;
+}
+
+// statistics partials only: the (mean, rstd) finalisation is folded into launch_gn_apply, which must be the next user of `ws`
+int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st) {
+  (void)stats;
+  if (gn_check(C, G)) return -1;
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
   double* partial = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, HW, C, G, ppb, partial);
   PIDM_CHECK_LAUNCH("gn_stats_partial_kernel");
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(cdiv(B * G, 256)), dim3(256), 0, st, partial, nchunk, G, B,
-                     (double)HW * (C / G), 1e-5f, stats);
-  PIDM_CHECK_LAUNCH("gn_stats_final_kernel");
   return 0;
 }
 
-int launch_gn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* ss,
-                    const float* ssb, int ldss, const float* res, float* y, int B, int HW, int C, int G, hipStream_t st) {
-  if (C % 4) return fail("groupnorm: C=%d must be a multiple of 4", C);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks((size_t)B * HW * C / 4)), dim3(256), 0, st, x, stats, gamma, beta, ss,
-                     ssb, ldss, res, y, B, HW, C, G);
+// ws != null: holds launch_gn_stats' partials, `stats` [B][G][2] is WRITTEN (and used); ws == null: `stats` is read
+int launch_gn_apply(const float* x, float* stats, const float* gamma, const float* beta, const float* ss, const float* ssb,
+                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st) {
+  if (gn_check(C, G)) return -1;
+  const int nchunk = gn_chunks(HW, B);
+  const int ppb = cdiv(HW, nchunk);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws), nchunk,
+                     (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb);
   PIDM_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }
@@ -529,7 +623,7 @@ int launch_gn_apply(const float* x, const float* stats, const float* gamma, cons
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
                   void* ws, hipStream_t st) {
-  if (!((256 % C == 0) || (C % 256 == 0)) || C > 1024 * 4) return fail("groupnorm bwd: unsupported C=%d", C);
+  if (gn_check(C, G)) return -1;
   if (C > 1024) return fail("groupnorm bwd: C=%d > 1024", C);
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
@@ -537,19 +631,14 @@ int launch_gn_bwd(const float* x, const float* dy, const float* stats, const flo
   double* partial = reinterpret_cast<double*>(w);
   w += (size_t)B * nchunk * C * 2 * sizeof(double);
   float* dgb = reinterpret_cast<float*>(w);
-  w += (size_t)B * 2 * C * sizeof(float);
-  float* coef = reinterpret_cast<float*>(w);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, HW, C,
                      G, ppb, partial);
   PIDM_CHECK_LAUNCH("gn_bwd_reduce_kernel");
-  hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, gamma, beta, ss, ssb, ldss, dss, HW, C, G,
-                     dgb, coef);
-  PIDM_CHECK_LAUNCH("gn_bwd_final_kernel");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, partial,
+                     nchunk, dss, dgb, dx, HW, C, G, ppb);
+  PIDM_CHECK_LAUNCH("gn_bwd_apply_kernel");
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dgb, B, C, dgamma, dbeta);
   PIDM_CHECK_LAUNCH("gn_param_grad_kernel");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * C / 4)), dim3(256), 0, st, x, dy, stats, gamma, beta,
-                     ss, ssb, ldss, coef, dx, B, HW, C, G);
-  PIDM_CHECK_LAUNCH("gn_bwd_apply_kernel");
   return 0;
 }
 

@@ -447,17 +447,17 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
   m.bact = act_alloc(r, n);
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
-  RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.st));
+  RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.scratch, r.st));
   m.c = act_alloc(r, n);
   if (conv_fwd(r, m.c2, m.bact, nullptr, nullptr, m.c)) return -1;
   m.st2 = act_alloc(r, (size_t)B * G * 2);
   RUN(launch_gn_stats(m.c, B, HW, Co, G, m.st2, r.scratch, r.st));
   if (m.has_res) {
     float* d = r.tmp.alloc(n);
-    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.st));
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.scratch, r.st));
     if (conv_fwd(r, m.cr, x0, x1, d, out)) return -1;
   } else {
-    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.st));
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.scratch, r.st));
   }
   if (!r.train) r.tmp.release(mk);
   else r.tmp.release(mk);

@@ -959,6 +959,58 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// all deferred reductions of one backward pass in ONE launch (descriptor table on the device, binary search per block
+// like pack_multi_kernel); same arithmetic as wgrad_reduce_kernel with 4 independent chains per split lane
+__global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __restrict__ table, int ndesc) {
+  __shared__ float red[8][32];
+  int lo = 0, hi = ndesc - 1;
+  const unsigned bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const ReduceDesc d = table[lo];
+  const int tid = threadIdx.x, ol = tid & 31, sl = tid >> 5;
+  const long nw = (long)d.M * d.T * d.N;
+  const long o = (long)(bid - d.blk0) * 32 + ol;
+  const float* p = nullptr;
+  size_t sstride = 0;
+  long dsti = -1;
+  float* dptr = nullptr;
+  if (o < nw) {
+    const int n = (int)(o % d.N), t = (int)((o / d.N) % d.T), m = (int)(o / ((long)d.N * d.T));
+    p = d.src + ((size_t)m * d.T + t) * d.NP + n;
+    sstride = d.sstride;
+    dptr = d.dst;
+    dsti = ((long)m * d.N + n) * d.T + t;
+  } else if (d.bdst && o < nw + d.M) {
+    const int m = (int)(o - nw);
+    p = d.bsrc + m;
+    sstride = (size_t)d.MP;
+    dptr = d.bdst;
+    dsti = m;
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (p) {
+    int sp = sl;
+    for (; sp + 24 < d.nsplit; sp += 32) {
+      s0 += p[(size_t)sp * sstride];
+      s1 += p[(size_t)(sp + 8) * sstride];
+      s2 += p[(size_t)(sp + 16) * sstride];
+      s3 += p[(size_t)(sp + 24) * sstride];
+    }
+    for (; sp < d.nsplit; sp += 8) s0 += p[(size_t)sp * sstride];
+  }
+  red[sl][ol] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && dptr) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][ol];
+    dptr[dsti] = a;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // column sums (bias gradients etc.): out[c] = sum_r x[r*ld + c], two deterministic stages
 // ---------------------------------------------------------------------------------------------------
@@ -1099,6 +1151,13 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->nblk = (unsigned)((total + 2047) / 2048);
   return d->nblk;
 }
+int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st) {
+  if (ndesc <= 0 || nblocks == 0) return 0;
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc);
+  PIDM_CHECK_LAUNCH("reduce_multi_kernel");
+  return 0;
+}
+
 int launch_pack_multi(const PackDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st) {
   hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc);
   PIDM_CHECK_LAUNCH("pack_multi_kernel");
@@ -1227,7 +1286,7 @@ size_t wgrad_ws_bytes(const ConvGeom& g) {
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
 // dbias (may be null) = column sums of dy, fused into the same two launches
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 float* dbias, void* workspace, hipStream_t st) {
+                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer) {
   if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
@@ -1290,6 +1349,10 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
+  if (defer) {   // the caller keeps `workspace` alive until its reduce_multi launch
+    defer->push(partial, dw_ref, bias_partial, dbias, (size_t)wg.MP * T * wg.NP, wg.nsplit, g.Cout, g.Cin, T, wg.MP, wg.NP);
+    return 0;
+  }
   const size_t total = (size_t)g.Cout * g.Cin * T + (dbias ? g.Cout : 0);
   const int blocks = (int)((total + 31) / 32);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, dw_ref, bias_partial, dbias, wg.nsplit, g.Cout,

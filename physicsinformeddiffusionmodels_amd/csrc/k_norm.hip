@@ -622,7 +622,7 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
 // dx, dgamma, dbeta and (if ss) dss[b][off..off+2C) from dy
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
-                  void* ws, hipStream_t st) {
+                  void* ws, hipStream_t st, float* dgb_persist, ReduceQueue* defer) {
   if (gn_check(C, G)) return -1;
   if (C > 1024) return fail("groupnorm bwd: C=%d > 1024", C);
   const int nchunk = gn_chunks(HW, B);
@@ -630,13 +630,18 @@ int launch_gn_bwd(const float* x, const float* dy, const float* stats, const flo
   char* w = reinterpret_cast<char*>(ws);
   double* partial = reinterpret_cast<double*>(w);
   w += (size_t)B * nchunk * C * 2 * sizeof(double);
-  float* dgb = reinterpret_cast<float*>(w);
+  float* dgb = (defer && dgb_persist) ? dgb_persist : reinterpret_cast<float*>(w);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, HW, C,
                      G, ppb, partial);
   PIDM_CHECK_LAUNCH("gn_bwd_reduce_kernel");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, partial,
                      nchunk, dss, dgb, dx, HW, C, G, ppb);
   PIDM_CHECK_LAUNCH("gn_bwd_apply_kernel");
+  if (defer && dgb_persist) {   // dgamma[c] = sum_b dgb[b][0][c], dbeta[c] = sum_b dgb[b][1][c]
+    defer->push(dgb, dgamma, nullptr, nullptr, (size_t)2 * C, B, 1, C, 1, 1, C);
+    defer->push(dgb + C, dbeta, nullptr, nullptr, (size_t)2 * C, B, 1, C, 1, 1, C);
+    return 0;
+  }
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dgb, B, C, dgamma, dbeta);
   PIDM_CHECK_LAUNCH("gn_param_grad_kernel");
   return 0;
@@ -666,13 +671,17 @@ size_t layernorm_bwd_ws_bytes(int C) { return (size_t)1024 * C * sizeof(float); 
 
 // dx = LN_bwd(dy) + res ; dgamma = sum_pix dy * xhat
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st) {
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
   const int nb = ln_blocks(npix, C);
   float* partial = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, npix, C,
                      1e-5f);
   PIDM_CHECK_LAUNCH("layernorm_bwd");
+  if (defer) {   // `ws` (the per-block partial rows) stays alive until the caller's reduce_multi launch
+    defer->push(partial, dgamma, nullptr, nullptr, (size_t)C, nb, 1, C, 1, 1, C);
+    return 0;
+  }
   // fixed-order sum of the per-block partials
   char* ws2 = reinterpret_cast<char*>(ws) + (size_t)nb * C * sizeof(float);
   return launch_colsum(partial, (size_t)nb, C, C, dgamma, ws2, st);

@@ -79,4 +79,17 @@ struct PackDesc {
   unsigned blk0, nblk;
 };
 
+// one deferred fixed-order reduction (k_conv.hip: reduce_multi_kernel), queued during backward and run in ONE launch:
+//   dst[(m*N + n)*T + t] = sum_{s < nsplit} src[s*sstride + (m*T + t)*NP + n]     (m < M, n < N, t < T)
+//   bdst[m]              = sum_{s < nsplit} bsrc[s*MP + m]                         (optional)
+struct ReduceDesc {
+  const float* src;
+  float* dst;
+  const float* bsrc;
+  float* bdst;
+  size_t sstride;
+  int nsplit, M, N, T, MP, NP;
+  unsigned blk0, nblk;
+};
+
 }  // namespace pidm

@@ -1,8 +1,28 @@
 // Host-side launcher declarations shared between the kernel translation units and the UNet engine.
 #pragma once
+#include <vector>
+
 #include "pidm_common.h"
 
 namespace pidm {
+// queue of deferred reductions (split-K weight gradients, per-sample norm-parameter gradients): the producers leave their
+// partial buffers alive and the engine runs ONE reduce_multi launch at the end of backward instead of ~120 tiny launches
+struct ReduceQueue {
+  std::vector<ReduceDesc> v;
+  unsigned nblocks = 0;
+  void push(const float* src, float* dst, const float* bsrc, float* bdst, size_t sstride, int nsplit, int M, int N, int T,
+            int MP, int NP) {
+    ReduceDesc d;
+    d.src = src; d.dst = dst; d.bsrc = bsrc; d.bdst = bdst; d.sstride = sstride;
+    d.nsplit = nsplit; d.M = M; d.N = N; d.T = T; d.MP = MP; d.NP = NP;
+    const size_t total = (size_t)M * N * T + (bdst ? M : 0);
+    d.blk0 = nblocks;
+    d.nblk = (unsigned)((total + 31) / 32);
+    nblocks += d.nblk;
+    v.push_back(d);
+  }
+};
+int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st);
 // k_conv.hip
 int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int ld0, int ld1, int Cout, int KH, int KW,
               int stride, int pad, int out_nchw, int ldo, int ldr);
@@ -17,7 +37,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
                 const float* residual, float* out, int sigmoid_last, hipStream_t st);
 size_t wgrad_ws_bytes(const ConvGeom& g);
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 float* dbias, void* workspace, hipStream_t st);
+                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer = nullptr);
 size_t colsum_ws_bytes(size_t rows, int C);
 int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st);
 // k_norm.hip
@@ -27,11 +47,11 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
                     int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st);
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
-                  void* ws, hipStream_t st);
+                  void* ws, hipStream_t st, float* dgb_persist = nullptr, ReduceQueue* defer = nullptr);
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st);
 size_t layernorm_bwd_ws_bytes(int C);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st);
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer = nullptr);
 int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);
 int launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
 int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st);

@@ -92,11 +92,15 @@ struct pidm_unet {
   std::vector<const float*> down_in;  // input of each downsample
   std::vector<const float*> up_in;    // input of each upsample
   std::map<int, std::pair<size_t, size_t>> ws_cache[2];  // B -> (tape bytes, tmp bytes) for inference/training
+  std::map<int, size_t> defer_cache;                     // B -> bytes of the deferred-reduction arena (training)
+  std::vector<ReduceDesc> red_table;                     // host copy of the last uploaded reduction table
+  const void* red_table_dev = nullptr;
 };
 
 namespace pidm {
 
 static const size_t kMaxPackDesc = 1024;
+static const size_t kMaxReduceDesc = 1024;
 
 struct Run {
   pidm_unet* U;
@@ -107,6 +111,13 @@ struct Run {
   Arena tape, tmp;
   float* scratch = nullptr;  // shared scratch for wgrad partials / norm reductions
   size_t scratch_floats = 0;
+  // backward: split-K / per-sample partial buffers that must outlive their producer are taken from `defer` and their
+  // fixed-order sums are queued in `rq`, run by ONE reduce_multi launch at the end of backward
+  Arena defer;
+  ReduceQueue rq;
+  bool defer_on = false;
+  float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
+  ReduceQueue* q() { return defer_on ? &rq : nullptr; }
 };
 
 #define RUN(call)                 \
@@ -560,11 +571,13 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
   const int Ho = out_h(L);
   if (L.transposed) {
     if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
-    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, r.scratch, r.st));
+    float* part = r.part_alloc(wgrad_ws_bytes(g));
+    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, r.st, r.q()));
     if (L.b >= 0) RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], r.scratch, r.st));
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
-    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, r.scratch, r.st));
+    float* part = r.part_alloc(wgrad_ws_bytes(g));
+    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, r.st, r.q()));
   }
   return 0;
 }
@@ -585,8 +598,10 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   const size_t n = (size_t)B * HW * Co;
   const size_t mk = r.tmp.mark();
   float* g_c = r.tmp.alloc(n);
+  float* dgb2 = r.defer_on ? r.defer.alloc((size_t)B * 2 * Co) : nullptr;   // allocated outside RUN: dry runs size the arena
+  float* dgb1 = r.defer_on ? r.defer.alloc((size_t)B * 2 * Co) : nullptr;
   RUN(launch_gn_bwd(m.c, g_out, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, g_c, U->G[m.gn2w],
-                    U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st));
+                    U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st, dgb2, r.q()));
   if (conv_wgrad(r, m.c2, m.bact, nullptr, g_c)) return -1;
   float* g_b = r.tmp.alloc(n);
   if (conv_dgrad(r, m.c2, g_c, nullptr, g_b)) return -1;
@@ -594,7 +609,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
   RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
-                    g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st));
+                    g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st, dgb1, r.q()));
   if (conv_wgrad(r, m.c1, m.x0, m.x1, g_a)) return -1;
   if (m.has_res) {
     if (conv_wgrad(r, m.cr, m.x0, m.x1, g_out)) return -1;
@@ -628,7 +643,8 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   float* g_xn = g_attn;  // reuse (npix*HD >= npix*C is not guaranteed) -> allocate when C > HD
   if (C > HD) g_xn = r.tmp.alloc(npix * C);
   if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
-  RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, r.scratch, r.st));
+  float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
+  RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
   r.tmp.release(mk);
   return 0;
 }
@@ -666,6 +682,10 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   pidm_unet* U = r.U;
   const int B = r.B, P = U->cfg.image_size, dim = U->cfg.dim, n = U->n_lv, td = U->tdim, od = U->cfg.out_dim;
   const size_t HW = (size_t)P * P;
+  r.defer_on = true;
+  r.rq.v.clear();
+  r.rq.nblocks = 0;
+  ReduceDesc* red_dev = reinterpret_cast<ReduceDesc*>(r.defer.alloc(kMaxReduceDesc * sizeof(ReduceDesc) / 4));
   float* dss = r.tmp.alloc((size_t)B * U->ss_total);
   float* g_o = r.tmp.alloc((size_t)B * HW * od);
   RUN(launch_nchw_to_nhwc(grad_out_nchw, g_o, B, od, (int)HW, U->cfg.sigmoid_last_channel ? U->out_nchw : nullptr, r.st));
@@ -675,7 +695,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (U->have_grads || r.dry) {
       ConvGeom g;
       if (geom_fwd_layer(L, B, 0, &g)) return -1;
-      RUN(launch_wgrad(g, U->xfinal, nullptr, g_o, od, U->G[L.w], U->G[L.b], r.scratch, r.st));
+      float* part = r.part_alloc(wgrad_ws_bytes(g));
+      RUN(launch_wgrad(g, U->xfinal, nullptr, g_o, od, U->G[L.w], U->G[L.b], part, r.st, r.q()));
     }
   }
   float* g_x = r.tmp.alloc((size_t)B * HW * dim);
@@ -754,7 +775,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     ConvGeom g;
     if (geom_fwd_layer(U->lincat, B, 0, &g)) return -1;
     // all FiLM weights and biases at once (contiguous in the flat gradient buffer)
-    RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], U->G[nf], r.scratch, r.st));
+    float* part = r.part_alloc(wgrad_ws_bytes(g));
+    RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], U->G[nf], part, r.st, r.q()));
     float* d_st = r.tmp.alloc((size_t)B * td);
     if (conv_dgrad(r, U->lincat, dss, nullptr, d_st)) return -1;
     float* d_temb = r.tmp.alloc((size_t)B * td);
@@ -765,6 +787,19 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     float* d_h1 = r.tmp.alloc((size_t)B * td);
     RUN(launch_act_bwd(U->h1, d_h1g, d_h1, (size_t)B * td, 1, r.st));
     if (conv_wgrad(r, U->lin1, U->emb, nullptr, d_h1)) return -1;
+  }
+  // ---- every queued fixed-order reduction (weight/bias/norm-parameter gradients) in one launch ----
+  if (!r.dry && !r.rq.v.empty()) {
+    if (r.rq.v.size() > kMaxReduceDesc) return fail("backward: reduction table overflow (%zu)", r.rq.v.size());
+    const bool same = U->red_table_dev == red_dev && U->red_table.size() == r.rq.v.size() &&
+                      memcmp(U->red_table.data(), r.rq.v.data(), r.rq.v.size() * sizeof(ReduceDesc)) == 0;
+    if (!same) {
+      U->red_table = r.rq.v;   // persistent host copy (source of the async upload)
+      if (hipMemcpyAsync(red_dev, U->red_table.data(), U->red_table.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
+        return fail("backward: reduction table upload failed");
+      U->red_table_dev = red_dev;
+    }
+    RUN(launch_reduce_multi(red_dev, (int)r.rq.v.size(), r.rq.nblocks, r.st));
   }
   return 0;
 }
@@ -777,9 +812,10 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
     *tmp_bytes = it->second.second;
     return 0;
   }
+  auto keep_defer = U->defer_cache;
   Run r;
   r.U = U; r.B = B; r.train = training != 0; r.dry = true; r.st = nullptr; r.wpack = nullptr;
-  r.tape.dry = r.tmp.dry = true;
+  r.tape.dry = r.tmp.dry = r.defer.dry = true;
   // state touched by a dry run is restored afterwards
   pidm_unet saved_ptrs = *U;
   r.scratch_floats = scratch_floats_needed(U, B);
@@ -789,16 +825,20 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
     r.tmp.release(align_up(r.scratch_floats * sizeof(float), 256));
     rc = backward_impl(r, nullptr, reinterpret_cast<float*>(16));
   }
-  const size_t tb = r.tape.hwm, mb = r.tmp.hwm;
+  const size_t tb = r.tape.hwm, mb = r.tmp.hwm, db = align_up(r.defer.hwm + 4096, 4096);
   auto keep_cache0 = U->ws_cache[0];
   auto keep_cache1 = U->ws_cache[1];
   *U = saved_ptrs;
   U->ws_cache[0] = keep_cache0;
   U->ws_cache[1] = keep_cache1;
+  U->defer_cache = keep_defer;
   if (rc) return rc;
-  cache[B] = {tb + 4096, mb + 4096};
+  // the deferred-reduction arena is the tail of the temporaries region
+  const size_t mb_al = align_up(mb + 4096, 4096);
+  if (training) U->defer_cache[B] = db;
+  cache[B] = {tb + 4096, mb_al + (training ? db : 0)};
   *tape_bytes = tb + 4096;
-  *tmp_bytes = mb + 4096;
+  *tmp_bytes = mb_al + (training ? db : 0);
   return 0;
 }
 
@@ -813,7 +853,9 @@ static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, s
   r.U = h; r.B = B; r.train = train; r.dry = false; r.st = as_stream(stream);
   r.wpack = reinterpret_cast<float*>(w);
   r.tape.base = w + packed_b; r.tape.cap = tape_b;
-  r.tmp.base = w + packed_b + tape_b; r.tmp.cap = tmp_b;
+  const size_t defer_b = train ? h->defer_cache[B] : 0;
+  r.tmp.base = w + packed_b + tape_b; r.tmp.cap = tmp_b - defer_b;
+  r.defer.base = r.tmp.base + r.tmp.cap; r.defer.cap = defer_b;
   r.scratch_floats = scratch_floats_needed(h, B);
   r.scratch = r.tmp.alloc(r.scratch_floats);
   return 0;
@@ -852,6 +894,6 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   Run r;
   if (setup_run(r, h, B, true, workspace, workspace_bytes, stream)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
-  if (r.tmp.overflow()) return fail("unet_backward: internal arena overflow");
+  if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
   return 0;
 }

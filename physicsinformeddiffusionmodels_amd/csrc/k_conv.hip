@@ -18,6 +18,9 @@
 // (M = Cout, N = Cin, K = pixels) with a deterministic split-K over pixel tiles.
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "pidm_launch.h"
 
 namespace pidm {
@@ -225,8 +228,11 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   for (int k = 0; k < BMAX; ++k) {
     const int e = tid + k * 256;
     const int row = (brow0 + (k * 256 / Q)) % BN, tl = (e < nB) ? e / (Q * BN) : 0;
+    // NT == 4 ("permuted" 128-channel tile): output channel 4j+s of the tile is computed by lane j of accumulator s, so
+    // that a lane's 4 accumulators are 4 CONSECUTIVE channels (16-byte stores); its weight row sits at LDS row 32s+j
+    const int lrow = (NT == 4) ? ((row & 3) * 32 + (row >> 2)) : row;
     b_g[k] = (row * T + tl) * CinP + 4 * bq;
-    b_l[k] = (e < nB) ? (tl * BN + row) * KCP + 4 * bq : -1;
+    b_l[k] = (e < nB) ? (tl * BN + lrow) * KCP + 4 * bq : -1;
   }
   const float* wn = wz + (size_t)n0 * T * CinP;
   f32x4 ra[AMAX], rb[BMAX];  // native vectors: stay in VGPRs across the loop back-edge
@@ -311,6 +317,43 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   }
 #undef PIDM_PREFETCH
 
+  if constexpr (NT == 4) {
+    // permuted tile: lane l31 owns channels n0 + 4*l31 .. +3 (one per accumulator) of 16 pixel rows -> one 16-byte
+    // store per row: a wave instruction writes 2 x 512 contiguous bytes instead of 2 x 128
+    const int c = n0 + 4 * l31;
+    const bool vec = g.soc == 1 && ((g.sox | g.soy | g.sob) & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                     (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) && c + 4 <= g.Cout;
+    float bv[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) bv[s4] = (bias && c + s4 < g.Cout) ? bias[c + s4] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int p = wave * 32 + row;
+      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+      const int b = b0 + img;
+      if (b >= g.B || img >= g.NI) continue;
+      const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+      float* op = out + (size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox;
+      const float* rp = residual ? residual + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr : nullptr;
+      if (vec) {
+        f32x4 o = {acc[0][r] + bv[0], acc[1][r] + bv[1], acc[2][r] + bv[2], acc[3][r] + bv[3]};
+        if (rp) o += *reinterpret_cast<const f32x4*>(rp + c);
+        if (sigmoid_last && c + 4 == g.Cout) o[3] = 1.f / (1.f + expf(-o[3]));
+        *reinterpret_cast<f32x4*>(op + c) = o;
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          if (c + s4 >= g.Cout) continue;
+          float o = acc[s4 % NT][r] + bv[s4];
+          if (rp) o += rp[c + s4];
+          if (sigmoid_last && c + s4 == g.Cout - 1) o = 1.f / (1.f + expf(-o));
+          op[(size_t)(c + s4) * g.soc] = o;
+        }
+      }
+    }
+    return;
+  }
   if (g.Wv >= 32) {
     // the wave's 32 pixels are consecutive in x inside one image row: one 64-bit base per (wave, n-tile), then
     // row * (os*sox) steps with compile-time row constants (no per-row index math)
@@ -599,16 +642,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
 
 // software-pipelined wgrad (3x3 / 1x1, 16-byte aligned operands): the (halo pixel, quad) decode is done once, the
 // next pixel tile is prefetched into registers while the 16 x nt MFMAs per wave of the current one run.
-template <int KH, int KW, bool PHASED>
-__global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
+// second launch-bound argument = minimum waves per SIMD: it caps the register allocation (512 / n) so that 2 (3x3: 144
+// accumulators) resp. 4 (1x1) workgroups share a CU and hide each other's barrier / staging phases
+// WIDE: the wave's 32 pixels are consecutive in x inside one image row (Wv >= 32): pointer bumps instead of a per-step
+// decode.  A compile-time switch: as a runtime branch the two loops made the register allocator copy all accumulators.
+template <int KH, int KW, bool PHASED, bool WIDE, int MINW>
+__global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ dy,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial) {
-  constexpr int XMAX = 9, YMAX = 4, T_ = KH * KW;
-  // T_ >= 4: TAP-SPLIT - wave w owns taps {w, w+4, w+8} and walks the whole 128-pixel tile (<= 3 accumulators per
-  // wave: three workgroups per CU, no cross-wave reduction).  T_ == 1 (1x1 conv): K-SPLIT - the 4 waves split the
-  // pixel tile and are reduced through LDS at the end.
-  constexpr bool TAPSPLIT = false;  // measured on MI355X: K-split 53 TF vs tap-split 48 TF for 3x3 (kept for reference)
-  constexpr int MAXT = TAPSPLIT ? (T_ + 3) / 4 : T_;
+  constexpr int XMAX = (KH * KW == 1 && !PHASED) ? 4 : 9, YMAX = 4, T_ = KH * KW;   // 1x1: the tile has no halo (128 pixels)
+  constexpr int MAXT = T_;   // all taps of a 32x32 (dY-channel x X-channel) tile live in this wave's accumulators; the 4 waves
+                             // split the 128-pixel tile (K-split) and are reduced through LDS at the end
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -631,17 +675,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   const int xld = (cx < g.C0) ? g.ld0 : g.ld1;
   const int cy = m0 + 4 * q;
   const bool cy_ok = cy < g.Cout;
-  int x_dec[XMAX];   // packed (img << 20 | hy << 10 | hx), -1: slot unused
-#pragma unroll
-  for (int k = 0; k < XMAX; ++k) {
-    const int hp = (tid + k * 256) >> 3;
-    x_dec[k] = -1;
-    if (hp < npixA && cx_ok) {
-      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;
-      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
-      x_dec[k] = (img << 20) | (hy << 10) | hx;
-    }
-  }
+  // the (halo pixel) -> (image, row, column) decode of a staging slot is recomputed per tile (a few VALU ops against
+  // 144 MFMAs) instead of being kept in registers: the accumulators leave no room for it at 2 waves per SIMD
   f32x4 rx[XMAX], ry[YMAX];
 
 #define PIDM_WG_PREFETCH(tile_)                                                                                   \
@@ -652,9 +687,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
     const int ix0__ = PHASED ? -g.ph_pad_x[ph] : -g.pad_x[0];                                                      \
     _Pragma("unroll") for (int k = 0; k < XMAX; ++k) {                                                            \
       rx[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                          \
-      if (x_dec[k] >= 0) {                                                                                        \
-        const int b = b0__ + (x_dec[k] >> 20);                                                                    \
-        int iy = iy0__ + ((x_dec[k] >> 10) & 1023), ix = ix0__ + (x_dec[k] & 1023);                                \
+      const int hp = (tid + k * 256) >> 3;                                                                        \
+      if (hp < npixA && cx_ok) {                                                                                  \
+        const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;                                     \
+        const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;                                   \
+        const int b = b0__ + img;                                                                                 \
+        int iy = iy0__ + hy, ix = ix0__ + hx;                                                                     \
         if (PHASED) { iy = iy * g.in_step + g.ph_oy[ph]; ix = ix * g.in_step + g.ph_ox[ph]; }                      \
         if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                               \
           rx[k] = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * g.Hi + iy) * g.Wi + ix) * xld);            \
@@ -699,31 +737,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
 #pragma unroll
       for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
     }
-    if (TAPSPLIT) {
-      // this wave's tap offsets (floats) inside the halo tile
-      int toff[MAXT];
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-        const int t = wave + 4 * i;
-        toff[i] = (t < T_) ? ((t / KW) * g.IWt + (t % KW)) * 32 : 0;
-      }
-#pragma unroll 4
-      for (int ks = 0; ks < 64; ++ks) {
-        const int p = 2 * ks + half;
-        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-        const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
-        const float a = Ys[p * 32 + l31];
-        const float* xrow = Xs + (size_t)xb * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i) {
-          if (wave + 4 * i < T_) {
-            const float bv = xrow[toff[i]];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
-          }
-        }
-      }
-    } else if (g.Wv >= 32) {
-      // the wave's 32 pixels are consecutive in x inside one image row: pointer bumps instead of per-step decode
+    if constexpr (WIDE) {
       const int p0 = wave * 32;
       const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
       const int xb0 = (img0 < g.NI) ? (img0 * g.IHt + ty0 * g.stride) * g.IWt + tx0 * g.stride : 0;
@@ -744,6 +758,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
         }
       }
     } else {
+#pragma unroll 2
       for (int ks = 0; ks < 16; ++ks) {
         const int p = wave * 32 + 2 * ks + half;
         const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
@@ -763,22 +778,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_pipe_kernel(WgradGeom wg, cons
   }
 #undef PIDM_WG_PREFETCH
   float* red = smem;  // [4][1024]
-  if (TAPSPLIT) {
-    // every wave owns complete sums for its taps: write them straight to the split-K partial buffer
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + 4 * i;
-      if (t < T_) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          partial[(((size_t)split * wg.MP + (m0 + row)) * T + t) * wg.NP + n0 + l31] = acc[i][r];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int tl = 0; tl < (TAPSPLIT ? 0 : MAXT); ++tl) {
+  for (int tl = 0; tl < MAXT; ++tl) {
     {
       __syncthreads();
 #pragma unroll
@@ -1199,16 +1200,23 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_>), grid, dim3(256),       \
                        lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
-    if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3, false)
-    else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true)
-    else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false)
-    else PIDM_LAUNCH_PIPE(1, 1, false)
+    if constexpr (NT == 4) {
+      PIDM_LAUNCH_PIPE(1, 1, false)   // the permuted 128-channel tile exists for 1x1 convolutions only (conv_nt4_ok)
+    } else {
+      if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3, false)
+      else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true)
+      else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false)
+      else PIDM_LAUNCH_PIPE(1, 1, false)
+    }
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
     PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
     return 0;
   }
   if (g.nph > 1) return fail("conv: phased 4x4/s2 geometry is not eligible for the pipelined kernel (tile too large)");
+  if constexpr (NT == 4) {
+    return fail("conv: internal error - permuted 128-channel tile selected for an ineligible geometry");
+  } else {
   // ---- generic kernel (tap groups, ragged channels, scalar staging) ----
   const size_t budget = 72 * 1024;  // keep two workgroups per CU where the halo tile allows
   int tgs = T;
@@ -1231,11 +1239,30 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_igemm_kernel");
   return 0;
+  }
+}
+
+// 1x1 convolutions with Cout % 128 == 0 and enough pixel tiles: 128 output channels per workgroup in the permuted
+// layout (16-byte stores).  These launches are store-bound (qkv projections: 12.6 MB/sample at 64x64).
+static bool conv_nt4_ok(const ConvGeom& g, int KC) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("PIDM_NO_NT4"); off = (e && atoi(e)) ? 1 : 0; }
+  if (off) return false;
+  const char* mw = getenv("PIDM_NT4_MIN_WGS");   // tests lower the occupancy threshold to reach this path with small shapes
+  const long min_wgs = mw ? atol(mw) : 512;
+  const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % KC == 0) && (g.C0 % KC == 0);
+  return KC == 16 && g.KH == 1 && g.KW == 1 && g.nph == 1 && g.nz == 1 && aligned && (g.Cout % 128 == 0) &&
+         g.NI * g.IHt * g.IWt * (KC / 4) <= 5 * 256 && (long)g.tiles_m * (g.Cout / 128) >= min_wgs;
 }
 
 int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
                 const float* residual, float* out, int sigmoid_last, hipStream_t st) {
   const int KC = pick_kc(g.Cin), NT = pick_nt(g.Cout, g.tiles_m * g.nz);
+  const bool nt4 = conv_nt4_ok(g, KC);
+  if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
+    fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
+            g.KW, g.nph, KC, nt4 ? 4 : NT);
+  if (nt4) return launch_conv_t<16, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 16 && NT == 1) return launch_conv_t<16, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 8 && NT == 2) return launch_conv_t<8, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
@@ -1269,8 +1296,9 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   for (int tps = 1; tps <= g.tiles_m; ++tps) {
     const long wgs = (long)blocks_mn * cdiv(g.tiles_m, tps);
     if (wgs > 4096 && tps < g.tiles_m) continue;
-    const double cost = (T == 9) ? (double)((wgs + 255) / 256) * (tps + 1.5)    // 3x3: 144 accumulators, 1 workgroup per CU
-                                 : (double)((wgs + 511) / 512) * (tps + 1.0);   // 1x1: two workgroups per CU
+    const double cost = (T == 9)   ? (double)((wgs + 255) / 256) * (tps + 1.5)      // 3x3: 144 accumulators, 1 workgroup per CU
+                        : (T == 1) ? (double)((wgs + 1023) / 1024) * (tps + 1.0)    // 1x1: <= 128 registers, 4 workgroups per CU
+                                   : (double)((wgs + 511) / 512) * (tps + 1.0);     // 2x2 (phased 4x4/s2): two per CU
     if (cost < best_cost - 1e-9) { best_cost = cost; best_tps = tps; }
   }
   wg->tiles_per_split = best_tps;
@@ -1325,24 +1353,30 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<4>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
   } else if (g.nph > 1) {
     if (!aligned || g.NI * g.IHt * g.IWt * 8 > 9 * 256) return fail("wgrad: phased 4x4/s2 geometry not eligible for the pipelined kernel");
-    static bool attr_ph = false;
-    if (!attr_ph) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_ph = true;
-    }
     const dim3 gridp(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<2, 2, true>), gridp, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-  } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 && g.IHt < 1024 && g.IWt < 1024) {
-    static bool attr_p = false;
-    if (!attr_p) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<3, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<1, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_p = true;
+#define PIDM_LAUNCH_WG(KH_, KW_, PH_, WIDE_, MINW_, grid_)                                                                 \
+  {                                                                                                                        \
+    static bool attr_ = false;                                                                                             \
+    if (!attr_) {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
+      attr_ = true;                                                                                                        \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_>), grid_, dim3(256), lds, st, wg, \
+                       src0, src1 ? src1 : src0, dy, partial, bias_partial);                                              \
+  }
+    if (g.Wv >= 32) PIDM_LAUNCH_WG(2, 2, true, true, 2, gridp)
+    else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
+  } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 &&
+             g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {
+    if (g.KH == 1) {
+      if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
+      else PIDM_LAUNCH_WG(1, 1, false, false, 4, grid)
+    } else {
+      if (g.Wv >= 32) PIDM_LAUNCH_WG(3, 3, false, true, 1, grid)
+      else PIDM_LAUNCH_WG(3, 3, false, false, 1, grid)
     }
-    if (g.KH == 1)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<1, 1, false>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<3, 3, false>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+#undef PIDM_LAUNCH_WG
   } else if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else

@@ -30,6 +30,19 @@ CASES = [
 ]
 
 
+NT4_CASES = [   # 1x1 convs that take the permuted 128-channel tile (forward resp. dgrad) once the occupancy gate is lowered
+    (2, 16, 16, 0, 128, 1, 1, 0, 0),
+    (3, 8, 128, 128, 16, 1, 1, 0, 0),
+    (1, 16, 32, 0, 256, 1, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", NT4_CASES)
+def test_conv_1x1_permuted_tile(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_NT4_MIN_WGS", "1")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", CASES)
 def test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed):
     L, dev = backend

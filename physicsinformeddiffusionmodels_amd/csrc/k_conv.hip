@@ -166,7 +166,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // in the prologue; per chunk the thread issues its <= AMAX + BMAX global loads for chunk i+1 into registers right
 // after the barrier that publishes chunk i, so HBM/L2 latency hides under the 9*KC/2*NT MFMAs of chunk i.
 // ---------------------------------------------------------------------------------------------------
-template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED>
+// PERSIST: a workgroup walks g.tpw consecutive m-tiles of one n-tile; (tile, Cin-chunk) stages form ONE software
+// pipeline - the first chunk of the next tile is prefetched under the MFMAs of the current tile's last chunk and the
+// epilogue stores drain under the next tile's MFMAs.  Short-K layers (64x64: Cin = 32, two chunks per tile) otherwise
+// spend most of a workgroup's life in its prologue/epilogue with the matrix pipe idle (PMC: 45 % MFMA busy).
+template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED, bool PERSIST>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
                                                               const float* __restrict__ bias,
@@ -180,16 +184,15 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int half = lane >> 5, l31 = lane & 31;
   const int z = blockIdx.z;
   const int tiles_n = (g.Cout + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int tile_n = blockIdx.x % tiles_n;
+  const int tm_first = PERSIST ? (int)(blockIdx.x / tiles_n) * g.tpw : (int)(blockIdx.x / tiles_n);
+  const int tm_end = PERSIST ? ((tm_first + g.tpw < g.tiles_m) ? tm_first + g.tpw : g.tiles_m) : tm_first + 1;
   const int n0 = tile_n * BN;
   constexpr int T = KH * KW;
   const int npixA = g.NI * g.IHt * g.IWt;
   float* As = smem;
   float* Bs = smem + (size_t)npixA * KCP;
   const int tpi = g.Hv / g.TH;
-  const int b0 = (tile_m / tpi) * g.NI;
-  const int vy0 = (tile_m % tpi) * g.TH;
-  const int iy0 = vy0 * g.stride - g.pad_y[z];
   const int ix0 = -g.pad_x[z];
   const float* wz = wp + g.w_off[z];
 
@@ -197,7 +200,8 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
   const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
 
-  // ---- prologue: decode this thread's staging slots once (q = tid % Q is the same for every slot) ----
+  // ---- staging slots of this thread (q = tid % Q is the same for every slot).  The LDS side is tile independent;
+  //      the global side (a_pix) is decoded per tile by PIDM_SET_TILE ----
   const int nA = npixA * Q, nB = T * BN * Q;
   const int aq = tid % Q;
   int a_pix[AMAX];    // global pixel index, -1: zero fill (PHASED: packed tile-relative (img<<20 | hy<<10 | hx))
@@ -206,19 +210,30 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   for (int k = 0; k < AMAX; ++k) {
     const int e = tid + k * 256;
     a_pix[k] = -1;
-    a_lds[k] = -1;
-    if (e < nA) {
-      const int hp = e / Q;
-      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;      // halo row index, column
-      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
-      const int b = b0 + img, iy = iy0 + hy, ix = ix0 + hx;
-      a_lds[k] = hp * KCP + 4 * aq;
-      if (PHASED) {
-        a_pix[k] = (img << 20) | (hy << 10) | hx;   // the source pixel depends on the K-phase: resolved per prefetch
-      } else if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) {
-        a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;
-      }
-    }
+    a_lds[k] = (e < nA) ? (e / Q) * KCP + 4 * aq : -1;
+  }
+  int p_b0 = 0, p_vy0 = 0;   // geometry of the tile the NEXT prefetch belongs to
+#define PIDM_SET_TILE(tm_)                                                                                         \
+  {                                                                                                                \
+    const int tm__ = (tm_);                                                                                        \
+    p_b0 = (tm__ / tpi) * g.NI;                                                                                    \
+    p_vy0 = (tm__ % tpi) * g.TH;                                                                                   \
+    const int iy0__ = p_vy0 * g.stride - g.pad_y[z];                                                               \
+    _Pragma("unroll") for (int k = 0; k < AMAX; ++k) {                                                             \
+      const int e = tid + k * 256;                                                                                 \
+      a_pix[k] = -1;                                                                                               \
+      if (e < nA) {                                                                                                \
+        const int hp = e / Q;                                                                                      \
+        const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;                                      \
+        const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;                                    \
+        const int b = p_b0 + img, iy = iy0__ + hy, ix = ix0 + hx;                                                  \
+        if (PHASED) {                                                                                              \
+          a_pix[k] = (img << 20) | (hy << 10) | hx;   /* the source pixel depends on the K-phase */                \
+        } else if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) {                                      \
+          a_pix[k] = (b * g.Hi + iy) * g.Wi + ix;                                                                  \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
   }
   const int CinP = g.Kw;  // packed weight row length (nph * Cin); Cin % KC == 0 for this kernel
   // B slot k of this thread: e = tid + 256k -> (q = e % Q, row = (e / Q) % BN, tl = e / (Q*BN)); all powers of two
@@ -248,8 +263,8 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       ra[k] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                           \
       if (PHASED) {                                                                                                \
         if (a_lds[k] >= 0) {                                                                                       \
-          const int b = b0 + (a_pix[k] >> 20);                                                                     \
-          const int iy = (vy0 - g.ph_pad_y[ph__] + ((a_pix[k] >> 10) & 1023)) * g.in_step + g.ph_oy[ph__];         \
+          const int b = p_b0 + (a_pix[k] >> 20);                                                                   \
+          const int iy = (p_vy0 - g.ph_pad_y[ph__] + ((a_pix[k] >> 10) & 1023)) * g.in_step + g.ph_oy[ph__];       \
           const int ix = ((a_pix[k] & 1023) - g.ph_pad_x[ph__]) * g.in_step + g.ph_ox[ph__];                       \
           if (b < g.B && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)                                             \
             ra[k] = *reinterpret_cast<const f32x4*>(sp__ + (((size_t)b * g.Hi + iy) * g.Wi + ix) * ld__ + 4 * aq); \
@@ -266,7 +281,10 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   for (int i = 0; i < NT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  PIDM_SET_TILE(tm_first)
   PIDM_PREFETCH(0)
+  for (int tm = tm_first; tm < tm_end; ++tm) {
+  const int b0 = p_b0, vy0 = p_vy0;   // geometry of the tile being computed (its epilogue runs after the next prefetch)
   for (int c0 = 0; c0 < CinP; c0 += KC) {
     __syncthreads();          // previous chunk's LDS reads are done
 #pragma unroll
@@ -276,7 +294,12 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     for (int k = 0; k < BMAX; ++k)
       if (b_l[k] >= 0) *reinterpret_cast<f32x4*>(Bs + b_l[k]) = rb[k];
     __syncthreads();          // chunk c0 visible
-    if (c0 + KC < CinP) PIDM_PREFETCH(c0 + KC)
+    if (c0 + KC < CinP) {
+      PIDM_PREFETCH(c0 + KC)
+    } else if (PERSIST && tm + 1 < tm_end) {
+      PIDM_SET_TILE(tm + 1)
+      PIDM_PREFETCH(0)
+    }
     // taps fully unrolled (compile-time KHxKW).  The LDS fragments of tap t+1 are fetched into a second register set
     // BEFORE the MFMAs of tap t are issued, so the ~128-cycle ds_read latency hides under 8*NT*KC/8 MFMAs instead of
     // stalling the matrix pipe once per tap.
@@ -315,8 +338,8 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     }
 #undef PIDM_LOAD_FRAGS
   }
-#undef PIDM_PREFETCH
 
+  // ---- epilogue of tile tm: bias, residual, (sigmoid), store; PERSIST: the accumulators restart at zero ----
   if constexpr (NT == 4) {
     // permuted tile: lane l31 owns channels n0 + 4*l31 .. +3 (one per accumulator) of 16 pixel rows -> one 16-byte
     // store per row: a wave instruction writes 2 x 512 contiguous bytes instead of 2 x 128
@@ -352,9 +375,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         }
       }
     }
-    return;
-  }
-  if (g.Wv >= 32) {
+  } else if (g.Wv >= 32) {
     // the wave's 32 pixels are consecutive in x inside one image row: one 64-bit base per (wave, n-tile), then
     // row * (os*sox) steps with compile-time row constants (no per-row index math)
     const int p0 = wave * 32;
@@ -383,27 +404,35 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         }
       }
     }
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int ni = 0; ni < NT; ++ni) {
-    const int c = n0 + ni * 32 + l31;
-    if (c >= g.Cout) continue;
-    const float bv = bias ? bias[c] : 0.f;
+    for (int ni = 0; ni < NT; ++ni) {
+      const int c = n0 + ni * 32 + l31;
+      if (c >= g.Cout) continue;
+      const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int p = wave * 32 + row;
-      const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-      const int b = b0 + img;
-      if (b >= g.B || img >= g.NI) continue;
-      const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
-      float v = acc[ni][r] + bv;
-      if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
-      if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
-      out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int p = wave * 32 + row;
+        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+        const int b = b0 + img;
+        if (b >= g.B || img >= g.NI) continue;
+        const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+        float v = acc[ni][r] + bv;
+        if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
+        if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
+        out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+      }
     }
   }
+  if constexpr (PERSIST) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
+  }
+#undef PIDM_PREFETCH
+#undef PIDM_SET_TILE
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1188,25 +1217,41 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
     const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
-#define PIDM_LAUNCH_PIPE(KH_, KW_, PH_)                                                                                    \
+#define PIDM_LAUNCH_PIPE(KH_, KW_, PH_, PS_, grid_)                                                                                \
   {                                                                                                                        \
     constexpr int BMAXk = (KH_ * KW_ * BN * Q + 255) / 256;                                                                \
     static bool attr_pipe = false;                                                                                         \
     if (!attr_pipe) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_, PS_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
       attr_pipe = true;                                                                                                    \
     }                                                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_>), grid, dim3(256),       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_, PS_>), grid_, dim3(256), \
                        lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
     if constexpr (NT == 4) {
-      PIDM_LAUNCH_PIPE(1, 1, false)   // the permuted 128-channel tile exists for 1x1 convolutions only (conv_nt4_ok)
+      PIDM_LAUNCH_PIPE(1, 1, false, false, grid)   // the permuted 128-channel tile exists for 1x1 convolutions only (conv_nt4_ok)
     } else {
-      if (g.KH == 3) PIDM_LAUNCH_PIPE(3, 3, false)
-      else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true)
-      else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false)
-      else PIDM_LAUNCH_PIPE(1, 1, false)
+      if (g.KH == 3) {
+        // persistent walk when the launch has more tiles than resident workgroup slots: 2 workgroups per CU, each
+        // owning tpw consecutive m-tiles of one n-tile
+        const char* pe = getenv("PIDM_PERSIST_SLOTS");   // experiments / tests: 0 = off, else resident workgroup slots
+        const long slots = pe ? atol(pe) : 512;
+        const long nwork = (long)g.tiles_m * tiles_n * g.nz;
+        bool persist = false;
+        if constexpr (NT == 1) {   // the 64-channel tile needs > 256 registers in the persistent form (1 workgroup per CU)
+          if (slots > 0 && nwork > slots) {
+            persist = true;
+            g.tpw = (int)((nwork + slots - 1) / slots);
+            const dim3 gridp(cdiv(g.tiles_m, g.tpw) * tiles_n, 1, g.nz);
+            PIDM_LAUNCH_PIPE(3, 3, false, true, gridp)
+          }
+        }
+        if (!persist) PIDM_LAUNCH_PIPE(3, 3, false, false, grid)
+      }
+      else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true, false, grid)
+      else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false, false, grid)
+      else PIDM_LAUNCH_PIPE(1, 1, false, false, grid)
     }
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);

@@ -69,6 +69,7 @@ struct ConvGeom {
   int IHt, IWt;      // input halo tile extent per image
   unsigned mIWt, mIHt;  // ceil(2^32 / IWt), ceil(2^32 / IHt): n / d == __umulhi(n, m) for n*d < 2^32 (d > 1)
   int tiles_m;       // number of 128-pixel tiles
+  int tpw;           // persistent conv kernels: consecutive m-tiles walked by one workgroup (0/1: one tile per workgroup)
 };
 
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)

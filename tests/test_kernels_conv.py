@@ -43,6 +43,19 @@ def test_conv_1x1_permuted_tile(backend, monkeypatch, B, H, C0, C1, Cout, K, str
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+PERSIST_CASES = [   # 3x3 convs walked persistently (several m-tiles per workgroup) once the slot count is lowered
+    (6, 16, 32, 0, 32, 3, 1, 1, 0),      # 12 m-tiles -> 3 workgroups x 4 tiles, two Cin chunks
+    (5, 8, 16, 16, 64, 3, 1, 1, 0),      # two images per tile, ragged last workgroup, two n-tiles, concat source
+    (1, 64, 16, 0, 8, 3, 1, 1, 0),       # wide rows (Wv = 64), single chunk
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", PERSIST_CASES)
+def test_conv_3x3_persistent(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_PERSIST_SLOTS", "3")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", CASES)
 def test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed):
     L, dev = backend

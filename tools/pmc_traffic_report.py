@@ -6,7 +6,8 @@ printed next to the result so the correction can be judged on this very run."""
 import collections, csv, glob, json, sys
 
 d, batch = sys.argv[1], int(sys.argv[2])
-CLASSES = [("conv_igemm", "conv"), ("conv_wgrad", "conv"), ("wgrad_reduce", "conv_aux"), ("pack_", "conv_aux"),
+CLASSES = [("conv_igemm", "conv"), ("conv_wgrad", "conv"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
+           ("pack_", "conv_aux"), ("clip_adam", "optimizer"), ("sqsum", "optimizer"),
            ("colsum", "conv_aux"), ("gn_", "norm"), ("layernorm", "norm"), ("la_", "attn"), ("mid_attn", "attn"),
            ("darcy", "darcy"), ("qsample", "darcy")]
 
@@ -15,7 +16,7 @@ def cls(name):
     for pat, c in CLASSES:
         if pat in name:
             return c
-    return "calib_copy" if ("elementwise" in name or "copy" in name.lower()) and "pidm" not in name else "other"
+    return "torch_elementwise_and_copies" if ("elementwise" in name or "copy" in name.lower()) and "pidm" not in name else "other"
 
 
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -30,7 +31,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             v = float(r["Counter_Value"])
             tot[c][counter] += v
             cnt[c][counter] += 1
-            if c == "calib_copy":
+            if c == "torch_elementwise_and_copies":
                 big[counter][r["Dispatch_Id"]] = max(big[counter].get(r["Dispatch_Id"], 0.0), v)
 res = {"batch": batch, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; 2 steps (1 warm-up + 1 timed)"}
 for c in tot:

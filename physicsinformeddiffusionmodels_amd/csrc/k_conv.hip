@@ -1229,8 +1229,10 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_, PS_>), grid_, dim3(256), \
                        lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
-    if constexpr (NT == 4) {
-      PIDM_LAUNCH_PIPE(1, 1, false, false, grid)   // the permuted 128-channel tile exists for 1x1 convolutions only (conv_nt4_ok)
+    if constexpr (NT == 4 || KC == 32) {
+      // the permuted 128-channel tile and the 32-channel chunk exist for 1x1 convolutions only (conv_nt4_ok / launch_conv)
+      if (g.KH != 1 || g.KW != 1 || g.nph != 1) return fail("conv: internal error - 1x1-only tile configuration on a %dx%d conv", g.KH, g.KW);
+      PIDM_LAUNCH_PIPE(1, 1, false, false, grid)
     } else {
       if (g.KH == 3) {
         // persistent walk when the launch has more tiles than resident workgroup slots: 2 workgroups per CU, each
@@ -1259,8 +1261,8 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
     return 0;
   }
   if (g.nph > 1) return fail("conv: phased 4x4/s2 geometry is not eligible for the pipelined kernel (tile too large)");
-  if constexpr (NT == 4) {
-    return fail("conv: internal error - permuted 128-channel tile selected for an ineligible geometry");
+  if constexpr (NT == 4 || KC == 32) {
+    return fail("conv: internal error - 1x1-only tile configuration selected for an ineligible geometry");
   } else {
   // ---- generic kernel (tap groups, ragged channels, scalar staging) ----
   const size_t budget = 72 * 1024;  // keep two workgroups per CU where the halo tile allows
@@ -1307,7 +1309,24 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
-  if (nt4) return launch_conv_t<16, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+  if (nt4) {
+    // K == 32 (the qkv projections of the 64x64 level, to_out dgrad): one 32-channel chunk = ONE dependent load round per
+    // workgroup instead of two (PIDM_KC32=0 disables, for A/B measurements)
+    static int kc32 = -1;
+    if (kc32 < 0) { const char* e = getenv("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
+    if (kc32 && g.Cin == 32 && g.C0 == 32) return launch_conv_t<32, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+    return launch_conv_t<16, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+  }
+  {
+    // 1x1 convolutions with Cin % 32 == 0: 32-channel chunks (half the barriers / dependent load rounds per tile)
+    static int kc32 = -1;
+    if (kc32 < 0) { const char* e = getenv("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
+    const bool al32 = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % 32 == 0) && (g.C0 % 32 == 0);
+    if (kc32 && KC == 16 && g.KH == 1 && g.KW == 1 && g.nph == 1 && al32 && g.NI * g.IHt * g.IWt * 8 <= 5 * 256) {
+      if (NT == 2) return launch_conv_t<32, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+      return launch_conv_t<32, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+    }
+  }
   if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 16 && NT == 1) return launch_conv_t<16, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 8 && NT == 2) return launch_conv_t<8, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);

@@ -95,6 +95,25 @@ int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, const float* 
                            const int32_t* elem_dofs, const int32_t* dof_elems, int nel, const float* g_residual,
                            const float* g_model_out, const float* g_comp_shift, float* g_x0_pred, int B, void* stream);
 
+/* Topology-optimisation evaluation block      replaces src/residuals_mechanics_K.py:276-347,369-380
+ *   pidm_mech_apply:  residual = K_closed(rho) u - f and comp_uf = u.f for nodal displacement images u [B,2,nn,nn]
+ *                     (the "residual of opt_disp should be zero" check and compliance_data, :293-296)
+ *   pidm_mech_solve:  u = K_closed(rho')^-1 f per sample (reference: torch.linalg.solve on the dense 8450^2 matrix, :321-323)
+ *                     by Jacobi-preconditioned CG on the matrix-free operator in fp64; rho' = rho if bin_threshold < 0,
+ *                     else (rho > bin_threshold ? bin_hi : bin_lo)  (:299-301).  compliance[b] = f.u, rho_mean[b] = mean(rho').
+ *                     Stops at ||r|| <= rtol ||f|| or max_iter; iters / relres (may be NULL) report what happened.
+ *   pidm_floating_material: number of 8-connected components of {rho > threshold} per sample (cv2.connectedComponents, :369-380)
+ * rho: [B, nel*nel]; bcs: [B,4,nn,nn]; workspace: pidm_mech_solve_ws_bytes(nel, B). */
+int pidm_mech_apply(const float* rho, const float* u_img, const float* bcs, const float* kloc, int kloc_stride,
+                    const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* residual, float* comp_uf, int B,
+                    void* stream);
+size_t pidm_mech_solve_ws_bytes(int nel, int B);
+int pidm_mech_solve(const float* rho, const float* bcs, const float* kloc, int kloc_stride, const int32_t* elem_dofs,
+                    const int32_t* dof_elems, int nel, float bin_threshold, float bin_hi, float bin_lo, int max_iter,
+                    double rtol, float* u_dofs, float* compliance, float* rho_mean, int32_t* iters, float* relres,
+                    void* workspace, int B, void* stream);
+int pidm_floating_material(const float* rho, float threshold, int nel, int32_t* n_components, int B, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * UNet engine                           replaces Unet3D.forward src/unet_model.py:542-623 + autograd
  * ------------------------------------------------------------------------------------------- */

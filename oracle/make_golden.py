@@ -31,6 +31,7 @@ _spec = importlib.util.spec_from_file_location("pidm_oracle", os.path.join(HERE,
 _oracle = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_oracle)
 fill_state_dict = _oracle.fill_state_dict
+O = _oracle
 
 # --- genuine reference imports -------------------------------------------------------------------
 from src.unet_model import Unet3D  # noqa: E402
@@ -289,9 +290,58 @@ def g10():
     print("g10 mech loss", loss.item(), data_l, res_l, ineq_l, opt_l, len(names))
 
 
+# G11: topology-optimisation evaluation block (reference :276-347 with topopt_eval=True, sample=True): FE solve of the
+# binarised prediction (fp32 torch.linalg.solve in the reference), data compliance, volume-fraction error, floating material.
+# The data "solution" is manufactured: displacements that solve K_closed(rho_simp) u = f (float64 solve, stored as fp32).
+def g11():
+    import tempfile
+    from src.residuals_mechanics_K import ResidualsMechanics
+    folder = tempfile.mkdtemp() + "/"
+    write_synthetic_mesh(folder)
+    res = ResidualsMechanics(model=None, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder=folder, device="cpu",
+                             topopt_eval=True)
+    B = 2
+    yy, xx = np.meshgrid(np.arange(64), np.arange(64), indexing="ij")
+    # predicted densities: sample 0 = one solid cantilever band reaching the clamped edge and the load; sample 1 = the same
+    # band plus a detached island (floating material)
+    band = (np.abs(yy - 32) < 12).astype(np.float64)
+    rho_pred = np.stack([0.1 + 0.8 * band, 0.1 + 0.8 * band])
+    rho_pred[1][(np.abs(yy - 6) < 3) & (np.abs(xx - 40) < 5)] = 0.9
+    rho_pred += 0.05 * npy(seeded((B, 64, 64), 71))
+    x0 = torch.zeros(B, 3, 64, 64)
+    x0[:, :2] = seeded((B, 2, 64, 64), 72, 0.1)
+    x0[:, 2] = torch.from_numpy(rho_pred).float()
+    bcs = torch.zeros(B, 4, 65, 65)
+    bcs[:, 0, :, 0] = 1.0
+    bcs[:, 1, :, 0] = 1.0
+    bcs[0, 3, 32, 64] = -0.01
+    bcs[1, 3, 30, 64] = -0.02
+    vf = torch.tensor([0.4, 0.35])
+    kloc = npy(res.stiffs.tot_local_stiffness[0]).astype(np.float64)
+    elem_dofs = npy(res.stiffs.glob_assembler_idcs[:, :8, 1]).astype(np.int64)
+    # data solution: SIMP-like density (smooth, in [0.05, 1]) and its exact displacement field
+    rho_simp = np.clip(0.05 + 0.95 * np.stack([band, band]) * (0.7 + 0.3 * npy(torch.sigmoid(seeded((B, 64, 64), 73)))), 0.05, 1.0)
+    solution = torch.zeros(B, 3, 65, 65)
+    for b in range(B):
+        u, _ = O.mechanics_fe_solve(rho_simp[b].reshape(-1), npy(bcs[b]), kloc, elem_dofs)
+        solution[b, :2] = torch.from_numpy(u.reshape(65, 65, 2).transpose(2, 0, 1)).float()
+        solution[b, 2, :64, :64] = torch.from_numpy(rho_simp[b]).float()
+    out = res.compute_residual((x0, bcs, vf, solution), reduce="none", return_model_out=False, return_optimizer=True,
+                               return_inequality=True, sample=True, pass_through=True)
+    truth = O.mechanics_topopt_metrics(rho_pred=npy(x0[:, 2]), bcs=npy(bcs), vf=npy(vf), solution=npy(solution), kloc=kloc,
+                                       elem_dofs=elem_dofs)
+    np.savez_compressed(os.path.join(OUT, "g11_topopt_eval.npz"), x0=npy(x0), bcs=npy(bcs), vf=npy(vf), solution=npy(solution),
+                        rel_CE_error=npy(out["rel_CE_error_full_batch"]), vf_error=npy(out["vf_error_full_batch"]),
+                        fm=npy(out["fm_error_full_batch"]).astype(np.int64),
+                        rel_CE_error_f64=truth["rel_CE_error"], compliance_true_f64=truth["compliance_true"],
+                        compliance_data_f64=truth["compliance_data"])
+    print("g11 topopt eval: reference rel_CE", npy(out["rel_CE_error_full_batch"]), "float64 restatement", truth["rel_CE_error"],
+          "vf_err", npy(out["vf_error_full_batch"]), truth["vf_error"], "fm", npy(out["fm_error_full_batch"]), truth["fm"])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10"):
-        {"g9": g9, "g10": g10}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11"):
+        {"g9": g9, "g10": g10, "g11": g11}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -303,4 +353,5 @@ if __name__ == "__main__":
     g8("g8_sampler_dim8_p16", dim=8, P=16, B=2, n_steps=5)
     g9()
     g10()
+    g11()
     print("golden vectors written to", OUT)

@@ -424,3 +424,70 @@ def mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs):
     compliance = (U * Ku_bc).sum(dim=1)
     shift = rho.mean(dim=1) - vf
     return residual, compliance, shift
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Topology-optimisation evaluation block (reference src/residuals_mechanics_K.py:276-347,369-380), restated with a
+# DENSE float64 assembly + direct solve on the free dofs.  The reference solves the row-replaced system in fp32
+# (torch.linalg.solve); with f_D = 0 both give u_D = 0 and K_FF u_F = f_F.
+# cv2.connectedComponents (8-connectivity, background label counted) is a third-party routine that is not installed
+# here: restated with scipy.ndimage.label - "parity unpinned" for the floating-material flag (documented OpenCV
+# semantics: default connectivity 8, return value = number of labels including the background).
+# ---------------------------------------------------------------------------------------------------------------------
+def _dense_K(rho_flat, kloc, elem_dofs, neq):
+    D = np.asarray(elem_dofs, dtype=np.int64)
+    k = np.asarray(kloc, dtype=np.float64)
+    K = np.zeros((neq, neq))
+    for a in range(8):
+        for b in range(8):
+            np.add.at(K, (D[:, a], D[:, b]), rho_flat * k[a, b])
+    return K
+
+
+def mechanics_fe_solve(rho_flat, bcs_b, kloc, elem_dofs):
+    """rho_flat [E] float64, bcs_b [4,nn,nn] -> (u [neq], f [neq]) of K_closed(rho) u = f, float64."""
+    nn = bcs_b.shape[-1]
+    neq = 2 * nn * nn
+    f = np.asarray(bcs_b[2:4], dtype=np.float64).transpose(1, 2, 0).reshape(neq).copy()
+    mask = np.asarray(bcs_b[0:2]).transpose(1, 2, 0).reshape(neq) != 0
+    f[mask] = 0.0
+    K = _dense_K(np.asarray(rho_flat, dtype=np.float64), kloc, elem_dofs, neq)
+    free = ~mask
+    u = np.zeros(neq)
+    u[free] = np.linalg.solve(K[np.ix_(free, free)], f[free])
+    return u, f
+
+
+def count_foreground_components(img, thr=0.5):
+    from scipy import ndimage
+    _, n = ndimage.label(np.asarray(img) > thr, structure=np.ones((3, 3), dtype=int))
+    return int(n)
+
+
+def mechanics_topopt_metrics(rho_pred, bcs, vf, solution, kloc, elem_dofs):
+    """rho_pred [B,nel,nel], bcs [B,4,nn,nn], vf [B], solution [B,3,nn,nn] -> dict of numpy arrays
+    (rel_CE_error, vf_error, fm, compliance_true, compliance_data, residual_data_abs_mean)."""
+    rho_pred, bcs, vf, solution = (np.asarray(t, dtype=np.float64) for t in (rho_pred, bcs, vf, solution))
+    B, nel = rho_pred.shape[0], rho_pred.shape[-1]
+    nn = nel + 1
+    neq = 2 * nn * nn
+    out = {k: np.zeros(B) for k in ("rel_CE_error", "vf_error", "compliance_true", "compliance_data", "residual_data_abs_mean")}
+    out["fm"] = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        u_data = solution[b, :2].transpose(1, 2, 0).reshape(neq)
+        rho_simp = solution[b, 2, :-1, :-1].reshape(-1)
+        f = bcs[b, 2:4].transpose(1, 2, 0).reshape(neq).copy()
+        mask = bcs[b, 0:2].transpose(1, 2, 0).reshape(neq) != 0
+        f[mask] = 0.0
+        Kd = _dense_K(rho_simp, kloc, elem_dofs, neq)
+        Ku = Kd @ u_data
+        out["residual_data_abs_mean"][b] = np.abs(np.where(mask, u_data, Ku) - f).mean()
+        c_data = float(u_data @ f)
+        rb = np.where(rho_pred[b].reshape(-1) > 0.5, 1.0, 1.0e-3)
+        u, _ = mechanics_fe_solve(rb, bcs[b], kloc, elem_dofs)
+        c_true = float(u @ f)
+        out["compliance_true"][b], out["compliance_data"][b] = c_true, c_data
+        out["rel_CE_error"][b] = (c_true - c_data) / c_data
+        out["vf_error"][b] = abs(rb.mean() - vf[b]) / vf[b]
+        out["fm"][b] = int(count_foreground_components(rho_pred[b]) != 1)
+    return out

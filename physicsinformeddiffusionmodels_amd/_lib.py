@@ -55,6 +55,10 @@ class PidmLib:
         self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
         self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
         self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
+        self._sig("pidm_mech_apply", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, i, vp])
+        self._sig("pidm_mech_solve_ws_bytes", [i, i], sz)
+        self._sig("pidm_mech_solve", [vp, vp, vp, i, vp, vp, i, f, f, f, i, C.c_double, vp, vp, vp, vp, vp, vp, i, vp])
+        self._sig("pidm_floating_material", [vp, f, i, vp, i, vp])
         self._sig("pidm_clip_adam_ws_bytes", [], sz)
         self._sig("pidm_clip_adam_step", [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                           C.c_double, vp, vp, vp])

@@ -208,6 +208,221 @@ __global__ void __launch_bounds__(256) mech_kernel(MechMesh ms, const float* __r
   }
 }
 
+
+// =====================================================================================================================
+// Topology-optimisation EVALUATION block (reference src/residuals_mechanics_K.py:276-347,369-380):
+//   * mech_apply_kernel: r = K_closed(rho) u - f and c = u.f for nodal displacement IMAGES (the data fields)
+//   * mech_pcg_kernel:   u = K_closed(rho_bin)^-1 f  - the reference calls torch.linalg.solve on the dense 8450^2 matrix
+//                        per sample; here a Jacobi-preconditioned conjugate gradient on the matrix-free operator, one
+//                        workgroup per sample, fp64 vectors (the search direction lives in LDS), compliance c = f.u
+//   * floating_material_kernel: number of 8-connected foreground components (replaces cv2.connectedComponents)
+// With Dirichlet dofs pinned (identity rows, f = 0 there) the iterates keep u_D = 0, so the row-replaced operator acts
+// as the symmetric positive definite K_FF on the free dofs.
+// =====================================================================================================================
+__device__ __forceinline__ float rho_eff(float r, float thr, float hi, float lo) { return thr < 0.f ? r : (r > thr ? hi : lo); }
+
+__device__ __forceinline__ double block_sum(double v, double* red4) {   // all 256 threads; result broadcast
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+__global__ void __launch_bounds__(256) mech_apply_kernel(MechMesh ms, const float* __restrict__ rho,     // [B][E]
+                                                         const float* __restrict__ u_img,   // [B][2][nn][nn]
+                                                         const float* __restrict__ bcs,     // [B][4][nn][nn]
+                                                         float* __restrict__ residual,      // [B][ndof]
+                                                         float* __restrict__ comp_uf) {     // [B]  u . f
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ double red4[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nn = ms.nn, E = ms.E, ndof = ms.ndof;
+  float* sU = smem;
+  float* sR = smem + ndof;
+  const float* bb = bcs + (size_t)b * 4 * nn * nn;
+  for (int i = tid; i < ndof; i += 256) sU[i] = u_img[((size_t)b * 2 + (i & 1)) * nn * nn + (i >> 1)];
+  for (int e = tid; e < E; e += 256) sR[e] = rho[(size_t)b * E + e];
+  __syncthreads();
+  double cs = 0.0;
+  for (int i = tid; i < ndof; i += 256) {
+    double ku = 0.0;
+    for (int s = 0; s < 4; ++s) {
+      const int e = ms.dof_elems[(i * 4 + s) * 2], a = ms.dof_elems[(i * 4 + s) * 2 + 1];
+      if (e < 0) continue;
+      const float* k = ms.kloc + (size_t)e * ms.kloc_stride + a * 8;
+      const int* D = ms.elem_dofs + (size_t)e * 8;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += (double)k[q] * (double)sU[D[q]];
+      ku += (double)sR[e] * acc;
+    }
+    const int node = i >> 1, d = i & 1;
+    const bool masked = bb[(size_t)d * nn * nn + node] != 0.f;
+    const double f = masked ? 0.0 : (double)bb[(size_t)(2 + d) * nn * nn + node];
+    residual[(size_t)b * ndof + i] = (float)((masked ? (double)sU[i] : ku) - f);
+    cs += (double)sU[i] * f;
+  }
+  const double c = block_sum(cs, red4);
+  if (tid == 0) comp_uf[b] = (float)c;
+}
+
+// workspace per sample: x | r | Ap | Minv  (4 * ndof doubles); LDS: p (ndof doubles) | rho_eff (E floats)
+__global__ void __launch_bounds__(256) mech_pcg_kernel(MechMesh ms, const float* __restrict__ rho, const float* __restrict__ bcs,
+                                                       float thr, float hi, float lo, int max_iter, double rtol,
+                                                       double* __restrict__ ws, float* __restrict__ u_out,
+                                                       float* __restrict__ comp_out, float* __restrict__ rho_mean_out,
+                                                       int* __restrict__ iters_out, float* __restrict__ relres_out) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ double red4[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nn = ms.nn, E = ms.E, ndof = ms.ndof;
+  double* sP = reinterpret_cast<double*>(smem);
+  float* sR = reinterpret_cast<float*>(sP + ndof);
+  double* X = ws + (size_t)b * 4 * ndof;
+  double* R = X + ndof;
+  double* AP = R + ndof;
+  double* MI = AP + ndof;
+  const float* bb = bcs + (size_t)b * 4 * nn * nn;
+  double rs = 0.0;
+  for (int e = tid; e < E; e += 256) {
+    const float rv = rho_eff(rho[(size_t)b * E + e], thr, hi, lo);
+    sR[e] = rv;
+    rs += rv;
+  }
+  const double rsum = block_sum(rs, red4);   // (also publishes sR)
+  if (tid == 0 && rho_mean_out) rho_mean_out[b] = (float)(rsum / E);
+  // x = 0, r = f, Minv = 1/diag(K_closed), p = z = Minv r
+  double rz_l = 0.0, rr_l = 0.0;
+  for (int i = tid; i < ndof; i += 256) {
+    const int node = i >> 1, d = i & 1;
+    const bool masked = bb[(size_t)d * nn * nn + node] != 0.f;
+    double diag = 0.0;
+    for (int s = 0; s < 4; ++s) {
+      const int e = ms.dof_elems[(i * 4 + s) * 2], a = ms.dof_elems[(i * 4 + s) * 2 + 1];
+      if (e < 0) continue;
+      diag += (double)sR[e] * (double)ms.kloc[(size_t)e * ms.kloc_stride + a * 8 + a];
+    }
+    const double mi = masked ? 1.0 : 1.0 / diag;
+    const double f = masked ? 0.0 : (double)bb[(size_t)(2 + d) * nn * nn + node];
+    X[i] = 0.0;
+    R[i] = f;
+    MI[i] = mi;
+    const double z = mi * f;
+    sP[i] = z;
+    rz_l += f * z;
+    rr_l += f * f;
+  }
+  double rz = block_sum(rz_l, red4);
+  const double r0 = sqrt(block_sum(rr_l, red4));
+  int it = 0;
+  double rr = r0 * r0;
+  if (r0 > 0.0) {
+    for (it = 0; it < max_iter; ++it) {
+      // Ap = K_closed p
+      double pap_l = 0.0;
+      for (int i = tid; i < ndof; i += 256) {
+        const int node = i >> 1, d = i & 1;
+        const bool masked = bb[(size_t)d * nn * nn + node] != 0.f;
+        double ku = 0.0;
+        if (!masked) {
+          for (int s = 0; s < 4; ++s) {
+            const int e = ms.dof_elems[(i * 4 + s) * 2], a = ms.dof_elems[(i * 4 + s) * 2 + 1];
+            if (e < 0) continue;
+            const float* k = ms.kloc + (size_t)e * ms.kloc_stride + a * 8;
+            const int* D = ms.elem_dofs + (size_t)e * 8;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (double)k[q] * sP[D[q]];
+            ku += (double)sR[e] * acc;
+          }
+        } else {
+          ku = sP[i];
+        }
+        AP[i] = ku;
+        pap_l += sP[i] * ku;
+      }
+      const double pap = block_sum(pap_l, red4);
+      const double alpha = rz / pap;
+      double rz_n = 0.0, rr_n = 0.0;
+      for (int i = tid; i < ndof; i += 256) {
+        X[i] += alpha * sP[i];
+        const double r = R[i] - alpha * AP[i];
+        R[i] = r;
+        rz_n += r * MI[i] * r;
+        rr_n += r * r;
+      }
+      const double rz_new = block_sum(rz_n, red4);
+      rr = block_sum(rr_n, red4);
+      if (sqrt(rr) <= rtol * r0) { ++it; break; }
+      const double beta = rz_new / rz;
+      rz = rz_new;
+      for (int i = tid; i < ndof; i += 256) sP[i] = MI[i] * R[i] + beta * sP[i];
+      __syncthreads();
+    }
+  }
+  double c_l = 0.0;
+  for (int i = tid; i < ndof; i += 256) {
+    const int node = i >> 1, d = i & 1;
+    const bool masked = bb[(size_t)d * nn * nn + node] != 0.f;
+    const double f = masked ? 0.0 : (double)bb[(size_t)(2 + d) * nn * nn + node];
+    const double x = X[i];
+    if (u_out) u_out[(size_t)b * ndof + i] = (float)x;
+    c_l += f * x;
+  }
+  const double c = block_sum(c_l, red4);
+  if (tid == 0) {
+    comp_out[b] = (float)c;
+    if (iters_out) iters_out[b] = it;
+    if (relres_out) relres_out[b] = (float)(r0 > 0.0 ? sqrt(rr) / r0 : 0.0);
+  }
+}
+
+// 8-connected components of {rho > thr} by min-label propagation in LDS; ncomp[b] = number of foreground components
+__global__ void __launch_bounds__(256) floating_material_kernel(const float* __restrict__ rho, float thr, int nel,
+                                                                int* __restrict__ ncomp) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ int changed, count;
+  int* lab = reinterpret_cast<int*>(smem);
+  const int b = blockIdx.x, tid = threadIdx.x, E = nel * nel;
+  for (int e = tid; e < E; e += 256) lab[e] = rho[(size_t)b * E + e] > thr ? e + 1 : 0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 4 * E; ++sweep) {
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    bool any = false;
+    for (int e = tid; e < E; e += 256) {
+      int l = lab[e];
+      if (l == 0) continue;
+      const int y = e / nel, x = e - y * nel;
+      int m = l;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= nel) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx;
+          if (xx < 0 || xx >= nel) continue;
+          const int ln = lab[yy * nel + xx];
+          if (ln != 0 && ln < m) m = ln;
+        }
+      }
+      if (m < l) { lab[e] = m; any = true; }   // monotone decreasing labels: races only delay convergence
+    }
+    if (any) changed = 1;
+    __syncthreads();
+    if (!changed) break;
+    __syncthreads();
+  }
+  if (tid == 0) count = 0;
+  __syncthreads();
+  int c = 0;
+  for (int e = tid; e < E; e += 256) c += (lab[e] == e + 1) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((tid & 63) == 0 && c) atomicAdd(&count, c);   // integer add: order independent
+  __syncthreads();
+  if (tid == 0) ncomp[b] = count;
+}
+
 }  // namespace pidm
 
 using namespace pidm;
@@ -263,5 +478,66 @@ extern "C" int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, co
   hipLaunchKernelGGL(HIP_KERNEL_NAME(mech_kernel<true>), dim3(B), dim3(256), lds, as_stream(stream), ms, x0_pred, bcs, nullptr, nullptr,
                      nullptr, nullptr, g_residual, g_model_out, g_comp_shift, g_x0_pred);
   PIDM_CHECK_LAUNCH("mech_kernel<bwd>");
+  return 0;
+}
+
+
+extern "C" int pidm_mech_apply(const float* rho, const float* u_img, const float* bcs, const float* kloc, int kloc_stride,
+                               const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* residual, float* comp_uf,
+                               int B, void* stream) {
+  const int E = nel * nel, nn = nel + 1, ndof = 2 * nn * nn;
+  if (mech_args(nel, E, ndof, kloc, elem_dofs, dof_elems)) return -1;
+  if (!rho || !u_img || !bcs || !residual || !comp_uf) return fail("mech_apply: null buffer");
+  MechMesh ms{elem_dofs, dof_elems, kloc, kloc_stride, E, ndof, nel, nn};
+  const size_t lds = (size_t)(ndof + E) * sizeof(float);
+  if (lds > 150 * 1024) return fail("mech: mesh does not fit LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mech_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(mech_apply_kernel, dim3(B), dim3(256), lds, as_stream(stream), ms, rho, u_img, bcs, residual, comp_uf);
+  PIDM_CHECK_LAUNCH("mech_apply_kernel");
+  return 0;
+}
+
+extern "C" size_t pidm_mech_solve_ws_bytes(int nel, int B) {
+  return (size_t)B * 4 * (2 * (size_t)(nel + 1) * (nel + 1)) * sizeof(double) + 256;
+}
+
+extern "C" int pidm_mech_solve(const float* rho, const float* bcs, const float* kloc, int kloc_stride, const int32_t* elem_dofs,
+                               const int32_t* dof_elems, int nel, float bin_threshold, float bin_hi, float bin_lo, int max_iter,
+                               double rtol, float* u_dofs, float* compliance, float* rho_mean, int32_t* iters, float* relres,
+                               void* workspace, int B, void* stream) {
+  const int E = nel * nel, nn = nel + 1, ndof = 2 * nn * nn;
+  if (mech_args(nel, E, ndof, kloc, elem_dofs, dof_elems)) return -1;
+  if (!rho || !bcs || !compliance || !workspace) return fail("mech_solve: null buffer");
+  if (max_iter < 1 || !(rtol > 0.0)) return fail("mech_solve: max_iter >= 1 and rtol > 0 required");
+  MechMesh ms{elem_dofs, dof_elems, kloc, kloc_stride, E, ndof, nel, nn};
+  const size_t lds = (size_t)ndof * sizeof(double) + (size_t)E * sizeof(float);
+  if (lds > 150 * 1024) return fail("mech_solve: mesh does not fit LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mech_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  double* ws = reinterpret_cast<double*>((reinterpret_cast<size_t>(workspace) + 255) & ~(size_t)255);
+  hipLaunchKernelGGL(mech_pcg_kernel, dim3(B), dim3(256), lds, as_stream(stream), ms, rho, bcs, bin_threshold, bin_hi, bin_lo, max_iter,
+                     rtol, ws, u_dofs, compliance, rho_mean, iters, relres);
+  PIDM_CHECK_LAUNCH("mech_pcg_kernel");
+  return 0;
+}
+
+extern "C" int pidm_floating_material(const float* rho, float threshold, int nel, int32_t* n_components, int B, void* stream) {
+  if (!rho || !n_components) return fail("floating_material: null buffer");
+  const size_t lds = (size_t)nel * nel * sizeof(int);
+  if (nel < 1 || lds > 150 * 1024) return fail("floating_material: nel=%d out of range", nel);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&floating_material_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(floating_material_kernel, dim3(B), dim3(256), lds, as_stream(stream), rho, threshold, nel, n_components);
+  PIDM_CHECK_LAUNCH("floating_material_kernel");
   return 0;
 }

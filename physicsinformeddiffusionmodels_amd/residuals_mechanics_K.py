@@ -6,8 +6,9 @@ The reference assembles a dense 8450 x 8450 stiffness matrix PER SAMPLE (285.6 M
 dof gathers its <= 4 incident elements in fixed order) and its hand-written adjoint; the bilinear 64<->65 resizes
 (torchvision Resize, antialias=False) are folded into the same kernels.  No CPU fallback.
 
-Not on the accelerated path: the `topopt_eval and sample` evaluation block (per-sample FE solve
-+ OpenCV connected components, reference :276-347) - requesting it raises NotImplementedError.
+The `topopt_eval and sample` evaluation block (reference :276-347) runs on the GPU as well: the
+per-sample dense `torch.linalg.solve` becomes a matrix-free Jacobi-PCG in fp64 (one workgroup per sample), the OpenCV
+connected-components call a label-propagation kernel (`pidm_mech_apply / pidm_mech_solve / pidm_floating_material`).
 """
 from __future__ import annotations
 
@@ -197,14 +198,52 @@ class ResidualsMechanics:
             self._lib = get_lib()
         return self._lib
 
+    # evaluation-only knobs of the FE solve (the reference uses a direct dense solve, :321-323)
+    pcg_max_iter = 20000
+    pcg_rtol = 1e-9
+
+    def topopt_metrics(self, rho_pred, bcs, vf, solution):
+        """Reference :276-347: compliance error of the BINARISED predicted density (true displacements by an FE solve)
+        relative to the compliance of the data solution, volume-fraction error, floating-material flag.
+        rho_pred [B,nel,nel]; bcs [B,4,nn,nn]; vf [B]; solution [B,3,nn,nn] = (u_x, u_y, rho_simp zero-padded)."""
+        lib, st = self.lib, self.stiffs
+        dev = rho_pred.device
+        B, nel = rho_pred.shape[0], self.pixels_per_dim
+        nn = nel + 1
+        bc = bcs.contiguous().float()
+        opt_disp = solution[:, :2].contiguous().float()
+        rho_simp = solution[:, 2, :-1, :-1].contiguous().float()
+        mesh = (ptr(st.kloc_dev), st.kloc_stride, ptr(st.elem_dofs32), ptr(st.dof_elems32), nel)
+        # compliance of the data and the "residual of opt_disp should be zero" sanity check (:293-296)
+        res_data = torch.empty(B, st.neq, dtype=torch.float32, device=dev)
+        comp_data = torch.empty(B, dtype=torch.float32, device=dev)
+        lib.check(lib.pidm_mech_apply(ptr(rho_simp), ptr(opt_disp), ptr(bc), *mesh, ptr(res_data), ptr(comp_data), B,
+                                      stream_ptr(dev)), "pidm_mech_apply")
+        assert torch.isclose(res_data.abs().mean(), torch.tensor(0., device=dev), atol=1.e-5), 'Residual of opt_disp is not zero.'
+        # FE solve on the binarised prediction (:299-323)
+        rho = rho_pred.contiguous().float()
+        comp_true = torch.empty(B, dtype=torch.float32, device=dev)
+        rho_mean = torch.empty(B, dtype=torch.float32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        relres = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pidm_mech_solve_ws_bytes(nel, B), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_mech_solve(ptr(rho), ptr(bc), *mesh, 0.5, 1.0, 1.e-3, int(self.pcg_max_iter), float(self.pcg_rtol),
+                                      None, ptr(comp_true), ptr(rho_mean), ptr(iters), ptr(relres), ptr(ws), B,
+                                      stream_ptr(dev)), "pidm_mech_solve")
+        self.last_solve_info = {'iterations': iters, 'relative_residual': relres}
+        ncomp = torch.empty(B, dtype=torch.int32, device=dev)
+        lib.check(lib.pidm_floating_material(ptr(rho), 0.5, nel, ptr(ncomp), B, stream_ptr(dev)), "pidm_floating_material")
+        vfd = vf.to(dev).float()
+        return {'rel_CE_error_full_batch': (comp_true - comp_data) / comp_data,
+                'vf_error_full_batch': torch.abs(rho_mean - vfd) / vfd,
+                # cv2.connectedComponents counts the background label too: "!= 2" <=> not exactly one foreground component
+                'fm_error_full_batch': (ncomp != 1).to(torch.int64).cpu()}
+
     def compute_residual(self, input_tuple, reduce='none', return_model_out=False, return_optimizer=False,
                          return_inequality=False, sample=False, ddim_func=None, pass_through=False):
         self.deriv_mode = 'stiffness'
         input, bcs, vf = input_tuple[0], input_tuple[1], input_tuple[2]
         lib = self.lib
-        if self.topopt_eval and sample:
-            raise NotImplementedError('topology-optimisation evaluation metrics (FE solve, floating material) are SURVEY '
-                                      '8(f) rank 2; construct ResidualsMechanics(topopt_eval=False)')
         if pass_through:
             assert isinstance(input, torch.Tensor), 'Input is assumed to directly be given output.'
             x0_pred = input
@@ -229,6 +268,9 @@ class ResidualsMechanics:
             output['optimizer'] = compliance
         if return_inequality:
             output['inequality'] = shift
+        if self.topopt_eval and sample:
+            with torch.no_grad():
+                output.update(self.topopt_metrics(x0_pred[:, -1].detach(), bcs, vf, input_tuple[3]))
         if reduce == 'full':
             return {k: v.mean() for k, v in output.items()}
         elif reduce == 'per-batch':

@@ -60,6 +60,11 @@ int pidm_darcy_loss_fwd_bwd(const float* x0, const float* x0_pred, const float* 
                             float* residual, float* grad_x0_pred, float* out_scalars, void* workspace,
                             int B, int P, void* stream);
 
+/* CoCoGen residual correction: max over all entries of d residual / d p per sample
+ *   replaces the dense vmap(jacfwd) Jacobian of src/residuals_darcy.py:217-231 (400 MB per 64x64 sample) by the
+ *   analytic stencil rows.  x0: [B,2,P,P] (p, K); max_dr_dp: [B]. */
+int pidm_darcy_jacobian_max(const float* x0, float inv_h0, float inv_h1, float* max_dr_dp, int B, int P, void* stream);
+
 /* q-sample  x_t = a[t_b] x0 + am1[t_b] eps          replaces src/denoising_utils.py:633-638
  * writes x_t in channels-last [B,P*P,C] (what the UNet consumes) from NCHW x0/eps. */
 int pidm_qsample_nhwc(const float* x0, const float* eps, const float* a_t, const float* am1_t, float* xt_nhwc,

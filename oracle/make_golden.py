@@ -339,9 +339,26 @@ def g11():
           "vf_err", npy(out["vf_error_full_batch"]), truth["vf_error"], "fm", npy(out["fm_error_full_batch"]), truth["fm"])
 
 
+# G12: CoCoGen residual correction (reference ResidualsDarcy.residual_correction incl. its vmap(jacfwd) Jacobian maximum)
+def g12():
+    P, B = 16, 2
+    res = ResidualsDarcy(model=None, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True, device="cpu",
+                         bcs="none", domain_length=1.)
+    x = seeded((B, P * P, 2), 81)
+    x[:, :, 1] = torch.exp(0.5 * x[:, :, 1])
+    x_in = x.clone()
+    from torch.func import jacfwd, vmap
+    jac = vmap(jacfwd(res.compute_residual_direct, argnums=0, has_aux=False), in_dims=0, out_dims=0)(x_in.clone()).squeeze(1)[:, :, :, :, 0]
+    mx = jac.reshape(B, -1).max(dim=1)[0]
+    x_out, r_out = res.residual_correction(x)          # corrects x in place
+    np.savez_compressed(os.path.join(OUT, "g12_cocogen_p16.npz"), x_in=npy(x_in), x_out=npy(x_out), delta_p=npy(x_out[:, :, 0] - x_in[:, :, 0]),
+                        residual_corrected=npy(r_out), max_dr_dp=npy(mx))
+    print("g12 cocogen: max_dr_dp", npy(mx), "max |delta p|", float((x_out - x_in).abs().max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11"):
-        {"g9": g9, "g10": g10, "g11": g11}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -354,4 +371,5 @@ if __name__ == "__main__":
     g9()
     g10()
     g11()
+    g12()
     print("golden vectors written to", OUT)

@@ -491,3 +491,35 @@ def mechanics_topopt_metrics(rho_pred, bcs, vf, solution, kloc, elem_dofs):
         out["vf_error"][b] = abs(rb.mean() - vf[b]) / vf[b]
         out["fm"][b] = int(count_foreground_components(rho_pred[b]) != 1)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CoCoGen residual correction (reference src/residuals_darcy.py:209-238), restated on the oracle's residual:
+# the reference takes max over the dense vmap(jacfwd) Jacobian d residual / d p; here torch.func.jacfwd on the same map.
+# ---------------------------------------------------------------------------------------------------------------------
+def darcy_jacobian_max(x0_img: torch.Tensor) -> torch.Tensor:
+    """x0_img [B,2,P,P] -> [B]: signed max over all entries of d residual[n,k] / d p[m] (structural zeros included)."""
+    from torch.func import jacfwd
+    out = []
+    for b in range(x0_img.shape[0]):
+        K = x0_img[b, 1]
+
+        def r_of_p(p):
+            return darcy_residual(torch.stack([p, K]).unsqueeze(0))[0]
+        J = jacfwd(r_of_p)(x0_img[b, 0])          # [N,3,P,P]
+        out.append(J.max())
+    return torch.stack(out)
+
+
+def darcy_residual_correction(x_bnc: torch.Tensor):
+    """x_bnc [B,P*P,2] -> (corrected copy, residual of the corrected field, max_dr_dp, dr_dp)."""
+    B, N, _ = x_bnc.shape
+    P = int(round(N ** 0.5))
+    x = x_bnc.detach().clone().requires_grad_(True)
+    img = x.permute(0, 2, 1).reshape(B, 2, P, P)
+    r = darcy_residual(img)
+    dr_dp = torch.autograd.grad((r ** 2).sum(), x)[0][:, :, 0]
+    mx = torch.clamp(darcy_jacobian_max(img.detach()), max=1e12)
+    out = x_bnc.detach().clone()
+    out[:, :, 0] -= (1.0e-6 / mx).unsqueeze(1) * dr_dp
+    return out, darcy_residual(out.permute(0, 2, 1).reshape(B, 2, P, P)), mx, dr_dp

@@ -53,6 +53,7 @@ class PidmLib:
         self._sig("pidm_darcy_residual_bwd", [vp, vp, f, f, vp, i, i, vp])
         self._sig("pidm_darcy_loss_ws", [i, i], sz)
         self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
+        self._sig("pidm_darcy_jacobian_max", [vp, f, f, vp, i, i, vp])
         self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
         self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
         self._sig("pidm_mech_apply", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, i, vp])

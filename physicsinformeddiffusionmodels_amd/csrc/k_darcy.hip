@@ -214,6 +214,51 @@ static FdAxis make_axis(double inv_h) {
   return a;
 }
 
+// max over ALL entries of the Jacobian d residual[n,k] / d p[m] of one sample (signed max, zeros included) - what the
+// reference obtains from a dense vmap(jacfwd) Jacobian of 4096x3 x 4096x2 entries (400 MB per sample,
+// src/residuals_darcy.py:217-231).  Analytic from the stencil rows: for pixel (i,j)
+//   d eq / d p(k,j) = -K D00[i][k] - K0 D0[i][k]      (k in the column stencil of row i)
+//   d eq / d p(i,l) = -K D11[j][l] - K1 D1[j][l]      (l in the row stencil of column j); the two meet at (i,j)
+//   d bc0 / d p(k,j) = s0(i) D0[i][k],  d bc1 / d p(i,l) = s1(j) D1[j][l]
+__global__ void __launch_bounds__(256) darcy_jacmax_kernel(const float* __restrict__ pred, float bc1_sign, FdAxis ax0, FdAxis ax1,
+                                                           float* __restrict__ out, int P) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ float red[4];
+  const int N = P * P;
+  float* sK = smem;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int n = tid; n < N; n += 256) sK[n] = pred[(size_t)b * 2 * N + N + n];
+  __syncthreads();
+  float mx = 0.f;   // the dense Jacobian contains structural zeros
+  for (int n = tid; n < N; n += 256) {
+    const int i = n / P, j = n - i * P;
+    const float Kv = sK[n];
+    const float K0 = fd_apply(ax0.c1, sK + j, i, P, P, 3);
+    const float K1 = fd_apply(ax1.c1, sK + i * P, j, P, 1, 3);
+    const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
+    const float s1 = (j == 0) ? bc1_sign : ((j == P - 1) ? -bc1_sign : 0.f);
+    const int klo = (i == 0) ? 0 : ((i == P - 1) ? P - 4 : i - 1), khi = (i == 0) ? 3 : ((i == P - 1) ? P - 1 : i + 1);
+    const int llo = (j == 0) ? 0 : ((j == P - 1) ? P - 4 : j - 1), lhi = (j == 0) ? 3 : ((j == P - 1) ? P - 1 : j + 1);
+    const float e1_c = -Kv * fd_coef(ax1.c2, j, j, P, 4) - K1 * fd_coef(ax1.c1, j, j, P, 3);
+    for (int k = klo; k <= khi; ++k) {
+      const float d0 = fd_coef(ax0.c1, i, k, P, 3);
+      float e = -Kv * fd_coef(ax0.c2, i, k, P, 4) - K0 * d0;
+      if (k == i) e += e1_c;
+      mx = fmaxf(mx, e);
+      mx = fmaxf(mx, s0 * d0);
+    }
+    for (int l = llo; l <= lhi; ++l) {
+      const float d1 = fd_coef(ax1.c1, j, l, P, 3);
+      if (l != j) mx = fmaxf(mx, -Kv * fd_coef(ax1.c2, j, l, P, 4) - K1 * d1);
+      mx = fmaxf(mx, s1 * d1);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) out[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 template <int MODE>
 static int launch_darcy(const float* x0, const float* pred, const float* f_s, const float* grad_res, const float* p2w,
                         const float* inv_var, float c_data, float c_res, float inv_h0, float inv_h1, float* residual,
@@ -265,5 +310,21 @@ extern "C" int pidm_darcy_loss_fwd_bwd(const float* x0, const float* x0_pred, co
   hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(64), 0, as_stream(stream), partial, p2w, inv_var, c_data,
                      c_residual, B, P * P, out_scalars);
   PIDM_CHECK_LAUNCH("darcy_loss_finalize");
+  return 0;
+}
+
+extern "C" int pidm_darcy_jacobian_max(const float* x0, float inv_h0, float inv_h1, float* max_dr_dp, int B, int P, void* stream) {
+  if (!x0 || !max_dr_dp) return fail("darcy_jacobian_max: null buffer");
+  if (B <= 0 || P < 5) return fail("darcy: need B>0 and P>=5 (got B=%d P=%d)", B, P);
+  const size_t lds = (size_t)P * P * sizeof(float);
+  if (lds > 160 * 1024 - 256) return fail("darcy: P=%d does not fit the 160 KiB LDS", P);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_jacmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(darcy_jacmax_kernel, dim3(B), dim3(256), lds, as_stream(stream), x0, (inv_h1 < 0.f) ? 1.f : -1.f,
+                     make_axis(inv_h0), make_axis(inv_h1), max_dr_dp, P);
+  PIDM_CHECK_LAUNCH("darcy_jacmax_kernel");
   return 0;
 }

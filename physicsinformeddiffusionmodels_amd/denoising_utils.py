@@ -325,8 +325,7 @@ class DenoisingDiffusion(nn.Module):
     def p_sample(self, x, conditioning_input, t, save_output=False, surpress_noise=False, use_dynamic_threshold=False,
                  residual_func=None, eval_residuals=False, return_optimizer=False, return_inequality=False,
                  residual_correction=False, correction_mode='none'):
-        if residual_correction:
-            raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3')
+        assert correction_mode in ['x0', 'xt'] or not residual_correction, 'Correction mode unknown or not given.'
         if use_dynamic_threshold:
             raise NotImplementedError('dynamic thresholding is off in main.py/sample.py and not on the accelerated path')
         x_init = x.detach()
@@ -352,6 +351,9 @@ class DenoisingDiffusion(nn.Module):
             model_out, residual = out_dict['model_out'], out_dict['residual']
             if model_out.dim() == 3:
                 model_out = generalized_b_xy_c_to_image(model_out)
+            if residual_correction and correction_mode == 'x0':      # CoCoGen (:434-436)
+                model_out, residual = residual_func.residual_correction(generalized_image_to_b_xy_c(model_out).contiguous())
+                model_out = generalized_b_xy_c_to_image(model_out)
             model_intermediate = model_out.clone() if save_output else None
             ht = self._host_tables
             c1, c2 = float(ht['posterior_mean_coef1'][t_int]), float(ht['posterior_mean_coef2'][t_int])
@@ -365,6 +367,9 @@ class DenoisingDiffusion(nn.Module):
             out = torch.empty_like(xi)
             lib.check(lib.pidm_psample_update(ptr(x0p), ptr(xi), ptr(z), c1, c2, sigma, ptr(out), xi.numel(),
                                               stream_ptr(xi.device)), 'pidm_psample_update')
+            if residual_correction and correction_mode == 'xt':      # CoCoGen (:457-459)
+                out, residual = residual_func.residual_correction(generalized_image_to_b_xy_c(out).contiguous())
+                out = generalized_b_xy_c_to_image(out).contiguous()
         if t_int == 0 and eval_residuals:
             aux_out = {'residual': residual}
             if return_optimizer:
@@ -382,20 +387,30 @@ class DenoisingDiffusion(nn.Module):
                       M_correction=0, N_correction=0, correction_mode='none', keep_history=True):
         """`keep_history=False` (extension) skips the two blocking D2H copies per step the reference performs
         (src/denoising_utils.py:531-532) and returns only the final state in the lists."""
-        if M_correction or N_correction:
-            raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3')
         cur_x = torch.randn(shape, device=self.diff_dict['alphas'].device)
         x_seq = [cur_x.detach().cpu()] if keep_history else []
         interm_imgs = [torch.zeros(shape)] if (save_output and keep_history) else []
         output = None
         for i in reversed(range(self.n_steps)):
+            residual_correction = False
+            if i < N_correction:            # CoCoGen correction inside the last N steps (:520-523)
+                residual_correction = True
+                eval_residuals = True
             output = self.p_sample(cur_x.detach(), conditioning_input, i, save_output, surpress_noise, use_dynamic_threshold,
                                    residual_func=residual_func, eval_residuals=eval_residuals,
-                                   return_optimizer=return_optimizer, return_inequality=return_inequality)
+                                   return_optimizer=return_optimizer, return_inequality=return_inequality,
+                                   residual_correction=residual_correction, correction_mode=correction_mode)
             cur_x, interm_img = output[0]
             if keep_history:
                 x_seq.append(cur_x.detach().cpu())
                 interm_imgs.append(interm_img.detach().cpu())
+        for i in range(M_correction):       # CoCoGen post-correction (:535-540)
+            cur_x, residual = residual_func.residual_correction(generalized_image_to_b_xy_c(cur_x).contiguous())
+            cur_x = generalized_b_xy_c_to_image(cur_x).contiguous()
+            if keep_history:
+                x_seq.append(cur_x.detach().cpu())
+            if eval_residuals and i == M_correction - 1:
+                output[1]['residual'] = residual
         if not keep_history:
             x_seq.append(cur_x.detach())
             if save_output:

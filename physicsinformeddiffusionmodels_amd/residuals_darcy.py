@@ -139,6 +139,28 @@ class ResidualsDarcy:
             return output
         raise ValueError('Unknown reduction method.')
 
+    def jacobian_max(self, x0_img):
+        """max over all entries of d residual / d p per sample ([B,2,P,P] -> [B]).  The reference builds the dense
+        vmap(jacfwd) Jacobian for this (400 MB per 64x64 sample, src/residuals_darcy.py:217-231); the kernel evaluates the
+        stencil rows analytically."""
+        x = x0_img.detach().contiguous().float()
+        B, _, P, _ = x.shape
+        out = torch.empty(B, dtype=torch.float32, device=x.device)
+        self.lib.check(self.lib.pidm_darcy_jacobian_max(ptr(x), self.inv_h0, self.inv_h1, ptr(out), B, P, stream_ptr(x.device)),
+                       'pidm_darcy_jacobian_max')
+        return out
+
     def residual_correction(self, x0_pred_in):
-        raise NotImplementedError('CoCoGen residual correction is SURVEY 8(f) rank 3 (N_correction/M_correction '
-                                  'default 0 in model.yaml:10-11)')
+        """CoCoGen correction step (src/residuals_darcy.py:209-238): p <- p - (1e-6 / max dr/dp) * d(sum r^2)/dp,
+        applied IN PLACE to x0_pred_in [B, P*P, 2]; returns (x0_pred_in, residual of the corrected field)."""
+        assert len(x0_pred_in.shape) == 3, 'Model output must be a tensor shaped as b_xy_c.'
+        with torch.enable_grad():
+            x0_pred = x0_pred_in.detach().clone().requires_grad_(True)
+            residual_x0_pred = self.compute_residual(generalized_b_xy_c_to_image(x0_pred), pass_through=True)['residual']
+            dr_dp = torch.autograd.grad(torch.sum(residual_x0_pred ** 2), x0_pred)[0][:, :, 0]
+        max_dr_dp = torch.clamp(self.jacobian_max(generalized_b_xy_c_to_image(x0_pred_in.detach())), max=1e12)
+        correction_eps = 1.e-6 / max_dr_dp
+        with torch.no_grad():
+            x0_pred_in[:, :, 0] -= correction_eps.unsqueeze(1) * dr_dp.detach()
+            residual_corrected = self.compute_residual(generalized_b_xy_c_to_image(x0_pred_in), pass_through=True)['residual']
+        return x0_pred_in, residual_corrected

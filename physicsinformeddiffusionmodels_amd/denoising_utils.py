@@ -139,6 +139,39 @@ def load_model(path, model, strict=True):
     return model
 
 
+def save_training_state(path, model, optimizer=None, ema=None, iteration=0, extra=None):
+    """Extension: everything needed to resume a run bit-exactly - the reference checkpoints hold the
+    model weights only (src/denoising_utils.py:273-287).  `model` keys are the reference's 317 `state_dict` entries, so the
+    file doubles as a `load_model` checkpoint.  optimizer: torch.optim.Adam or optim.FusedClipAdam; ema: EMA."""
+    state = {'model': model.state_dict(), 'iteration': int(iteration), 'rng_cpu': torch.get_rng_state()}
+    if torch.cuda.is_available():
+        state['rng_cuda'] = torch.cuda.get_rng_state_all()
+    if optimizer is not None:
+        state['optimizer'] = optimizer.state_dict()
+    if ema is not None:
+        state['ema'] = ema.state_dict()
+    if extra is not None:
+        state['extra'] = extra
+    with open(path, 'wb') as f:
+        torch.save(state, f)
+
+
+def load_training_state(path, model, optimizer=None, ema=None, strict=True):
+    """Restores what save_training_state wrote (in place); returns (iteration, extra)."""
+    with open(path, 'rb') as f:
+        state = torch.load(f, map_location='cpu', weights_only=False)
+    model.load_state_dict(state['model'], strict=strict)      # copies into the existing (possibly flattened) Parameters
+    if optimizer is not None and 'optimizer' in state:
+        optimizer.load_state_dict(state['optimizer'])
+    if ema is not None and 'ema' in state:
+        dev = next(model.parameters()).device
+        ema.shadow = {k: v.to(dev) for k, v in state['ema'].items()}
+    torch.set_rng_state(state['rng_cpu'])
+    if 'rng_cuda' in state and torch.cuda.is_available():
+        torch.cuda.set_rng_state_all(state['rng_cuda'])
+    return state['iteration'], state.get('extra')
+
+
 class _DarcyPidmLossFn(torch.autograd.Function):
     """loss = c_data*mean_b(w_t*mse) + mean(c_r*0.5*r^2/var_t) in one kernel, together with d loss/d x0_pred
     (src/denoising_utils.py:666-692).  Returns (loss, scalars[4], residual)."""

@@ -111,6 +111,6 @@ class FusedClipAdam:
         if list(sd["param_names"]) != list(self.eng.names):
             raise PidmError("FusedClipAdam.load_state_dict: parameter order mismatch")
         self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.exp_avg.copy_(sd["exp_avg"].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(self.exp_avg_sq.device))
         self.lr, self.betas, self.eps, self.max_norm = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"]), sd["max_norm"]

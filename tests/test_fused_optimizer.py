@@ -98,3 +98,51 @@ def test_fused_optimizer_training_steps_match_torch(backend):
     opt_c = FusedClipAdam(mb, lr=1e-3, max_norm=1.0, image_size=P, lib=lib)
     opt_c.load_state_dict(sd)
     assert opt_c.step_count == 3 and torch.equal(opt_c.exp_avg, opt_b.exp_avg)
+
+
+def test_full_state_resume_is_bit_exact(backend, tmp_path):
+    """save_training_state / load_training_state (extension): 2 steps + save + 2 steps == load + 2 steps."""
+    from physicsinformeddiffusionmodels_amd.denoising_utils import EMA, load_training_state, save_training_state
+    L, dev = backend
+    lib = L if dev.type == "cpu" else None
+    dim, P, B = 8, 16, 2
+
+    def make():
+        m, diff, res, _ = setup(backend, dim, P, 100)
+        opt = FusedClipAdam(m, lr=1e-3, max_norm=1.0, image_size=P, lib=lib)
+        ema = EMA(0.99)
+        ema.register(m)
+        return m, diff, res, opt, ema
+
+    def run(m, diff, res, opt, ema, n, x0):
+        for _ in range(n):
+            loss, *_ = diff.model_estimation_loss(x0, residual_func=res, c_data=1., c_residual=1e-3)   # draws t, eps from the RNG
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            ema.update(m)
+
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(B, 2, P, P, generator=g)
+    x0[:, 1] = torch.exp(0.3 * x0[:, 1])
+    x0 = x0.to(dev)
+    torch.manual_seed(77)
+    a = make()
+    run(*a, 2, x0)
+    ck = str(tmp_path / "state.pt")
+    save_training_state(ck, a[0], a[3], a[4], iteration=2, extra={"note": "x"})
+    run(*a, 2, x0)
+    b = make()
+    torch.manual_seed(12345)                       # a different RNG position: must be overwritten by the checkpoint
+    it, extra = load_training_state(ck, b[0], b[3], b[4])
+    assert it == 2 and extra == {"note": "x"}
+    run(*b, 2, x0)
+    for (k, pa), (_, pb) in zip(a[0].named_parameters(), b[0].named_parameters()):
+        assert torch.equal(pa, pb), k
+    assert a[3].step_count == b[3].step_count == 4 and torch.equal(a[3].exp_avg, b[3].exp_avg)
+    for k in a[4].shadow:
+        assert torch.equal(a[4].shadow[k], b[4].shadow[k]), k
+    # the same file is a valid reference-style checkpoint for load_model
+    from physicsinformeddiffusionmodels_amd.denoising_utils import load_model
+    c = make()[0]
+    load_model(ck, c)

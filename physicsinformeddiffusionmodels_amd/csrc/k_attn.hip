@@ -26,7 +26,24 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
   float m = -3.0e38f, s = 0.f;
   if (j < HD) {
     const float* base = qkv + (size_t)b * N * 3 * HD + HD + j;
-    for (int n = n_lo + rl; n < n_hi; n += 4) {
+    // 8 independent loads in flight per thread, then ONE rescale per group (max of the group first): the dependent
+    // load -> exp -> exp chain of a per-element online softmax left this streaming kernel latency bound
+    int n = n_lo + rl;
+    for (; n + 28 < n_hi; n += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(n + 4 * u) * 3 * HD];
+      float gm = v[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) gm = fmaxf(gm, v[u]);
+      const float mn = fmaxf(m, gm);
+      float gs = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gs += expf(v[u] - mn);
+      s = s * expf(m - mn) + gs;
+      m = mn;
+    }
+    for (; n < n_hi; n += 4) {
       const float v = base[(size_t)n * 3 * HD];
       const float mn = fmaxf(m, v);
       s = s * expf(m - mn) + expf(v - mn);
@@ -135,6 +152,9 @@ __global__ void __launch_bounds__(256) la_nreduce_final_kernel(const float* __re
 
 // ---- out[n][h*32+e] = sum_d ctx[d][e] * softmax_d(q[n][h*32+:])[d] * scale ; qstat = (max, 1/sum) -------
 // one wave = 32 pixels, loops over heads.  lane (pixel l31, half) owns d in [16*half, 16*half+16).
+// ALIGNED (N % 32 == 0): the wave's 32 pixels share one image -> matrix-core path.  A compile-time switch: as a runtime
+// branch the register-hungry fallback (a 32-float row per lane) set the allocation of the hot path too (236 VGPRs).
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                      float* __restrict__ out, float* __restrict__ qstat, int N, int heads,
                                                      size_t npix, float scale) {
@@ -177,7 +197,7 @@ __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ q
     // a wave's 32 pixels may straddle two images only when N < 32; handle by per-lane b below
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (N % 32 == 0) {
+    if constexpr (ALIGNED) {
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
         const float a = qv[s2] * inv * scale;
@@ -525,8 +545,12 @@ int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, f
                      1.f / (float)N);
   PIDM_CHECK_LAUNCH("la_context_final");
   const size_t npix = (size_t)B * N;
-  hipLaunchKernelGGL(la_out_kernel, dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn, qstat, N, heads, npix,
-                     scale);
+  if (N % 32 == 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<true>), dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn,
+                       qstat, N, heads, npix, scale);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<false>), dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn,
+                       qstat, N, heads, npix, scale);
   PIDM_CHECK_LAUNCH("la_out_kernel");
   return 0;
 }

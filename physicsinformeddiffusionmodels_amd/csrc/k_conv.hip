@@ -170,7 +170,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // pipeline - the first chunk of the next tile is prefetched under the MFMAs of the current tile's last chunk and the
 // epilogue stores drain under the next tile's MFMAs.  Short-K layers (64x64: Cin = 32, two chunks per tile) otherwise
 // spend most of a workgroup's life in its prologue/epilogue with the matrix pipe idle (PMC: 45 % MFMA busy).
-template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED, bool PERSIST>
+// MT = m-tiles (32 pixels each) per wave: MT == 2 is the 256-pixel workgroup tile (two independent accumulator chains per
+// wave, half the barriers / weight staging / B-fragment reads per MFMA).
+template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED, bool PERSIST, int MT>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
                                                               const float* __restrict__ bias,
@@ -196,9 +198,13 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   const int ix0 = -g.pad_x[z];
   const float* wz = wp + g.w_off[z];
 
-  const int pm = wave * 32 + l31;
-  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
-  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int pm = mt * 128 + wave * 32 + l31;
+    const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+    abase[mt] = (a_img < g.NI) ? (a_img * g.IHt + a_ty * g.stride) * g.IWt + a_tx * g.stride : 0;
+  }
 
   // ---- staging slots of this thread (q = tid % Q is the same for every slot).  The LDS side is tile independent;
   //      the global side (a_pix) is decoded per tile by PIDM_SET_TILE ----
@@ -276,9 +282,9 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     _Pragma("unroll") for (int k = 0; k < BMAX; ++k) rb[k] = *reinterpret_cast<const f32x4*>(wn + b_g[k] + kk__);   \
   }
 
-  f32x16 acc[NT];
+  f32x16 acc[MT * NT];   // [mt][ni]
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < MT * NT; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   PIDM_SET_TILE(tm_first)
@@ -303,21 +309,23 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     // taps fully unrolled (compile-time KHxKW).  The LDS fragments of tap t+1 are fetched into a second register set
     // BEFORE the MFMAs of tap t are issued, so the ~128-cycle ds_read latency hides under 8*NT*KC/8 MFMAs instead of
     // stalling the matrix pipe once per tap.
-    const float* abase_p = As + (size_t)abase * KCP + 4 * half;
     const float* bbase_p = Bs + (size_t)l31 * KCP + 4 * half;
-    f32x4 fa[2][KC / 8], fb[2][KC / 8][NT];
+    f32x4 fa[2][MT][KC / 8], fb[2][KC / 8][NT];
 #define PIDM_LOAD_FRAGS(set_, t_)                                                                                  \
   {                                                                                                                \
-    const float* arow = abase_p + (size_t)(((t_) / KW) * g.IWt + ((t_) % KW)) * KCP;                               \
     const float* brow = bbase_p + (size_t)((t_)*BN) * KCP;                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                            \
+      const float* arow = As + (size_t)(abase[mt] + ((t_) / KW) * g.IWt + ((t_) % KW)) * KCP + 4 * half;           \
+      _Pragma("unroll") for (int g8 = 0; g8 < KC / 8; ++g8)                                                        \
+          fa[set_][mt][g8] = *reinterpret_cast<const f32x4*>(arow + 8 * g8);                                       \
+    }                                                                                                              \
     _Pragma("unroll") for (int g8 = 0; g8 < KC / 8; ++g8) {                                                        \
-      fa[set_][g8] = *reinterpret_cast<const f32x4*>(arow + 8 * g8);                                               \
       _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                                                            \
           fb[set_][g8][ni] = *reinterpret_cast<const f32x4*>(brow + (size_t)ni * 32 * KCP + 8 * g8);               \
     }                                                                                                              \
   }
     PIDM_LOAD_FRAGS(0, 0)
-    __builtin_amdgcn_sched_group_barrier(0x100, (1 + NT) * (KC / 8), 0);   // tap 0's reads form their own group
+    __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * (KC / 8), 0);   // tap 0's reads form their own group
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int cur = t & 1;
@@ -328,18 +336,21 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni)
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][s], fb[cur][g8][ni][s], acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt * NT + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][g8][s], fb[cur][g8][ni][s], acc[mt * NT + ni], 0, 0, 0);
         }
       }
       // pin the order hipcc otherwise undoes (it sinks the next tap's ds_reads below this tap's MFMAs):
-      // first the (1 + NT) * KC/8 LDS reads of tap t+1, then the 4 * NT * KC/8 MFMAs of tap t
-      if (t + 1 < T) __builtin_amdgcn_sched_group_barrier(0x100, (1 + NT) * (KC / 8), 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * (KC / 8), 0);
+      // first the (MT + NT) * KC/8 LDS reads of tap t+1, then the 4 * MT * NT * KC/8 MFMAs of tap t
+      if (t + 1 < T) __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * (KC / 8), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT * (KC / 8), 0);
     }
 #undef PIDM_LOAD_FRAGS
   }
 
   // ---- epilogue of tile tm: bias, residual, (sigmoid), store; PERSIST: the accumulators restart at zero ----
+  static_assert(NT != 4 || MT == 1, "the permuted 128-channel tile is a 1x1-conv configuration (MT == 1)");
   if constexpr (NT == 4) {
     // permuted tile: lane l31 owns channels n0 + 4*l31 .. +3 (one per accumulator) of 16 pixel rows -> one 16-byte
     // store per row: a wave instruction writes 2 x 512 contiguous bytes instead of 2 x 128
@@ -378,7 +389,9 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   } else if (g.Wv >= 32) {
     // the wave's 32 pixels are consecutive in x inside one image row: one 64-bit base per (wave, n-tile), then
     // row * (os*sox) steps with compile-time row constants (no per-row index math)
-    const int p0 = wave * 32;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+    const int p0 = mt * 128 + wave * 32;
     const int tx0 = p0 & (g.Wv - 1), ty = (p0 >> g.wsh) & (g.TH - 1), img = p0 >> (g.wsh + g.tsh);
     const int b = b0 + img;
     if (b < g.B && img < g.NI) {
@@ -397,14 +410,17 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = (r & 3) + 8 * (r >> 2);   // compile-time part of the row index
-          float v = acc[ni][r] + bv;
+          float v = acc[mt * NT + ni][r] + bv;
           if (rp) v += rp[rowc * rrstep];
           if (sig) v = 1.f / (1.f + expf(-v));
           op[rowc * rstep] = v;
         }
       }
     }
+    }
   } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int c = n0 + ni * 32 + l31;
@@ -413,12 +429,12 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int p = wave * 32 + row;
+        const int p = mt * 128 + wave * 32 + row;
         const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
         const int b = b0 + img;
         if (b >= g.B || img >= g.NI) continue;
         const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
-        float v = acc[ni][r] + bv;
+        float v = acc[mt * NT + ni][r] + bv;
         if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
         if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
         out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
@@ -427,7 +443,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   }
   if constexpr (PERSIST) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < MT * NT; ++i)
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   }
   }
@@ -766,43 +782,52 @@ __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg
 #pragma unroll
       for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
     }
-    if constexpr (WIDE) {
-      const int p0 = wave * 32;
-      const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
-      const int xb0 = (img0 < g.NI) ? (img0 * g.IHt + ty0 * g.stride) * g.IWt + tx0 * g.stride : 0;
-      const float* ap = Ys + (size_t)(p0 + half) * 32 + l31;
-      const float* xp = Xs + (size_t)(xb0 + half * g.stride) * 32 + l31;
+    // k-loop over the wave's 32 pixels (16 MFMA k-steps of 2 pixels), explicitly double buffered: the T+1 LDS fragments of
+    // step ks+1 are fetched into the second register set BEFORE the T MFMAs of step ks issue, pinned with
+    // sched_group_barrier - otherwise hipcc re-uses one register triple and every 3 MFMAs wait for a full LDS round trip
+    // (1 wave per SIMD at 144 accumulators: nothing else hides it; measured 44 % MFMA busy).
+    {
+      float fa_[2], fb_[2][T_];
+      int xb_w = 0;
+      const float* ap = nullptr;
+      const float* xp = nullptr;
+      if constexpr (WIDE) {
+        const int p0 = wave * 32;
+        const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
+        xb_w = (img0 < g.NI) ? (img0 * g.IHt + ty0 * g.stride) * g.IWt + tx0 * g.stride : 0;
+        ap = Ys + (size_t)(p0 + half) * 32 + l31;
+        xp = Xs + (size_t)(xb_w + half * g.stride) * 32 + l31;
+      }
       const int xstep = 2 * g.stride * 32;
-#pragma unroll 4
+#define PIDM_WG_FRAGS(set_, ks_)                                                                                   \
+  {                                                                                                                \
+    const float* xrow__;                                                                                           \
+    if constexpr (WIDE) {                                                                                          \
+      fa_[set_] = ap[(ks_)*64];                                                                                    \
+      xrow__ = xp + (size_t)(ks_)*xstep;                                                                           \
+    } else {                                                                                                       \
+      const int p__ = wave * 32 + 2 * (ks_) + half;                                                                \
+      const int tx__ = p__ & (g.Wv - 1), ty__ = (p__ >> g.wsh) & (g.TH - 1), img__ = p__ >> (g.wsh + g.tsh);       \
+      const int xb__ = (img__ < g.NI) ? (img__ * g.IHt + ty__ * g.stride) * g.IWt + tx__ * g.stride : 0;           \
+      fa_[set_] = Ys[p__ * 32 + l31];                                                                              \
+      xrow__ = Xs + (size_t)xb__ * 32 + l31;                                                                       \
+    }                                                                                                              \
+    _Pragma("unroll") for (int t__ = 0; t__ < T_; ++t__)                                                           \
+        fb_[set_][t__] = xrow__[((t__ / KW) * g.IWt + (t__ % KW)) * 32];                                           \
+  }
+      PIDM_WG_FRAGS(0, 0)
+#pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const float a = ap[ks * 64];
-        const float* xrow = xp + (size_t)ks * xstep;
+        const int cur = ks & 1;
+        if (ks + 1 < 16) PIDM_WG_FRAGS(cur ^ 1, ks + 1)
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-#pragma unroll
-          for (int kx = 0; kx < KW; ++kx) {
-            const float bv = xrow[(ky * g.IWt + kx) * 32];
-            acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
-          }
-        }
+        for (int t = 0; t < T_; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[cur], fb_[cur][t], acc[t], 0, 0, 0);
+        // order: the DS reads of step ks+1 (grouped first), then the T MFMAs of step ks
+        if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, T_ + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, T_, 0);
       }
-    } else {
-#pragma unroll 2
-      for (int ks = 0; ks < 16; ++ks) {
-        const int p = wave * 32 + 2 * ks + half;
-        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-        const int xb = (img < g.NI) ? (img * g.IHt + ty * g.stride) * g.IWt + tx * g.stride : 0;
-        const float a = Ys[p * 32 + l31];
-        const float* xrow = Xs + (size_t)xb * 32 + l31;
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-#pragma unroll
-          for (int kx = 0; kx < KW; ++kx) {
-            const float bv = xrow[(ky * g.IWt + kx) * 32];
-            acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * KW + kx], 0, 0, 0);
-          }
-        }
-      }
+#undef PIDM_WG_FRAGS
     }
   }
 #undef PIDM_WG_PREFETCH
@@ -1194,6 +1219,23 @@ int launch_pack_multi(const PackDesc* table_dev, int ndesc, unsigned nblocks, hi
   return 0;
 }
 
+// re-tile a stride-1 geometry for a bm-pixel workgroup tile (bm = 256: two m-tiles per wave)
+static bool retile_bm(ConvGeom* g, int bm) {
+  if (g->Wv > bm || g->nz != 1 || g->nph != 1) return false;
+  const int TH = bm / g->Wv < g->Hv ? bm / g->Wv : g->Hv;
+  if (g->Hv % TH) return false;
+  int tsh = 0;
+  while ((1 << tsh) < TH) ++tsh;
+  if ((1 << tsh) != TH) return false;
+  const int NI = bm / (g->Wv * TH);
+  if (NI * g->Wv * TH != bm) return false;
+  g->TH = TH; g->tsh = tsh; g->NI = NI;
+  g->IHt = (TH - 1) * g->stride + g->KH;
+  g->mIHt = g->IHt > 1 ? (unsigned)((0x100000000ULL + g->IHt - 1) / g->IHt) : 0;
+  g->tiles_m = (NI > 1) ? cdiv(g->B, NI) : g->B * (g->Hv / TH);
+  return true;
+}
+
 template <int KC, int NT>
 static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const float* wp, const float* bias,
                          const float* residual, float* out, int sigmoid_last, hipStream_t st) {
@@ -1217,22 +1259,22 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
     const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
-#define PIDM_LAUNCH_PIPE(KH_, KW_, PH_, PS_, grid_)                                                                                \
+#define PIDM_LAUNCH_PIPE(KH_, KW_, PH_, PS_, MT_, AMAX_, grid_)                                                                                \
   {                                                                                                                        \
     constexpr int BMAXk = (KH_ * KW_ * BN * Q + 255) / 256;                                                                \
     static bool attr_pipe = false;                                                                                         \
     if (!attr_pipe) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_, PS_>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pipe_kernel<KC, NT, AMAX_, BMAXk, KH_, KW_, PH_, PS_, MT_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
       attr_pipe = true;                                                                                                    \
     }                                                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX, BMAXk, KH_, KW_, PH_, PS_>), grid_, dim3(256), \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_pipe_kernel<KC, NT, AMAX_, BMAXk, KH_, KW_, PH_, PS_, MT_>), grid_, dim3(256), \
                        lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
     if constexpr (NT == 4 || KC == 32) {
       // the permuted 128-channel tile and the 32-channel chunk exist for 1x1 convolutions only (conv_nt4_ok / launch_conv)
       if (g.KH != 1 || g.KW != 1 || g.nph != 1) return fail("conv: internal error - 1x1-only tile configuration on a %dx%d conv", g.KH, g.KW);
-      PIDM_LAUNCH_PIPE(1, 1, false, false, grid)
+      PIDM_LAUNCH_PIPE(1, 1, false, false, 1, AMAX, grid)
     } else {
       if (g.KH == 3) {
         // persistent walk when the launch has more tiles than resident workgroup slots: 2 workgroups per CU, each
@@ -1241,19 +1283,40 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
         const long slots = pe ? atol(pe) : 512;
         const long nwork = (long)g.tiles_m * tiles_n * g.nz;
         bool persist = false;
-        if constexpr (NT == 1) {   // the 64-channel tile needs > 256 registers in the persistent form (1 workgroup per CU)
+        if constexpr (KC == 16) {
+          // 256-pixel workgroup tile (MT = 2) when the launch still fills the chip: two accumulator chains per wave,
+          // half the barriers and weight staging per MFMA
+          const char* me = getenv("PIDM_MT2_MIN_WGS");   // experiments / tests: 0 = off, else the occupancy gate
+          const long mt2_min = me ? atol(me) : 512;
+          ConvGeom g2 = g;
+          if (mt2_min > 0 && retile_bm(&g2, 256)) {
+            const size_t lds2 = (size_t)g2.NI * g2.IHt * g2.IWt * KCP * sizeof(float) + (size_t)T * b_tap;
+            if (g2.NI * g2.IHt * g2.IWt * Q <= 8 * 256 && lds2 <= 80 * 1024 && (long)g2.tiles_m * tiles_n >= mt2_min) {
+              const ConvGeom g_outer = g;
+              {
+                const ConvGeom g = g2;
+                const size_t lds_pipe = lds2;
+                const dim3 grid2(g.tiles_m * tiles_n, 1, 1);
+                PIDM_LAUNCH_PIPE(3, 3, false, false, 2, 8, grid2)
+              }
+              (void)g_outer;
+              persist = true;   // launched
+            }
+          }
+        }
+        if constexpr (NT == 1) if (!persist) {   // the 64-channel tile needs > 256 registers in the persistent form (1 workgroup per CU)
           if (slots > 0 && nwork > slots) {
             persist = true;
             g.tpw = (int)((nwork + slots - 1) / slots);
             const dim3 gridp(cdiv(g.tiles_m, g.tpw) * tiles_n, 1, g.nz);
-            PIDM_LAUNCH_PIPE(3, 3, false, true, gridp)
+            PIDM_LAUNCH_PIPE(3, 3, false, true, 1, AMAX, gridp)
           }
         }
-        if (!persist) PIDM_LAUNCH_PIPE(3, 3, false, false, grid)
+        if (!persist) PIDM_LAUNCH_PIPE(3, 3, false, false, 1, AMAX, grid)
       }
-      else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true, false, grid)
-      else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false, false, grid)
-      else PIDM_LAUNCH_PIPE(1, 1, false, false, grid)
+      else if (g.KH == 2 && g.nph > 1) PIDM_LAUNCH_PIPE(2, 2, true, false, 1, AMAX, grid)
+      else if (g.KH == 2) PIDM_LAUNCH_PIPE(2, 2, false, false, 1, AMAX, grid)
+      else PIDM_LAUNCH_PIPE(1, 1, false, false, 1, AMAX, grid)
     }
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
@@ -1435,7 +1498,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
              g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {
     if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
-      else PIDM_LAUNCH_WG(1, 1, false, false, 4, grid)
+      else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
     } else {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(3, 3, false, true, 1, grid)
       else PIDM_LAUNCH_WG(3, 3, false, false, 1, grid)

@@ -56,6 +56,20 @@ def test_conv_3x3_persistent(backend, monkeypatch, B, H, C0, C1, Cout, K, stride
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+MT2_CASES = [   # 3x3 convs on the 256-pixel workgroup tile (two m-tiles per wave) once the occupancy gate is lowered
+    (2, 64, 16, 0, 32, 3, 1, 1, 0),      # 4 rows of 64 per tile
+    (3, 16, 16, 16, 64, 3, 1, 1, 0),     # one whole 16x16 image per tile, concat source, 64-channel tile (NT = 2)
+    (5, 8, 32, 0, 32, 3, 1, 1, 0),       # four 8x8 images per tile, ragged last tile (5 images)
+    (2, 32, 32, 0, 40, 3, 1, 1, 0),      # 8 rows of 32, Cout not a multiple of 32
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", MT2_CASES)
+def test_conv_3x3_two_mtiles_per_wave(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_MT2_MIN_WGS", "1")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", CASES)
 def test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed):
     L, dev = backend

@@ -1283,9 +1283,10 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
         const long slots = pe ? atol(pe) : 512;
         const long nwork = (long)g.tiles_m * tiles_n * g.nz;
         bool persist = false;
-        if constexpr (KC == 16) {
+        if constexpr (KC == 16 && NT == 1) {
           // 256-pixel workgroup tile (MT = 2) when the launch still fills the chip: two accumulator chains per wave,
-          // half the barriers and weight staging per MFMA
+          // half the barriers and weight staging per MFMA (measured on MI355X: +0..5 % over the persistent 128-pixel
+          // walk for 32-channel tiles; with 64-channel tiles it needs 272 registers = one workgroup per CU, so NT == 1 only)
           const char* me = getenv("PIDM_MT2_MIN_WGS");   // experiments / tests: 0 = off, else the occupancy gate
           const long mt2_min = me ? atol(me) : 512;
           ConvGeom g2 = g;

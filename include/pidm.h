@@ -153,6 +153,14 @@ int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, void* const
  * save_for_backward != 0 keeps activations in the workspace until pidm_unet_backward. */
 int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B,
                       int save_for_backward, int repack_weights, void* workspace, size_t workspace_bytes, void* stream);
+/* Gradient-guidance conditioning branch (src/unet_model.py:521-528,571-587: x = combine_conv(cat(init_conv(x), emb_conv(cond)))).
+ * Its 6 parameters (emb_conv.0/2, combine_conv; weight+bias) are the LAST pidm_unet_num_cond_params() entries of the
+ * canonical list.  pidm_unet_enable_cond sizes the workspace for the branch (call it before pidm_unet_workspace_bytes);
+ * pidm_unet_set_condition hands the (already classifier-free-masked) field [B,P*P,C] to the NEXT pidm_unet_forward only.
+ * A backward whose forward had no conditioning input zero-fills the gradients of those 6 parameters. */
+int pidm_unet_num_cond_params(const pidm_unet* h);
+int pidm_unet_enable_cond(pidm_unet* h, int on);
+int pidm_unet_set_condition(pidm_unet* h, const float* cond_nhwc);
 /* grad_out: [B,out_dim,P,P] NCHW.  grad_x (may be NULL): [B,P*P,C].  Writes all bound grads. */
 int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, float* grad_x_nhwc, int B, void* workspace,
                        size_t workspace_bytes, void* stream);

@@ -356,9 +356,51 @@ def g12():
     print("g12 cocogen: max_dr_dp", npy(mx), "max |delta p|", float((x_out - x_in).abs().max()))
 
 
+# G13: gradient-guidance baseline (residual_grad_guidance=True): training loss with a fixed classifier-free mask, and one
+# guided sampler step (forward_with_guidance_scale, scale 3)
+def g13():
+    import src.unet_model as um
+    dim, P, B = 8, 16, 3
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(100, "cpu", residual_grad_guidance=True)
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True, device="cpu", bcs="none",
+                         domain_length=1., residual_grad_guidance=True)
+    x0 = seeded((B, 2, P, P), 91)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = seeded((B, 2, P, P), 92)
+    t = torch.tensor([2, 40, 97], dtype=torch.long)
+    mask = torch.tensor([False, True, False])
+    orig = torch.randint, torch.randn_like, um.prob_mask_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda *a, **k: eps.clone()
+    um.prob_mask_like = lambda shape, prob, device: mask.clone() if 0 < prob < 1 else orig[2](shape, prob, device)
+    try:
+        loss, data_l, res_l, _, _ = diff.model_estimation_loss(x0, residual_func=res, c_data=1.0, c_residual=1e-3, c_ineq=0., lambda_opt=0.)
+        loss.backward()
+        names, norms = [], []
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None:
+                names.append(k)
+                norms.append(p_.grad.double().norm().item())
+        # guided sampler step at t = 5 (sample=True -> forward_with_guidance_scale)
+        xs = seeded((B, 2, P, P), 93)
+        z = seeded((B, 2, P, P), 94)
+        torch.randn_like = lambda *a, **k: z.clone()
+        (x_next, x0_pred), _ = diff.p_sample(xs, None, 5, save_output=True, surpress_noise=True, residual_func=res)
+    finally:
+        torch.randint, torch.randn_like, um.prob_mask_like = orig
+    np.savez_compressed(os.path.join(OUT, "g13_guidance_dim8_p16.npz"), x0=npy(x0), eps=npy(eps), t=npy(t), mask=npy(mask),
+                        loss=np.array(loss.item()), data_loss=np.array(data_l), residual_abs_mean=np.array(res_l),
+                        grad_names=np.array(names), grad_norms=np.array(norms), xs=npy(xs), z=npy(z), x_next=npy(x_next),
+                        x0_pred_guided=npy(x0_pred))
+    print("g13 guidance: loss", loss.item(), data_l, res_l, "grads", len(names))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -372,4 +414,5 @@ if __name__ == "__main__":
     g10()
     g11()
     g12()
+    g13()
     print("golden vectors written to", OUT)

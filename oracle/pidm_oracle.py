@@ -269,9 +269,10 @@ def time_embedding(p, t, dim):
     return F.linear(h, p["time_mlp.3.weight"], p["time_mlp.3.bias"])
 
 
-def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg) -> torch.Tensor:
+def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg, cond: torch.Tensor | None = None) -> torch.Tensor:
     """x: [B,C,P,P] (NCHW) or [B,P*P,C]; t: int64 [B].  Returns [B,out_dim,P,P].
-    src/unet_model.py:542-623 (image path: no self-conditioning, no cond)."""
+    src/unet_model.py:542-623 (image path, no self-conditioning).  `cond` [B,P*P,C] (already classifier-free masked) is the
+    gradient-guidance field: x = combine_conv(cat(init_conv(x), emb_conv(cond))) (:571-587)."""
     if x.dim() == 3:
         B, N, C = x.shape
         P = int(round(math.sqrt(N)))
@@ -279,6 +280,13 @@ def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg) -> tor
     g = cfg.groups
     kinit = p["init_conv.weight"].shape[-1]
     x = F.conv2d(x, _w2d(p["init_conv.weight"]), p["init_conv.bias"], padding=kinit // 2)
+    if cond is not None:
+        B, N, C = cond.shape
+        P = int(round(math.sqrt(N)))
+        ci = cond.reshape(B, P, P, C).permute(0, 3, 1, 2)
+        e = F.conv2d(ci, p["emb_conv.0.weight"], p["emb_conv.0.bias"])
+        e = F.conv2d(F.gelu(e), p["emb_conv.2.weight"], p["emb_conv.2.bias"], padding=1)
+        x = F.conv2d(torch.cat((x, e), dim=1), p["combine_conv.weight"], p["combine_conv.bias"])
     r = x
     te = time_embedding(p, t, cfg.dim)
     n_res = len(cfg.dim_mults)
@@ -523,3 +531,36 @@ def darcy_residual_correction(x_bnc: torch.Tensor):
     out = x_bnc.detach().clone()
     out[:, :, 0] -= (1.0e-6 / mx).unsqueeze(1) * dr_dp
     return out, darcy_residual(out.permute(0, 2, 1).reshape(B, 2, P, P)), mx, dr_dp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gradient-guidance baseline (reference src/residuals_darcy.py:116-126): the model is conditioned on
+# d mean|r(x_t)| / d x_t; training drops the condition per sample (mask given explicitly here), sampling combines a
+# conditioned and an unconditioned pass with guidance scale 3.
+# ---------------------------------------------------------------------------------------------------------------------
+def darcy_guidance_field(xt_bnc: torch.Tensor) -> torch.Tensor:
+    B, N, _ = xt_bnc.shape
+    P = int(round(N ** 0.5))
+    with torch.enable_grad():
+        x = xt_bnc.detach().clone().requires_grad_(True)
+        r = darcy_residual(x.permute(0, 2, 1).reshape(B, 2, P, P))
+        return torch.autograd.grad(r.abs().mean(), x)[0]
+
+
+def darcy_guidance_training_loss(p, cfg, tables, x0, t, eps, null_mask, c_data=1.0, c_residual=1e-3):
+    """null_mask: bool [B], True = condition dropped (the reference draws it with prob 0.1)."""
+    B, _, P, _ = x0.shape
+    xt = q_sample(tables, x0, t, eps)
+    xt_bnc = xt.permute(0, 2, 3, 1).reshape(B, P * P, 2)
+    cond = darcy_guidance_field(xt_bnc)
+    cond = torch.where(null_mask.view(-1, 1, 1), torch.zeros_like(cond), cond)
+    x0_pred = unet_forward(p, xt_bnc, t, cfg, cond=cond)
+    loss, data, rabs, _ = darcy_loss_from_pred(tables, x0, x0_pred, t, c_data, c_residual)
+    return loss, data, rabs, x0_pred
+
+
+def darcy_guided_x0(p, cfg, xt_bnc, t, scale=3.0):
+    cond = darcy_guidance_field(xt_bnc)
+    a = unet_forward(p, xt_bnc, t, cfg, cond=cond)
+    b = unet_forward(p, xt_bnc, t, cfg, cond=torch.zeros_like(cond))
+    return b + (a - b) * scale

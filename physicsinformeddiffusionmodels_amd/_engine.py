@@ -47,6 +47,8 @@ class UnetEngine:
             if named[k].numel() != ne:
                 raise PidmError(f"parameter {k}: numel {named[k].numel()} != engine's {ne}")
         self.params = [named[k] for k in self.names]
+        self.n_cond = self.lib.pidm_unet_num_cond_params(self.handle)   # trailing entries: emb_conv / combine_conv
+        self.cond_enabled = False
         self.flat_grad = None
         self.grad_views = None
         self._bound_key = None
@@ -90,7 +92,7 @@ class UnetEngine:
             self._bound_key = key
 
     def _ensure_workspace(self, B: int, training: bool, device):
-        key = (B, training, str(device))
+        key = (B, training, str(device), self.cond_enabled)
         if self._ws_key != key or self.workspace is None:
             nbytes = self.lib.pidm_unet_workspace_bytes(self.handle, B, int(training))
             if nbytes == 0:
@@ -102,10 +104,16 @@ class UnetEngine:
         return self.workspace
 
     # ---- forward / backward ------------------------------------------------------------------------------
-    def forward(self, x_nhwc: torch.Tensor, t: torch.Tensor, training: bool, repack: bool = True) -> torch.Tensor:
+    def forward(self, x_nhwc: torch.Tensor, t: torch.Tensor, training: bool, repack: bool = True,
+                cond: torch.Tensor | None = None) -> torch.Tensor:
         B = x_nhwc.shape[0]
         dev = x_nhwc.device
         self._ensure_bound(training)
+        if cond is not None:
+            if not self.cond_enabled:          # size the workspace for the conditioning branch from now on
+                self.lib.check(self.lib.pidm_unet_enable_cond(self.handle, 1), "pidm_unet_enable_cond")
+                self.cond_enabled = True
+            self.lib.check(self.lib.pidm_unet_set_condition(self.handle, ptr(cond)), "pidm_unet_set_condition")
         ws = self._ensure_workspace(B, training, dev)
         P = self.image_size
         out = torch.empty(B, self.lib_out_dim, P, P, dtype=torch.float32, device=dev)
@@ -134,8 +142,9 @@ class _UnetFunction(torch.autograd.Function):
     Parameters that forward never reads keep `grad is None`, exactly like the reference."""
 
     @staticmethod
-    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool):
+    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool, cond=None):
         ctx.engine = engine
+        ctx.used_cond = cond is not None
         ctx.x_requires_grad = x_nhwc.requires_grad
         ctx.channels = x_nhwc.shape[-1]
         ctx.training = training
@@ -143,9 +152,12 @@ class _UnetFunction(torch.autograd.Function):
             engine.tape_generation += 1
             engine.tape_busy = True
         ctx.generation = engine.tape_generation
-        out = engine.forward(x_nhwc, t, training=training)
-        # the engine keeps RAW pointers to its input and output until backward: keep both tensors alive
-        ctx.save_for_backward(out, x_nhwc)
+        out = engine.forward(x_nhwc, t, training=training, cond=cond)
+        # the engine keeps RAW pointers to its inputs and output until backward: keep the tensors alive
+        if cond is not None:
+            ctx.save_for_backward(out, x_nhwc, cond)
+        else:
+            ctx.save_for_backward(out, x_nhwc)
         return out
 
     @staticmethod
@@ -159,15 +171,18 @@ class _UnetFunction(torch.autograd.Function):
                             "tape: not supported yet)")
         gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
         eng.tape_busy = False
-        for p, g in zip(eng.params, eng.grad_views):
+        n_plain = len(eng.params) - eng.n_cond
+        for i, (p, g) in enumerate(zip(eng.params, eng.grad_views)):
             if not p.requires_grad:
                 continue
+            if i >= n_plain and not ctx.used_cond:
+                continue        # conditioning branch not used by this forward: grads stay None, as in the reference
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g)
             # else: p.grad already aliases the engine buffer, which now holds this step's gradient
-        return None, gx, None, None, None
+        return None, gx, None, None, None, None
 
 
 def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0) -> UnetEngine:
@@ -181,11 +196,12 @@ def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0
     return eng
 
 
-def used_parameter_names(model, image_size: int = 64):
-    return list(get_engine(model, image_size).names)
+def used_parameter_names(model, image_size: int = 64, with_condition: bool = False):
+    eng = get_engine(model, image_size)
+    return list(eng.names) if with_condition else list(eng.names[:len(eng.names) - eng.n_cond])
 
 
-def unet_apply(model, x, time, lib: PidmLib | None = None):
+def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None):
     """x: [B,P*P,C] (reference interchange layout), [B,C,P,P] or [B,C,1,P,P]; time: int64 [B].
     Returns [B,out_dim,P,P] (or [B,out_dim,1,P,P] for 5-D input), as reference Unet3D.forward does."""
     video = False
@@ -225,7 +241,11 @@ def unet_apply(model, x, time, lib: PidmLib | None = None):
         while get_engine(model, P, lib, slot).tape_busy:
             slot += 1
         eng = get_engine(model, P, lib, slot)
-    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training)
+    if cond is not None:
+        if cond.shape != (B, P * P, model.channels):
+            raise ValueError(f'cond must be [B, P*P, {model.channels}], got {tuple(cond.shape)}')
+        cond = cond.detach().contiguous().float()
+    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training, cond)
     if video:
         out = out.unsqueeze(2)
     return out

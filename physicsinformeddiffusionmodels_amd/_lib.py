@@ -60,6 +60,9 @@ class PidmLib:
         self._sig("pidm_mech_solve_ws_bytes", [i, i], sz)
         self._sig("pidm_mech_solve", [vp, vp, vp, i, vp, vp, i, f, f, f, i, C.c_double, vp, vp, vp, vp, vp, vp, i, vp])
         self._sig("pidm_floating_material", [vp, f, i, vp, i, vp])
+        self._sig("pidm_unet_num_cond_params", [vp])
+        self._sig("pidm_unet_enable_cond", [vp, i])
+        self._sig("pidm_unet_set_condition", [vp, vp])
         self._sig("pidm_clip_adam_ws_bytes", [], sz)
         self._sig("pidm_clip_adam_step", [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                           C.c_double, vp, vp, vp])

@@ -73,6 +73,13 @@ struct pidm_unet {
   int tdim = 0, ss_total = 0, n_lv = 0, heads = 8, groups = 8;
   std::vector<int> dims;  // [init_dim, dim*m0, dim*m1, ...]
   ConvLayer init_conv, lin1, lin2, lincat, final_conv;
+  // gradient-guidance conditioning branch (src/unet_model.py:521-528,571-587): x = combine_conv(cat(init_conv(x),
+  // emb_conv(cond))).  Its 6 parameters are the LAST entries of the canonical list; they are used (and get gradients)
+  // only by a forward that was given a conditioning field (pidm_unet_set_condition).
+  ConvLayer emb1, emb2, comb;
+  int cond_first_param = -1;
+  bool cond_enabled = false;          // workspace sized for the conditioning branch
+  const float* cond_next = nullptr;   // conditioning input of the NEXT forward (consumed by it)
   std::vector<ResBlock> rb;       // order: downs (2 per level), mid1, mid2, ups (2 per level), final
   std::vector<AttnBlock> attn;    // order: downs (1 per level), mid, ups (1 per level)
   std::vector<ConvLayer> down, up;
@@ -88,6 +95,9 @@ struct pidm_unet {
   float *emb = nullptr, *h1 = nullptr, *h1g = nullptr, *temb = nullptr, *st = nullptr, *ss = nullptr, *h0 = nullptr;
   float* xfinal = nullptr;
   const float* out_nchw = nullptr;
+  bool tape_cond = false;
+  const float* cond_in = nullptr;
+  float *e1 = nullptr, *e1g = nullptr, *e2 = nullptr, *h0pre = nullptr;
   std::vector<const float*> skip;     // per level
   std::vector<const float*> down_in;  // input of each downsample
   std::vector<const float*> up_in;    // input of each upsample
@@ -290,6 +300,13 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
   make_resblock(U, U->rb[irb], "final_conv.0.", dim, dim, dim, P, false); irb++;
   U->final_conv.C0 = dim; U->final_conv.Cout = cfg->out_dim; U->final_conv.K = 1; U->final_conv.H = P;
   conv_param(U, U->final_conv, "final_conv.1", true);
+  U->cond_first_param = (int)U->names.size();
+  U->emb1.C0 = cfg->channels; U->emb1.Cout = dim; U->emb1.K = 1; U->emb1.H = P; U->emb1.dgrad = false;
+  conv_param(U, U->emb1, "emb_conv.0", true);
+  U->emb2.C0 = dim; U->emb2.Cout = dim; U->emb2.K = 3; U->emb2.pad = 1; U->emb2.H = P;
+  conv_param(U, U->emb2, "emb_conv.2", true);
+  U->comb.C0 = dim; U->comb.C1 = dim; U->comb.Cout = dim; U->comb.K = 1; U->comb.H = P;
+  conv_param(U, U->comb, "combine_conv", true);
 
   // ---- packed-weight region ----
   int rc = 0;
@@ -311,6 +328,9 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
     rc |= reserve_packed(U, U->up[i]);
   }
   rc |= reserve_packed(U, U->final_conv);
+  rc |= reserve_packed(U, U->emb1);
+  rc |= reserve_packed(U, U->emb2);
+  rc |= reserve_packed(U, U->comb);
   if (rc) {
     delete U;
     return -1;
@@ -423,6 +443,9 @@ static int pack_all(Run& r) {
     rc |= pack_layer(r, U->up[i]);
   }
   rc |= pack_layer(r, U->final_conv);
+  rc |= pack_layer(r, U->emb1);
+  rc |= pack_layer(r, U->emb2);
+  rc |= pack_layer(r, U->comb);
   if (rc) return rc;
   if (U->pack_table.size() > kMaxPackDesc) return fail("pack: descriptor table overflow");
   if (hipMemcpyAsync(table_dev, U->pack_table.data(), U->pack_table.size() * sizeof(PackDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
@@ -502,7 +525,7 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   return 0;
 }
 
-static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* out_nchw) {
+static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* out_nchw, const float* cond_nhwc) {
   pidm_unet* U = r.U;
   const int B = r.B, P = U->cfg.image_size, dim = U->cfg.dim, n = U->n_lv, td = U->tdim;
   U->tape_B = B;
@@ -524,6 +547,23 @@ static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* ou
 
   U->h0 = act_alloc(r, (size_t)B * P * P * dim);
   if (conv_fwd(r, U->init_conv, x_nhwc, nullptr, nullptr, U->h0)) return -1;
+  U->tape_cond = cond_nhwc != nullptr;
+  if (cond_nhwc) {
+    // x = combine_conv(cat(x, emb_conv(cond)));  emb_conv = 1x1 conv, GELU, 3x3 conv.  The concatenation is never
+    // materialised (two-source conv); everything downstream (first block AND the final skip) sees the combined field.
+    const size_t nh = (size_t)B * P * P * dim;
+    U->cond_in = cond_nhwc;
+    U->h0pre = U->h0;
+    U->e1 = act_alloc(r, nh);
+    if (conv_fwd(r, U->emb1, cond_nhwc, nullptr, nullptr, U->e1)) return -1;
+    U->e1g = act_alloc(r, nh);
+    RUN(launch_act_fwd(U->e1, U->e1g, nh, 1, r.st));
+    U->e2 = act_alloc(r, nh);
+    if (conv_fwd(r, U->emb2, U->e1g, nullptr, nullptr, U->e2)) return -1;
+    float* hc = act_alloc(r, nh);
+    if (conv_fwd(r, U->comb, U->h0pre, U->e2, nullptr, hc)) return -1;
+    U->h0 = hc;
+  }
   float* x = U->h0;
   int irb = 0, iat = 0;
   for (int i = 0; i < n; ++i) {
@@ -765,6 +805,28 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   // h0 feeds both the first resblock and the final concat
   float* g_h0 = r.tmp.alloc((size_t)B * HW * dim);
   RUN(launch_copy_add(g_h0, dim, g_x, dim, g_r, dim, (size_t)B * HW, dim, r.st));
+  if (U->tape_cond) {
+    const size_t nh = (size_t)B * HW * dim;
+    if (conv_wgrad(r, U->comb, U->h0pre, U->e2, g_h0)) return -1;
+    float* g_cc = r.tmp.alloc(2 * nh);
+    if (conv_dgrad(r, U->comb, g_h0, nullptr, g_cc)) return -1;
+    float* g_h0p = r.tmp.alloc(nh);
+    float* g_e2 = r.tmp.alloc(nh);
+    RUN(launch_copy_add(g_h0p, dim, g_cc, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
+    RUN(launch_copy_add(g_e2, dim, g_cc + dim, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
+    if (conv_wgrad(r, U->emb2, U->e1g, nullptr, g_e2)) return -1;
+    float* g_e1g = r.tmp.alloc(nh);
+    if (conv_dgrad(r, U->emb2, g_e2, nullptr, g_e1g)) return -1;
+    float* g_e1 = r.tmp.alloc(nh);
+    RUN(launch_act_bwd(U->e1, g_e1g, g_e1, nh, 1, r.st));
+    if (conv_wgrad(r, U->emb1, U->cond_in, nullptr, g_e1)) return -1;
+    g_h0 = g_h0p;
+  } else if (!r.dry && U->have_grads) {
+    // the conditioning parameters were not used by this forward: their slots of the (flat) gradient buffer must not keep
+    // an earlier step's values (the wrapper leaves p.grad = None for them, as the reference does)
+    for (size_t i = (size_t)U->cond_first_param; i < U->names.size(); ++i)
+      if (hipMemsetAsync(U->G[i], 0, U->numels[i] * sizeof(float), r.st) != hipSuccess) return fail("backward: memset failed");
+  }
   if (conv_wgrad(r, U->init_conv, U->x_in, nullptr, g_h0)) return -1;
   if (grad_x_nhwc) {
     if (conv_dgrad(r, U->init_conv, g_h0, nullptr, grad_x_nhwc)) return -1;
@@ -820,7 +882,7 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   pidm_unet saved_ptrs = *U;
   r.scratch_floats = scratch_floats_needed(U, B);
   r.scratch = r.tmp.alloc(r.scratch_floats);
-  int rc = forward_impl(r, nullptr, nullptr, nullptr);
+  int rc = forward_impl(r, nullptr, nullptr, nullptr, U->cond_enabled ? reinterpret_cast<const float*>(16) : nullptr);
   if (!rc && training) {
     r.tmp.release(align_up(r.scratch_floats * sizeof(float), 256));
     rc = backward_impl(r, nullptr, reinterpret_cast<float*>(16));
@@ -881,7 +943,10 @@ extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_
   if (repack_weights || h->packed_zeroed_for != r.wpack || !h->pack_table_valid) {
     if (pack_all(r)) return -1;
   }
-  if (forward_impl(r, x_nhwc, t, out_nchw)) return -1;
+  const float* cond = h->cond_next;
+  h->cond_next = nullptr;
+  if (cond && !h->cond_enabled) return fail("unet_forward: conditioning input given but pidm_unet_enable_cond was not called");
+  if (forward_impl(r, x_nhwc, t, out_nchw, cond)) return -1;
   if (r.tape.overflow() || r.tmp.overflow()) return fail("unet_forward: internal arena overflow");
   return 0;
 }
@@ -895,5 +960,25 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   if (setup_run(r, h, B, true, workspace, workspace_bytes, stream)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
+  return 0;
+}
+
+extern "C" int pidm_unet_num_cond_params(const pidm_unet* h) { return h ? (int)h->names.size() - h->cond_first_param : 0; }
+
+extern "C" int pidm_unet_enable_cond(pidm_unet* h, int on) {
+  if (!h) return fail("unet_enable_cond: null handle");
+  const bool v = on != 0;
+  if (v != h->cond_enabled) {
+    h->cond_enabled = v;
+    h->ws_cache[0].clear();
+    h->ws_cache[1].clear();
+    h->defer_cache.clear();
+  }
+  return 0;
+}
+
+extern "C" int pidm_unet_set_condition(pidm_unet* h, const float* cond_nhwc) {
+  if (!h) return fail("unet_set_condition: null handle");
+  h->cond_next = cond_nhwc;
   return 0;
 }

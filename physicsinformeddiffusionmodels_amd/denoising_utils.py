@@ -274,7 +274,8 @@ class DenoisingDiffusion(nn.Module):
 
     # ---- training loss (src/denoising_utils.py:616-710) ---------------------------------------------------------
     def _darcy_fast_path_ok(self, residual_func, c_ineq, lambda_opt, x):
-        return (isinstance(residual_func, ResidualsDarcy) and not residual_func.use_ddim_x0 and c_ineq <= 0.
+        return (isinstance(residual_func, ResidualsDarcy) and not residual_func.use_ddim_x0
+                and not residual_func.residual_grad_guidance and c_ineq <= 0.
                 and lambda_opt <= 0. and x.dtype == torch.float32 and (x.is_cuda or self._lib is not None))
 
     def model_estimation_loss(self, input, residual_func=None, c_data=1., c_residual=0., c_ineq=0., lambda_opt=0.):

@@ -83,7 +83,10 @@ class FusedClipAdam:
         eng = self.eng
         if eng.flat_grad is None:
             raise PidmError("FusedClipAdam.step(): no gradient yet (run a training forward + backward first)")
-        for p, g in zip(eng.params, eng.grad_views):
+        n_plain = len(eng.params) - eng.n_cond
+        for i, (p, g) in enumerate(zip(eng.params, eng.grad_views)):
+            if i >= n_plain and p.grad is None:
+                continue    # conditioning branch unused this step: the engine zero-filled its gradient slots
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 raise PidmError("FusedClipAdam.step(): p.grad does not alias the engine's flat gradient buffer "
                                 "(gradients were re-assigned or only partially computed)")

@@ -48,8 +48,6 @@ class ResidualsDarcy:
             raise NotImplementedError('the gfx950 stencil kernel implements fd_acc=2 (model.yaml:13)')
         if bcs == 'periodic':
             raise NotImplementedError("periodic stencils are not on the accelerated path (reference default bcs='none')")
-        if residual_grad_guidance:
-            raise NotImplementedError('residual gradient guidance is SURVEY 8(f) rank 3 (off by default, model.yaml:8)')
         self.gov_eqs = 'darcy'
         self.model = model
         self.pixels_at_boundary = pixels_at_boundary
@@ -122,7 +120,19 @@ class ResidualsDarcy:
             assert len(input[0]) == 2 and isinstance(input[0], tuple), \
                 'Input[0] must be a tuple consisting of noisy signal and time.'
             noisy_in, time = input[0]
-            if self.use_ddim_x0:
+            if self.residual_grad_guidance:
+                # gradient-guidance baseline (src/residuals_darcy.py:116-126): condition the model on d mean|r(x_t)| / d x_t
+                assert not self.use_ddim_x0, 'Residual gradient guidance is not implemented with sample estimation for residual.'
+                with torch.enable_grad():
+                    xin = noisy_in.detach().clone().requires_grad_(True)
+                    residual_noisy_in = self.residual_of(generalized_b_xy_c_to_image(xin))
+                    dr_dx = torch.autograd.grad(residual_noisy_in.abs().mean(), xin)[0]
+                if sample:
+                    x0_pred = self.model.forward_with_guidance_scale(noisy_in, time, cond=dr_dx, guidance_scale=3.)
+                else:
+                    x0_pred = self.model(noisy_in, time, cond=dr_dx, null_cond_prob=0.1)
+                model_out = x0_pred
+            elif self.use_ddim_x0:
                 x0_pred, model_out = ddim_func(noisy_in, time, self.model, noisy_in.shape, self.ddim_steps, 0.)
             else:
                 x0_pred = self.model(noisy_in, time)

@@ -15,6 +15,15 @@ import torch
 from torch import nn
 
 
+def prob_mask_like(shape, prob, device):
+    """Classifier-free dropout mask, True = drop (src/unet_model.py:63-69; same RNG consumption)."""
+    if prob == 1:
+        return torch.ones(shape, device=device, dtype=torch.bool)
+    elif prob == 0:
+        return torch.zeros(shape, device=device, dtype=torch.bool)
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
 def exists(x):
     return x is not None
 
@@ -265,13 +274,21 @@ class Unet3D(nn.Module):
         return used_parameter_names(self)
 
     def forward(self, x, time, x_self_cond=None, cond=None, null_cond_prob=0.):
-        if cond is not None or x_self_cond is not None:
-            raise NotImplementedError('gradient-guidance / self-conditioning branch is not on the accelerated '
-                                      'path (SURVEY 8(f) rank 3)')
+        """`cond` [B, P*P, C] = the residual-gradient conditioning field of the guidance baseline
+        (src/unet_model.py:571-587): per-sample classifier-free dropout with probability `null_cond_prob` (same RNG call
+        as the reference's prob_mask_like), then emb_conv / combine_conv inside the engine."""
+        if x_self_cond is not None or self.self_condition:
+            raise NotImplementedError('self-conditioning is not on the accelerated path (self_condition=False in main.py)')
         from ._engine import unet_apply
-        return unet_apply(self, x, time, lib=self._pidm_lib)
+        if cond is not None:
+            if cond.dim() != 3:
+                raise ValueError('Input must be [BxP*PxC].')
+            mask = prob_mask_like((cond.shape[0],), null_cond_prob, device=cond.device)
+            cond = torch.where(mask.view(-1, 1, 1), torch.zeros_like(cond), cond)
+        return unet_apply(self, x, time, lib=self._pidm_lib, cond=cond)
 
     def forward_with_guidance_scale(self, *args, **kwargs):
+        """null + (cond - null) * scale from two forward passes (src/unet_model.py:530-540)."""
         guidance_scale = kwargs.pop('guidance_scale', 3.)
         logits = self.forward(*args, null_cond_prob=0., **kwargs)
         if guidance_scale == 1:

@@ -1523,22 +1523,28 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   return 0;
 }
 
-size_t colsum_ws_bytes(size_t rows, int C) {
-  size_t nblk = rows / 256;
+static size_t colsum_blocks(size_t rows) {
+  size_t nblk = rows / 64;          // >= 64 rows (16 per thread row-lane) per block, at most 1024 blocks
   if (nblk < 1) nblk = 1;
-  if (nblk > 256) nblk = 256;
-  return nblk * (size_t)C * sizeof(float);
+  if (nblk > 1024) nblk = 1024;
+  return nblk;
 }
 
-int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st) {
-  size_t nblk = rows / 256;
-  if (nblk < 1) nblk = 1;
-  if (nblk > 256) nblk = 256;
+size_t colsum_ws_bytes(size_t rows, int C) { return colsum_blocks(rows) * (size_t)C * sizeof(float); }
+
+// `defer` != null: only the per-block partial sums are produced here (into `workspace`, which the caller keeps alive); the
+// fixed-order sum over blocks joins the caller's single reduce_multi launch.
+int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st, ReduceQueue* defer) {
+  size_t nblk = colsum_blocks(rows);
   const size_t rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk, cdiv(C, 64)), dim3(256), 0, st, x, rows, C, ld, rpb, partial);
   PIDM_CHECK_LAUNCH("colsum_partial_kernel");
+  if (defer) {
+    defer->push(partial, out, nullptr, nullptr, (size_t)C, (int)nblk, 1, C, 1, 1, C);
+    return 0;
+  }
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, (int)nblk, C, out);
   PIDM_CHECK_LAUNCH("colsum_final_kernel");
   return 0;

@@ -39,7 +39,8 @@ size_t wgrad_ws_bytes(const ConvGeom& g);
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
                  float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer = nullptr);
 size_t colsum_ws_bytes(size_t rows, int C);
-int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st);
+int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st,
+                  ReduceQueue* defer = nullptr);
 // k_norm.hip
 size_t gn_ws_bytes(int B, int HW, int C, int G);
 int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st);

@@ -80,6 +80,7 @@ struct pidm_unet {
   int cond_first_param = -1;
   bool cond_enabled = false;          // workspace sized for the conditioning branch
   const float* cond_next = nullptr;   // conditioning input of the NEXT forward (consumed by it)
+  bool cond_grads_dirty = true;       // the conditioning gradient slots may hold non-zero values
   std::vector<ResBlock> rb;       // order: downs (2 per level), mid1, mid2, ups (2 per level), final
   std::vector<AttnBlock> attn;    // order: downs (1 per level), mid, ups (1 per level)
   std::vector<ConvLayer> down, up;
@@ -361,6 +362,7 @@ extern "C" int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, 
     h->G[i] = grad_ptrs_host ? reinterpret_cast<float*>(grad_ptrs_host[i]) : nullptr;
   }
   h->have_grads = grad_ptrs_host != nullptr;
+  h->cond_grads_dirty = true;    // new gradient buffers: contents unknown
   h->pack_table_valid = false;   // parameter pointers may have changed
   if (h->have_grads) {
     // the FiLM linear gradients must be contiguous (see pidm_unet_create)
@@ -613,7 +615,10 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
     if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
     RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, r.st, r.q()));
-    if (L.b >= 0) RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], r.scratch, r.st));
+    if (L.b >= 0) {
+      float* cpart = r.part_alloc(colsum_ws_bytes((size_t)r.B * Ho * Ho, L.Cout));
+      RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], cpart, r.st, r.q()));
+    }
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
@@ -821,11 +826,14 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     RUN(launch_act_bwd(U->e1, g_e1g, g_e1, nh, 1, r.st));
     if (conv_wgrad(r, U->emb1, U->cond_in, nullptr, g_e1)) return -1;
     g_h0 = g_h0p;
-  } else if (!r.dry && U->have_grads) {
+    if (!r.dry) U->cond_grads_dirty = true;
+  } else if (!r.dry && U->have_grads && U->cond_grads_dirty) {
     // the conditioning parameters were not used by this forward: their slots of the (flat) gradient buffer must not keep
-    // an earlier step's values (the wrapper leaves p.grad = None for them, as the reference does)
+    // an earlier step's values (the wrapper leaves p.grad = None for them, as the reference does).  Freshly bound
+    // buffers count as dirty; after one zero-fill nothing needs to be done until the branch is used again.
     for (size_t i = (size_t)U->cond_first_param; i < U->names.size(); ++i)
       if (hipMemsetAsync(U->G[i], 0, U->numels[i] * sizeof(float), r.st) != hipSuccess) return fail("backward: memset failed");
+    U->cond_grads_dirty = false;
   }
   if (conv_wgrad(r, U->init_conv, U->x_in, nullptr, g_h0)) return -1;
   if (grad_x_nhwc) {

@@ -398,9 +398,29 @@ def g13():
     print("g13 guidance: loss", loss.item(), data_l, res_l, "grads", len(names))
 
 
+# G14: ddim_sample_x0 with ddim_steps in {0, 2}: outputs and RNG consumption (the value of the next torch.rand draw)
+def g14():
+    dim, P, B = 8, 16, 2
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(100, "cpu")
+    xt = seeded((B, P * P, 2), 95)
+    t = torch.tensor([37, 80], dtype=torch.long)
+    out = {}
+    for k in (0, 2):
+        torch.manual_seed(4321)
+        with torch.no_grad():
+            x0_pred, model_out = diff.ddim_sample_x0(xt, t, m, (B, 2, P, P), k, 0.)
+        out[f"x0_pred_k{k}"] = npy(x0_pred)
+        out[f"model_out_k{k}"] = npy(model_out)
+        out[f"next_rand_k{k}"] = npy(torch.rand(4))
+    np.savez_compressed(os.path.join(OUT, "g14_ddim_x0.npz"), xt=npy(xt), t=npy(t), **out)
+    print("g14 ddim: |x0_pred_k0 - x0_pred_k2| max", float(np.abs(out["x0_pred_k0"] - out["x0_pred_k2"]).max()), out["next_rand_k0"], out["next_rand_k2"])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -415,4 +435,5 @@ if __name__ == "__main__":
     g11()
     g12()
     g13()
+    g14()
     print("golden vectors written to", OUT)

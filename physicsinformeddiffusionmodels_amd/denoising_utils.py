@@ -454,11 +454,14 @@ class DenoisingDiffusion(nn.Module):
         return x_seq, interm_imgs
 
     def ddim_sample_x0(self, xt, t, model, shape, reduced_n_steps, ddim_sampling_eta, gov_eqs=None, self_cond=None):
-        """Sample estimation with ddim_steps = 0 (the manuscript's setting, model.yaml:7): the reference evaluates
-        the model at (x_t, t) and again at (x_t, 0) - its loop never updates `model_input`
-        (src/denoising_utils.py:741-753) - and returns (second output, first output)."""
-        if reduced_n_steps != 0:
-            raise NotImplementedError('ddim_steps > 0 is not on the accelerated path (model.yaml: ddim_steps 0)')
+        """Sample estimation (src/denoising_utils.py:712-788).  The reference walks ddim_steps + 2 time levels from t down to 0
+        but never updates `model_input`: every model call sees the same x_t, the value it returns is
+        the LAST call's output (at time 0) and `model_out` is the FIRST call's (at time t); the intermediate calls only
+        feed a `cur_x` that the final assignment overwrites.  So for any ddim_steps the result is two UNet evaluations;
+        the ddim_steps + 1 noise tensors the reference draws along the way are drawn here too (and discarded), so a seeded
+        run consumes the RNG identically."""
+        if reduced_n_steps < 0:
+            raise ValueError('ddim_steps must be >= 0')
         batch = shape[0]
         if len(t) == 1:
             t = torch.ones(batch, device=xt.device, dtype=torch.long) * t
@@ -468,4 +471,11 @@ class DenoisingDiffusion(nn.Module):
             x0_pred = model(xt, torch.zeros_like(t))
         finally:
             model._pidm_multi_tape = False
+        # RNG parity with :775: the same randn_like call on a tensor of the same shape AND strides as the reference's cur_x
+        # (a permuted view of x_t - the CPU generator consumes differently for non-contiguous outputs); sigma is 0 for
+        # eta = 0, so the values never matter
+        xt_img = generalized_b_xy_c_to_image(xt) if xt.dim() == 3 else xt
+        cur_x = xt_img[:, :3] if gov_eqs == 'mechanics' else xt_img
+        for _ in range(reduced_n_steps + 1):
+            torch.randn_like(cur_x)
         return x0_pred, model_out

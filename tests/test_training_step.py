@@ -219,3 +219,21 @@ def test_multi_step_training_trajectory_vs_oracle(backend):
         # Adam normalises every element's update to ~lr whatever the gradient magnitude, so fp32 differences in tiny gradient
         # entries show up as a small fraction of the total travel lr * n_it (= 8e-3 here)
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-3) + 0.03 * 2e-3 * n_it, k
+
+
+@pytest.mark.parametrize("k", [0, 2])
+def test_ddim_sample_x0_outputs_and_rng_consumption(backend, k):
+    """Golden g14 (genuine reference): for any ddim_steps the result equals two UNet calls (at t and at 0), and the
+    ddim_steps + 1 noise draws of the reference loop are consumed (checked on the CPU generator through the next draw)."""
+    L, dev = backend
+    g = np.load(os.path.join(G, "g14_ddim_x0.npz"))
+    m, diff, res, _ = setup(backend, 8, 16, 100)
+    xt = torch.from_numpy(g["xt"]).to(dev)
+    t = torch.from_numpy(g["t"]).to(dev)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        x0_pred, model_out = diff.ddim_sample_x0(xt, t, m, (2, 2, 16, 16), k, 0.)
+    for mine, ref in ((x0_pred, g[f"x0_pred_k{k}"]), (model_out, g[f"model_out_k{k}"])):
+        assert (mine.cpu() - torch.from_numpy(ref)).abs().max().item() < 3e-5 * np.abs(ref).max()
+    if dev.type == "cpu":
+        np.testing.assert_array_equal(torch.rand(4).numpy(), g[f"next_rand_k{k}"])

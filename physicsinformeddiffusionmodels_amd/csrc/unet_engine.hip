@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "pidm_launch.h"
 
 namespace pidm {
@@ -81,6 +83,11 @@ struct pidm_unet {
   bool cond_enabled = false;          // workspace sized for the conditioning branch
   const float* cond_next = nullptr;   // conditioning input of the NEXT forward (consumed by it)
   bool cond_grads_dirty = true;       // the conditioning gradient slots may hold non-zero values
+  // backward overlap: weight-gradient kernels (nothing inside backward depends on them before the final reduction) run on
+  // a side stream while the input-gradient chain continues on the caller's stream; fork/join through two events
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_ok = false;
   std::vector<ResBlock> rb;       // order: downs (2 per level), mid1, mid2, ups (2 per level), final
   std::vector<AttnBlock> attn;    // order: downs (1 per level), mid, ups (1 per level)
   std::vector<ConvLayer> down, up;
@@ -127,6 +134,8 @@ struct Run {
   Arena defer;
   ReduceQueue rq;
   bool defer_on = false;
+  bool overlap = false;        // weight gradients on the side stream (real backward runs only)
+  bool side_pending = false;   // side-stream work issued since the last join
   float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
   ReduceQueue* q() { return defer_on ? &rq : nullptr; }
 };
@@ -345,7 +354,15 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
   return 0;
 }
 
-extern "C" void pidm_unet_destroy(pidm_unet* h) { delete h; }
+extern "C" void pidm_unet_destroy(pidm_unet* h) {
+  if (!h) return;
+  if (h->side_ok) {
+    (void)hipStreamDestroy(h->side);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+  }
+  delete h;
+}
 extern "C" int pidm_unet_num_params(const pidm_unet* h) { return (int)h->names.size(); }
 extern "C" const char* pidm_unet_param_name(const pidm_unet* h, int i) {
   return (i >= 0 && i < (int)h->names.size()) ? h->names[i].c_str() : "";
@@ -606,23 +623,46 @@ static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* ou
 // ------------------------------------------------------------------------------------------------------
 // backward building blocks
 // ------------------------------------------------------------------------------------------------------
+// side stream waits for everything issued so far on the caller's stream (the operands of the next weight-gradient kernel)
+static hipStream_t fork_side(Run& r) {
+  if (!r.overlap) return r.st;
+  pidm_unet* U = r.U;
+  if (hipEventRecord(U->ev_fork, r.st) != hipSuccess || hipStreamWaitEvent(U->side, U->ev_fork, 0) != hipSuccess) {
+    r.overlap = false;   // degrade to in-order execution
+    return r.st;
+  }
+  r.side_pending = true;
+  return U->side;
+}
+// caller's stream waits for the side stream: required before anything consumes the weight-gradient partials (the deferred
+// reduction) - and it orders all later work on the caller's stream after the side stream's reads
+static int join_side(Run& r) {
+  if (!r.side_pending) return 0;
+  pidm_unet* U = r.U;
+  if (hipEventRecord(U->ev_join, U->side) != hipSuccess || hipStreamWaitEvent(r.st, U->ev_join, 0) != hipSuccess)
+    return fail("backward: stream join failed");
+  r.side_pending = false;
+  return 0;
+}
+
 static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* dy) {
   pidm_unet* U = r.U;
   if (!U->have_grads && !r.dry) return 0;
   ConvGeom g;
   const int Ho = out_h(L);
+  const hipStream_t wst = r.dry ? r.st : fork_side(r);
   if (L.transposed) {
     if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
-    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, r.st, r.q()));
+    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, wst, r.q()));
     if (L.b >= 0) {
       float* cpart = r.part_alloc(colsum_ws_bytes((size_t)r.B * Ho * Ho, L.Cout));
-      RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], cpart, r.st, r.q()));
+      RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], cpart, wst, r.q()));
     }
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
-    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, r.st, r.q()));
+    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q()));
   }
   return 0;
 }
@@ -650,7 +690,8 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   if (conv_wgrad(r, m.c2, m.bact, nullptr, g_c)) return -1;
   float* g_b = r.tmp.alloc(n);
   if (conv_dgrad(r, m.c2, g_c, nullptr, g_b)) return -1;
-  float* g_a = g_c;  // g_c is dead after the two uses above
+  // g_c is dead on THIS stream after the two uses above, but the side-stream wgrad of c2 may still be reading it
+  float* g_a = r.overlap || r.dry ? r.tmp.alloc(n) : g_c;
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
   RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
@@ -663,7 +704,9 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   } else {
     if (conv_dgrad(r, m.c1, g_a, g_out, g_x)) return -1;
   }
-  r.tmp.release(mk);
+  // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
+  // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
+  if (!(r.overlap || r.dry)) r.tmp.release(mk);
   return 0;
 }
 
@@ -690,7 +733,9 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
   float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
   RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
-  r.tmp.release(mk);
+  // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
+  // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
+  if (!(r.overlap || r.dry)) r.tmp.release(mk);
   return 0;
 }
 
@@ -859,6 +904,7 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (conv_wgrad(r, U->lin1, U->emb, nullptr, d_h1)) return -1;
   }
   // ---- every queued fixed-order reduction (weight/bias/norm-parameter gradients) in one launch ----
+  if (join_side(r)) return -1;
   if (!r.dry && !r.rq.v.empty()) {
     if (r.rq.v.size() > kMaxReduceDesc) return fail("backward: reduction table overflow (%zu)", r.rq.v.size());
     const bool same = U->red_table_dev == red_dev && U->red_table.size() == r.rq.v.size() &&
@@ -966,6 +1012,18 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   if (!h->have_grads) return fail("unet_backward: gradient buffers not bound");
   Run r;
   if (setup_run(r, h, B, true, workspace, workspace_bytes, stream)) return -1;
+  if (!h->side_ok && !h->side) {
+    // created once per handle; PIDM_NO_OVERLAP=1 keeps the whole backward on the caller's stream (A/B measurements)
+    const char* e = getenv("PIDM_NO_OVERLAP");
+    if (!(e && atoi(e))) {
+      h->side_ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+    } else {
+      h->side = reinterpret_cast<hipStream_t>(1);   // marks "decided: off"
+    }
+  }
+  r.overlap = h->side_ok;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
   return 0;

@@ -202,6 +202,9 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
             "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 MFMA implicit GEMM: fwd, dgrad, wgrad)",
+            "timing": "HIP events per launch in extra steps after the timed region; the library keeps the weight-gradient "
+                      "side-stream overlap OFF while these hooks are on (a kernel that shares the chip has no duration of its own); "
+                      "`value` is measured with the overlap on",
             "launches_per_step": conv_n // nprof, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "kernel_ms_per_step": round(conv_ms / nprof, 3),
             "fwd_dgrad": {"ms_per_step": round(ms[0] / nprof, 3), "tflops": round(work[0] / max(ms[0], 1e-9) / 1e9, 2)},

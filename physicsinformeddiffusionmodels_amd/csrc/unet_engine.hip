@@ -1023,7 +1023,9 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
       h->side = reinterpret_cast<hipStream_t>(1);   // marks "decided: off"
     }
   }
-  r.overlap = h->side_ok;
+  // per-kernel HIP-event timing (bench.py's roofline leg) needs kernels that own the chip: concurrent kernels share it and
+  // their individual durations stop being a property of the kernel - the overlap is off while the profiler hooks are on
+  r.overlap = h->side_ok && !prof_enabled();
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
   return 0;

@@ -16,8 +16,16 @@
 //
 // Backward: dgrad runs the SAME kernel on a flipped/transposed weight packing; wgrad is its own kernel
 // (M = Cout, N = Cin, K = pixels) with a deterministic split-K over pixel tiles.
-#include <stdlib.h>
-
+//
+// Kernels in this file:
+//   conv_igemm_kernel<KC,NT>                       generic forward/dgrad (ragged channels, 7x7, tap groups, scalar staging)
+//   conv_igemm_pipe_kernel<KC,NT,..,PHASED,PERSIST,MT>   software-pipelined forward/dgrad (the hot one) and its variants:
+//        PHASED  4x4/s2 as 4 K-phases of 2x2 taps;  NT=4 permuted 128-channel tile (1x1);  KC=32 chunks (1x1);
+//        PERSIST several m-tiles per workgroup in one pipeline;  MT=2 256-pixel tile (two m-tiles per wave)
+//   pack_kernel / pack_multi_kernel                reference weight layouts -> [Cout_p][tap][K_p] (all tensors in one launch)
+//   conv_wgrad_kernel<MAXT>, conv_wgrad_smallc_kernel, conv_wgrad_pipe_kernel<KH,KW,PHASED,WIDE,MINW>   weight gradients
+//   wgrad_reduce_kernel / reduce_multi_kernel      fixed-order split-K sums (immediate / all deferred sums of a backward)
+//   colsum_partial_kernel / colsum_final_kernel    bias gradients of transposed convs, LayerNorm gamma
 #include <stdio.h>
 #include <stdlib.h>
 

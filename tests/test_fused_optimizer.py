@@ -62,7 +62,7 @@ def test_fused_optimizer_training_steps_match_torch(backend):
         assert torch.equal(v_, sd0[k]), k
     opt_b = FusedClipAdam(mb, lr=1e-3, max_norm=1.0, image_size=P, lib=lib)
     g = torch.Generator().manual_seed(0)
-    for it in range(3):
+    for it in range(2 if dev.type == "cpu" else 3):
         x0 = torch.randn(B, 2, P, P, generator=g)
         x0[:, 1] = torch.exp(0.3 * x0[:, 1])
         x0 = x0.to(dev)
@@ -97,7 +97,7 @@ def test_fused_optimizer_training_steps_match_torch(backend):
     sd = copy.deepcopy(opt_b.state_dict())
     opt_c = FusedClipAdam(mb, lr=1e-3, max_norm=1.0, image_size=P, lib=lib)
     opt_c.load_state_dict(sd)
-    assert opt_c.step_count == 3 and torch.equal(opt_c.exp_avg, opt_b.exp_avg)
+    assert opt_c.step_count == opt_b.step_count and torch.equal(opt_c.exp_avg, opt_b.exp_avg)
 
 
 def test_full_state_resume_is_bit_exact(backend, tmp_path):
@@ -128,18 +128,19 @@ def test_full_state_resume_is_bit_exact(backend, tmp_path):
     x0 = x0.to(dev)
     torch.manual_seed(77)
     a = make()
-    run(*a, 2, x0)
+    n1 = 1 if dev.type == "cpu" else 2          # the host emulator is slow: one step per phase is enough to catch a lost state
+    run(*a, n1, x0)
     ck = str(tmp_path / "state.pt")
     save_training_state(ck, a[0], a[3], a[4], iteration=2, extra={"note": "x"})
-    run(*a, 2, x0)
+    run(*a, n1, x0)
     b = make()
     torch.manual_seed(12345)                       # a different RNG position: must be overwritten by the checkpoint
     it, extra = load_training_state(ck, b[0], b[3], b[4])
     assert it == 2 and extra == {"note": "x"}
-    run(*b, 2, x0)
+    run(*b, n1, x0)
     for (k, pa), (_, pb) in zip(a[0].named_parameters(), b[0].named_parameters()):
         assert torch.equal(pa, pb), k
-    assert a[3].step_count == b[3].step_count == 4 and torch.equal(a[3].exp_avg, b[3].exp_avg)
+    assert a[3].step_count == b[3].step_count == 2 * n1 and torch.equal(a[3].exp_avg, b[3].exp_avg)
     for k in a[4].shadow:
         assert torch.equal(a[4].shadow[k], b[4].shadow[k]), k
     # the same file is a valid reference-style checkpoint for load_model

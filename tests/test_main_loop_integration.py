@@ -16,7 +16,7 @@ def test_training_ema_checkpoint_sampling_loop(backend, tmp_path):
     L, dev = backend
     lib = L if dev.type == "cpu" else None
     dim, P = 8, 16
-    n_it, n_steps = (4, 5) if dev.type == "cpu" else (40, 20)    # the host emulator is ~1000x slower than the GPU
+    n_it, n_steps = (3, 4) if dev.type == "cpu" else (40, 20)    # the host emulator is ~1000x slower than the GPU
     torch.manual_seed(0)
     model = Unet3D(dim=dim, channels=2).to(dev)
     model._pidm_lib = lib

@@ -187,7 +187,8 @@ def test_multi_step_training_trajectory_vs_oracle(backend):
     from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
     L, dev = backend
     lib = L if dev.type == "cpu" else None
-    dim, P, B, n_it = 8, 16, 2, 4
+    dim, P, B = 8, 16, 2
+    n_it = 3 if dev.type == "cpu" else 5
     m, diff, res, _ = setup(backend, dim, P, 100)
     opt = FusedClipAdam(m, lr=2e-3, max_norm=1.0, image_size=P, lib=lib)
     # oracle side: plain tensors + torch optimizer

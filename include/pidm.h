@@ -135,6 +135,7 @@ typedef struct pidm_unet_cfg {
   int init_kernel;    /* 7 */
   int image_size;     /* P (square images) */
   int sigmoid_last_channel;
+  int self_condition; /* 1: init_conv reads 2*channels inputs, cat(x_self_cond, x) (src/unet_model.py:428,564-566) */
 } pidm_unet_cfg;
 
 int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out);

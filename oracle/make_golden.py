@@ -418,9 +418,32 @@ def g14():
     print("g14 ddim: |x0_pred_k0 - x0_pred_k2| max", float(np.abs(out["x0_pred_k0"] - out["x0_pred_k2"]).max()), out["next_rand_k0"], out["next_rand_k2"])
 
 
+# G15: self-conditioning (Unet3D(self_condition=True)): forward with and without x_self_cond, gradient norms
+def g15():
+    dim, P, B = 8, 16, 2
+    m = Unet3D(dim=dim, channels=2, self_condition=True)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    x = seeded((B, 2, P, P), 96)
+    sc = seeded((B, 2, P, P), 97)
+    t = torch.tensor([9, 66], dtype=torch.long)
+    out_sc = m(x, t, x_self_cond=sc.unsqueeze(2))   # the reference concatenates after lifting x to [B,C,1,P,P] (:556-566)
+    out_none = m(x, t)
+    w = seeded(tuple(out_sc.shape), 98)
+    (out_sc * w).sum().backward()
+    names, norms = [], []
+    for k, p_ in m.named_parameters():
+        if p_.grad is not None:
+            names.append(k)
+            norms.append(p_.grad.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "g15_selfcond_dim8_p16.npz"), x=npy(x), sc=npy(sc), t=npy(t), out_sc=npy(out_sc),
+                        out_none=npy(out_none), w=npy(w), grad_names=np.array(names), grad_norms=np.array(norms),
+                        init_conv_shape=np.array(m.init_conv.weight.shape))
+    print("g15 selfcond:", tuple(m.init_conv.weight.shape), float(out_sc.abs().max()), len(names))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -436,4 +459,5 @@ if __name__ == "__main__":
     g12()
     g13()
     g14()
+    g15()
     print("golden vectors written to", OUT)

@@ -175,7 +175,8 @@ def darcy_residual(x0: torch.Tensor, domain_length: float = 1.0, pixels_at_bound
 # ----------------------------------------------------------------------------------------------
 class UnetCfg:
     def __init__(self, dim, channels=2, out_dim=None, dim_mults=(1, 2, 4, 8), heads=8, dim_head=32,
-                 groups=8, sigmoid_last_channel=False):
+                 groups=8, sigmoid_last_channel=False, self_condition=False):
+        self.self_condition = self_condition
         self.dim = dim
         self.channels = channels
         self.out_dim = out_dim if out_dim is not None else channels
@@ -269,7 +270,8 @@ def time_embedding(p, t, dim):
     return F.linear(h, p["time_mlp.3.weight"], p["time_mlp.3.bias"])
 
 
-def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg, cond: torch.Tensor | None = None) -> torch.Tensor:
+def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg, cond: torch.Tensor | None = None,
+                 x_self_cond: torch.Tensor | None = None) -> torch.Tensor:
     """x: [B,C,P,P] (NCHW) or [B,P*P,C]; t: int64 [B].  Returns [B,out_dim,P,P].
     src/unet_model.py:542-623 (image path, no self-conditioning).  `cond` [B,P*P,C] (already classifier-free masked) is the
     gradient-guidance field: x = combine_conv(cat(init_conv(x), emb_conv(cond))) (:571-587)."""
@@ -279,6 +281,11 @@ def unet_forward(p: dict, x: torch.Tensor, t: torch.Tensor, cfg: UnetCfg, cond: 
         x = x.reshape(B, P, P, C).permute(0, 3, 1, 2)
     g = cfg.groups
     kinit = p["init_conv.weight"].shape[-1]
+    if cfg.self_condition:      # src/unet_model.py:564-566: cat(x_self_cond or zeros, x) on the channel axis
+        sc = torch.zeros_like(x) if x_self_cond is None else x_self_cond
+        if sc.dim() == 3:
+            sc = sc.reshape(x.shape[0], x.shape[2], x.shape[3], -1).permute(0, 3, 1, 2)
+        x = torch.cat((sc, x), dim=1)
     x = F.conv2d(x, _w2d(p["init_conv.weight"]), p["init_conv.bias"], padding=kinit // 2)
     if cond is not None:
         B, N, C = cond.shape

@@ -33,6 +33,7 @@ class UnetEngine:
         cfg.init_kernel = model.init_kernel_size
         cfg.image_size = image_size
         cfg.sigmoid_last_channel = int(bool(model.sigmoid_last_channel))
+        cfg.self_condition = int(bool(model.self_condition))
         self.image_size = image_size
         self.handle = vp()
         self.lib.check(self.lib.pidm_unet_create(C.byref(cfg), C.byref(self.handle)), "pidm_unet_create")
@@ -80,11 +81,14 @@ class UnetEngine:
                 self.grad_views.append(self.flat_grad[off:off + ne].view(p.shape))
                 off += ne
             self._bound_key = None
-        key = (tuple(p.data_ptr() for p in self.params), need_grad and self.flat_grad.data_ptr())
+        # once a gradient buffer exists it stays bound: an inference-mode forward between a training forward and its
+        # backward (EMA evaluation, sampling inside a step) must not unbind it
+        with_grad = need_grad or self.flat_grad is not None
+        key = (tuple(p.data_ptr() for p in self.params), with_grad and self.flat_grad.data_ptr())
         if key != self._bound_key:
             n = len(self.params)
             pp = (vp * n)(*[vp(p.data_ptr()) for p in self.params])
-            if need_grad:
+            if with_grad:
                 gp = (vp * n)(*[vp(g.data_ptr()) for g in self.grad_views])
                 self.lib.check(self.lib.pidm_unet_bind(self.handle, pp, gp), "pidm_unet_bind")
             else:
@@ -201,7 +205,7 @@ def used_parameter_names(model, image_size: int = 64, with_condition: bool = Fal
     return list(eng.names) if with_condition else list(eng.names[:len(eng.names) - eng.n_cond])
 
 
-def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None):
+def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None, x_self_cond=None):
     """x: [B,P*P,C] (reference interchange layout), [B,C,P,P] or [B,C,1,P,P]; time: int64 [B].
     Returns [B,out_dim,P,P] (or [B,out_dim,1,P,P] for 5-D input), as reference Unet3D.forward does."""
     video = False
@@ -226,6 +230,19 @@ def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None):
         raise ValueError(f'expected {model.channels} input channels, got {Cc}')
     if lib is None and not x.is_cuda:
         raise PidmError("Unet3D.forward needs tensors on an MI355X (cuda device): the gfx950 engine has no CPU fallback")
+    if model.self_condition:
+        # init_conv reads cat(x_self_cond, x) (src/unet_model.py:564-566); absent self-conditioning input = zeros
+        if x_self_cond is None:
+            sc = torch.zeros_like(x_nhwc)
+        elif x_self_cond.dim() == 3:
+            sc = x_self_cond
+        elif x_self_cond.dim() == 4:
+            sc = x_self_cond.permute(0, 2, 3, 1).reshape(B, P * P, Cc)
+        else:
+            sc = x_self_cond[:, :, 0].permute(0, 2, 3, 1).reshape(B, P * P, Cc)
+        x_nhwc = torch.cat((sc.to(x_nhwc.dtype), x_nhwc), dim=-1)
+    elif x_self_cond is not None:
+        raise ValueError('x_self_cond given but the model was built with self_condition=False')
     x_nhwc = x_nhwc.contiguous().float()
     t = time.to(device=x.device, dtype=torch.int64).contiguous()
     if t.numel() != B:
@@ -241,6 +258,10 @@ def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None):
         while get_engine(model, P, lib, slot).tape_busy:
             slot += 1
         eng = get_engine(model, P, lib, slot)
+    if not training and eng.tape_busy:
+        # an inference-mode forward while a training forward of this model still waits for its backward (evaluation inside a
+        # step): run it on a sibling engine so that the activation tape and its pointers stay intact
+        eng = get_engine(model, P, lib, slot=-1)
     if cond is not None:
         if cond.shape != (B, P * P, model.channels):
             raise ValueError(f'cond must be [B, P*P, {model.channels}], got {tuple(cond.shape)}')

@@ -19,7 +19,8 @@ vp = C.c_void_p
 class UnetCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("channels", C.c_int), ("out_dim", C.c_int), ("n_levels", C.c_int),
                 ("dim_mults", C.c_int * 8), ("heads", C.c_int), ("dim_head", C.c_int), ("groups", C.c_int),
-                ("init_kernel", C.c_int), ("image_size", C.c_int), ("sigmoid_last_channel", C.c_int)]
+                ("init_kernel", C.c_int), ("image_size", C.c_int), ("sigmoid_last_channel", C.c_int),
+                ("self_condition", C.c_int)]
 
 
 class ConvDesc(C.Structure):

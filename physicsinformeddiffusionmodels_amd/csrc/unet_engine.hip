@@ -267,7 +267,7 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
   U->ss_total = off;
   for (auto& f : film) add_param(U, f.first + "mlp.1.bias", (size_t)2 * f.second);
 
-  U->init_conv.C0 = cfg->channels; U->init_conv.Cout = dim; U->init_conv.K = cfg->init_kernel;
+  U->init_conv.C0 = cfg->channels * (cfg->self_condition ? 2 : 1); U->init_conv.Cout = dim; U->init_conv.K = cfg->init_kernel;
   U->init_conv.pad = cfg->init_kernel / 2; U->init_conv.H = P; U->init_conv.dgrad = true;
   conv_param(U, U->init_conv, "init_conv", true);
   U->lin1.C0 = dim; U->lin1.Cout = td; conv_param(U, U->lin1, "time_mlp.1", true);

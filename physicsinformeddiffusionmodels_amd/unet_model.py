@@ -190,13 +190,11 @@ class Unet3D(nn.Module):
         super().__init__()
         if padding_mode != 'zeros':
             raise ValueError('Unknown padding mode: {} (the gfx950 engine implements zero padding)'.format(padding_mode))
-        if self_condition:
-            raise NotImplementedError('self_condition is not on the accelerated path (main.py:53 sets it False)')
         if not use_sparse_linear_attn:
             raise NotImplementedError('use_sparse_linear_attn=False is not on the accelerated path')
         self.dim = dim
         self.channels = channels
-        self.input_channels = channels
+        self.input_channels = channels * (2 if self_condition else 1)
         self.self_condition = self_condition
         self.dim_mults = tuple(dim_mults)
         self.attn_heads = attn_heads
@@ -277,15 +275,13 @@ class Unet3D(nn.Module):
         """`cond` [B, P*P, C] = the residual-gradient conditioning field of the guidance baseline
         (src/unet_model.py:571-587): per-sample classifier-free dropout with probability `null_cond_prob` (same RNG call
         as the reference's prob_mask_like), then emb_conv / combine_conv inside the engine."""
-        if x_self_cond is not None or self.self_condition:
-            raise NotImplementedError('self-conditioning is not on the accelerated path (self_condition=False in main.py)')
         from ._engine import unet_apply
         if cond is not None:
             if cond.dim() != 3:
                 raise ValueError('Input must be [BxP*PxC].')
             mask = prob_mask_like((cond.shape[0],), null_cond_prob, device=cond.device)
             cond = torch.where(mask.view(-1, 1, 1), torch.zeros_like(cond), cond)
-        return unet_apply(self, x, time, lib=self._pidm_lib, cond=cond)
+        return unet_apply(self, x, time, lib=self._pidm_lib, cond=cond, x_self_cond=x_self_cond)
 
     def forward_with_guidance_scale(self, *args, **kwargs):
         """null + (cond - null) * scale from two forward passes (src/unet_model.py:530-540)."""

@@ -173,7 +173,16 @@ class _UnetFunction(torch.autograd.Function):
             raise PidmError("the engine's activation tape was overwritten by a later training-mode forward of the same "
                             "model (two differentiable UNet calls per step, e.g. x0_estimation='sample', need a second "
                             "tape: not supported yet)")
+        # the engine WRITES its flat gradient buffer.  If p.grad already aliases that buffer (a second backward without
+        # zero_grad, or zero_grad(set_to_none=False)), torch semantics are accumulation: keep the old contents and add them
+        # back afterwards (one 4-byte-per-parameter copy, only on this path - main.py's zero_grad() sets grads to None)
+        first = eng.params[0]
+        prev = None
+        if eng.grad_views is not None and first.grad is not None and first.grad.data_ptr() == eng.grad_views[0].data_ptr():
+            prev = eng.flat_grad.clone()
         gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
+        if prev is not None:
+            eng.flat_grad.add_(prev)
         eng.tape_busy = False
         n_plain = len(eng.params) - eng.n_cond
         for i, (p, g) in enumerate(zip(eng.params, eng.grad_views)):

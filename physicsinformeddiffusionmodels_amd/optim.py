@@ -64,6 +64,9 @@ class FusedClipAdam:
         self.image_size = image_size
         self.eng = get_engine(model, image_size, lib)
         self.lib = self.eng.lib
+        if any(not p.requires_grad for p in self.eng.params):
+            raise PidmError("FusedClipAdam updates the whole flat parameter buffer: frozen parameters (requires_grad=False) "
+                            "are not supported - use torch.optim.Adam for partially frozen models")
         self.flat = flatten_parameters(model, image_size, lib)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)

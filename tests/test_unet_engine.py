@@ -134,3 +134,32 @@ def test_inference_forward_between_training_forward_and_backward(backend):
     assert a.keys() == b.keys() and len(a) == 259
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_gradient_accumulation_across_backward_calls(backend):
+    """Two backward passes without zero_grad accumulate (torch semantics), although the engine writes its flat buffer."""
+    L, dev = backend
+    m = Unet3D(dim=8, channels=2)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = L if dev.type == "cpu" else None
+    g = torch.Generator().manual_seed(4)
+    xa, xb = (torch.randn(2, 256, 2, generator=g).to(dev) for _ in range(2))
+    t = torch.tensor([10, 60], device=dev)
+
+    def one(x):
+        for p in m.parameters():
+            p.grad = None
+        m(x, t).square().sum().backward()
+        return {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    ga, gb = one(xa), one(xb)
+    for p in m.parameters():
+        p.grad = None
+    m(xa, t).square().sum().backward()
+    m(xb, t).square().sum().backward()          # no zero_grad in between
+    for k, v in m.named_parameters():
+        if v.grad is None:
+            continue
+        ref = ga[k] + gb[k]
+        assert (v.grad - ref).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1e-12), k

@@ -441,9 +441,58 @@ def g15():
     print("g15 selfcond:", tuple(m.init_conv.weight.shape), float(out_sc.abs().max()), len(names))
 
 
+# G16: mechanics sampler steps (p_sample with conditioning_input): t = 3 (no evaluation) and t = 0 with topopt_eval=True
+def g16():
+    import tempfile
+    from src.residuals_mechanics_K import ResidualsMechanics
+    folder = tempfile.mkdtemp() + "/"
+    write_synthetic_mesh(folder)
+    m = Unet3D(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(100, "cpu")
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder=folder, device="cpu", topopt_eval=True)
+    B = 2
+    x = seeded((B, 3, 65, 65), 101)
+    cond = torch.zeros(B, 3, 65, 65)
+    cond[:, 0] = torch.tensor([0.3, 0.45]).view(B, 1, 1)
+    cond[:, 1:3] = seeded((B, 2, 65, 65), 102)
+    bcs = torch.zeros(B, 4, 65, 65)
+    bcs[:, 0, :, 0] = 1.0
+    bcs[:, 1, :, 0] = 1.0
+    bcs[0, 3, 32, 64] = -0.01
+    bcs[1, 3, 30, 64] = -0.02
+    yy = np.arange(64).reshape(64, 1) * np.ones((1, 64))
+    band = (np.abs(yy - 32) < 12).astype(np.float64)
+    rho_simp = np.clip(0.05 + 0.95 * np.stack([band, band]) * (0.7 + 0.3 * npy(torch.sigmoid(seeded((B, 64, 64), 103)))), 0.05, 1.0)
+    kloc = npy(res.stiffs.tot_local_stiffness[0]).astype(np.float64)
+    elem_dofs = npy(res.stiffs.glob_assembler_idcs[:, :8, 1]).astype(np.int64)
+    solution = torch.zeros(B, 3, 65, 65)
+    for b in range(B):
+        u, _ = O.mechanics_fe_solve(rho_simp[b].reshape(-1), npy(bcs[b]), kloc, elem_dofs)
+        solution[b, :2] = torch.from_numpy(u.reshape(65, 65, 2).transpose(2, 0, 1)).float()
+        solution[b, 2, :64, :64] = torch.from_numpy(rho_simp[b]).float()
+    z = seeded((B, 3, 65, 65), 104)
+    orig = torch.randn_like
+    torch.randn_like = lambda *a, **k: z.clone()
+    try:
+        (x3, mo3), aux3 = diff.p_sample(x, (cond, bcs, solution), 3, save_output=True, surpress_noise=True, residual_func=res,
+                                        eval_residuals=True, return_optimizer=True, return_inequality=True)
+        (x0, mo0), aux0 = diff.p_sample(x, (cond, bcs, solution), 0, save_output=True, surpress_noise=True, residual_func=res,
+                                        eval_residuals=True, return_optimizer=True, return_inequality=True)
+    finally:
+        torch.randn_like = orig
+    assert aux3 is None
+    np.savez_compressed(os.path.join(OUT, "g16_mech_sampler_dim8.npz"), x=npy(x), cond=npy(cond), bcs=npy(bcs), solution=npy(solution),
+                        z=npy(z), x3=npy(x3), mo3=npy(mo3), x0=npy(x0), mo0=npy(mo0), residual0=npy(aux0["residual"]),
+                        compliance0=npy(aux0["optimized_quant"]), shift0=npy(aux0["inequality_quant"]),
+                        rel_CE=npy(aux0["rel_CE_error_full_batch"]), vf_err=npy(aux0["vf_error_full_batch"]),
+                        fm=npy(aux0["fm_error_full_batch"]).astype(np.int64))
+    print("g16 mech sampler: rel_CE", npy(aux0["rel_CE_error_full_batch"]), "vf", npy(aux0["vf_error_full_batch"]), "fm", npy(aux0["fm_error_full_batch"]))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -460,4 +509,5 @@ if __name__ == "__main__":
     g13()
     g14()
     g15()
+    g16()
     print("golden vectors written to", OUT)

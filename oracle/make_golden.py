@@ -490,9 +490,30 @@ def g16():
     print("g16 mech sampler: rel_CE", npy(aux0["rel_CE_error_full_batch"]), "vf", npy(aux0["vf_error_full_batch"]), "fm", npy(aux0["fm_error_full_batch"]))
 
 
+# G17: dataset readers (src/data_utils.py:31-119): CSV-per-channel Dataset and .npy-per-sample Dataset_Paths
+def g17():
+    import tempfile
+    from src.data_utils import Dataset, Dataset_Paths
+    d = tempfile.mkdtemp()
+    rng = np.random.default_rng(7)
+    p_csv, k_csv = rng.normal(size=(3, 16)), rng.normal(size=(3, 16))
+    np.savetxt(d + "/p.csv", p_csv, delimiter=",")
+    np.savetxt(d + "/K.csv", k_csv, delimiter=",")
+    ds = Dataset((d + "/p.csv", d + "/K.csv"), use_double=False)
+    os.makedirs(d + "/fields")
+    arrs = [rng.normal(size=(5, 5, 10)) for _ in range(3)]
+    for i, name in enumerate(("10", "2", "33")):          # numeric (not lexicographic) file order
+        np.save(d + f"/fields/{name}.npy", arrs[i])
+    dp = Dataset_Paths(d + "/fields/", use_double=False)
+    np.savez_compressed(os.path.join(OUT, "g17_datasets.npz"), p_csv=p_csv, k_csv=k_csv, ds_data=npy(torch.stack([ds[i] for i in range(len(ds))])),
+                        npy_arrays=np.stack(arrs), npy_names=np.array(["10", "2", "33"]),
+                        dp_items=npy(torch.stack([dp[i] for i in range(len(dp))])))
+    print("g17 datasets:", tuple(ds[0].shape), len(ds), tuple(dp[0].shape), len(dp))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -510,4 +531,5 @@ if __name__ == "__main__":
     g14()
     g15()
     g16()
+    g17()
     print("golden vectors written to", OUT)

@@ -9,7 +9,6 @@
 // about performance and it is never loaded by the product package: the product path loads
 // libpidm_hip.so only and fails loudly without it.
 #pragma once
-#include <ucontext.h>
 
 #include <atomic>
 #include <cmath>
@@ -56,14 +55,14 @@ static inline int2 make_int2(int a, int b) { int2 v = {a, b}; return v; }
 namespace hipemu {
 enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 struct Fiber {
-  ucontext_t ctx;
+  void* sp;        // saved stack pointer (callee-saved registers live on the fiber's own stack)
   char* stack;
   int state;
 };
 struct BlockRunner {
   std::vector<Fiber> fibers;
   std::vector<uint64_t> xa, xb;  // cross-lane exchange slots
-  ucontext_t sched;
+  void* sched_sp = nullptr;
   int cur = 0;
   int nthreads = 0;
   char* dyn = nullptr;

@@ -1,4 +1,5 @@
-// hipemu scheduler: one ucontext fiber per GPU thread, blocks distributed over host threads.
+// hipemu scheduler: one fiber per GPU thread (hand-rolled x86-64 context switch: glibc's swapcontext makes a sigprocmask
+// system call per switch, which dominated the run time of barrier-heavy kernels), blocks distributed over host threads.
 // TEST INFRASTRUCTURE ONLY - see hip/hip_runtime.h in this directory.
 #include <hip/hip_runtime.h>
 
@@ -14,18 +15,48 @@ static const size_t kStack = 96 * 1024;
 
 char* dyn_smem() { return g_runner->dyn; }
 
+#if !defined(__x86_64__)
+#error "hipemu's context switch is written for x86-64 (System V ABI)"
+#endif
+// void hipemu_switch(void** save_sp, void* new_sp): push the callee-saved registers, publish the stack pointer, adopt the
+// other one, pop its registers, return into it.  (MXCSR / x87 control words are never changed by the emulated code.)
+extern "C" void hipemu_switch(void** save_sp, void* new_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch, .-hipemu_switch
+)");
+
 void yield_state(int st) {
   BlockRunner* r = g_runner;
   Fiber& f = r->fibers[r->cur];
   f.state = st;
-  swapcontext(&f.ctx, &r->sched);
+  hipemu_switch(&f.sp, r->sched_sp);
 }
 
 static void fiber_entry() {
   BlockRunner* r = g_runner;
   r->body();
   r->fibers[r->cur].state = DONE;
-  swapcontext(&r->fibers[r->cur].ctx, &r->sched);
+  hipemu_switch(&r->fibers[r->cur].sp, r->sched_sp);
+  __builtin_trap();   // a finished fiber is never resumed
 }
 
 static void run_block(BlockRunner* r, dim3 block, size_t shmem) {
@@ -45,11 +76,14 @@ static void run_block(BlockRunner* r, dim3 block, size_t shmem) {
   }
   for (int i = 0; i < n; ++i) {
     Fiber& f = r->fibers[i];
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    // initial frame: six zeroed callee-saved registers, then fiber_entry as the return address; after that `ret` the stack
+    // pointer is 8 (mod 16), exactly as after a call instruction
+    uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStack) & ~(uintptr_t)15;
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;                                   // alignment slot
+    *--sp = reinterpret_cast<void*>(&fiber_entry);     // return address of the first switch
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;       // rbp rbx r12 r13 r14 r15
+    f.sp = sp;
     f.state = READY;
   }
   int ndone = 0;
@@ -62,7 +96,7 @@ static void run_block(BlockRunner* r, dim3 block, size_t shmem) {
       g_tid.x = i % block.x;
       g_tid.y = (i / block.x) % block.y;
       g_tid.z = i / (block.x * block.y);
-      swapcontext(&r->sched, &f.ctx);
+      hipemu_switch(&r->sched_sp, f.sp);
       progressed = true;
       if (f.state == DONE) ++ndone;
     }

@@ -64,11 +64,15 @@ def test_unet_dim8_p16(backend):
     run_case(backend, "g5_unet_dim8_p16", 8, True)
 
 
-@pytest.mark.slow
 def test_unet_dim16_p32(backend):
-    if backend[1].type == "cpu" and not os.environ.get("PIDM_SLOW"):
-        pytest.skip("emulated dim16/P32 UNet takes minutes; set PIDM_SLOW=1")
     run_case(backend, "g5b_unet_dim16_p32", 16, True)
+
+
+def test_unet_dim32_p64_emulated():
+    """The full Darcy model (dim=32, 64x64: golden g6 from the genuine reference) through the host emulator, ~15 s
+    (the same golden runs on the real GPU in test_unet_dim32_p64_gpu)."""
+    from tests.emu_util import emu_lib
+    run_case((emu_lib(), torch.device("cpu")), "g6_unet_dim32_p64", 32, False)
 
 
 @pytest.mark.gpu

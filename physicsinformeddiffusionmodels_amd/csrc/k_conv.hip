@@ -1264,7 +1264,8 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
   const size_t lds_pipe = a_bytes + (size_t)T * b_tap;
   if (g.nph > 1 && !aligned) return fail("conv: phased 4x4/s2 path needs 16-byte aligned channel counts");
   const bool khw_ok = (g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1) || (g.KH == 2 && g.KW == 2);
-  if (aligned && khw_ok && nA <= AMAX * 256 && lds_pipe <= 80 * 1024) {
+  const int amax_eff = (KC == 32 && g.KH == 3) ? 9 : AMAX;
+  if (aligned && khw_ok && nA <= amax_eff * 256 && lds_pipe <= 80 * 1024) {
     if (prof) prof_begin_launch(0, flops, st);
     const dim3 grid(g.tiles_m * tiles_n, 1, g.nz);
 #define PIDM_LAUNCH_PIPE(KH_, KW_, PH_, PS_, MT_, AMAX_, grid_)                                                                                \
@@ -1280,7 +1281,16 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
                        lds_pipe, st, g, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);                 \
   }
     if constexpr (NT == 4 || KC == 32) {
-      // the permuted 128-channel tile and the 32-channel chunk exist for 1x1 convolutions only (conv_nt4_ok / launch_conv)
+      // the permuted 128-channel tile exists for 1x1 convolutions only; the 32-channel chunk for 1x1 and (NT == 1) 3x3
+      // convolutions
+      if constexpr (KC == 32 && NT == 1) {
+        if (g.KH == 3 && g.KW == 3 && g.nph == 1) {
+          PIDM_LAUNCH_PIPE(3, 3, false, false, 1, 9, grid)
+          if (prof) prof_end_launch(st);
+          PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
+          return 0;
+        }
+      }
       if (g.KH != 1 || g.KW != 1 || g.nph != 1) return fail("conv: internal error - 1x1-only tile configuration on a %dx%d conv", g.KH, g.KW);
       PIDM_LAUNCH_PIPE(1, 1, false, false, 1, AMAX, grid)
     } else {
@@ -1398,6 +1408,14 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       if (NT == 2) return launch_conv_t<32, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
       return launch_conv_t<32, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
     }
+  }
+  if (KC == 16 && NT == 1 && g.KH == 3 && g.KW == 3 && g.nph == 1 && g.nz == 1 && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) &&
+      ((g.ld0 | g.ld1) & 3) == 0 && g.NI * g.IHt * g.IWt * 8 <= 9 * 256 &&
+      ((size_t)g.NI * g.IHt * g.IWt + 9 * 32) * 36 * sizeof(float) <= 80 * 1024) {
+    // 32-channel chunks for 32-channel-tile 3x3 convolutions: 144 MFMAs per wave between barriers instead of 72 (two
+    // workgroups per CU instead of three); +3..14 % on the 8x8 / 64x64 levels, neutral elsewhere (PIDM_KC32_3X3=0: off)
+    const char* e = getenv("PIDM_KC32_3X3");
+    if (!(e && !atoi(e))) return launch_conv_t<32, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   }
   if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   if (KC == 16 && NT == 1) return launch_conv_t<16, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);

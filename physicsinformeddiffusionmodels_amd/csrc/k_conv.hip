@@ -1022,6 +1022,83 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// 1x1 (stride 1) weight gradient without LDS and without barriers: dW[m][n] = sum_p dY[p][m] X[p][n] is a pure stream over
+// the pixels - a wave reads its own MFMA fragments straight from global memory (32 consecutive channels = one 128-byte
+// line per pixel and operand; every dY element is used exactly once per n-tile) and keeps UNR independent loads per
+// operand in flight.  The LDS-staged kernel did 16 MFMAs per wave between two barriers and ran at half the byte rate.
+// Pixel range of a workgroup: tiles [split*tps, ...) of 128 pixels, one contiguous quarter per wave; cross-wave sum
+// through LDS at the end, split-K partials as everywhere else.
+__global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg, const float* __restrict__ src0,
+                                                                    const float* __restrict__ src1, const float* __restrict__ dy,
+                                                                    float* __restrict__ partial, float* __restrict__ bias_partial) {
+  __shared__ float red[4][1024];
+  const ConvGeom& g = wg.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int ntn = wg.NP / 32;
+  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int split = blockIdx.x;
+  const size_t ptot = (size_t)g.B * g.Hv * g.Wv;
+  size_t p_lo = (size_t)split * wg.tiles_per_split * 128, p_hi = p_lo + (size_t)wg.tiles_per_split * 128;
+  if (p_hi > ptot) p_hi = ptot;
+  if (p_lo > p_hi) p_lo = p_hi;
+  const size_t per = ((p_hi - p_lo + 7) / 8) * 2;                     // even number of pixels per wave
+  size_t w_lo = p_lo + (size_t)wave * per, w_hi = w_lo + per;
+  if (w_lo > p_hi) w_lo = p_hi;
+  if (w_hi > p_hi) w_hi = p_hi;
+  const int cx = n0 + l31, cy = m0 + l31;
+  const bool x_ok = cx < g.Cin, y_ok = cy < g.Cout;
+  const float* xsrc = (cx < g.C0) ? src0 + cx : src1 + (cx - g.C0);
+  const size_t xld = (cx < g.C0) ? g.ld0 : g.ld1;
+  const float* ysrc = dy + cy;
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0);
+  float bacc = 0.f;
+  constexpr int UNR = 8;
+  size_t p = w_lo + half;
+  for (; p + 2 * (UNR - 1) < w_hi; p += 2 * UNR) {
+    float a[UNR], b[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      a[u] = y_ok ? ysrc[(p + 2 * u) * wg.ld_dy] : 0.f;
+      b[u] = x_ok ? xsrc[(p + 2 * u) * xld] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+      bacc += a[u];
+    }
+  }
+  for (size_t q = p - half; q < w_hi; q += 2) {      // tail: both halves walk together (the MFMA is wave-wide)
+    const size_t pp = q + half;
+    const float a = (y_ok && pp < w_hi) ? ysrc[pp * wg.ld_dy] : 0.f;
+    const float b = (x_ok && pp < w_hi) ? xsrc[pp * xld] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    bacc += a;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    red[wave][row * 32 + l31] = acc[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {
+    const float sv = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    partial[((size_t)split * wg.MP + (m0 + (e >> 5))) * wg.NP + n0 + (e & 31)] = sv;
+  }
+  if (do_bias) {
+    __syncthreads();
+    red[0][tid] = bacc;           // lane (wave, half, l31): partial column sum of channel m0 + l31
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[0][k * 32 + tid];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
 // all deferred reductions of one backward pass in ONE launch (descriptor table on the device, binary search per block
 // like pack_multi_kernel); same arithmetic as wgrad_reduce_kernel with 4 independent chains per split lane
 __global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __restrict__ table, int ndesc) {
@@ -1523,7 +1600,9 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
   } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 &&
              g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {
-    if (g.KH == 1) {
+    if (g.KH == 1 && g.stride == 1 && (g.C1 == 0 || g.C0 % 32 == 0) && !getenv("PIDM_NO_WGRAD_STREAM")) {
+      hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, grid, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    } else if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
     } else {

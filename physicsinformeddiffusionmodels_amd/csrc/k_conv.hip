@@ -1056,8 +1056,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg
   const bool do_bias = (bias_partial != nullptr) && (tn == 0);
   float bacc = 0.f;
   constexpr int UNR = 8;
-  size_t p = w_lo + half;
-  for (; p + 2 * (UNR - 1) < w_hi; p += 2 * UNR) {
+  size_t q = w_lo;                                   // wave-uniform loop bounds: the MFMA ignores the exec mask
+  for (; q + 2 * UNR <= w_hi; q += 2 * UNR) {
+    const size_t p = q + half;
     float a[UNR], b[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -1070,7 +1071,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg
       bacc += a[u];
     }
   }
-  for (size_t q = p - half; q < w_hi; q += 2) {      // tail: both halves walk together (the MFMA is wave-wide)
+  for (; q < w_hi; q += 2) {
     const size_t pp = q + half;
     const float a = (y_ok && pp < w_hi) ? ysrc[pp * wg.ld_dy] : 0.f;
     const float b = (x_ok && pp < w_hi) ? xsrc[pp * xld] : 0.f;
@@ -1095,6 +1096,119 @@ __global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg
       float sb = 0.f;
       for (int k = 0; k < 8; ++k) sb += red[0][k * 32 + tid];
       bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
+// Same stream with a 128-channel "wide" operand read as one float4 per lane (lane l holds channels 4l..4l+3 of pixel p + half:
+// 1 KiB per wave-wide load instruction) against 32 channels of the other operand: four accumulators, MFMA tile t pairs
+// component t of the wide fragment (channel 4*lane + t - the permuted-tile trick of the NT=4 forward kernel) with the narrow
+// fragment, so the narrow operand is re-read four times less often than with 32x32 tiles.  WIDE_DY: the wide side is dY
+// (GEMM M), otherwise X (GEMM N).
+template <bool WIDE_DY>
+__global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradGeom wg, const float* __restrict__ src0,
+                                                                     const float* __restrict__ src1, const float* __restrict__ dy,
+                                                                     float* __restrict__ partial, float* __restrict__ bias_partial) {
+  __shared__ float red[4][1024];
+  const ConvGeom& g = wg.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int n_nar = WIDE_DY ? wg.NP / 32 : wg.MP / 32;          // 32-channel tiles of the narrow operand
+  // tile index fastest: workgroups launched together read neighbouring channel groups of the same pixel rows
+  const int t_nar = blockIdx.x % n_nar, t_wid = blockIdx.x / n_nar;
+  const int w0 = t_wid * 128, r0 = t_nar * 32;
+  const int split = blockIdx.y;
+  const size_t ptot = (size_t)g.B * g.Hv * g.Wv;
+  size_t p_lo = (size_t)split * wg.tiles_per_split * 128, p_hi = p_lo + (size_t)wg.tiles_per_split * 128;
+  if (p_hi > ptot) p_hi = ptot;
+  if (p_lo > p_hi) p_lo = p_hi;
+  const size_t per = ((p_hi - p_lo + 7) / 8) * 2;
+  size_t w_lo = p_lo + (size_t)wave * per, w_hi = w_lo + per;
+  if (w_lo > p_hi) w_lo = p_hi;
+  if (w_hi > p_hi) w_hi = p_hi;
+  // wide operand: channels cw..cw+3, narrow operand: channel cn
+  const int cw = w0 + 4 * l31, cn = r0 + l31;
+  const float* wsrc;
+  const float* nsrc;
+  size_t wld, nld;
+  bool w_ok, n_ok;
+  if (WIDE_DY) {
+    wsrc = dy + cw; wld = wg.ld_dy; w_ok = cw < g.Cout;
+    nsrc = (cn < g.C0) ? src0 + cn : src1 + (cn - g.C0); nld = (cn < g.C0) ? g.ld0 : g.ld1; n_ok = cn < g.Cin;
+  } else {
+    wsrc = (cw < g.C0) ? src0 + cw : src1 + (cw - g.C0); wld = (cw < g.C0) ? g.ld0 : g.ld1; w_ok = cw < g.Cin;
+    nsrc = dy + cn; nld = wg.ld_dy; n_ok = cn < g.Cout;
+  }
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool do_bias = (bias_partial != nullptr) && ((WIDE_DY ? t_nar : t_wid) == 0);
+  f32x4 bw = {0.f, 0.f, 0.f, 0.f};
+  float bn = 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int UNR = 4;
+  size_t q = w_lo;                                   // wave-uniform loop bounds: the MFMA ignores the exec mask
+  for (; q + 2 * UNR <= w_hi; q += 2 * UNR) {
+    const size_t p = q + half;
+    f32x4 w[UNR];
+    float n[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      w[u] = w_ok ? *reinterpret_cast<const f32x4*>(wsrc + (p + 2 * u) * wld) : zero4;
+      n[u] = n_ok ? nsrc[(p + 2 * u) * nld] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = WIDE_DY ? __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][t], n[u], acc[t], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(n[u], w[u][t], acc[t], 0, 0, 0);
+      if (WIDE_DY) bw += w[u]; else bn += n[u];
+    }
+  }
+  for (; q < w_hi; q += 2) {
+    const size_t pp = q + half;
+    const f32x4 w = (w_ok && pp < w_hi) ? *reinterpret_cast<const f32x4*>(wsrc + pp * wld) : zero4;
+    const float n = (n_ok && pp < w_hi) ? nsrc[pp * nld] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc[t] = WIDE_DY ? __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], n, acc[t], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x2f32(n, w[t], acc[t], 0, 0, 0);
+    if (WIDE_DY) bw += w; else bn += n;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[wave][row * 32 + l31] = acc[t][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const float sv = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      const int m = WIDE_DY ? w0 + 4 * (e >> 5) + t : r0 + (e >> 5);
+      const int n = WIDE_DY ? r0 + (e & 31) : w0 + 4 * (e & 31) + t;
+      if (m < wg.MP && n < wg.NP) partial[((size_t)split * wg.MP + m) * wg.NP + n] = sv;
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    if (WIDE_DY) {
+      for (int t = 0; t < 4; ++t) red[0][(wave * 2 + half) * 128 + 4 * l31 + t] = bw[t];
+      __syncthreads();
+      if (tid < 128 && w0 + tid < wg.MP) {
+        float sb = 0.f;
+        for (int k = 0; k < 8; ++k) sb += red[0][k * 128 + tid];
+        bias_partial[(size_t)split * wg.MP + w0 + tid] = sb;
+      }
+    } else {
+      red[0][tid] = bn;
+      __syncthreads();
+      if (tid < 32) {
+        float sb = 0.f;
+        for (int k = 0; k < 8; ++k) sb += red[0][k * 32 + tid];
+        bias_partial[(size_t)split * wg.MP + r0 + tid] = sb;
+      }
     }
   }
 }
@@ -1508,6 +1622,20 @@ static bool wgrad_smallc(const ConvGeom& g) {
 
 static int wgrad_taps(const ConvGeom& g) { return g.nph > 1 ? 16 : g.KH * g.KW; }   // taps of the weight tensor
 
+// 0: LDS-staged kernels, 1: LDS-free stream with 32x32 tiles, 2: stream with a 128-wide dY operand, 3: 128-wide X operand
+static int wgrad_stream_mode(const ConvGeom& g, int ld_dy) {
+  static const bool off = getenv("PIDM_NO_WGRAD_STREAM") != nullptr;
+  static const bool off4 = getenv("PIDM_NO_WGRAD_STREAM4") != nullptr;
+  if (off || g.KH != 1 || g.KW != 1 || g.stride != 1 || g.nph != 1 || g.nz != 1 || wgrad_smallc(g)) return 0;
+  if (g.C1 != 0 && g.C0 % 32 != 0) return 0;
+  if (off4) return 1;
+  const bool dy4 = g.Cout >= 128 && (g.Cout & 3) == 0 && (ld_dy & 3) == 0;
+  const bool x4 = g.Cin >= 128 && (g.Cin & 3) == 0 && (g.ld0 & 3) == 0 && (g.C1 == 0 || (g.ld1 & 3) == 0);
+  if (dy4 && (g.Cout >= g.Cin || !x4)) return 2;
+  if (x4) return 3;
+  return 1;
+}
+
 static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->g = g;
   wg->ld_dy = ld_dy;
@@ -1519,7 +1647,10 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->ntg = cdiv(T, wg->tgs);
   wg->MP = cdiv(g.Cout, 32) * 32;
   wg->NP = cdiv(g.Cin, 32) * 32;
-  const int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg * g.nph;
+  int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg * g.nph;
+  const int smode = wgrad_stream_mode(g, ld_dy);
+  if (smode == 2) blocks_mn = cdiv(wg->MP, 128) * (wg->NP / 32);
+  if (smode == 3) blocks_mn = cdiv(wg->NP, 128) * (wg->MP / 32);
   // two workgroups per CU are resident: pick tiles-per-split so that the number of workgroup "rounds" over the
   // 512 slots times the per-workgroup work (+ ~1 tile-equivalent of prologue / epilogue) is minimal
   int best_tps = g.tiles_m;
@@ -1539,7 +1670,10 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
 size_t wgrad_ws_bytes(const ConvGeom& g) {
   WgradGeom wg;
   wgrad_plan(g, 4, &wg);
-  return (size_t)wg.nsplit * wg.MP * wgrad_taps(g) * wg.NP * sizeof(float) + (size_t)wg.nsplit * wg.MP * sizeof(float) + 256;
+  WgradGeom wu;
+  wgrad_plan(g, 1, &wu);          // a dY leading dimension that is not a multiple of 4 picks another kernel and split
+  const size_t ns = wg.nsplit > wu.nsplit ? wg.nsplit : wu.nsplit;
+  return ns * wg.MP * wgrad_taps(g) * wg.NP * sizeof(float) + ns * wg.MP * sizeof(float) + 256;
 }
 
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
@@ -1566,6 +1700,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
                        ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
+  const int smode = wgrad_stream_mode(g, ld_dy);
   if (wgrad_smallc(g)) {
     // few input channels, many taps (init conv): (tap, channel) flattened into the GEMM N dimension
     const int NJ = T * g.Cin, ntl = cdiv(NJ, 32), maxn = cdiv(ntl, 4);
@@ -1598,11 +1733,17 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   }
     if (g.Wv >= 32) PIDM_LAUNCH_WG(2, 2, true, true, 2, gridp)
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
+  } else if (smode == 1) {
+    hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, grid, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  } else if (smode == 2) {
+    const dim3 grid4(cdiv(wg.MP, 128) * (wg.NP / 32), wg.nsplit, 1);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<true>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  } else if (smode == 3) {
+    const dim3 grid4(cdiv(wg.NP, 128) * (wg.MP / 32), wg.nsplit, 1);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<false>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 &&
              g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {
-    if (g.KH == 1 && g.stride == 1 && (g.C1 == 0 || g.C0 % 32 == 0) && !getenv("PIDM_NO_WGRAD_STREAM")) {
-      hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, grid, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-    } else if (g.KH == 1) {
+    if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
     } else {

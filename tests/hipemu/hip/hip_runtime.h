@@ -136,15 +136,28 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
 // ---- MFMA (f32 in / f32 acc), lane layouts per cdna_hip_programming.md section 3 -----------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
-static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+// The matrix instructions ignore the exec mask: a wave that reaches one in divergent control flow computes with whatever the
+// inactive lanes hold.  Every lane tags its operand slot with the call-site line; lanes of one wave meeting at different sites
+// (e.g. half the wave still in an unrolled main loop, the other half in its tail loop) abort instead of silently pairing up.
+static inline void hipemu_mfma_check(hipemu::BlockRunner* r, int wb, int lane, int line) {
+  if (lane != 0) return;
+  for (int l = 0; l < 64 && wb + l < r->nthreads; ++l)
+    if ((int)(r->xa[wb + l] >> 32) != line) {
+      fprintf(stderr, "hipemu: MFMA reached in divergent control flow (lane 0 at line %d, lane %d at line %d)\n", line, l,
+              (int)(r->xa[wb + l] >> 32));
+      abort();
+    }
+}
+static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int, int line = __builtin_LINE()) {
   hipemu::BlockRunner* r = hipemu::g_runner;
   int t = hipemu::flat_tid(), lane = t & 63, wb = t & ~63;
   uint32_t ua, ub;
   memcpy(&ua, &a, 4);
   memcpy(&ub, &b, 4);
-  r->xa[t] = ua;
+  r->xa[t] = ua | ((uint64_t)(uint32_t)line << 32);
   r->xb[t] = ub;
   hipemu::wave_sync();
+  hipemu_mfma_check(r, wb, lane, line);
   for (int reg = 0; reg < 16; ++reg) {
     int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
     float acc = c[reg];
@@ -160,15 +173,16 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x
   hipemu::wave_sync();
   return c;
 }
-static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int, int line = __builtin_LINE()) {
   hipemu::BlockRunner* r = hipemu::g_runner;
   int t = hipemu::flat_tid(), lane = t & 63, wb = t & ~63;
   uint32_t ua, ub;
   memcpy(&ua, &a, 4);
   memcpy(&ub, &b, 4);
-  r->xa[t] = ua;
+  r->xa[t] = ua | ((uint64_t)(uint32_t)line << 32);
   r->xb[t] = ub;
   hipemu::wave_sync();
+  hipemu_mfma_check(r, wb, lane, line);
   for (int reg = 0; reg < 4; ++reg) {
     int row = (lane >> 4) * 4 + reg, col = lane & 15;
     float acc = c[reg];

@@ -43,6 +43,20 @@ def test_conv_1x1_permuted_tile(backend, monkeypatch, B, H, C0, C1, Cout, K, str
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+STREAM_CASES = [   # 1x1 weight gradients on the LDS-free streaming kernels: ragged pixel counts and channel groups
+    (75, 1, 32, 0, 200, 1, 1, 0, 0),     # 128-wide dY operand, last group ragged (72 of 128), 75 pixels (1x1 images)
+    (49, 1, 32, 100, 24, 1, 1, 0, 0),    # 128-wide X operand across a concat boundary (32 + 100 channels), Cout < 32, 49 pixels
+    (9, 1, 16, 0, 40, 1, 1, 0, 0),       # 32x32 tiles, 9 pixels (fewer than one per wave pair)
+    (2, 16, 128, 0, 384, 1, 1, 0, 0),    # both operands wide: dY side taken
+    (63, 1, 16, 0, 40, 1, 1, 0, 0),      # last wave gets 15 pixels: the unrolled loop bound must stay wave-uniform (MFMA ignores exec)
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM_CASES)
+def test_conv_1x1_stream_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 PERSIST_CASES = [   # 3x3 convs walked persistently (several m-tiles per workgroup) once the slot count is lowered
     (6, 16, 32, 0, 32, 3, 1, 1, 0),      # 12 m-tiles -> 3 workgroups x 4 tiles, two Cin chunks
     (5, 8, 16, 16, 64, 3, 1, 1, 0),      # two images per tile, ragged last workgroup, two n-tiles, concat source

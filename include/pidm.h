@@ -194,6 +194,17 @@ size_t pidm_conv_wgrad_ws(const pidm_conv_desc* d);
 int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const float* src1, const float* dy, int ld_dy,
                     float* dw_ref, float* dbias, void* workspace, void* stream);
 
+/* Linear attention core of SpatialLinearAttention.forward (src/unet_model.py:281-299) between the to_qkv and to_out 1x1
+ * convolutions: q.softmax(dim=-2) * scale, k.softmax(dim=-1), context = k v^T / N, out = context^T q.
+ *   qkv  [B][N][3*heads*32] channels-last (q | k | v, head-major), N = h*w pixels;  out [B][N][heads*32]
+ *   saved for the backward: kstat [B][heads*32][2], ctx [B][heads][32][32], qstat [B][N][heads][2]
+ *   backward: d_out [B][N][heads*32] -> dqkv [B][N][3*heads*32]                                                     */
+size_t pidm_linear_attention_ws(int B, int N, int heads);
+int pidm_linear_attention_forward(const float* qkv, float* out, float* kstat, float* ctx, float* qstat, int B, int N,
+                                  int heads, void* workspace, void* stream);
+int pidm_linear_attention_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
+                                   const float* d_out, float* dqkv, int B, int N, int heads, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

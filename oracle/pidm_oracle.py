@@ -220,11 +220,10 @@ def _chan_layernorm(x, gamma):
     return (x - mean) / (var + 1e-5).sqrt() * gamma.reshape(1, -1, 1, 1)
 
 
-def _linear_attention(p, pre, x, heads, dim_head):
-    """Residual(PreNorm(SpatialLinearAttention)): src/unet_model.py:281-299, 139-145, 212-220."""
-    B, C, H, W = x.shape
-    xn = _chan_layernorm(x, p[pre + "norm.gamma"])
-    qkv = F.conv2d(xn, p[pre + "fn.to_qkv.weight"])
+def linear_attention_core(qkv, heads, dim_head):
+    """The attention proper of SpatialLinearAttention.forward, src/unet_model.py:287-297 (between to_qkv and to_out):
+    qkv [B, 3*heads*dim_head, H, W] -> [B, heads*dim_head, H, W]."""
+    B, _, H, W = qkv.shape
     q, k, v = qkv.chunk(3, dim=1)
     q = q.reshape(B, heads, dim_head, H * W)
     k = k.reshape(B, heads, dim_head, H * W)
@@ -233,7 +232,14 @@ def _linear_attention(p, pre, x, heads, dim_head):
     k = k.softmax(dim=-1)
     v = v / (H * W)
     ctx = torch.einsum("bhdn,bhen->bhde", k, v)
-    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, heads * dim_head, H, W)
+    return torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, heads * dim_head, H, W)
+
+
+def _linear_attention(p, pre, x, heads, dim_head):
+    """Residual(PreNorm(SpatialLinearAttention)): src/unet_model.py:281-299, 139-145, 212-220."""
+    xn = _chan_layernorm(x, p[pre + "norm.gamma"])
+    qkv = F.conv2d(xn, p[pre + "fn.to_qkv.weight"])
+    out = linear_attention_core(qkv, heads, dim_head)
     out = F.conv2d(out, p[pre + "fn.to_out.weight"], p[pre + "fn.to_out.bias"])
     return out + x
 

@@ -86,6 +86,9 @@ class PidmLib:
         self._sig("pidm_conv_dgrad", [C.POINTER(ConvDesc), vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_conv_wgrad_ws", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_wgrad", [C.POINTER(ConvDesc), vp, vp, vp, i, vp, vp, vp, vp])
+        self._sig("pidm_linear_attention_ws", [i, i, i], sz)
+        self._sig("pidm_linear_attention_forward", [vp, vp, vp, vp, vp, i, i, i, vp, vp])
+        self._sig("pidm_linear_attention_backward", [vp, vp, vp, vp, vp, vp, i, i, i, vp, vp])
         if L.pidm_version() != 1:
             raise PidmError(f"{path}: ABI version {L.pidm_version()} != 1")
 

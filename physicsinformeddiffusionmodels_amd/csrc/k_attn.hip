@@ -595,3 +595,26 @@ int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N,
 }
 
 }  // namespace pidm
+
+// ---- unit-level C ABI (include/pidm.h): workspace = [dctx | rowdot | kernel scratch] ---------------------------------
+extern "C" size_t pidm_linear_attention_ws(int B, int N, int heads) {
+  return ((size_t)B * heads * (1024 + 32) + pidm::la_scratch_floats(B, N, heads)) * sizeof(float);
+}
+extern "C" int pidm_linear_attention_forward(const float* qkv, float* out, float* kstat, float* ctx, float* qstat, int B, int N,
+                                             int heads, void* workspace, void* stream) {
+  if (!qkv || !out || !kstat || !ctx || !qstat || !workspace || B < 1 || N < 1 || heads < 1)
+    return pidm::fail("linear attention: bad arguments");
+  float* scratch = reinterpret_cast<float*>(workspace) + (size_t)B * heads * (1024 + 32);
+  return pidm::launch_la_forward(qkv, kstat, ctx, out, qstat, B, N, heads, scratch, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pidm_linear_attention_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
+                                              const float* d_out, float* dqkv, int B, int N, int heads, void* workspace,
+                                              void* stream) {
+  if (!qkv || !kstat || !qstat || !ctx || !d_out || !dqkv || !workspace || B < 1 || N < 1 || heads < 1)
+    return pidm::fail("linear attention backward: bad arguments");
+  float* dctx = reinterpret_cast<float*>(workspace);
+  float* rowdot = dctx + (size_t)B * heads * 1024;
+  float* scratch = rowdot + (size_t)B * heads * 32;
+  return pidm::launch_la_backward(qkv, kstat, qstat, ctx, d_out, dctx, rowdot, dqkv, B, N, heads, scratch,
+                                  reinterpret_cast<hipStream_t>(stream));
+}

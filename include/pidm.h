@@ -204,6 +204,13 @@ int pidm_linear_attention_forward(const float* qkv, float* out, float* kstat, fl
                                   int heads, void* workspace, void* stream);
 int pidm_linear_attention_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
                                    const float* d_out, float* dqkv, int B, int N, int heads, void* workspace, void* stream);
+/* The same backward fused with the to_out 1x1 projection (src/unet_model.py:298): takes the gradient d_y [B][N][Cout] of the
+ * projection's output and its weights w_out [Cout][heads*32] (reference layout), returns dqkv and the projection's weight
+ * gradient dw_out [Cout][heads*32] without materialising d_out.  N % 128 == 0, Cout in {32, 64, 128}. */
+size_t pidm_linear_attention_out_backward_ws(int B, int N, int heads, int Cout);
+int pidm_linear_attention_out_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
+                                       const float* d_y, int ld_dy, const float* w_out, int Cout, float* dqkv, float* dw_out,
+                                       int B, int N, int heads, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

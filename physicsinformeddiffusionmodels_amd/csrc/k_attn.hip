@@ -410,6 +410,235 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Backward fused with the to_out 1x1 convolution (weights W[Cout][HD], output gradient dY[B][N][Cout]):
+// dA = dY W is never written.  With G[b,h][d][c] = sum_n qs[n][(h,d)] dY[n][c]  (qs = softmax_d(q)*scale):
+//   dctx[b,h][d][e]   = sum_n qs[n][d] dA[n][e]         = sum_c G[d][c] W[c][(h,e)]
+//   dW[c][(h,e)]      = sum_n dY[n][c] out[n][(h,e)]    = sum_b sum_d G[b,h][d][c] ctx[b,h][d][e]
+// so one n-reduction (reads q and the Cout-channel dY instead of q and the HD-channel dA) replaces the conv dgrad, the
+// dctx reduction and the conv wgrad (which read the materialised attention output); the per-pixel kernel rebuilds its
+// dA tile from dY on the matrix cores.
+// ---------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv, const float* __restrict__ qstat,
+                                                   const float* __restrict__ dy, int ld_dy, float* __restrict__ Gpart, int N,
+                                                   int heads, float scale) {
+  __shared__ float red[4][1024];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+  const int ns = blockIdx.y, NS = gridDim.y;
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[NT];
+  for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int per_blk = (N + NS - 1) / NS;
+  const int blk_lo = ns * per_blk, blk_hi = (blk_lo + per_blk < N) ? blk_lo + per_blk : N;
+  const int per = (blk_hi - blk_lo + 3) / 4;
+  const int n_lo = blk_lo + wave * per, n_hi = (n_lo + per < blk_hi) ? n_lo + per : blk_hi;
+  const float* qb = qkv + (size_t)b * N * 3 * HD + h * DH + l31;
+  const float* sb = qstat + ((size_t)b * N * heads + h) * 2;
+  const float* yb = dy + (size_t)b * N * ld_dy + l31;
+  constexpr int UNR = (NT <= 2) ? 4 : 2;
+  int n0 = n_lo;
+  for (; n0 + 2 * UNR <= n_hi; n0 += 2 * UNR) {       // wave-uniform bounds, UNR independent pixel pairs in flight
+    float qa[UNR], bv[UNR][NT];
+    float2 qs[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const size_t n = (size_t)(n0 + 2 * u + half);
+      qa[u] = qb[n * 3 * HD];
+      qs[u] = *reinterpret_cast<const float2*>(sb + n * heads * 2);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[u][t] = yb[n * ld_dy + 32 * t];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float a = expf(qa[u] - qs[u].x) * qs[u].y * scale;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[u][t], acc[t], 0, 0, 0);
+    }
+  }
+  for (; n0 < n_hi; n0 += 2) {
+    const int n = n0 + half;
+    float a = 0.f, bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = 0.f;
+    if (n < n_hi) {
+      const float2 qs = *reinterpret_cast<const float2*>(sb + (size_t)n * heads * 2);
+      a = expf(qb[(size_t)n * 3 * HD] - qs.x) * qs.y * scale;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = yb[(size_t)n * ld_dy + 32 * t];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[wave][row * 32 + l31] = acc[t][r];
+    }
+    __syncthreads();
+    float* out = Gpart + (((size_t)bh * NS + ns) * NT + t) * 1024;
+    for (int e = tid; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+}
+
+// per (b,h): G = sum of the pixel-split partials (fixed order); dctx = G W_h; rowdot[d] = sum_e dctx[d][e] ctx[d][e];
+// this image's share of the to_out weight gradient dWpart[b][c][(h,e)] = sum_d G[d][c] ctx[d][e] (summed over b by the
+// caller's deterministic split reduction).  Cout = 32*NT.
+template <int NT>
+__global__ void __launch_bounds__(256) la_g_final_kernel(const float* __restrict__ Gpart, const float* __restrict__ ctx,
+                                                         const float* __restrict__ w_out, float* __restrict__ dctx,
+                                                         float* __restrict__ rowdot, float* __restrict__ dwpart, int NS,
+                                                         int heads) {
+  constexpr int CO = 32 * NT;
+  __shared__ float sG[32][CO + 1], sC[32][33], sP[32][33];
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  const int HD = heads * DH;
+  for (int i = tid; i < NT * 1024; i += 256) {
+    const int t = i >> 10, r = i & 1023;
+    float v = 0.f;
+    for (int k = 0; k < NS; ++k) v += Gpart[(((size_t)bh * NS + k) * NT + t) * 1024 + r];
+    sG[r >> 5][32 * t + (r & 31)] = v;
+  }
+  for (int i = tid; i < 1024; i += 256) sC[i >> 5][i & 31] = ctx[(size_t)bh * 1024 + i];
+  __syncthreads();
+  const int e = tid & 31, r0 = tid >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < CO; ++c) {
+    const float w = w_out[(size_t)c * HD + h * DH + e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fmaf(sG[r0 + 8 * i][c], w, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = r0 + 8 * i;
+    dctx[(size_t)bh * 1024 + d * 32 + e] = acc[i];
+    sP[d][e] = acc[i] * sC[d][e];
+  }
+  for (int c = r0; c < CO; c += 8) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) a = fmaf(sG[d][c], sC[d][e], a);
+    dwpart[((size_t)b * CO + c) * HD + h * DH + e] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float sacc = 0.f;
+    for (int j = 0; j < 32; ++j) sacc += sP[tid][j];
+    rowdot[(size_t)bh * 32 + tid] = sacc;
+  }
+}
+
+// per pixel (N % 128 == 0): one wave = 32 pixels, loops over heads.  The dq branch runs transposed: dA^T = W_h^T dY^T lands in
+// the MFMA C layout (row = channel e, column = pixel), which IS the B-operand layout of dq'^T = ctx dA^T (k = e in the
+// accumulator's own row order) - no shuffle, no LDS round trip; dq'^T again has one pixel per lane, so the softmax-Jacobian
+// dot over d is an in-lane sum plus one cross-half exchange, and q / dq move as float4.  dk and dv as in la_bwd_pix_mfma.
+__global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                               const float* __restrict__ qstat, const float* __restrict__ ctx,
+                                                               const float* __restrict__ dctx, const float* __restrict__ rowdot,
+                                                               const float* __restrict__ dy, int ld_dy,
+                                                               const float* __restrict__ w_out, int Cout,
+                                                               float* __restrict__ dqkv, int N, int heads, float scale) {
+  __shared__ float sc[32][33], sd[32][33], srd[32], skm[32], skis[32];
+  HIP_DYNAMIC_SHARED(float, sw)                            // [Cout][32]: this head's slice of the to_out weights
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const size_t pblk = (size_t)blockIdx.x * 128;
+  const int b = (int)(pblk / N);
+  const size_t pw = pblk + wave * 32;
+  const size_t pa = pw + l31;
+  const float invN = 1.f / (float)N;
+  const int CC = Cout / 32;
+  for (int h = 0; h < heads; ++h) {
+    const int bh = b * heads + h;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      sc[e >> 5][e & 31] = ctx[(size_t)bh * 1024 + e];
+      sd[e >> 5][e & 31] = dctx[(size_t)bh * 1024 + e];
+    }
+    for (int e = tid; e < Cout * 32; e += 256) sw[e] = w_out[(size_t)(e >> 5) * HD + h * DH + (e & 31)];
+    if (tid < 32) {
+      srd[tid] = rowdot[(size_t)bh * 32 + tid];
+      skm[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2];
+      skis[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2 + 1];
+    }
+    __syncthreads();
+    const float* rowA = qkv + pa * 3 * HD + h * DH;
+    f32x4 a_v[4], a_k[4], q4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a_k[j] = *reinterpret_cast<const f32x4*>(rowA + HD + 16 * half + 4 * j);
+      a_v[j] = *reinterpret_cast<const f32x4*>(rowA + 2 * HD + 16 * half + 4 * j);
+      q4[j] = *reinterpret_cast<const f32x4*>(rowA + 8 * j + 4 * half);          // q[pixel][d = 8j + 4half + 0..3]
+    }
+    const float2 qst = *reinterpret_cast<const float2*>(qstat + (pa * heads + h) * 2);
+    // dA^T[e][pixel] = sum_c W[c][(h,e)] dY[pixel][c]      (k = c = 32cc + 16half + s)
+    f32x16 accT;
+    for (int r = 0; r < 16; ++r) accT[r] = 0.f;
+    for (int cc = 0; cc < CC; ++cc) {
+      f32x4 by[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) by[j] = *reinterpret_cast<const f32x4*>(dy + pa * ld_dy + 32 * cc + 16 * half + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          accT = __builtin_amdgcn_mfma_f32_32x32x2f32(sw[(32 * cc + 16 * half + 4 * j + c) * 32 + l31], by[j][c], accT, 0, 0, 0);
+    }
+    f32x16 acc1, acc2, acc3;
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    // dq'^T[d][pixel] = sum_e ctx[d][e] dA^T[e][pixel]: register r of accT holds e = (r&3) + 8(r>>2) + 4half
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[l31][(r & 3) + 8 * (r >> 2) + 4 * half], accT[r], acc1, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kk = 16 * half + 4 * j + c;
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31][kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
+        const float pA = expf(a_k[j][c] - skm[kk]) * skis[kk];
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk][l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
+      }
+    }
+    // dq: this lane's pixel, d = (r&3) + 8(r>>2) + 4half = component (r&3) of q4[r>>2]
+    f32x4 qs4[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qs4[j][c] = expf(q4[j][c] - qst.x) * qst.y;
+        dot = fmaf(qs4[j][c], acc1[4 * j + c], dot);
+      }
+    dot += __shfl_xor(dot, 32);
+    float* orow = dqkv + pa * 3 * HD + h * DH;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = scale * qs4[j][c] * (acc1[4 * j + c] - dot);
+      *reinterpret_cast<f32x4*>(orow + 8 * j + 4 * half) = o;
+    }
+    // dk, dv in the C layout: row r -> pixel pw + prow, column l31 -> channel
+    const float km = skm[l31], kis = skis[l31], rd = srd[l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int prow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const size_t p = pw + prow;
+      const float kv = qkv[p * 3 * HD + HD + h * DH + l31];
+      float* o = dqkv + p * 3 * HD + h * DH + l31;
+      const float P = expf(kv - km) * kis;
+      o[HD] = P * (acc2[r] * invN - rd);
+      o[2 * HD] = acc3[r] * invN;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // bottleneck softmax attention over N <= 64 tokens, one workgroup per (b, h)
 // ---------------------------------------------------------------------------------------------------
 template <bool BWD>
@@ -576,6 +805,41 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
   return 0;
 }
 
+// backward of attention + to_out projection; dy [B][N][Cout] (leading dimension ld_dy), w_out [Cout][HD] (reference layout);
+// dwpart [B][Cout][HD]: per-image shares of the to_out weight gradient.  Eligibility: la_fused_ok.
+bool la_fused_ok(int N, int heads, int Cout, int ld_dy) {
+  static const bool off = getenv("PIDM_NO_LA_FUSED") != nullptr;
+  return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1;
+}
+size_t la_fused_scratch_floats(int B, int N, int heads, int Cout) {
+  return (size_t)B * heads * la_nsplit(N) * (Cout / 32) * 1024 + 64;
+}
+int launch_la_backward_fused(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dy, int ld_dy,
+                             const float* w_out, int Cout, float* dctx, float* rowdot, float* dqkv, float* dwpart, int B, int N,
+                             int heads, float* scratch, hipStream_t st) {
+  if (!la_fused_ok(N, heads, Cout, ld_dy)) return fail("fused attention backward: N=%d Cout=%d not eligible", N, Cout);
+  const float scale = 0.17677669529663687f;
+  const int NS = la_nsplit(N);
+  float* gpart = scratch;
+  const dim3 grid(B * heads, NS);
+#define PIDM_LA_G(NT_)                                                                                                        \
+  {                                                                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_g_kernel<NT_>), grid, dim3(256), 0, st, qkv, qstat, dy, ld_dy, gpart, N, heads, scale); \
+    PIDM_CHECK_LAUNCH("la_g_kernel");                                                                                         \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_g_final_kernel<NT_>), dim3(B * heads), dim3(256), 0, st, gpart, ctx, w_out, dctx,    \
+                       rowdot, dwpart, NS, heads);                                                                            \
+    PIDM_CHECK_LAUNCH("la_g_final_kernel");                                                                                   \
+  }
+  if (Cout == 32) PIDM_LA_G(1)
+  else if (Cout == 64) PIDM_LA_G(2)
+  else PIDM_LA_G(4)
+#undef PIDM_LA_G
+  hipLaunchKernelGGL(la_bwd_pix_fused_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), (size_t)Cout * 32 * sizeof(float), st,
+                     qkv, kstat, qstat, ctx, dctx, rowdot, dy, ld_dy, w_out, Cout, dqkv, N, heads, scale);
+  PIDM_CHECK_LAUNCH("la_bwd_pix_fused_kernel");
+  return 0;
+}
+
 int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st) {
   if (N > 64) return fail("mid attention: %d tokens > 64", N);
   const float scale = 0.17677669529663687f;
@@ -617,4 +881,24 @@ extern "C" int pidm_linear_attention_backward(const float* qkv, const float* kst
   float* scratch = rowdot + (size_t)B * heads * 32;
   return pidm::launch_la_backward(qkv, kstat, qstat, ctx, d_out, dctx, rowdot, dqkv, B, N, heads, scratch,
                                   reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" size_t pidm_linear_attention_out_backward_ws(int B, int N, int heads, int Cout) {
+  return ((size_t)B * heads * (1024 + 32) + (size_t)B * Cout * heads * 32 + pidm::la_fused_scratch_floats(B, N, heads, Cout)) *
+         sizeof(float);
+}
+extern "C" int pidm_linear_attention_out_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
+                                                  const float* d_y, int ld_dy, const float* w_out, int Cout, float* dqkv,
+                                                  float* dw_out, int B, int N, int heads, void* workspace, void* stream) {
+  if (!qkv || !kstat || !qstat || !ctx || !d_y || !w_out || !dqkv || !dw_out || !workspace || B < 1)
+    return pidm::fail("fused attention backward: bad arguments");
+  const int HD = heads * 32;
+  float* dctx = reinterpret_cast<float*>(workspace);
+  float* rowdot = dctx + (size_t)B * heads * 1024;
+  float* dwpart = rowdot + (size_t)B * heads * 32;
+  float* scratch = dwpart + (size_t)B * Cout * HD;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pidm::launch_la_backward_fused(qkv, kstat, qstat, ctx, d_y, ld_dy, w_out, Cout, dctx, rowdot, dqkv, dwpart, B, N, heads,
+                                     scratch, st))
+    return -1;
+  return pidm::launch_split_reduce(dwpart, dw_out, nullptr, nullptr, B, Cout, HD, 1, Cout, HD, st);
 }

@@ -1405,6 +1405,16 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->nblk = (unsigned)((total + 2047) / 2048);
   return d->nblk;
 }
+// dst[(m*N + n)*T + t] = sum over nsplit slabs partial[split][MP][T][NP] (fixed order); optional bias column sums
+int launch_split_reduce(const float* partial, float* dst, const float* bias_partial, float* dbias, int nsplit, int M, int N, int T,
+                        int MP, int NP, hipStream_t st) {
+  const size_t total = (size_t)M * N * T + (dbias ? M : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, partial, dst, bias_partial, dbias,
+                     nsplit, M, N, T, MP, NP);
+  PIDM_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return 0;
+}
+
 int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st) {
   if (ndesc <= 0 || nblocks == 0) return 0;
   hipLaunchKernelGGL(reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc);

@@ -23,6 +23,8 @@ struct ReduceQueue {
   }
 };
 int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st);
+int launch_split_reduce(const float* partial, float* dst, const float* bias_partial, float* dbias, int nsplit, int M, int N, int T,
+                        int MP, int NP, hipStream_t st);
 // k_conv.hip
 int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int ld0, int ld1, int Cout, int KH, int KW,
               int stride, int pad, int out_nchw, int ldo, int ldr);
@@ -62,6 +64,11 @@ int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int HW, cons
 size_t la_scratch_floats(int B, int N, int heads);
 int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
                       float* scratch, hipStream_t st);
+bool la_fused_ok(int N, int heads, int Cout, int ld_dy);
+size_t la_fused_scratch_floats(int B, int N, int heads, int Cout);
+int launch_la_backward_fused(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dy, int ld_dy,
+                             const float* w_out, int Cout, float* dctx, float* rowdot, float* dqkv, float* dwpart, int B, int N,
+                             int heads, float* scratch, hipStream_t st);
 int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
                        float* rowdot, float* dqkv, int B, int N, int heads, float* scratch, hipStream_t st);
 int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st);

@@ -716,20 +716,41 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
   const size_t npix = (size_t)B * N;
   const size_t mk = r.tmp.mark();
-  if (conv_wgrad(r, a.out, a.attn, nullptr, g_out)) return -1;
-  float* g_attn = r.tmp.alloc(npix * HD);
-  if (conv_dgrad(r, a.out, g_out, nullptr, g_attn)) return -1;
-  float* g_qkv = r.tmp.alloc(npix * 3 * HD);
-  if (a.mid) {
-    RUN(launch_mid_attn(a.qkvb, g_attn, g_qkv, B, N, heads, true, r.st));
-  } else {
+  float* g_qkv = nullptr;
+  float* g_xn = nullptr;
+  if (!a.mid && la_fused_ok(N, heads, C, C)) {
+    // attention backward fused with the to_out projection: the gradient of the attention output (npix*HD floats), the
+    // projection's dgrad and its wgrad over the materialised attention output are all replaced (k_attn.hip)
+    g_qkv = r.tmp.alloc(npix * 3 * HD);
     float* dctx = r.tmp.alloc((size_t)B * heads * 1024);
     float* rowdot = r.tmp.alloc((size_t)B * heads * 32);
-    RUN(launch_la_backward(a.qkvb, a.kstat, a.qstat, a.ctx, g_attn, dctx, rowdot, g_qkv, B, N, heads, r.scratch, r.st));
+    const size_t dwn = (size_t)B * C * HD;
+    float* dwpart = r.defer_on ? r.defer.alloc(dwn) : r.tmp.alloc(dwn);
+    float* cpart = (a.out.b >= 0) ? r.part_alloc(colsum_ws_bytes(npix, C)) : nullptr;
+    RUN(launch_la_backward_fused(a.qkvb, a.kstat, a.qstat, a.ctx, g_out, C, U->P[a.out.w], C, dctx, rowdot, g_qkv, dwpart, B, N,
+                                 heads, r.scratch, r.st));
+    if (U->have_grads && !r.dry) {
+      if (r.q()) r.q()->push(dwpart, U->G[a.out.w], nullptr, nullptr, (size_t)C * HD, B, C, HD, 1, C, HD);
+      else RUN(launch_split_reduce(dwpart, U->G[a.out.w], nullptr, nullptr, B, C, HD, 1, C, HD, r.st));
+      if (a.out.b >= 0) RUN(launch_colsum(g_out, npix, C, C, U->G[a.out.b], cpart, r.st, r.q()));
+    }
+    g_xn = r.tmp.alloc(npix * C);
+  } else {
+    if (conv_wgrad(r, a.out, a.attn, nullptr, g_out)) return -1;
+    float* g_attn = r.tmp.alloc(npix * HD);
+    if (conv_dgrad(r, a.out, g_out, nullptr, g_attn)) return -1;
+    g_qkv = r.tmp.alloc(npix * 3 * HD);
+    if (a.mid) {
+      RUN(launch_mid_attn(a.qkvb, g_attn, g_qkv, B, N, heads, true, r.st));
+    } else {
+      float* dctx = r.tmp.alloc((size_t)B * heads * 1024);
+      float* rowdot = r.tmp.alloc((size_t)B * heads * 32);
+      RUN(launch_la_backward(a.qkvb, a.kstat, a.qstat, a.ctx, g_attn, dctx, rowdot, g_qkv, B, N, heads, r.scratch, r.st));
+    }
+    g_xn = g_attn;  // reuse (npix*HD >= npix*C is not guaranteed) -> allocate when C > HD
+    if (C > HD) g_xn = r.tmp.alloc(npix * C);
   }
   if (conv_wgrad(r, a.qkv, a.xn, nullptr, g_qkv)) return -1;
-  float* g_xn = g_attn;  // reuse (npix*HD >= npix*C is not guaranteed) -> allocate when C > HD
-  if (C > HD) g_xn = r.tmp.alloc(npix * C);
   if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
   float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
   RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
@@ -763,6 +784,7 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
     conv_ws(a.qkv); conv_ws(a.out);
     upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
     upd(la_scratch_floats(B, a.H * a.H, U->heads) * sizeof(float));
+    if (!a.mid && la_fused_ok(a.H * a.H, U->heads, a.C, a.C)) upd(la_fused_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
   }
   for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }
   return mx;

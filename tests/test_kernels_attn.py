@@ -53,3 +53,48 @@ def test_linear_attention_fwd_bwd(backend, B, H, heads):
     for c in range(3):                                    # dq, dk, dv have very different magnitudes: compare each to its own scale
         sl = slice(c * HD, (c + 1) * HD)
         assert rel(gg[:, sl], gref[:, sl]) < 2e-5, "qkv"[c]
+
+
+FUSED_CASES = [
+    # B, H, heads, Cout
+    (2, 16, 4, 32),     # N = 256, one pixel split
+    (1, 32, 2, 64),     # N = 1024, two pixel splits, two output-channel tiles
+    (2, 16, 3, 128),    # four output-channel tiles (the 16x16 level of the Darcy model)
+    (1, 64, 2, 32),     # N = 4096: eight pixel splits
+]
+
+
+@pytest.mark.parametrize("B,H,heads,Cout", FUSED_CASES)
+def test_linear_attention_backward_fused_with_projection(backend, B, H, heads, Cout):
+    """dqkv and the to_out weight gradient from the gradient of the projection's OUTPUT (d_out = d_y W never stored)."""
+    import torch.nn.functional as F
+    L, dev = backend
+    st = stream_ptr(dev)
+    N, HD = H * H, heads * 32
+    g = torch.Generator().manual_seed(23 + H + Cout)
+    qkv = torch.randn(B, 3 * HD, H, H, generator=g) * 1.5
+    qkv[:, HD:2 * HD] += 2.0 * torch.randn(B, HD, 1, 1, generator=g)
+    w_out = torch.randn(Cout, HD, 1, 1, generator=g) * 0.2
+    d_y = torch.randn(B, Cout, H, H, generator=g)
+    qr, wr = qkv.clone().requires_grad_(True), w_out.clone().requires_grad_(True)
+    y = F.conv2d(O.linear_attention_core(qr, heads, 32), wr)
+    gq_ref, gw_ref = torch.autograd.grad(y, (qr, wr), d_y)
+
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    qd, dyd, wd = nhwc(qkv), nhwc(d_y), w_out.reshape(Cout, HD).contiguous().to(dev)
+    out = torch.empty(B, N, HD, device=dev)
+    kstat = torch.empty(B * HD * 2, device=dev)
+    ctx = torch.empty(B * heads * 1024, device=dev)
+    qstat = torch.empty(B * N * heads * 2, device=dev)
+    ws = torch.empty(max(L.pidm_linear_attention_ws(B, N, heads), L.pidm_linear_attention_out_backward_ws(B, N, heads, Cout)),
+                     dtype=torch.uint8, device=dev)
+    L.check(L.pidm_linear_attention_forward(ptr(qd), ptr(out), ptr(kstat), ptr(ctx), ptr(qstat), B, N, heads, ptr(ws), st))
+    dqkv = torch.empty(B, N, 3 * HD, device=dev)
+    dw = torch.empty(Cout, HD, device=dev)
+    L.check(L.pidm_linear_attention_out_backward(ptr(qd), ptr(kstat), ptr(qstat), ptr(ctx), ptr(dyd), Cout, ptr(wd), Cout,
+                                                 ptr(dqkv), ptr(dw), B, N, heads, ptr(ws), st))
+    gg = dqkv.reshape(B, H, H, 3 * HD).permute(0, 3, 1, 2)
+    for c in range(3):
+        sl = slice(c * HD, (c + 1) * HD)
+        assert rel(gg[:, sl], gq_ref[:, sl]) < 2e-5, "qkv"[c]
+    assert rel(dw, gw_ref.reshape(Cout, HD)) < 1e-5

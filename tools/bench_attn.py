@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from physicsinformeddiffusionmodels_amd._lib import get_lib, ptr, stream_ptr  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = get_lib(); dev = torch.device("cuda:0"); st = stream_ptr(dev)
-heads, HD = 4, 128
+heads, HD = 8, 256
 tot = [0.0, 0.0]
 for H in (64, 32, 16, 8):
     N = H * H

@@ -207,6 +207,11 @@ int pidm_linear_attention_backward(const float* qkv, const float* kstat, const f
 /* The same backward fused with the to_out 1x1 projection (src/unet_model.py:298): takes the gradient d_y [B][N][Cout] of the
  * projection's output and its weights w_out [Cout][heads*32] (reference layout), returns dqkv and the projection's weight
  * gradient dw_out [Cout][heads*32] without materialising d_out.  N % 128 == 0, Cout in {32, 64, 128}. */
+/* forward counterpart: y [B][N][Cout] = to_out(attention(qkv)) + bias + residual (either may be NULL) without storing the
+ * heads*32-channel attention output; workspace as pidm_linear_attention_ws. */
+int pidm_linear_attention_out_forward(const float* qkv, const float* w_out, const float* bias, const float* residual, float* y,
+                                      int Cout, float* kstat, float* ctx, float* qstat, int B, int N, int heads, void* workspace,
+                                      void* stream);
 size_t pidm_linear_attention_out_backward_ws(int B, int N, int heads, int Cout);
 int pidm_linear_attention_out_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx,
                                        const float* d_y, int ld_dy, const float* w_out, int Cout, float* dqkv, float* dw_out,

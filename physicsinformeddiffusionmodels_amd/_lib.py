@@ -89,6 +89,7 @@ class PidmLib:
         self._sig("pidm_linear_attention_ws", [i, i, i], sz)
         self._sig("pidm_linear_attention_forward", [vp, vp, vp, vp, vp, i, i, i, vp, vp])
         self._sig("pidm_linear_attention_backward", [vp, vp, vp, vp, vp, vp, i, i, i, vp, vp])
+        self._sig("pidm_linear_attention_out_forward", [vp, vp, vp, vp, vp, i, vp, vp, vp, i, i, i, vp, vp])
         self._sig("pidm_linear_attention_out_backward_ws", [i, i, i, i], sz)
         self._sig("pidm_linear_attention_out_backward", [vp, vp, vp, vp, vp, i, vp, i, vp, vp, i, i, i, vp, vp])
         if L.pidm_version() != 1:

@@ -418,6 +418,74 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
 // dctx reduction and the conv wgrad (which read the materialised attention output); the per-pixel kernel rebuilds its
 // dA tile from dY on the matrix cores.
 // ---------------------------------------------------------------------------------------------------
+// Forward fused with the projection: y[n][c] = sum_(h,e) out[n][(h,e)] W[c][(h,e)] + bias[c] + resid[n][c]; the attention output
+// out (HD channels per pixel) is never written.  Same transposed chaining: T^T[e][pixel] = sum_d ctx[d][e] qs[pixel][d] leaves
+// the matrix core in the B-operand layout of y^T[c][pixel] += W_h[c][e] T^T[e][pixel]; y^T has one pixel per lane with
+// groups of four consecutive channels -> float4 bias / residual / store.  One wave = 32 pixels, N % 128 == 0, Cout = 32*CT.
+template <int CT>
+__global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                          const float* __restrict__ w_out, const float* __restrict__ bias,
+                                                          const float* __restrict__ resid, float* __restrict__ y,
+                                                          float* __restrict__ qstat, int N, int heads, float scale) {
+  constexpr int CO = 32 * CT, COP = CO + 1;
+  __shared__ float sw[32 * COP];                           // [e][c]: this head's slice of W, transposed
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const size_t p = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;
+  const size_t b = ((size_t)blockIdx.x * 128) / N;
+  f32x16 accY[CT];
+  for (int t = 0; t < CT; ++t)
+    for (int r = 0; r < 16; ++r) accY[t][r] = 0.f;
+  for (int h = 0; h < heads; ++h) {
+    __syncthreads();
+    for (int i = tid; i < CO * 32; i += 256) sw[(i & 31) * COP + (i >> 5)] = w_out[(size_t)(i >> 5) * HD + h * DH + (i & 31)];
+    float qv[16];
+    const float* qp = qkv + p * 3 * HD + h * DH + 16 * half;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * k);
+      qv[4 * k] = v[0]; qv[4 * k + 1] = v[1]; qv[4 * k + 2] = v[2]; qv[4 * k + 3] = v[3];
+    }
+    float m = qv[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, qv[k]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      qv[k] = expf(qv[k] - m);
+      sum += qv[k];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    if (half == 0) *reinterpret_cast<float2*>(qstat + (p * heads + h) * 2) = make_float2(m, inv);
+    const float* cb = ctx + (b * heads + h) * 1024;
+    f32x16 accT;
+    for (int r = 0; r < 16; ++r) accT[r] = 0.f;
+    const float is = inv * scale;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      accT = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(16 * half + s2) * 32 + l31], qv[s2] * is, accT, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sw[((r & 3) + 8 * (r >> 2) + 4 * half) * COP + 32 * t + l31], accT[r],
+                                                       accY[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c0 = 32 * t + 8 * j + 4 * half;
+      f32x4 o = {accY[t][4 * j], accY[t][4 * j + 1], accY[t][4 * j + 2], accY[t][4 * j + 3]};
+      if (bias) o += *reinterpret_cast<const f32x4*>(bias + c0);
+      if (resid) o += *reinterpret_cast<const f32x4*>(resid + p * CO + c0);
+      *reinterpret_cast<f32x4*>(y + p * CO + c0) = o;
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv, const float* __restrict__ qstat,
                                                    const float* __restrict__ dy, int ld_dy, float* __restrict__ Gpart, int N,
@@ -811,6 +879,36 @@ bool la_fused_ok(int N, int heads, int Cout, int ld_dy) {
   static const bool off = getenv("PIDM_NO_LA_FUSED") != nullptr;
   return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1;
 }
+// forward: k statistics, context, then attention output x projection (+ bias + residual) in one kernel; y [B][N][Cout]
+int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* qstat, const float* w_out, const float* bias,
+                            const float* resid, float* y, int Cout, int B, int N, int heads, float* scratch, hipStream_t st) {
+  if (!la_fused_ok(N, heads, Cout, Cout)) return fail("fused attention forward: N=%d Cout=%d not eligible", N, Cout);
+  const int HD = heads * DH;
+  const float scale = 0.17677669529663687f;
+  const int nseg = la_kseg(N), NS = la_nsplit(N);
+  float* kpart = scratch;
+  float* dpart = scratch + (size_t)B * nseg * HD * 2;
+  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart);
+  PIDM_CHECK_LAUNCH("la_kstats_kernel");
+  hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
+  PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads, NS), dim3(256), 0, st, qkv, kstat, nullptr, nullptr,
+                     dpart, N, heads, scale);
+  PIDM_CHECK_LAUNCH("la_context");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
+                     1.f / (float)N);
+  PIDM_CHECK_LAUNCH("la_context_final");
+  const dim3 grid((unsigned)((size_t)B * N / 128));
+  if (Cout == 32)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<1>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+  else if (Cout == 64)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<2>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+  PIDM_CHECK_LAUNCH("la_out_proj_kernel");
+  return 0;
+}
+
 size_t la_fused_scratch_floats(int B, int N, int heads, int Cout) {
   return (size_t)B * heads * la_nsplit(N) * (Cout / 32) * 1024 + 64;
 }
@@ -901,4 +999,12 @@ extern "C" int pidm_linear_attention_out_backward(const float* qkv, const float*
                                      scratch, st))
     return -1;
   return pidm::launch_split_reduce(dwpart, dw_out, nullptr, nullptr, B, Cout, HD, 1, Cout, HD, st);
+}
+extern "C" int pidm_linear_attention_out_forward(const float* qkv, const float* w_out, const float* bias, const float* residual,
+                                                 float* y, int Cout, float* kstat, float* ctx, float* qstat, int B, int N,
+                                                 int heads, void* workspace, void* stream) {
+  if (!qkv || !w_out || !y || !kstat || !ctx || !qstat || !workspace || B < 1) return pidm::fail("fused attention forward: bad arguments");
+  float* scratch = reinterpret_cast<float*>(workspace) + (size_t)B * heads * (1024 + 32);
+  return pidm::launch_la_forward_fused(qkv, kstat, ctx, qstat, w_out, bias, residual, y, Cout, B, N, heads, scratch,
+                                       reinterpret_cast<hipStream_t>(stream));
 }

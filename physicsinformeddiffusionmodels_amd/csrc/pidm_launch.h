@@ -66,6 +66,8 @@ int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, f
                       float* scratch, hipStream_t st);
 bool la_fused_ok(int N, int heads, int Cout, int ld_dy);
 size_t la_fused_scratch_floats(int B, int N, int heads, int Cout);
+int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* qstat, const float* w_out, const float* bias,
+                            const float* resid, float* y, int Cout, int B, int N, int heads, float* scratch, hipStream_t st);
 int launch_la_backward_fused(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dy, int ld_dy,
                              const float* w_out, int Cout, float* dctx, float* rowdot, float* dqkv, float* dwpart, int B, int N,
                              int heads, float* scratch, hipStream_t st);

@@ -529,6 +529,19 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
   a.qkvb = act_alloc(r, npix * 3 * HD);
   if (conv_fwd(r, a.qkv, a.xn, nullptr, nullptr, a.qkvb)) return -1;
+  if (!a.mid && la_fused_ok(N, heads, C, C)) {
+    // attention output x to_out projection in one kernel: the HD-channel attention output is neither stored nor re-read
+    // (the fused backward does not need it either)
+    a.attn = nullptr;
+    a.kstat = act_alloc(r, (size_t)B * HD * 2);
+    a.ctx = act_alloc(r, (size_t)B * heads * 1024);
+    a.qstat = act_alloc(r, npix * heads * 2);
+    RUN(launch_la_forward_fused(a.qkvb, a.kstat, a.ctx, a.qstat, U->P[a.out.w], a.out.b >= 0 ? U->P[a.out.b] : nullptr, x, out, C, B,
+                                N, heads, r.scratch, r.st));
+    r.tmp.release(mk);
+    *out_p = out;
+    return 0;
+  }
   a.attn = act_alloc(r, npix * HD);
   if (a.mid) {
     RUN(launch_mid_attn(a.qkvb, nullptr, a.attn, B, N, heads, false, r.st));

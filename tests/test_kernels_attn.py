@@ -65,8 +65,9 @@ FUSED_CASES = [
 
 
 @pytest.mark.parametrize("B,H,heads,Cout", FUSED_CASES)
-def test_linear_attention_backward_fused_with_projection(backend, B, H, heads, Cout):
-    """dqkv and the to_out weight gradient from the gradient of the projection's OUTPUT (d_out = d_y W never stored)."""
+def test_linear_attention_fused_with_projection(backend, B, H, heads, Cout):
+    """forward: to_out(attention) + bias + residual without the attention output; backward: dqkv and the to_out weight gradient
+    from the gradient of the projection's OUTPUT (d_out = d_y W never stored), on the statistics the fused forward saved."""
     import torch.nn.functional as F
     L, dev = backend
     st = stream_ptr(dev)
@@ -82,13 +83,19 @@ def test_linear_attention_backward_fused_with_projection(backend, B, H, heads, C
 
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
     qd, dyd, wd = nhwc(qkv), nhwc(d_y), w_out.reshape(Cout, HD).contiguous().to(dev)
-    out = torch.empty(B, N, HD, device=dev)
     kstat = torch.empty(B * HD * 2, device=dev)
     ctx = torch.empty(B * heads * 1024, device=dev)
     qstat = torch.empty(B * N * heads * 2, device=dev)
     ws = torch.empty(max(L.pidm_linear_attention_ws(B, N, heads), L.pidm_linear_attention_out_backward_ws(B, N, heads, Cout)),
                      dtype=torch.uint8, device=dev)
-    L.check(L.pidm_linear_attention_forward(ptr(qd), ptr(out), ptr(kstat), ptr(ctx), ptr(qstat), B, N, heads, ptr(ws), st))
+    bias = torch.randn(Cout, generator=g)
+    resid = torch.randn(B, Cout, H, H, generator=g)
+    yd = torch.empty(B, N, Cout, device=dev)
+    bd, rd = bias.to(dev), nhwc(resid)
+    L.check(L.pidm_linear_attention_out_forward(ptr(qd), ptr(wd), ptr(bd), ptr(rd), ptr(yd), Cout, ptr(kstat), ptr(ctx), ptr(qstat),
+                                                B, N, heads, ptr(ws), st))
+    y_ref = y.detach() + bias.reshape(1, -1, 1, 1) + resid
+    assert rel(yd.reshape(B, H, H, Cout).permute(0, 3, 1, 2), y_ref) < 5e-6
     dqkv = torch.empty(B, N, 3 * HD, device=dev)
     dw = torch.empty(Cout, HD, device=dev)
     L.check(L.pidm_linear_attention_out_backward(ptr(qd), ptr(kstat), ptr(qstat), ptr(ctx), ptr(dyd), Cout, ptr(wd), Cout,

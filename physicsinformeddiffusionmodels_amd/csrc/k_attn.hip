@@ -13,6 +13,12 @@
 namespace pidm {
 
 static const int DH = 32;  // dim_head (the 32x32 MFMA tile)
+static const int kLaHeadLds = 2 * 32 * 33 + 96;   // floats of LDS per head in la_bwd_pix_fused_kernel: ctx, dctx, rowdot, k max, k 1/sum
+
+// softmax exponentials: arguments are <= 0 after the max subtraction, so the hardware exp2 of x*log2(e) (2 instructions, relative
+// error <= |x| * 1e-7 on a term of size e^x) replaces the ~15-instruction libm expf; the per-pixel kernels issue 16-48 of these per
+// lane and head, which was on a par with their matrix-core time.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
 
 // ---- k softmax statistics over pixels: kstat[b][j] = (max_n, 1/sum_n exp(k - max)) -----------------
 // stage 1: online (max, sum) over one segment of pixels per block; stage 2 merges the segments.
@@ -39,14 +45,14 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
       const float mn = fmaxf(m, gm);
       float gs = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) gs += expf(v[u] - mn);
-      s = s * expf(m - mn) + gs;
+      for (int u = 0; u < 8; ++u) gs += fexp(v[u] - mn);
+      s = s * fexp(m - mn) + gs;
       m = mn;
     }
     for (; n < n_hi; n += 4) {
       const float v = base[(size_t)n * 3 * HD];
       const float mn = fmaxf(m, v);
-      s = s * expf(m - mn) + expf(v - mn);
+      s = s * fexp(m - mn) + fexp(v - mn);
       m = mn;
     }
   }
@@ -56,7 +62,7 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
   if (rl == 0 && j < HD) {
     float M = fmaxf(fmaxf(sm[0][cl], sm[1][cl]), fmaxf(sm[2][cl], sm[3][cl]));
     float S = 0.f;
-    for (int r = 0; r < 4; ++r) S += ssum[r][cl] * expf(sm[r][cl] - M);
+    for (int r = 0; r < 4; ++r) S += ssum[r][cl] * fexp(sm[r][cl] - M);
     kpart[(((size_t)b * nseg + seg) * HD + j) * 2] = M;
     kpart[(((size_t)b * nseg + seg) * HD + j) * 2 + 1] = S;
   }
@@ -70,7 +76,7 @@ __global__ void la_kstats_final_kernel(const float* __restrict__ kpart, int B, i
   float S = 0.f;
   for (int sg = 0; sg < nseg; ++sg) {
     const float* p = kpart + (((size_t)b * nseg + sg) * HD + j) * 2;
-    S += p[1] * expf(p[0] - M);
+    S += p[1] * fexp(p[0] - M);
   }
   kstat[(size_t)i * 2] = M;
   kstat[(size_t)i * 2 + 1] = 1.f / S;
@@ -88,7 +94,8 @@ __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
   const int ns = blockIdx.y, NS = gridDim.y;
   const int HD = heads * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar pixel ranges / row pointers (see la_g_kernel)
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* q0 = qkv + (size_t)b * N * 3 * HD;
@@ -101,17 +108,44 @@ __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict
   const int blk_lo = ns * per_blk, blk_hi = (blk_lo + per_blk < N) ? blk_lo + per_blk : N;
   const int per = (blk_hi - blk_lo + 3) / 4;
   const int n_lo = blk_lo + wave * per, n_hi = (n_lo + per < blk_hi) ? n_lo + per : blk_hi;
-  for (int n0 = n_lo; n0 < n_hi; n0 += 2) {
+  int n0 = n_lo;
+  {
+    // UNR independent pixel pairs in flight per wave (wave-uniform bounds): one load -> exp -> MFMA round trip per pair
+    // left this stream latency bound
+    constexpr int UNR = 4;
+    const int la = half * 3 * HD + (MODE == 0 ? HD : 0) + h * DH + l31;       // A source: k (MODE 0) or q (MODE 1)
+    const int lb = (MODE == 0) ? half * 3 * HD + 2 * HD + h * DH + l31 : half * HD + h * DH + l31;
+    const int ls = (half * heads + h) * 2;
+    for (; n0 + 2 * UNR <= n_hi; n0 += 2 * UNR) {
+      const float* qrow = q0 + (size_t)n0 * 3 * HD;
+      const float* brow = (MODE == 0) ? qrow : dA + ((size_t)b * N + n0) * HD;
+      const float* srow = (MODE == 0) ? nullptr : stat + ((size_t)b * N + n0) * heads * 2;
+      float av[UNR], bvv[UNR];
+      float2 qs[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        av[u] = (qrow + (size_t)(2 * u) * 3 * HD)[la];
+        bvv[u] = (brow + (size_t)(2 * u) * (MODE == 0 ? 3 * HD : HD))[lb];
+        if (MODE == 1) qs[u] = *reinterpret_cast<const float2*>(srow + (size_t)(2 * u) * heads * 2 + ls);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const float a = (MODE == 0) ? fexp(av[u] - cm) * cis : fexp(av[u] - qs[u].x) * qs[u].y * scale;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv[u], acc, 0, 0, 0);
+      }
+    }
+  }
+  for (; n0 < n_hi; n0 += 2) {
     const int n = n0 + half;
     float a = 0.f, bv = 0.f;
     if (n < n_hi) {
       const float* row = q0 + (size_t)n * 3 * HD;
       if (MODE == 0) {
-        a = expf(row[HD + h * DH + l31] - cm) * cis;
+        a = fexp(row[HD + h * DH + l31] - cm) * cis;
         bv = row[2 * HD + h * DH + l31];
       } else {
         const float* qs = stat + (((size_t)b * N + n) * heads + h) * 2;
-        a = expf(row[h * DH + l31] - qs[0]) * qs[1] * scale;
+        a = fexp(row[h * DH + l31] - qs[0]) * qs[1] * scale;
         bv = dA[((size_t)b * N + n) * HD + h * DH + l31];
       }
     }
@@ -184,7 +218,7 @@ __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ q
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      qv[k] = expf(qv[k] - m);
+      qv[k] = fexp(qv[k] - m);
       s += qv[k];
     }
     s += __shfl_xor(s, 32);
@@ -279,7 +313,7 @@ __global__ void __launch_bounds__(256) la_bwd_pix_kernel(const float* __restrict
     float dqp = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) dqp = fmaf(sc[d][e], da[e], dqp);
-    const float qs = expf(q[d] - qm) * qis;
+    const float qs = fexp(q[d] - qm) * qis;
     q[d] = qs;
     tmp[d] = dqp;
     dot = fmaf(qs, dqp, dot);
@@ -301,10 +335,10 @@ __global__ void __launch_bounds__(256) la_bwd_pix_kernel(const float* __restrict
   for (int k = 0; k < 8; ++k) {
     const float4 kk = *reinterpret_cast<const float4*>(row + HD + 4 * k);
     const float4 vv = *reinterpret_cast<const float4*>(row + 2 * HD + 4 * k);
-    P[4 * k] = expf(kk.x - skm[4 * k]) * skis[4 * k];
-    P[4 * k + 1] = expf(kk.y - skm[4 * k + 1]) * skis[4 * k + 1];
-    P[4 * k + 2] = expf(kk.z - skm[4 * k + 2]) * skis[4 * k + 2];
-    P[4 * k + 3] = expf(kk.w - skm[4 * k + 3]) * skis[4 * k + 3];
+    P[4 * k] = fexp(kk.x - skm[4 * k]) * skis[4 * k];
+    P[4 * k + 1] = fexp(kk.y - skm[4 * k + 1]) * skis[4 * k + 1];
+    P[4 * k + 2] = fexp(kk.z - skm[4 * k + 2]) * skis[4 * k + 2];
+    P[4 * k + 3] = fexp(kk.w - skm[4 * k + 3]) * skis[4 * k + 3];
     v[4 * k] = vv.x; v[4 * k + 1] = vv.y; v[4 * k + 2] = vv.z; v[4 * k + 3] = vv.w;
   }
 #pragma unroll
@@ -384,7 +418,7 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
         const int s = 4 * j + c, kk = 16 * half + s;
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dA[j][c], sc[l31][kk], acc1, 0, 0, 0);   // dq'[n][d] += dA[n][e] ctx[d][e]
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31][kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
-        const float pA = expf(a_k[j][c] - skm[kk]) * skis[kk];
+        const float pA = fexp(a_k[j][c] - skm[kk]) * skis[kk];
         acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk][l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
       }
     }
@@ -396,13 +430,13 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
       const size_t p = pw + prow;
       const float* rowC = qkv + p * 3 * HD + h * DH + l31;
       const float qm = qstat[(p * heads + h) * 2], qis = qstat[(p * heads + h) * 2 + 1];
-      const float qs = expf(rowC[0] - qm) * qis;
+      const float qs = fexp(rowC[0] - qm) * qis;
       float dot = qs * acc1[r];
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1) dot += __shfl_xor(dot, off);
       float* o = dqkv + p * 3 * HD + h * DH + l31;
       o[0] = scale * qs * (acc1[r] - dot);
-      const float P = expf(rowC[HD] - km) * kis;
+      const float P = fexp(rowC[HD] - km) * kis;
       o[HD] = P * (acc2[r] * invN - rd);
       o[2 * HD] = acc3[r] * invN;
     }
@@ -424,11 +458,12 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
 // groups of four consecutive channels -> float4 bias / residual / store.  One wave = 32 pixels, N % 128 == 0, Cout = 32*CT.
 template <int CT>
 __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                          const float* __restrict__ w_out, const float* __restrict__ bias,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
                                                           const float* __restrict__ resid, float* __restrict__ y,
                                                           float* __restrict__ qstat, int N, int heads, float scale) {
-  constexpr int CO = 32 * CT, COP = CO + 1;
-  __shared__ float sw[32 * COP];                           // [e][c]: this head's slice of W, transposed
+  // wt = W^T [HD][Cout] (la_wt_kernel): the A operand W_h[c = lane][e] is then a coalesced 128-byte row per e, served by L1/L2
+  // like the context - no LDS, no barrier, and the next head's q is in flight while this head computes
+  constexpr int CO = 32 * CT;
   const int HD = heads * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const size_t p = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;
@@ -436,15 +471,17 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
   f32x16 accY[CT];
   for (int t = 0; t < CT; ++t)
     for (int r = 0; r < 16; ++r) accY[t][r] = 0.f;
-  for (int h = 0; h < heads; ++h) {
-    __syncthreads();
-    for (int i = tid; i < CO * 32; i += 256) sw[(i & 31) * COP + (i >> 5)] = w_out[(size_t)(i >> 5) * HD + h * DH + (i & 31)];
-    float qv[16];
-    const float* qp = qkv + p * 3 * HD + h * DH + 16 * half;
+  const float* qp = qkv + p * 3 * HD + 16 * half;
+  f32x4 qn[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * k);
-      qv[4 * k] = v[0]; qv[4 * k + 1] = v[1]; qv[4 * k + 2] = v[2]; qv[4 * k + 3] = v[3];
+  for (int k = 0; k < 4; ++k) qn[k] = *reinterpret_cast<const f32x4*>(qp + 4 * k);
+  for (int h = 0; h < heads; ++h) {
+    float qv[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { qv[4 * k] = qn[k][0]; qv[4 * k + 1] = qn[k][1]; qv[4 * k + 2] = qn[k][2]; qv[4 * k + 3] = qn[k][3]; }
+    if (h + 1 < heads) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qn[k] = *reinterpret_cast<const f32x4*>(qp + (h + 1) * DH + 4 * k);
     }
     float m = qv[0];
 #pragma unroll
@@ -453,7 +490,7 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      qv[k] = expf(qv[k] - m);
+      qv[k] = fexp(qv[k] - m);
       sum += qv[k];
     }
     sum += __shfl_xor(sum, 32);
@@ -466,13 +503,12 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2)
       accT = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(16 * half + s2) * 32 + l31], qv[s2] * is, accT, 0, 0, 0);
-    __syncthreads();
+    const float* wh = wt + (size_t)(h * DH + 4 * half) * CO + l31;
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sw[((r & 3) + 8 * (r >> 2) + 4 * half) * COP + 32 * t + l31], accT[r],
-                                                       accY[t], 0, 0, 0);
+        accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[((r & 3) + 8 * (r >> 2)) * CO + 32 * t], accT[r], accY[t], 0, 0, 0);
   }
 #pragma unroll
   for (int t = 0; t < CT; ++t)
@@ -486,6 +522,12 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
     }
 }
 
+// wt[hd][c] = w[c][hd]  (Cout x HD, a few 10 KB)
+__global__ void la_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int HD) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Cout * HD) wt[(size_t)(i % HD) * Cout + i / HD] = w[i];
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv, const float* __restrict__ qstat,
                                                    const float* __restrict__ dy, int ld_dy, float* __restrict__ Gpart, int N,
@@ -494,7 +536,10 @@ __global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
   const int ns = blockIdx.y, NS = gridDim.y;
   const int HD = heads * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  // the wave index as a scalar: pixel ranges, loop bounds and row pointers then live in SGPRs and every load is
+  // (uniform row pointer) + (32-bit lane offset) - the 64-bit per-lane address arithmetic was ~20 VALU per MFMA
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   f32x16 acc[NT];
   for (int t = 0; t < NT; ++t)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -505,22 +550,25 @@ __global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv
   const float* qb = qkv + (size_t)b * N * 3 * HD + h * DH + l31;
   const float* sb = qstat + ((size_t)b * N * heads + h) * 2;
   const float* yb = dy + (size_t)b * N * ld_dy + l31;
+  const int lq = half * 3 * HD + h * DH + l31, ls = (half * heads + h) * 2, ly = half * ld_dy + l31;
   constexpr int UNR = (NT <= 2) ? 4 : 2;
   int n0 = n_lo;
   for (; n0 + 2 * UNR <= n_hi; n0 += 2 * UNR) {       // wave-uniform bounds, UNR independent pixel pairs in flight
     float qa[UNR], bv[UNR][NT];
     float2 qs[UNR];
+    const float* qrow = qkv + ((size_t)b * N + n0) * 3 * HD;
+    const float* srow = qstat + ((size_t)b * N + n0) * heads * 2;
+    const float* yrow = dy + ((size_t)b * N + n0) * ld_dy;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const size_t n = (size_t)(n0 + 2 * u + half);
-      qa[u] = qb[n * 3 * HD];
-      qs[u] = *reinterpret_cast<const float2*>(sb + n * heads * 2);
+      qa[u] = (qrow + (size_t)(2 * u) * 3 * HD)[lq];
+      qs[u] = *reinterpret_cast<const float2*>(srow + (size_t)(2 * u) * heads * 2 + ls);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[u][t] = yb[n * ld_dy + 32 * t];
+      for (int t = 0; t < NT; ++t) bv[u][t] = (yrow + (size_t)(2 * u) * ld_dy + 32 * t)[ly];
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const float a = expf(qa[u] - qs[u].x) * qs[u].y * scale;
+      const float a = fexp(qa[u] - qs[u].x) * qs[u].y * scale;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[u][t], acc[t], 0, 0, 0);
     }
@@ -532,7 +580,7 @@ __global__ void __launch_bounds__(256) la_g_kernel(const float* __restrict__ qkv
     for (int t = 0; t < NT; ++t) bv[t] = 0.f;
     if (n < n_hi) {
       const float2 qs = *reinterpret_cast<const float2*>(sb + (size_t)n * heads * 2);
-      a = expf(qb[(size_t)n * 3 * HD] - qs.x) * qs.y * scale;
+      a = fexp(qb[(size_t)n * 3 * HD] - qs.x) * qs.y * scale;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[t] = yb[(size_t)n * ld_dy + 32 * t];
     }
@@ -610,8 +658,10 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
                                                                const float* __restrict__ dy, int ld_dy,
                                                                const float* __restrict__ w_out, int Cout,
                                                                float* __restrict__ dqkv, int N, int heads, float scale) {
-  __shared__ float sc[32][33], sd[32][33], srd[32], skm[32], skis[32];
-  HIP_DYNAMIC_SHARED(float, sw)                            // [Cout][32]: this head's slice of the to_out weights
+  // all heads' ctx / dctx / k statistics are staged once (kLaHeadLds floats per head): no barrier inside the head loop, so the
+  // next head's operands are in flight while this head is on the matrix cores.  W_h rows come straight from global memory
+  // (lane = e: coalesced 128-byte rows, L1 / L2 resident).
+  HIP_DYNAMIC_SHARED(float, sm)
   const int HD = heads * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const size_t pblk = (size_t)blockIdx.x * 128;
@@ -620,33 +670,61 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
   const size_t pa = pw + l31;
   const float invN = 1.f / (float)N;
   const int CC = Cout / 32;
+  for (int i = tid; i < heads * 1024; i += 256) {
+    float* hs = sm + (size_t)(i >> 10) * kLaHeadLds;
+    const int e = i & 1023;
+    hs[(e >> 5) * 33 + (e & 31)] = ctx[(size_t)b * heads * 1024 + i];
+    hs[1056 + (e >> 5) * 33 + (e & 31)] = dctx[(size_t)b * heads * 1024 + i];
+  }
+  for (int i = tid; i < heads * 32; i += 256) {
+    float* hs = sm + (size_t)(i >> 5) * kLaHeadLds + 2112;
+    hs[i & 31] = rowdot[(size_t)b * heads * 32 + i];
+    hs[32 + (i & 31)] = kstat[((size_t)b * HD + i) * 2];
+    hs[64 + (i & 31)] = kstat[((size_t)b * HD + i) * 2 + 1];
+  }
+  __syncthreads();
+  const float* rowA = qkv + pa * 3 * HD;
+  f32x4 n_v[4], n_k[4], n_q[4];
+  float2 n_qst;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    n_k[j] = *reinterpret_cast<const f32x4*>(rowA + HD + 16 * half + 4 * j);
+    n_v[j] = *reinterpret_cast<const f32x4*>(rowA + 2 * HD + 16 * half + 4 * j);
+    n_q[j] = *reinterpret_cast<const f32x4*>(rowA + 8 * j + 4 * half);
+  }
+  n_qst = *reinterpret_cast<const float2*>(qstat + pa * heads * 2);
+  f32x4 by0[4];                                             // the dY tile is the same for every head (first 32 channels kept)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) by0[j] = *reinterpret_cast<const f32x4*>(dy + pa * ld_dy + 16 * half + 4 * j);
   for (int h = 0; h < heads; ++h) {
-    const int bh = b * heads + h;
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
-      sc[e >> 5][e & 31] = ctx[(size_t)bh * 1024 + e];
-      sd[e >> 5][e & 31] = dctx[(size_t)bh * 1024 + e];
-    }
-    for (int e = tid; e < Cout * 32; e += 256) sw[e] = w_out[(size_t)(e >> 5) * HD + h * DH + (e & 31)];
-    if (tid < 32) {
-      srd[tid] = rowdot[(size_t)bh * 32 + tid];
-      skm[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2];
-      skis[tid] = kstat[((size_t)b * HD + h * DH + tid) * 2 + 1];
-    }
-    __syncthreads();
-    const float* rowA = qkv + pa * 3 * HD + h * DH;
+    const float* sc = sm + (size_t)h * kLaHeadLds;          // [32][33]
+    const float* sd = sc + 1056;                            // [32][33]
+    const float* srd = sc + 2112;
+    const float* skm = srd + 32;
+    const float* skis = srd + 64;
     f32x4 a_v[4], a_k[4], q4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a_k[j] = *reinterpret_cast<const f32x4*>(rowA + HD + 16 * half + 4 * j);
-      a_v[j] = *reinterpret_cast<const f32x4*>(rowA + 2 * HD + 16 * half + 4 * j);
-      q4[j] = *reinterpret_cast<const f32x4*>(rowA + 8 * j + 4 * half);          // q[pixel][d = 8j + 4half + 0..3]
+    for (int j = 0; j < 4; ++j) { a_v[j] = n_v[j]; a_k[j] = n_k[j]; q4[j] = n_q[j]; }
+    const float2 qst = n_qst;
+    if (h + 1 < heads) {
+      const float* rn = rowA + (h + 1) * DH;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        n_k[j] = *reinterpret_cast<const f32x4*>(rn + HD + 16 * half + 4 * j);
+        n_v[j] = *reinterpret_cast<const f32x4*>(rn + 2 * HD + 16 * half + 4 * j);
+        n_q[j] = *reinterpret_cast<const f32x4*>(rn + 8 * j + 4 * half);          // q[pixel][d = 8j + 4half + 0..3]
+      }
+      n_qst = *reinterpret_cast<const float2*>(qstat + (pa * heads + h + 1) * 2);
     }
-    const float2 qst = *reinterpret_cast<const float2*>(qstat + (pa * heads + h) * 2);
     // dA^T[e][pixel] = sum_c W[c][(h,e)] dY[pixel][c]      (k = c = 32cc + 16half + s)
     f32x16 accT;
     for (int r = 0; r < 16; ++r) accT[r] = 0.f;
-    for (int cc = 0; cc < CC; ++cc) {
+    const float* wh = w_out + (size_t)(16 * half) * HD + h * DH + l31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(size_t)(4 * j + c) * HD], by0[j][c], accT, 0, 0, 0);
+    for (int cc = 1; cc < CC; ++cc) {
       f32x4 by[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) by[j] = *reinterpret_cast<const f32x4*>(dy + pa * ld_dy + 32 * cc + 16 * half + 4 * j);
@@ -654,22 +732,22 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          accT = __builtin_amdgcn_mfma_f32_32x32x2f32(sw[(32 * cc + 16 * half + 4 * j + c) * 32 + l31], by[j][c], accT, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(size_t)(32 * cc + 4 * j + c) * HD], by[j][c], accT, 0, 0, 0);
     }
     f32x16 acc1, acc2, acc3;
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
     // dq'^T[d][pixel] = sum_e ctx[d][e] dA^T[e][pixel]: register r of accT holds e = (r&3) + 8(r>>2) + 4half
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[l31][(r & 3) + 8 * (r >> 2) + 4 * half], accT[r], acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half], accT[r], acc1, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int kk = 16 * half + 4 * j + c;
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31][kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
-        const float pA = expf(a_k[j][c] - skm[kk]) * skis[kk];
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk][l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31 * 33 + kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
+        const float pA = fexp(a_k[j][c] - skm[kk]) * skis[kk];
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk * 33 + l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
       }
     }
     // dq: this lane's pixel, d = (r&3) + 8(r>>2) + 4half = component (r&3) of q4[r>>2]
@@ -679,7 +757,7 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        qs4[j][c] = expf(q4[j][c] - qst.x) * qst.y;
+        qs4[j][c] = fexp(q4[j][c] - qst.x) * qst.y;
         dot = fmaf(qs4[j][c], acc1[4 * j + c], dot);
       }
     dot += __shfl_xor(dot, 32);
@@ -699,7 +777,7 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
       const size_t p = pw + prow;
       const float kv = qkv[p * 3 * HD + HD + h * DH + l31];
       float* o = dqkv + p * 3 * HD + h * DH + l31;
-      const float P = expf(kv - km) * kis;
+      const float P = fexp(kv - km) * kis;
       o[HD] = P * (acc2[r] * invN - rd);
       o[2 * HD] = acc3[r] * invN;
     }
@@ -748,7 +826,7 @@ __global__ void __launch_bounds__(256) mid_attn_kernel(const float* __restrict__
     for (int j = 0; j < N; ++j) m = fmaxf(m, sS(tid, j));
     float s = 0.f;
     for (int j = 0; j < N; ++j) {
-      const float ex = expf(sS(tid, j) - m);
+      const float ex = fexp(sS(tid, j) - m);
       sS(tid, j) = ex;
       s += ex;
     }
@@ -821,7 +899,7 @@ static int la_kseg(int N) {
 // floats of scratch needed by launch_la_forward / launch_la_backward
 size_t la_scratch_floats(int B, int N, int heads) {
   const size_t a = (size_t)B * la_kseg(N) * heads * DH * 2, b = (size_t)B * heads * la_nsplit(N) * 1024;
-  return a + b + 64;
+  return a + b + (size_t)heads * DH * 128 + 64;   // + the transposed to_out weights of the fused forward (Cout <= 128)
 }
 
 int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
@@ -877,7 +955,7 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
 // dwpart [B][Cout][HD]: per-image shares of the to_out weight gradient.  Eligibility: la_fused_ok.
 bool la_fused_ok(int N, int heads, int Cout, int ld_dy) {
   static const bool off = getenv("PIDM_NO_LA_FUSED") != nullptr;
-  return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1;
+  return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1 && heads <= 14;
 }
 // forward: k statistics, context, then attention output x projection (+ bias + residual) in one kernel; y [B][N][Cout]
 int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* qstat, const float* w_out, const float* bias,
@@ -898,17 +976,28 @@ int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* q
   hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
                      1.f / (float)N);
   PIDM_CHECK_LAUNCH("la_context_final");
+  float* wt = dpart + (size_t)B * heads * NS * 1024;
+  hipLaunchKernelGGL(la_wt_kernel, dim3(cdiv(Cout * HD, 256)), dim3(256), 0, st, w_out, wt, Cout, HD);
+  PIDM_CHECK_LAUNCH("la_wt_kernel");
   const dim3 grid((unsigned)((size_t)B * N / 128));
   if (Cout == 32)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<1>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<1>), grid, dim3(256), 0, st, qkv, ctx, wt, bias, resid, y, qstat, N, heads, scale);
   else if (Cout == 64)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<2>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<2>), grid, dim3(256), 0, st, qkv, ctx, wt, bias, resid, y, qstat, N, heads, scale);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, w_out, bias, resid, y, qstat, N, heads, scale);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_proj_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, wt, bias, resid, y, qstat, N, heads, scale);
   PIDM_CHECK_LAUNCH("la_out_proj_kernel");
   return 0;
 }
 
+// the engine's choice: the fused per-pixel kernels do the projection's work per 128-pixel workgroup, which pays once the grid
+// fills the chip (>= one workgroup per CU); below that (16x16 level at batch 64: 128 workgroups) the separate projection convs
+// with their own tiling win by ~30 %.  PIDM_LA_FUSED_MIN_WGS overrides (tests: 1).
+bool la_fused_pays(int B, int N) {
+  const char* mw = getenv("PIDM_LA_FUSED_MIN_WGS");
+  const long min_wgs = mw ? atol(mw) : 256;
+  return (long)B * N / 128 >= min_wgs;
+}
 size_t la_fused_scratch_floats(int B, int N, int heads, int Cout) {
   return (size_t)B * heads * la_nsplit(N) * (Cout / 32) * 1024 + 64;
 }
@@ -932,7 +1021,13 @@ int launch_la_backward_fused(const float* qkv, const float* kstat, const float* 
   else if (Cout == 64) PIDM_LA_G(2)
   else PIDM_LA_G(4)
 #undef PIDM_LA_G
-  hipLaunchKernelGGL(la_bwd_pix_fused_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), (size_t)Cout * 32 * sizeof(float), st,
+  const size_t lds = (size_t)heads * kLaHeadLds * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_bwd_pix_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(la_bwd_pix_fused_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), lds, st,
                      qkv, kstat, qstat, ctx, dctx, rowdot, dy, ld_dy, w_out, Cout, dqkv, N, heads, scale);
   PIDM_CHECK_LAUNCH("la_bwd_pix_fused_kernel");
   return 0;

@@ -65,6 +65,7 @@ size_t la_scratch_floats(int B, int N, int heads);
 int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, float* qstat, int B, int N, int heads,
                       float* scratch, hipStream_t st);
 bool la_fused_ok(int N, int heads, int Cout, int ld_dy);
+bool la_fused_pays(int B, int N);
 size_t la_fused_scratch_floats(int B, int N, int heads, int Cout);
 int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* qstat, const float* w_out, const float* bias,
                             const float* resid, float* y, int Cout, int B, int N, int heads, float* scratch, hipStream_t st);

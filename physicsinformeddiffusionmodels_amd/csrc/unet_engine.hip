@@ -529,7 +529,7 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
   a.qkvb = act_alloc(r, npix * 3 * HD);
   if (conv_fwd(r, a.qkv, a.xn, nullptr, nullptr, a.qkvb)) return -1;
-  if (!a.mid && la_fused_ok(N, heads, C, C)) {
+  if (!a.mid && (la_fused_ok(N, heads, C, C) && la_fused_pays(B, N))) {
     // attention output x to_out projection in one kernel: the HD-channel attention output is neither stored nor re-read
     // (the fused backward does not need it either)
     a.attn = nullptr;
@@ -731,7 +731,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   const size_t mk = r.tmp.mark();
   float* g_qkv = nullptr;
   float* g_xn = nullptr;
-  if (!a.mid && la_fused_ok(N, heads, C, C)) {
+  if (!a.mid && (la_fused_ok(N, heads, C, C) && la_fused_pays(B, N))) {
     // attention backward fused with the to_out projection: the gradient of the attention output (npix*HD floats), the
     // projection's dgrad and its wgrad over the materialised attention output are all replaced (k_attn.hip)
     g_qkv = r.tmp.alloc(npix * 3 * HD);
@@ -797,7 +797,7 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
     conv_ws(a.qkv); conv_ws(a.out);
     upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
     upd(la_scratch_floats(B, a.H * a.H, U->heads) * sizeof(float));
-    if (!a.mid && la_fused_ok(a.H * a.H, U->heads, a.C, a.C)) upd(la_fused_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
+    if (!a.mid && la_fused_ok(a.H * a.H, U->heads, a.C, a.C) && la_fused_pays(B, a.H * a.H)) upd(la_fused_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
   }
   for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }
   return mx;

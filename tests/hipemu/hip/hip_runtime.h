@@ -198,6 +198,9 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
   hipemu::wave_sync();
   return c;
 }
+// v_readfirstlane_b32: lane 0's value for the whole wave (kernels use it to tell the compiler a value is wave-uniform)
+static inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 
@@ -210,6 +213,8 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return reinterpret_cast<std::atomic<int>*>(p)->fetch_add(v); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return reinterpret_cast<std::atomic<unsigned>*>(p)->fetch_add(v); }
+static inline float hipemu_fast_expf(float x) { return exp2f(x * 1.4426950408889634f); }   // v_mul_f32 + v_exp_f32
+#define __expf(x) hipemu_fast_expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -68,16 +68,19 @@ def test_unet_dim16_p32(backend):
     run_case(backend, "g5b_unet_dim16_p32", 16, True)
 
 
-def test_unet_dim32_p64_emulated():
+def test_unet_dim32_p64_emulated(monkeypatch):
     """The full Darcy model (dim=32, 64x64: golden g6 from the genuine reference) through the host emulator, ~15 s
     (the same golden runs on the real GPU in test_unet_dim32_p64_gpu)."""
     from tests.emu_util import emu_lib
+    monkeypatch.setenv("PIDM_LA_FUSED_MIN_WGS", "1")     # batch 2: take the attention+projection fused kernels as the full-size step does
     run_case((emu_lib(), torch.device("cpu")), "g6_unet_dim32_p64", 32, False)
 
 
 @pytest.mark.gpu
-def test_unet_dim32_p64_gpu():
+@pytest.mark.parametrize("fused_min_wgs", ["1", "1000000"])      # attention fused with the to_out projection / separate kernels
+def test_unet_dim32_p64_gpu(monkeypatch, fused_min_wgs):
     from physicsinformeddiffusionmodels_amd._lib import get_lib
+    monkeypatch.setenv("PIDM_LA_FUSED_MIN_WGS", fused_min_wgs)
     run_case((get_lib(), torch.device("cuda:0")), "g6_unet_dim32_p64", 32, False)
 
 

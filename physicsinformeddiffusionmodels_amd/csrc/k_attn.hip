@@ -13,7 +13,6 @@
 namespace pidm {
 
 static const int DH = 32;  // dim_head (the 32x32 MFMA tile)
-static const int kLaHeadLds = 2 * 32 * 33 + 96;   // floats of LDS per head in la_bwd_pix_fused_kernel: ctx, dctx, rowdot, k max, k 1/sum
 
 // softmax exponentials: arguments are <= 0 after the max subtraction, so the hardware exp2 of x*log2(e) (2 instructions, relative
 // error <= |x| * 1e-7 on a term of size e^x) replaces the ~15-instruction libm expf; the per-pixel kernels issue 16-48 of these per
@@ -475,13 +474,40 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
   f32x4 qn[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) qn[k] = *reinterpret_cast<const f32x4*>(qp + 4 * k);
+  // MFMA A operands (context rows, W^T rows) do not depend on the pixels: they are fetched one whole head ahead into registers.
+  // Left to the compiler, each dependent MFMA waited on a load issued four MFMAs earlier (L2 latency > 4 x 64 cycles): the
+  // chain ran at ~600 cycles per MFMA instead of 64.
+  constexpr int WT = (CT <= 2) ? CT : 1;                   // output-channel tiles whose W rows are fetched ahead (register budget)
+  float cn[16], wn[16 * WT];
+  {
+    const float* cb = ctx + (b * heads) * 1024 + (16 * half) * 32 + l31;
+    const float* wh = wt + (size_t)(4 * half) * CO + l31;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) cn[s2] = cb[s2 * 32];
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wn[16 * t + r] = wh[((r & 3) + 8 * (r >> 2)) * CO + 32 * t];
+  }
   for (int h = 0; h < heads; ++h) {
-    float qv[16];
+    float qv[16], ca[16], wa[16 * WT];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { qv[4 * k] = qn[k][0]; qv[4 * k + 1] = qn[k][1]; qv[4 * k + 2] = qn[k][2]; qv[4 * k + 3] = qn[k][3]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ca[i] = cn[i];
+#pragma unroll
+    for (int i = 0; i < 16 * WT; ++i) wa[i] = wn[i];
     if (h + 1 < heads) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) qn[k] = *reinterpret_cast<const f32x4*>(qp + (h + 1) * DH + 4 * k);
+      const float* cb = ctx + (b * heads + h + 1) * 1024 + (16 * half) * 32 + l31;
+      const float* wh = wt + (size_t)((h + 1) * DH + 4 * half) * CO + l31;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) cn[s2] = cb[s2 * 32];
+#pragma unroll
+      for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wn[16 * t + r] = wh[((r & 3) + 8 * (r >> 2)) * CO + 32 * t];
     }
     float m = qv[0];
 #pragma unroll
@@ -496,19 +522,26 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
     sum += __shfl_xor(sum, 32);
     const float inv = 1.f / sum;
     if (half == 0) *reinterpret_cast<float2*>(qstat + (p * heads + h) * 2) = make_float2(m, inv);
-    const float* cb = ctx + (b * heads + h) * 1024;
     f32x16 accT;
     for (int r = 0; r < 16; ++r) accT[r] = 0.f;
     const float is = inv * scale;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2)
-      accT = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[(16 * half + s2) * 32 + l31], qv[s2] * is, accT, 0, 0, 0);
-    const float* wh = wt + (size_t)(h * DH + 4 * half) * CO + l31;
+    for (int s2 = 0; s2 < 16; ++s2) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[s2], qv[s2] * is, accT, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[((r & 3) + 8 * (r >> 2)) * CO + 32 * t], accT[r], accY[t], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + r], accT[r], accY[t], 0, 0, 0);
+    if (WT < CT) {
+      const float* wh = wt + (size_t)(h * DH + 4 * half) * CO + l31;
+#pragma unroll
+      for (int t = WT; t < CT; ++t) {
+        float wl[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wl[r] = wh[((r & 3) + 8 * (r >> 2)) * CO + 32 * t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accY[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[r], accT[r], accY[t], 0, 0, 0);
+      }
+    }
   }
 #pragma unroll
   for (int t = 0; t < CT; ++t)
@@ -648,82 +681,61 @@ __global__ void __launch_bounds__(256) la_g_final_kernel(const float* __restrict
   }
 }
 
-// per pixel (N % 128 == 0): one wave = 32 pixels, loops over heads.  The dq branch runs transposed: dA^T = W_h^T dY^T lands in
-// the MFMA C layout (row = channel e, column = pixel), which IS the B-operand layout of dq'^T = ctx dA^T (k = e in the
-// accumulator's own row order) - no shuffle, no LDS round trip; dq'^T again has one pixel per lane, so the softmax-Jacobian
-// dot over d is an in-lane sum plus one cross-half exchange, and q / dq move as float4.  dk and dv as in la_bwd_pix_mfma.
-__global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
-                                                               const float* __restrict__ qstat, const float* __restrict__ ctx,
-                                                               const float* __restrict__ dctx, const float* __restrict__ rowdot,
-                                                               const float* __restrict__ dy, int ld_dy,
-                                                               const float* __restrict__ w_out, int Cout,
-                                                               float* __restrict__ dqkv, int N, int heads, float scale) {
-  // all heads' ctx / dctx / k statistics are staged once (kLaHeadLds floats per head): no barrier inside the head loop, so the
-  // next head's operands are in flight while this head is on the matrix cores.  W_h rows come straight from global memory
-  // (lane = e: coalesced 128-byte rows, L1 / L2 resident).
-  HIP_DYNAMIC_SHARED(float, sm)
+// per pixel (N % 128 == 0), one wave = 32 pixels, loops over heads; two kernels with disjoint inputs (dq: q, dY; dk/dv: k, v), each
+// small enough in registers for 3 waves per SIMD.  Everything runs TRANSPOSED (rows = channels, columns = pixels):
+//   dA^T = W_h^T dY^T lands in the MFMA C layout, which IS the B-operand layout of dq'^T = ctx dA^T (k = e in the accumulator's own
+//   row order) - no shuffle, no LDS round trip;
+//   every result has one pixel per lane and groups of four consecutive channels -> q / k / dq / dk / dv move as float4, the
+//   softmax-Jacobian dot over d is an in-lane sum plus one cross-half exchange, the k-softmax constants are LDS broadcasts.
+// All heads' 32x32 matrices are staged in LDS once: no barrier in the head loop, next head's operands in flight during the MFMAs.
+__global__ void __launch_bounds__(256, 3) la_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ qstat,
+                                                           const float* __restrict__ ctx, const float* __restrict__ dy, int ld_dy,
+                                                           const float* __restrict__ w_out, int Cout, float* __restrict__ dqkv,
+                                                           int N, int heads, float scale) {
+  HIP_DYNAMIC_SHARED(float, sm)                              // [heads][32][33] ctx
   const int HD = heads * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const size_t pblk = (size_t)blockIdx.x * 128;
   const int b = (int)(pblk / N);
-  const size_t pw = pblk + wave * 32;
-  const size_t pa = pw + l31;
-  const float invN = 1.f / (float)N;
+  const size_t pa = pblk + wave * 32 + l31;
   const int CC = Cout / 32;
-  for (int i = tid; i < heads * 1024; i += 256) {
-    float* hs = sm + (size_t)(i >> 10) * kLaHeadLds;
-    const int e = i & 1023;
-    hs[(e >> 5) * 33 + (e & 31)] = ctx[(size_t)b * heads * 1024 + i];
-    hs[1056 + (e >> 5) * 33 + (e & 31)] = dctx[(size_t)b * heads * 1024 + i];
-  }
-  for (int i = tid; i < heads * 32; i += 256) {
-    float* hs = sm + (size_t)(i >> 5) * kLaHeadLds + 2112;
-    hs[i & 31] = rowdot[(size_t)b * heads * 32 + i];
-    hs[32 + (i & 31)] = kstat[((size_t)b * HD + i) * 2];
-    hs[64 + (i & 31)] = kstat[((size_t)b * HD + i) * 2 + 1];
-  }
+  for (int i = tid; i < heads * 1024; i += 256) sm[(i >> 10) * 1056 + ((i & 1023) >> 5) * 33 + (i & 31)] = ctx[(size_t)b * heads * 1024 + i];
   __syncthreads();
   const float* rowA = qkv + pa * 3 * HD;
-  f32x4 n_v[4], n_k[4], n_q[4];
-  float2 n_qst;
+  f32x4 n_q[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    n_k[j] = *reinterpret_cast<const f32x4*>(rowA + HD + 16 * half + 4 * j);
-    n_v[j] = *reinterpret_cast<const f32x4*>(rowA + 2 * HD + 16 * half + 4 * j);
-    n_q[j] = *reinterpret_cast<const f32x4*>(rowA + 8 * j + 4 * half);
-  }
-  n_qst = *reinterpret_cast<const float2*>(qstat + pa * heads * 2);
+  for (int j = 0; j < 4; ++j) n_q[j] = *reinterpret_cast<const f32x4*>(rowA + 8 * j + 4 * half);
+  float2 n_qst = *reinterpret_cast<const float2*>(qstat + pa * heads * 2);
   f32x4 by0[4];                                             // the dY tile is the same for every head (first 32 channels kept)
 #pragma unroll
   for (int j = 0; j < 4; ++j) by0[j] = *reinterpret_cast<const f32x4*>(dy + pa * ld_dy + 16 * half + 4 * j);
-  for (int h = 0; h < heads; ++h) {
-    const float* sc = sm + (size_t)h * kLaHeadLds;          // [32][33]
-    const float* sd = sc + 1056;                            // [32][33]
-    const float* srd = sc + 2112;
-    const float* skm = srd + 32;
-    const float* skis = srd + 64;
-    f32x4 a_v[4], a_k[4], q4[4];
+  float wn[16];                                             // W rows (MFMA A operands) of the next head, fetched a head ahead
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a_v[j] = n_v[j]; a_k[j] = n_k[j]; q4[j] = n_q[j]; }
+  for (int i = 0; i < 16; ++i) wn[i] = w_out[(size_t)(16 * half + i) * HD + l31];
+  for (int h = 0; h < heads; ++h) {
+    const float* sc = sm + h * 1056;
+    f32x4 q4[4];
+    float wa[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q4[j] = n_q[j];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wa[i] = wn[i];
     const float2 qst = n_qst;
     if (h + 1 < heads) {
-      const float* rn = rowA + (h + 1) * DH;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        n_k[j] = *reinterpret_cast<const f32x4*>(rn + HD + 16 * half + 4 * j);
-        n_v[j] = *reinterpret_cast<const f32x4*>(rn + 2 * HD + 16 * half + 4 * j);
-        n_q[j] = *reinterpret_cast<const f32x4*>(rn + 8 * j + 4 * half);          // q[pixel][d = 8j + 4half + 0..3]
-      }
+      for (int i = 0; i < 16; ++i) wn[i] = w_out[(size_t)(16 * half + i) * HD + (h + 1) * DH + l31];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) n_q[j] = *reinterpret_cast<const f32x4*>(rowA + (h + 1) * DH + 8 * j + 4 * half);   // q[pixel][d = 8j + 4half + 0..3]
       n_qst = *reinterpret_cast<const float2*>(qstat + (pa * heads + h + 1) * 2);
     }
-    // dA^T[e][pixel] = sum_c W[c][(h,e)] dY[pixel][c]      (k = c = 32cc + 16half + s)
+    // dA^T[e][pixel] = sum_c W[c][(h,e)] dY[pixel][c]      (k = c = 32cc + 16half + s; W rows straight from global: lane = e)
     f32x16 accT;
     for (int r = 0; r < 16; ++r) accT[r] = 0.f;
     const float* wh = w_out + (size_t)(16 * half) * HD + h * DH + l31;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(size_t)(4 * j + c) * HD], by0[j][c], accT, 0, 0, 0);
+      for (int c = 0; c < 4; ++c) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * j + c], by0[j][c], accT, 0, 0, 0);
     for (int cc = 1; cc < CC; ++cc) {
       f32x4 by[4];
 #pragma unroll
@@ -734,23 +746,13 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
         for (int c = 0; c < 4; ++c)
           accT = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(size_t)(32 * cc + 4 * j + c) * HD], by[j][c], accT, 0, 0, 0);
     }
-    f32x16 acc1, acc2, acc3;
-    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
     // dq'^T[d][pixel] = sum_e ctx[d][e] dA^T[e][pixel]: register r of accT holds e = (r&3) + 8(r>>2) + 4half
+    f32x16 acc1;
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half], accT[r], acc1, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int kk = 16 * half + 4 * j + c;
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_v[j][c], sd[l31 * 33 + kk], acc2, 0, 0, 0);    // dP [n][d] += v[n][e] dctx[d][e]
-        const float pA = fexp(a_k[j][c] - skm[kk]) * skis[kk];
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA, sd[kk * 33 + l31], acc3, 0, 0, 0);           // dv [n][e] += P[n][d] dctx[d][e]
-      }
-    }
-    // dq: this lane's pixel, d = (r&3) + 8(r>>2) + 4half = component (r&3) of q4[r>>2]
+    // this lane's pixel, d = (r&3) + 8(r>>2) + 4half = component (r&3) of q4[r>>2]
     f32x4 qs4[4];
     float dot = 0.f;
 #pragma unroll
@@ -769,17 +771,80 @@ __global__ void __launch_bounds__(256) la_bwd_pix_fused_kernel(const float* __re
       for (int c = 0; c < 4; ++c) o[c] = scale * qs4[j][c] * (acc1[4 * j + c] - dot);
       *reinterpret_cast<f32x4*>(orow + 8 * j + 4 * half) = o;
     }
-    // dk, dv in the C layout: row r -> pixel pw + prow, column l31 -> channel
-    const float km = skm[l31], kis = skis[l31], rd = srd[l31];
+  }
+}
+
+// dk = P (dP/N - rowdot), dP^T[d][pixel] = sum_e dctx[d][e] v[pixel][e];  dv^T[e][pixel] = (1/N) sum_d dctx[d][e] P[pixel][d]
+static const int kLaDkvLds = 32 * 33 + 96;                  // floats per head: dctx, rowdot, k max, k 1/sum
+__global__ void __launch_bounds__(256, 3) la_bwd_dkdv_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                             const float* __restrict__ dctx, const float* __restrict__ rowdot,
+                                                             float* __restrict__ dqkv, int N, int heads) {
+  HIP_DYNAMIC_SHARED(float, sm)
+  const int HD = heads * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const size_t pblk = (size_t)blockIdx.x * 128;
+  const int b = (int)(pblk / N);
+  const size_t pa = pblk + wave * 32 + l31;
+  const float invN = 1.f / (float)N;
+  for (int i = tid; i < heads * 1024; i += 256)
+    sm[(i >> 10) * kLaDkvLds + ((i & 1023) >> 5) * 33 + (i & 31)] = dctx[(size_t)b * heads * 1024 + i];
+  for (int i = tid; i < heads * 32; i += 256) {
+    float* hs = sm + (i >> 5) * kLaDkvLds + 1056;
+    hs[i & 31] = rowdot[(size_t)b * heads * 32 + i];
+    hs[32 + (i & 31)] = kstat[((size_t)b * HD + i) * 2];
+    hs[64 + (i & 31)] = kstat[((size_t)b * HD + i) * 2 + 1];
+  }
+  __syncthreads();
+  const float* rowK = qkv + pa * 3 * HD + HD;
+  f32x4 n_k[4], n_v[4], n_k4[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int prow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const size_t p = pw + prow;
-      const float kv = qkv[p * 3 * HD + HD + h * DH + l31];
-      float* o = dqkv + p * 3 * HD + h * DH + l31;
-      const float P = fexp(kv - km) * kis;
-      o[HD] = P * (acc2[r] * invN - rd);
-      o[2 * HD] = acc3[r] * invN;
+  for (int j = 0; j < 4; ++j) {
+    n_k[j] = *reinterpret_cast<const f32x4*>(rowK + 16 * half + 4 * j);            // MFMA k order: channel 16half + 4j + c
+    n_v[j] = *reinterpret_cast<const f32x4*>(rowK + HD + 16 * half + 4 * j);
+    n_k4[j] = *reinterpret_cast<const f32x4*>(rowK + 8 * j + 4 * half);            // result row order: channel 8j + 4half + c
+  }
+  for (int h = 0; h < heads; ++h) {
+    const float* sd = sm + h * kLaDkvLds;
+    const float* srd = sd + 1056;
+    const float* skm = srd + 32;
+    const float* skis = srd + 64;
+    f32x4 a_k[4], a_v[4], k4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a_k[j] = n_k[j]; a_v[j] = n_v[j]; k4[j] = n_k4[j]; }
+    if (h + 1 < heads) {
+      const float* rn = rowK + (h + 1) * DH;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        n_k[j] = *reinterpret_cast<const f32x4*>(rn + 16 * half + 4 * j);
+        n_v[j] = *reinterpret_cast<const f32x4*>(rn + HD + 16 * half + 4 * j);
+        n_k4[j] = *reinterpret_cast<const f32x4*>(rn + 8 * j + 4 * half);
+      }
+    }
+    f32x16 acc2, acc3;
+    for (int r = 0; r < 16; ++r) { acc2[r] = 0.f; acc3[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kk = 16 * half + 4 * j + c;
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[l31 * 33 + kk], a_v[j][c], acc2, 0, 0, 0);      // dP^T[d][n] += dctx[d][e] v[n][e]
+        const float pB = fexp(a_k[j][c] - skm[kk]) * skis[kk];
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[kk * 33 + l31], pB, acc3, 0, 0, 0);             // dv^T[e][n] += dctx[d][e] P[n][d]
+      }
+    }
+    float* ok = dqkv + pa * 3 * HD + HD + h * DH;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 o_k, o_v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = 8 * j + 4 * half + c;
+        const float P = fexp(k4[j][c] - skm[d]) * skis[d];
+        o_k[c] = P * (acc2[4 * j + c] * invN - srd[d]);
+        o_v[c] = acc3[4 * j + c] * invN;
+      }
+      *reinterpret_cast<f32x4*>(ok + 8 * j + 4 * half) = o_k;
+      *reinterpret_cast<f32x4*>(ok + HD + 8 * j + 4 * half) = o_v;
     }
   }
 }
@@ -1021,15 +1086,13 @@ int launch_la_backward_fused(const float* qkv, const float* kstat, const float* 
   else if (Cout == 64) PIDM_LA_G(2)
   else PIDM_LA_G(4)
 #undef PIDM_LA_G
-  const size_t lds = (size_t)heads * kLaHeadLds * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_bwd_pix_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(la_bwd_pix_fused_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), lds, st,
-                     qkv, kstat, qstat, ctx, dctx, rowdot, dy, ld_dy, w_out, Cout, dqkv, N, heads, scale);
-  PIDM_CHECK_LAUNCH("la_bwd_pix_fused_kernel");
+  const dim3 gridp((unsigned)((size_t)B * N / 128));
+  hipLaunchKernelGGL(la_bwd_dq_kernel, gridp, dim3(256), (size_t)heads * 1056 * sizeof(float), st, qkv, qstat, ctx, dy, ld_dy, w_out, Cout,
+                     dqkv, N, heads, scale);
+  PIDM_CHECK_LAUNCH("la_bwd_dq_kernel");
+  hipLaunchKernelGGL(la_bwd_dkdv_kernel, gridp, dim3(256), (size_t)heads * kLaDkvLds * sizeof(float), st, qkv, kstat, dctx, rowdot, dqkv, N,
+                     heads);
+  PIDM_CHECK_LAUNCH("la_bwd_dkdv_kernel");
   return 0;
 }
 

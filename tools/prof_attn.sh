@@ -1,6 +1,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; export TMPDIR=/tmp PYTHONPATH=$R; out=$R/gpurun_out/pa; rm -rf $out; mkdir -p $out
-python $R/tools/bench_attn.py 64
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python $R/tools/bench_attn.py 64 > $out/log.txt 2>&1)
+true
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python $R/tools/bench_attn.py 64 64 > $out/log.txt 2>&1)
 python - "$out/p_kernel_trace.csv" <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

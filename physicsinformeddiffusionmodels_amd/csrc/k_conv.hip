@@ -1656,7 +1656,9 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   if (wgrad_smallc(g)) wg->tgs = T;   // (tap, channel) flattened: one block covers all taps
   wg->ntg = cdiv(T, wg->tgs);
   wg->MP = cdiv(g.Cout, 32) * 32;
-  wg->NP = cdiv(g.Cin, 32) * 32;
+  // small-C kernel: (tap, channel) is one flattened GEMM column index -> unpadded partial rows of T*Cin contiguous floats
+  // (padded to 32 channels, the init conv's 3136-element gradient cost 103 MB of scattered partial writes and reads)
+  wg->NP = wgrad_smallc(g) ? g.Cin : cdiv(g.Cin, 32) * 32;
   int blocks_mn = wgrad_smallc(g) ? (wg->MP / 32) : (wg->MP / 32) * (wg->NP / 32) * wg->ntg * g.nph;
   const int smode = wgrad_stream_mode(g, ld_dy);
   if (smode == 2) blocks_mn = cdiv(wg->MP, 128) * (wg->NP / 32);

@@ -945,6 +945,20 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     const bool same = U->red_table_dev == red_dev && U->red_table.size() == r.rq.v.size() &&
                       memcmp(U->red_table.data(), r.rq.v.data(), r.rq.v.size() * sizeof(ReduceDesc)) == 0;
     if (!same) {
+      if (getenv("PIDM_REDUCE_STATS")) {   // one line per table change: what the single deferred reduction reads
+        double bytes = 0, outs = 0;
+        int big = 0;
+        for (const ReduceDesc& d : r.rq.v) {
+          bytes += (double)d.nsplit * d.sstride * 4;
+          outs += (double)d.M * d.N * d.T;
+          if ((double)d.nsplit * d.sstride * 4 > 16e6) ++big;
+        }
+        fprintf(stderr, "[pidm] deferred reduction: %zu tensors, %.1f MB of partials -> %.2f M outputs, %u blocks, %d tensors > 16 MB\n",
+                r.rq.v.size(), bytes / 1e6, outs / 1e6, r.rq.nblocks, big);
+        for (const ReduceDesc& d : r.rq.v)
+          if ((double)d.nsplit * d.sstride * 4 > 8e6)
+            fprintf(stderr, "[pidm]   nsplit=%d M=%d N=%d T=%d: %.1f MB\n", d.nsplit, d.M, d.N, d.T, (double)d.nsplit * d.sstride * 4 / 1e6);
+      }
       U->red_table = r.rq.v;   // persistent host copy (source of the async upload)
       if (hipMemcpyAsync(red_dev, U->red_table.data(), U->red_table.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
         return fail("backward: reduction table upload failed");

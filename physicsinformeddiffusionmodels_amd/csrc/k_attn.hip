@@ -688,6 +688,7 @@ __global__ void __launch_bounds__(256) la_g_final_kernel(const float* __restrict
 //   every result has one pixel per lane and groups of four consecutive channels -> q / k / dq / dk / dv move as float4, the
 //   softmax-Jacobian dot over d is an in-lane sum plus one cross-half exchange, the k-softmax constants are LDS broadcasts.
 // All heads' 32x32 matrices are staged in LDS once: no barrier in the head loop, next head's operands in flight during the MFMAs.
+static const int kLaTileLd = 36;                            // row stride of a wave's 32x32 transposition tile (16-byte aligned, conflict-free)
 __global__ void __launch_bounds__(256, 3) la_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ qstat,
                                                            const float* __restrict__ ctx, const float* __restrict__ dy, int ld_dy,
                                                            const float* __restrict__ w_out, int Cout, float* __restrict__ dqkv,
@@ -701,6 +702,8 @@ __global__ void __launch_bounds__(256, 3) la_bwd_dq_kernel(const float* __restri
   const int CC = Cout / 32;
   for (int i = tid; i < heads * 1024; i += 256) sm[(i >> 10) * 1056 + ((i & 1023) >> 5) * 33 + (i & 31)] = ctx[(size_t)b * heads * 1024 + i];
   __syncthreads();
+  float* tb = sm + heads * 1056 + wave * (32 * kLaTileLd);
+  const int trow = lane >> 3, tcol = 4 * (lane & 7);
   const float* rowA = qkv + pa * 3 * HD;
   f32x4 n_q[4];
 #pragma unroll
@@ -763,13 +766,21 @@ __global__ void __launch_bounds__(256, 3) la_bwd_dq_kernel(const float* __restri
         dot = fmaf(qs4[j][c], acc1[4 * j + c], dot);
       }
     dot += __shfl_xor(dot, 32);
-    float* orow = dqkv + pa * 3 * HD + h * DH;
+    // one pixel per lane -> whole 128-byte lines through the wave's LDS tile (see la_bwd_dkdv_kernel)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 o;
 #pragma unroll
       for (int c = 0; c < 4; ++c) o[c] = scale * qs4[j][c] * (acc1[4 * j + c] - dot);
-      *reinterpret_cast<f32x4*>(orow + 8 * j + 4 * half) = o;
+      *reinterpret_cast<f32x4*>(tb + l31 * kLaTileLd + 8 * j + 4 * half) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* orow = dqkv + (pblk + wave * 32) * 3 * HD + h * DH;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (trow + 8 * it) * kLaTileLd + tcol);
+      *reinterpret_cast<f32x4*>(orow + (size_t)(trow + 8 * it) * 3 * HD + tcol) = v;
     }
   }
 }
@@ -795,6 +806,7 @@ __global__ void __launch_bounds__(256, 3) la_bwd_dkdv_kernel(const float* __rest
     hs[64 + (i & 31)] = kstat[((size_t)b * HD + i) * 2 + 1];
   }
   __syncthreads();
+  float* tb = sm + heads * kLaDkvLds + wave * (32 * kLaTileLd);
   const float* rowK = qkv + pa * 3 * HD + HD;
   f32x4 n_k[4], n_v[4], n_k4[4];
 #pragma unroll
@@ -832,19 +844,32 @@ __global__ void __launch_bounds__(256, 3) la_bwd_dkdv_kernel(const float* __rest
         acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[kk * 33 + l31], pB, acc3, 0, 0, 0);             // dv^T[e][n] += dctx[d][e] P[n][d]
       }
     }
-    float* ok = dqkv + pa * 3 * HD + HD + h * DH;
+    // results have one pixel per lane: written like that, a store instruction puts 32 bytes into each of 32 lines (measured
+    // 3.6 TB/s marginal against 5.6 for the loads).  Through a wave-private LDS tile they leave as whole 128-byte lines.
+    f32x4 o_k[4], o_v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f32x4 o_k, o_v;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int d = 8 * j + 4 * half + c;
         const float P = fexp(k4[j][c] - skm[d]) * skis[d];
-        o_k[c] = P * (acc2[4 * j + c] * invN - srd[d]);
-        o_v[c] = acc3[4 * j + c] * invN;
+        o_k[j][c] = P * (acc2[4 * j + c] * invN - srd[d]);
+        o_v[j][c] = acc3[4 * j + c] * invN;
       }
-      *reinterpret_cast<f32x4*>(ok + 8 * j + 4 * half) = o_k;
-      *reinterpret_cast<f32x4*>(ok + HD + 8 * j + 4 * half) = o_v;
+    }
+    float* ok = dqkv + (pblk + wave * 32) * 3 * HD + HD + h * DH;
+    const int trow = lane >> 3, tcol = 4 * (lane & 7);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __builtin_amdgcn_wave_barrier();                      // the previous tile has been read out
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(tb + l31 * kLaTileLd + 8 * j + 4 * half) = which ? o_v[j] : o_k[j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (trow + 8 * it) * kLaTileLd + tcol);
+        *reinterpret_cast<f32x4*>(ok + (size_t)(trow + 8 * it) * 3 * HD + which * HD + tcol) = v;
+      }
     }
   }
 }
@@ -1087,10 +1112,16 @@ int launch_la_backward_fused(const float* qkv, const float* kstat, const float* 
   else PIDM_LA_G(4)
 #undef PIDM_LA_G
   const dim3 gridp((unsigned)((size_t)B * N / 128));
-  hipLaunchKernelGGL(la_bwd_dq_kernel, gridp, dim3(256), (size_t)heads * 1056 * sizeof(float), st, qkv, qstat, ctx, dy, ld_dy, w_out, Cout,
+  static bool attr_done = false;
+  if (!attr_done) {   // more than 8 heads: the staged matrices + transposition tiles pass the 64 KiB default
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(la_bwd_dq_kernel, gridp, dim3(256), ((size_t)heads * 1056 + 4 * 32 * kLaTileLd) * sizeof(float), st, qkv, qstat, ctx, dy, ld_dy, w_out, Cout,
                      dqkv, N, heads, scale);
   PIDM_CHECK_LAUNCH("la_bwd_dq_kernel");
-  hipLaunchKernelGGL(la_bwd_dkdv_kernel, gridp, dim3(256), (size_t)heads * kLaDkvLds * sizeof(float), st, qkv, kstat, dctx, rowdot, dqkv, N,
+  hipLaunchKernelGGL(la_bwd_dkdv_kernel, gridp, dim3(256), ((size_t)heads * kLaDkvLds + 4 * 32 * kLaTileLd) * sizeof(float), st, qkv, kstat, dctx, rowdot, dqkv, N,
                      heads);
   PIDM_CHECK_LAUNCH("la_bwd_dkdv_kernel");
   return 0;

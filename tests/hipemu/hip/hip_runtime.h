@@ -108,6 +108,9 @@ inline T shfl_any(T v, int src_lane) {
 
 static inline void __syncthreads() { hipemu::yield_state(hipemu::WAIT_BLOCK); }
 static inline void __builtin_amdgcn_s_barrier() { hipemu::yield_state(hipemu::WAIT_BLOCK); }
+// s_nop-level scheduling barrier on the GPU (LDS operations of one wave execute in order); here the lanes of a wave are fibers, so
+// data exchanged through LDS inside a wave needs a real rendezvous
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 

@@ -38,6 +38,37 @@ __global__ void __launch_bounds__(256) slice_kernel(const float* x, float* out, 
   }
   if (s == 1234.5f) out[0] = 1.f;
 }
+// ---- the same question for stores: every variant writes each byte of the [pixels][C] tensor exactly once ----
+//   MODE 0 rows     : 1 KiB contiguous per wave instruction (a fill)
+//   MODE 1 line128  : one wave = 32 pixels; per instruction two pixels' 128-byte slices (4 B per lane; the MFMA C layout row-major)
+//   MODE 2 pix16    : lane = (pixel, half) stores 16 B: 32 B into each of 32 lines per instruction (result "one pixel per lane")
+//   MODE 3 seg512   : lane = 16 B of a 512-byte run of one pixel; two pixels per instruction (the 128-channel conv tile epilogue)
+template <int MODE>
+__global__ void __launch_bounds__(256) store_kernel(float* x, size_t npix, int C) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const f32x4 v4 = {1.f, 2.f, 3.f, 4.f};
+  if (MODE == 0) {
+    const size_t n4 = npix * C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) reinterpret_cast<f32x4*>(x)[i] = v4;
+    return;
+  }
+  const size_t p0 = w * 32;
+  if (p0 >= npix) return;
+  if (MODE == 1) {
+    for (int h = 0; h < C / 32; ++h)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[(p0 + 2 * k + half) * C + h * 32 + l31] = 1.f;
+  } else if (MODE == 2) {
+    for (int h = 0; h < C / 32; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(x + (p0 + l31) * C + h * 32 + 8 * k + 4 * half) = v4;
+  } else {
+    for (int g = 0; g < C / 128; ++g)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(x + (p0 + 2 * k + half) * C + g * 128 + 4 * l31) = v4;
+  }
+}
 template <class F> float timeit(F f) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   f(); hipDeviceSynchronize();
@@ -60,5 +91,13 @@ int main() {
   printf("slice128x4 %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
   t = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(slice_kernel<2>), dim3(grid), dim3(256), 0, 0, x, out, npix, C); });
   printf("planar     %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
+  t = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(store_kernel<0>), dim3(256 * 8), dim3(256), 0, 0, x, npix, C); });
+  printf("store rows     %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
+  t = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(store_kernel<1>), dim3(grid), dim3(256), 0, 0, x, npix, C); });
+  printf("store line128  %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
+  t = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(store_kernel<2>), dim3(grid), dim3(256), 0, 0, x, npix, C); });
+  printf("store pix16    %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
+  t = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(store_kernel<3>), dim3(grid), dim3(256), 0, 0, x, npix, C); });
+  printf("store seg512   %7.1f us  %5.2f TB/s\n", t * 1e3, gb / t);
   return 0;
 }

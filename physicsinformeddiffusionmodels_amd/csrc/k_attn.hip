@@ -8,6 +8,17 @@
 //   out[n][e]     = sum_d context[d][e] * softmax_d(q)[n][d]*scale   (K = 32)
 // q/k/v are never re-materialised after softmax: the softmax is applied on the fly from per-column (k) and
 // per-pixel (q) statistics.
+//
+// Kernel index
+//   la_kstats / la_kstats_final        k-softmax column statistics over the pixels (two stages)
+//   la_nreduce<MODE> / _final          32x32 pixel reductions per (image, head): context (MODE 0), dctx + rowdot (MODE 1)
+//   la_out<ALIGNED>                    out = context^T softmax_d(q)                          (separate-projection form)
+//   la_bwd_pix / la_bwd_pix_mfma       dq, dk, dv from dA                                    (separate-projection form)
+//   la_out_proj<CT>, la_wt             y = to_out(out) + bias + residual, out never stored   (fused form, forward)
+//   la_g<NT> / la_g_final<NT>          G = qs^T dY -> dctx = G W, rowdot, dW_out share       (fused form, backward)
+//   la_bwd_dq, la_bwd_dkdv             dq from (q, dY); dk, dv from (k, v); transposed MFMA chaining, full-line I/O
+//   mid_attn<BWD>                      bottleneck softmax attention (<= 64 tokens)
+// Launchers: launch_la_forward / _backward (separate), launch_la_forward_fused / _backward_fused (+ la_fused_ok, la_fused_pays).
 #include "pidm_launch.h"
 
 namespace pidm {

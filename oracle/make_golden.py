@@ -511,9 +511,39 @@ def g17():
     print("g17 datasets:", tuple(ds[0].shape), len(ds), tuple(dp[0].shape), len(dp))
 
 
+# G18: the SpatialLinearAttention module alone (src/unet_model.py:269-299), forward and all gradients ---------------------
+def g18():
+    from src.unet_model import SpatialLinearAttention
+    heads, dim, B, H = 2, 32, 2, 16
+    g = torch.Generator().manual_seed(1801)
+    m = SpatialLinearAttention(dim, heads=heads, dim_head=32)
+    with torch.no_grad():
+        m.to_qkv.weight.copy_(torch.randn(m.to_qkv.weight.shape, generator=g) * 0.25)
+        m.to_out.weight.copy_(torch.randn(m.to_out.weight.shape, generator=g) * 0.1)
+        m.to_out.bias.copy_(torch.randn(m.to_out.bias.shape, generator=g) * 0.1)
+    x = (torch.randn(B, dim, 1, H, H, generator=g) * 1.5).requires_grad_(True)
+    gy = torch.randn(B, dim, 1, H, H, generator=g)
+    qkv_keep = {}
+    def keep(mod, inp, out):
+        out.retain_grad()
+        qkv_keep["qkv"] = out
+
+    hk = m.to_qkv.register_forward_hook(keep)
+    y = m(x)
+    y.backward(gy)
+    hk.remove()
+    qkv = qkv_keep["qkv"]
+    np.savez_compressed(os.path.join(OUT, "g18_linear_attention.npz"), heads=heads, x=npy(x[:, :, 0]), gy=npy(gy[:, :, 0]),
+                        w_qkv=npy(m.to_qkv.weight[:, :, 0, 0]), w_out=npy(m.to_out.weight[:, :, 0, 0]), b_out=npy(m.to_out.bias),
+                        y=npy(y[:, :, 0]), d_qkv=npy(qkv.grad), d_x=npy(x.grad[:, :, 0]),
+                        d_w_qkv=npy(m.to_qkv.weight.grad[:, :, 0, 0]), d_w_out=npy(m.to_out.weight.grad[:, :, 0, 0]),
+                        d_b_out=npy(m.to_out.bias.grad))
+    print("g18 linear attention:", tuple(y.shape), float(y.abs().max()), float(qkv.grad.abs().max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"):
+        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -532,4 +562,5 @@ if __name__ == "__main__":
     g15()
     g16()
     g17()
+    g18()
     print("golden vectors written to", OUT)

@@ -105,3 +105,61 @@ def test_linear_attention_fused_with_projection(backend, B, H, heads, Cout):
         sl = slice(c * HD, (c + 1) * HD)
         assert rel(gg[:, sl], gq_ref[:, sl]) < 2e-5, "qkv"[c]
     assert rel(dw, gw_ref.reshape(Cout, HD)) < 1e-5
+
+
+def test_linear_attention_vs_reference_module_golden(backend):
+    """g18 (the genuine SpatialLinearAttention module run by oracle/make_golden.py): both forms of the kernels - attention with a
+    separate projection, and attention fused with to_out - against the reference's output and its gradients of qkv and
+    to_out.weight.  The two 1x1 convolutions around the attention are plain matrix products here."""
+    import os
+    import numpy as np
+    L, dev = backend
+    st = stream_ptr(dev)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g18_linear_attention.npz"))
+    heads = int(z["heads"])
+    x, gy = torch.tensor(z["x"]), torch.tensor(z["gy"])
+    w_qkv, w_out, b_out = torch.tensor(z["w_qkv"]), torch.tensor(z["w_out"]), torch.tensor(z["b_out"])
+    B, C, H, _ = x.shape
+    N, HD = H * H, heads * 32
+    xs = x.permute(0, 2, 3, 1).reshape(B, N, C)                              # channels-last pixels
+    qd = (xs @ w_qkv.t()).contiguous().to(dev)                               # to_qkv
+    gyd = gy.permute(0, 2, 3, 1).reshape(B, N, C).contiguous().to(dev)
+    wd, bd = w_out.contiguous().to(dev), b_out.to(dev)
+    kstat = torch.empty(B * HD * 2, device=dev)
+    ctx = torch.empty(B * heads * 1024, device=dev)
+    qstat = torch.empty(B * N * heads * 2, device=dev)
+    ws = torch.empty(max(L.pidm_linear_attention_ws(B, N, heads), L.pidm_linear_attention_out_backward_ws(B, N, heads, C)),
+                     dtype=torch.uint8, device=dev)
+    y_ref = torch.tensor(z["y"]).permute(0, 2, 3, 1).reshape(B, N, C)
+    dq_ref = torch.tensor(z["d_qkv"]).permute(0, 2, 3, 1).reshape(B, N, 3 * HD)
+
+    # (a) separate: attention kernels, projection as a matrix product
+    out = torch.empty(B, N, HD, device=dev)
+    L.check(L.pidm_linear_attention_forward(ptr(qd), ptr(out), ptr(kstat), ptr(ctx), ptr(qstat), B, N, heads, ptr(ws), st))
+    y_a = out.cpu() @ w_out.t() + b_out
+    assert rel(y_a, y_ref) < 5e-6
+    d_out = (gyd.cpu() @ w_out).contiguous().to(dev)
+    dqkv = torch.empty(B, N, 3 * HD, device=dev)
+    L.check(L.pidm_linear_attention_backward(ptr(qd), ptr(kstat), ptr(qstat), ptr(ctx), ptr(d_out), ptr(dqkv), B, N, heads, ptr(ws), st))
+    for c in range(3):
+        sl = slice(c * HD, (c + 1) * HD)
+        assert rel(dqkv[..., sl], dq_ref[..., sl]) < 2e-5, "qkv"[c]
+
+    # (b) fused with the projection
+    yd = torch.empty(B, N, C, device=dev)
+    L.check(L.pidm_linear_attention_out_forward(ptr(qd), ptr(wd), ptr(bd), None, ptr(yd), C, ptr(kstat), ptr(ctx), ptr(qstat), B, N, heads,
+                                                ptr(ws), st))
+    assert rel(yd, y_ref) < 5e-6
+    dqkv2 = torch.empty(B, N, 3 * HD, device=dev)
+    dw = torch.empty(C, HD, device=dev)
+    L.check(L.pidm_linear_attention_out_backward(ptr(qd), ptr(kstat), ptr(qstat), ptr(ctx), ptr(gyd), C, ptr(wd), C, ptr(dqkv2), ptr(dw),
+                                                 B, N, heads, ptr(ws), st))
+    for c in range(3):
+        sl = slice(c * HD, (c + 1) * HD)
+        assert rel(dqkv2[..., sl], dq_ref[..., sl]) < 2e-5, "qkv"[c]
+    assert rel(dw, torch.tensor(z["d_w_out"])) < 1e-5
+    # the gradients the reference reports for the surrounding convolutions follow from dqkv by plain products
+    d_x = dqkv2.cpu() @ w_qkv
+    assert rel(d_x, torch.tensor(z["d_x"]).permute(0, 2, 3, 1).reshape(B, N, C)) < 2e-5
+    d_wq = dqkv2.cpu().reshape(B * N, 3 * HD).t() @ xs.reshape(B * N, C)
+    assert rel(d_wq, torch.tensor(z["d_w_qkv"])) < 2e-5

@@ -153,3 +153,22 @@ def test_q4_stiffness_known_answers():
     assert np.abs(k @ tx).max() < 1e-12
     k2 = O.q4_plane_stress_stiffness(8.0 / 3.0, 1.0 / 3.0, 2.0)
     assert abs(k2[0, 0] - 8.0 / 6.0) < 1e-12  # SolidsPy documented example
+
+
+def test_linear_attention_module():
+    """g18: the genuine SpatialLinearAttention module (to_qkv -> attention -> to_out) with its gradients, including the gradient of
+    the qkv tensor itself (retained in the reference run) - the oracle's restatement of src/unet_model.py:281-299."""
+    import torch.nn.functional as F
+    z = load("g18_linear_attention.npz")
+    heads = int(z["heads"])
+    x = torch.tensor(z["x"]).requires_grad_(True)
+    w_qkv = torch.tensor(z["w_qkv"]).requires_grad_(True)
+    w_out = torch.tensor(z["w_out"]).requires_grad_(True)
+    b_out = torch.tensor(z["b_out"]).requires_grad_(True)
+    qkv = F.conv2d(x, w_qkv[:, :, None, None])
+    qkv.retain_grad()
+    y = F.conv2d(O.linear_attention_core(qkv, heads, 32), w_out[:, :, None, None], b_out)
+    y.backward(torch.tensor(z["gy"]))
+    assert rel_err(y.detach().numpy(), z["y"]) < 2e-6
+    for got, key in ((qkv.grad, "d_qkv"), (x.grad, "d_x"), (w_qkv.grad, "d_w_qkv"), (w_out.grad, "d_w_out"), (b_out.grad, "d_b_out")):
+        assert rel_err(got.numpy(), z[key]) < 5e-6, key

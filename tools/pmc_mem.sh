@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_mem.sh <outdir-name> <absolute python script + args...>   vector-memory path counters (TA / TCP / TD), own passes
+# NOTE (round 1, ROCm 7.2 on this pool): the TA_* and TCP_* groups abort rocprofv3 (signal 6) and then sit in their 200 s timeout;
+# only the third group (TD_TD_BUSY, TCP_GATE_EN*, TCP_TA_TCP_STATE_READ) returned data.  Budget ~7 GPU-minutes if you run it as is.
 R=${GRAFT_REPO_ROOT:-/root/repo}; name=$1; shift
 export TMPDIR=/tmp; mkdir -p $R/gpurun_out/pmc_$name
 i=0

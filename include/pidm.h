@@ -185,6 +185,11 @@ size_t pidm_conv_packed_weight_floats(const pidm_conv_desc* d);
 int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w_packed, int mode, void* stream);
 int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
                       const float* bias, const float* residual, float* out, void* stream);
+/* forward convolution feeding a GroupNorm (Block: proj -> norm, src/unet_model.py:227-241): besides `out`, the epilogue leaves
+ * per-(image, 32-pixel chunk, group) sums and sums of squares of the output in partial[B][chunks][groups][2] (doubles);
+ * returns chunks per image (H*W/32), 0 when the shape has no statistics epilogue (then only `out` is written), < 0 on error. */
+int pidm_conv_forward_gn_partials(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
+                                  const float* bias, float* out, int groups, double* partial, void* stream);
 /* adjoint wrt the input: dx[B,Hi,Wi,Cin] (+ residual) from dy[B,Ho,Wo,Cout]; weights packed with mode 1 */
 size_t pidm_conv_dgrad_packed_weight_floats(const pidm_conv_desc* d);
 int pidm_conv_dgrad(const pidm_conv_desc* d, const float* dy, int ld_dy, const float* w_packed_dgrad,

@@ -84,6 +84,7 @@ class PidmLib:
         self._sig("pidm_conv_forward", [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])
         self._sig("pidm_conv_dgrad_packed_weight_floats", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_dgrad", [C.POINTER(ConvDesc), vp, i, vp, vp, vp, i, vp])
+        self._sig("pidm_conv_forward_gn_partials", [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i, vp, vp])
         self._sig("pidm_conv_wgrad_ws", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_wgrad", [C.POINTER(ConvDesc), vp, vp, vp, i, vp, vp, vp, vp])
         self._sig("pidm_linear_attention_ws", [i, i, i], sz)

@@ -180,6 +180,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // spend most of a workgroup's life in its prologue/epilogue with the matrix pipe idle (PMC: 45 % MFMA busy).
 // MT = m-tiles (32 pixels each) per wave: MT == 2 is the 256-pixel workgroup tile (two independent accumulator chains per
 // wave, half the barriers / weight staging / B-fragment reads per MFMA).
+// GroupNorm partial statistics of a wave's 32-pixel x 32-channel output tile (ConvGeom::gn_part): each lane holds the sums over
+// its 16 rows of one channel; butterfly over the gn_cpg lanes of a group and the two lane halves, one lane per group writes.
+#define PIDM_GN_PARTIAL(s1_, s2_, b_, pix_in_img_, c_)                                                              \
+  {                                                                                                                 \
+    float a1__ = (s1_), a2__ = (s2_);                                                                               \
+    for (int off__ = 1; off__ < g.gn_cpg; off__ <<= 1) {                                                            \
+      a1__ += __shfl_xor(a1__, off__);                                                                              \
+      a2__ += __shfl_xor(a2__, off__);                                                                              \
+    }                                                                                                               \
+    a1__ += __shfl_xor(a1__, 32);                                                                                   \
+    a2__ += __shfl_xor(a2__, 32);                                                                                   \
+    if (half == 0 && (l31 & (g.gn_cpg - 1)) == 0) {                                                                 \
+      double* o__ = g.gn_part + (((size_t)(b_) * g.gn_nchunk + ((pix_in_img_) >> 5)) * g.gn_G + (c_) / g.gn_cpg) * 2; \
+      o__[0] = (double)a1__;                                                                                        \
+      o__[1] = (double)a2__;                                                                                        \
+    }                                                                                                               \
+  }
 template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED, bool PERSIST, int MT>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
@@ -415,6 +432,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         float* op = out + opix + (long)c * g.soc;
         const float* rp = residual ? residual + rpix + c : nullptr;
         const bool sig = sigmoid_last && c == g.Cout - 1;
+        float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = (r & 3) + 8 * (r >> 2);   // compile-time part of the row index
@@ -422,7 +440,10 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
           if (rp) v += rp[rowc * rrstep];
           if (sig) v = 1.f / (1.f + expf(-v));
           op[rowc * rstep] = v;
+          gs1 += v;
+          gs2 += v * v;
         }
+        if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
       }
     }
     }
@@ -434,6 +455,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       const int c = n0 + ni * 32 + l31;
       if (c >= g.Cout) continue;
       const float bv = bias ? bias[c] : 0.f;
+      float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -446,6 +468,13 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c];
         if (sigmoid_last && c == g.Cout - 1) v = 1.f / (1.f + expf(-v));
         out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)ox * g.sox + (size_t)c * g.soc] = v;
+        gs1 += v;
+        gs2 += v * v;
+      }
+      if (g.gn_part) {   // the wave's 32 pixels are whole rows of ONE image (32 % Wv == 0, H*W % 32 == 0): wave-uniform b and chunk
+        const int p0w = mt * 128 + wave * 32;
+        const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
+        if (b0 + img0 < g.B && img0 < g.NI) PIDM_GN_PARTIAL(gs1, gs2, b0 + img0, (vy0 + ty0) * g.Wv, c)
       }
     }
   }
@@ -1541,7 +1570,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
     PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
-    return 0;
+    return (g.gn_part && NT == 4) ? 1 : 0;   // 1: convolution done, the requested GroupNorm partials were NOT produced
   }
   if (g.nph > 1) return fail("conv: phased 4x4/s2 geometry is not eligible for the pipelined kernel (tile too large)");
   if constexpr (NT == 4 || KC == 32) {
@@ -1568,7 +1597,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
                      tgs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_igemm_kernel");
-  return 0;
+  return g.gn_part ? 1 : 0;   // the generic kernel has no statistics epilogue
   }
 }
 
@@ -1873,6 +1902,27 @@ extern "C" int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, con
   ConvGeom g;
   if (geom_fwd(d, &g)) return -1;
   return launch_conv(g, src0, src1, w_packed, bias, residual, out, 0, as_stream(stream));
+}
+
+// forward convolution that also leaves GroupNorm partial statistics of its output (ConvGeom::gn_part): returns the number of
+// 32-pixel chunks per image written to `partial` [B][chunks][groups][2] doubles, 0 if this shape / kernel has no statistics
+// epilogue (the convolution itself is done either way), < 0 on error
+extern "C" int pidm_conv_forward_gn_partials(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
+                                             const float* bias, float* out, int groups, double* partial, void* stream) {
+  ConvGeom g;
+  if (geom_fwd(d, &g)) return -1;
+  const int HW = g.Ho * g.Wo, cpg = (groups > 0 && g.Cout % groups == 0) ? g.Cout / groups : 0;
+  const bool ok = partial && g.Cout % 32 == 0 && cpg >= 4 && cpg <= 32 && (cpg & (cpg - 1)) == 0 && HW % 32 == 0 && g.nz == 1 &&
+                  g.nph == 1 && g.os == 1 && g.soc == 1 && g.KH == 3;
+  if (ok) {
+    g.gn_part = partial;
+    g.gn_cpg = cpg;
+    g.gn_G = groups;
+    g.gn_nchunk = HW / 32;
+  }
+  const int rc = launch_conv(g, src0, src1, w_packed, bias, nullptr, out, 0, as_stream(stream));
+  if (rc < 0) return rc;
+  return (ok && rc == 0) ? HW / 32 : 0;
 }
 
 extern "C" int pidm_conv_dgrad(const pidm_conv_desc* d, const float* dy, int ld_dy, const float* w_packed_dgrad,

@@ -583,7 +583,9 @@ static int gn_chunks(int HW, int B) {
 
 size_t gn_ws_bytes(int B, int HW, int C, int G) {
   const int nchunk = gn_chunks(HW, B);
-  const size_t part = (size_t)B * nchunk * (C > G ? C : G) * 2 * sizeof(double);
+  size_t part = (size_t)B * nchunk * (C > G ? C : G) * 2 * sizeof(double);
+  const size_t epi = (size_t)B * (HW / 32 + 1) * G * 2 * sizeof(double);   // statistics from a convolution epilogue (32-pixel chunks)
+  if (epi > part) part = epi;
   return part + (size_t)B * 2 * C * sizeof(float) + 256;
 }
 
@@ -608,12 +610,15 @@ int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, v
 }
 
 // ws != null: holds launch_gn_stats' partials, `stats` [B][G][2] is WRITTEN (and used); ws == null: `stats` is read
+// part_chunks > 0: `ws` holds part_chunks partial sums per (image, group) written by the producing convolution's epilogue
+// (ConvGeom::gn_part, 32-pixel chunks) instead of launch_gn_stats' partials
 int launch_gn_apply(const float* x, float* stats, const float* gamma, const float* beta, const float* ss, const float* ssb,
-                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st) {
+                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks) {
   if (gn_check(C, G)) return -1;
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws), nchunk,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws),
+                     (ws && part_chunks > 0) ? part_chunks : nchunk,
                      (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb);
   PIDM_CHECK_LAUNCH("gn_apply_kernel");
   return 0;

@@ -70,6 +70,11 @@ struct ConvGeom {
   unsigned mIWt, mIHt;  // ceil(2^32 / IWt), ceil(2^32 / IHt): n / d == __umulhi(n, m) for n*d < 2^32 (d > 1)
   int tiles_m;       // number of 128-pixel tiles
   int tpw;           // persistent conv kernels: consecutive m-tiles walked by one workgroup (0/1: one tile per workgroup)
+  // GroupNorm statistics of the OUTPUT from the epilogue (k_norm.hip consumes them): per (image, 32-pixel wave chunk, group)
+  // sum and sum of squares as doubles at gn_part[((b*gn_nchunk + chunk)*gn_G + g)*2]; gn_part == null: off.
+  // Requires Cout % 32 == 0, gn_cpg = Cout/gn_G a power of two in [4, 32], Ho*Wo % 32 == 0, channels-last output, no residual.
+  double* gn_part;
+  int gn_cpg, gn_G, gn_nchunk;
 };
 
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)

@@ -486,6 +486,31 @@ static int conv_fwd(Run& r, const ConvLayer& L, const float* x0, const float* x1
   return 0;
 }
 
+// Convolution whose output feeds a GroupNorm: the epilogue leaves the per-(image, 32-pixel chunk, group) sums in r.scratch and
+// gn_apply finalises them - one launch and one full read of the activation less than conv -> gn_stats -> gn_apply.
+// *part_chunks = chunks per image written (0: not produced - shape not eligible or kernel without the epilogue; the caller
+// then runs launch_gn_stats).
+static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float* x1, float* out, int G, int* part_chunks) {
+  static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr;
+  *part_chunks = 0;
+  ConvGeom g;
+  if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
+  const int HW = g.Ho * g.Wo, cpg = (G > 0 && L.Cout % G == 0) ? L.Cout / G : 0;
+  const bool ok = !off && L.Cout % 32 == 0 && cpg >= 4 && cpg <= 32 && (cpg & (cpg - 1)) == 0 && HW % 32 == 0 && g.nz == 1 &&
+                  g.nph == 1 && g.os == 1 && g.soc == 1 && g.KH == 3 && (32 % g.Wv == 0 || g.Wv % 32 == 0);
+  if (ok) {
+    g.gn_part = reinterpret_cast<double*>(r.scratch);
+    g.gn_cpg = cpg;
+    g.gn_G = G;
+    g.gn_nchunk = HW / 32;
+  }
+  if (r.dry) return 0;
+  const int rc = launch_conv(g, x0, x1, r.wpack + L.off_f, L.b >= 0 ? r.U->P[L.b] : nullptr, nullptr, out, 0, r.st);
+  if (rc < 0) return rc;
+  if (ok && rc == 0) *part_chunks = HW / 32;
+  return 0;
+}
+
 static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, float** out_p) {
   pidm_unet* U = r.U;
   const int B = r.B, HW = m.H * m.H, Co = m.Co, G = U->groups;
@@ -494,23 +519,24 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
   const size_t mk = r.tmp.mark();
   m.x0 = x0; m.x1 = x1;
   m.a = act_alloc(r, n);
-  if (conv_fwd(r, m.c1, x0, x1, nullptr, m.a)) return -1;
+  int pc1 = 0, pc2 = 0;
+  if (conv_fwd_gn(r, m.c1, x0, x1, m.a, G, &pc1)) return -1;
   m.st1 = act_alloc(r, (size_t)B * G * 2);
-  RUN(launch_gn_stats(m.a, B, HW, Co, G, m.st1, r.scratch, r.st));
+  if (!pc1) RUN(launch_gn_stats(m.a, B, HW, Co, G, m.st1, r.scratch, r.st));
   m.bact = act_alloc(r, n);
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
-  RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.scratch, r.st));
+  RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.scratch, r.st, pc1));
   m.c = act_alloc(r, n);
-  if (conv_fwd(r, m.c2, m.bact, nullptr, nullptr, m.c)) return -1;
+  if (conv_fwd_gn(r, m.c2, m.bact, nullptr, m.c, G, &pc2)) return -1;
   m.st2 = act_alloc(r, (size_t)B * G * 2);
-  RUN(launch_gn_stats(m.c, B, HW, Co, G, m.st2, r.scratch, r.st));
+  if (!pc2) RUN(launch_gn_stats(m.c, B, HW, Co, G, m.st2, r.scratch, r.st));
   if (m.has_res) {
     float* d = r.tmp.alloc(n);
-    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.scratch, r.st));
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.scratch, r.st, pc2));
     if (conv_fwd(r, m.cr, x0, x1, d, out)) return -1;
   } else {
-    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.scratch, r.st));
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.scratch, r.st, pc2));
   }
   if (!r.train) r.tmp.release(mk);
   else r.tmp.release(mk);

@@ -141,3 +141,50 @@ def test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, trans
     L.check(L.pidm_conv_wgrad(d, ptr(x0), ptr(x1), ptr(dyn), Cout, ptr(dw), ptr(db), ptr(ws), st))
     assert rel(dw, wr.grad) < 5e-6
     assert rel(db, br.grad) < 5e-6
+
+
+GN_EPILOGUE_CASES = [
+    # B, H, C0, C1, Cout, groups
+    (2, 64, 32, 0, 32, 8),      # 64-wide rows: a wave = half a row; 4 channels per group
+    (3, 32, 32, 32, 64, 8),     # concat source, two 32-channel accumulators per wave, 8 channels per group
+    (2, 16, 64, 0, 128, 8),     # 16-wide rows: a wave = two rows; 16 channels per group
+    (5, 8, 128, 0, 256, 8),     # two 8x8 images per tile (ragged last tile); a whole 32-channel tile per group
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,groups", GN_EPILOGUE_CASES)
+def test_conv_epilogue_groupnorm_partials(backend, B, H, C0, C1, Cout, groups):
+    """3x3 convolution whose epilogue also leaves the GroupNorm sums of its output (what launch_gn_stats would compute in a second
+    pass): per image and group, the partials must add up to sum / sum of squares of the convolution output."""
+    import torch.nn.functional as F
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(77 + H)
+    Cin = C0 + C1
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=C0, C1=C1, ld0=C0, ld1=C1, Cout=Cout, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=Cout)
+    x0 = nhwc(x[:, :C0]).to(dev)
+    x1 = nhwc(x[:, C0:]).to(dev) if C1 else None
+    wd = w.to(dev)
+    wp = torch.zeros(L.pidm_conv_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(wd), ptr(wp), 0, st))
+    out = torch.empty(B, H, H, Cout, device=dev)
+    chunks_max = H * H // 32
+    part = torch.full((B, chunks_max, groups, 2), float("nan"), dtype=torch.float64, device=dev)
+    nch = L.lib.pidm_conv_forward_gn_partials(d, ptr(x0), ptr(x1) if C1 else None, ptr(wp), ptr(bias.to(dev)), ptr(out), groups, ptr(part), st)
+    assert nch == chunks_max, L.lib.pidm_last_error().decode()
+    assert rel(out.permute(0, 3, 1, 2), ref) < 5e-6
+    cpg = Cout // groups
+    rg = ref.double().reshape(B, groups, cpg, H * H)
+    s1 = rg.sum(dim=(2, 3))
+    s2 = (rg * rg).sum(dim=(2, 3))
+    pc = part.cpu()
+    assert torch.isfinite(pc).all()                      # every (image, chunk, group) slot was written
+    assert (pc[..., 0].sum(dim=1) - s1).abs().max().item() < 1e-5 * s2.sqrt().max().item() * (H * H * cpg) ** 0.5
+    assert rel(pc[..., 1].sum(dim=1), s2) < 2e-6
+    # per chunk: 32 consecutive pixels of one image
+    ck = rg.reshape(B, groups, cpg, chunks_max, 32).sum(dim=(2, 4)).permute(0, 2, 1)
+    assert (pc[..., 0] - ck).abs().max().item() < 1e-4 * ck.abs().max().item()

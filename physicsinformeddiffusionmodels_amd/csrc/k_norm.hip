@@ -85,13 +85,31 @@ __device__ __forceinline__ GnLanes gn_lanes(int C) {
 // separate "final" launch); block x == 0 also publishes (mean, rstd) for the backward pass
 __device__ __forceinline__ void gn_finalize_stats(const double* __restrict__ partial, int nchunk, int G, int b, double count,
                                                   float eps, float* __restrict__ stats_out, float (*s_stat)[2]) {
+  // all 256 threads: thread (lane = tid / G, g = tid % G) sums chunks lane, lane + 256/G, ...; the lanes of a group are then added
+  // in a fixed order.  (With the partials of a convolution epilogue there are H*W/32 chunks per image - 128 at 64x64 - and a
+  // serial loop over them by G threads cost more than the statistics pass it replaced.)
+  __shared__ double s_red[256][2];
   const int tid = threadIdx.x;
-  if (tid < G) {
+  {
+    const int gg = tid % G, ln = tid / G, nl = 256 / G;
     double s = 0.0, ss = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
-      const double* p = partial + (((size_t)b * nchunk + c) * G + tid) * 2;
-      s += p[0];
-      ss += p[1];
+    if (ln < nl) {
+      for (int c = ln; c < nchunk; c += nl) {
+        const double* p = partial + (((size_t)b * nchunk + c) * G + gg) * 2;
+        s += p[0];
+        ss += p[1];
+      }
+    }
+    s_red[tid][0] = s;
+    s_red[tid][1] = ss;
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int nl = 256 / G;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nl; ++k) {
+      s += s_red[k * G + tid][0];
+      ss += s_red[k * G + tid][1];
     }
     const double mean = s / count;
     double var = ss / count - mean * mean;

@@ -298,12 +298,42 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   __shared__ float s_coef[64][2];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
-  for (int c = tid; c < C; c += 256) {
+  if (C < 256) {
+    // few channels: 256/C threads per channel share the chunk loop (fixed order: lane k sums chunks k, k + nl, ...; lanes added
+    // in order) instead of C threads walking all chunks while the rest of the block waits
+    __shared__ double sp[256][2];
+    const int c = tid % C, ln = tid / C, nl = 256 / C;
     double S1 = 0.0, S2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = ln; k < nchunk; k += nl) {
       const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
       S1 += p[0];
       S2 += p[1];
+    }
+    sp[tid][0] = S1;
+    sp[tid][1] = S2;
+    __syncthreads();
+    if (tid < C) {
+      S1 = 0.0; S2 = 0.0;
+      for (int k = 0; k < nl; ++k) {
+        S1 += sp[k * C + tid][0];
+        S2 += sp[k * C + tid][1];
+      }
+      ga[tid] = S1;
+      gb[tid] = S2;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += 256) {
+    double S1 = 0.0, S2 = 0.0;
+    if (C < 256) {
+      S1 = ga[c];
+      S2 = gb[c];
+    } else {
+      for (int k = 0; k < nchunk; ++k) {
+        const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
+        S1 += p[0];
+        S2 += p[1];
+      }
     }
     const double gm = gamma[c], bt = beta[c];
     double sc1 = 1.0;

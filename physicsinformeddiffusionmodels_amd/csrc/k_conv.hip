@@ -197,6 +197,39 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
       o__[1] = (double)a2__;                                                                                        \
     }                                                                                                               \
   }
+// GroupNorm-backward partial sums from a dgrad epilogue (ConvGeom::bn_part).  acc_ = the lane's 16 rows of dy for channel c_
+// (rows (r&3) + 8(r>>2) + 4half of the wave's 32 pixels), xrow_ = &x[first pixel of the wave][c_], xstep_ = floats between
+// consecutive pixels of the wave in x.  Same arithmetic as gn_recompute (k_norm.hip).
+#define PIDM_BN_PARTIAL(acc_, bv_, b_, pix_in_img_, c_, xrow_, xstep_)                                              \
+  {                                                                                                                 \
+    const int gI__ = (c_) / g.bn_cpg;                                                                               \
+    const float mean__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2], rstd__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2 + 1]; \
+    const float gm__ = g.bn_gamma[(c_)], bt__ = g.bn_beta[(c_)];                                                    \
+    float sc__ = 1.f, sh__ = 0.f;                                                                                   \
+    if (g.bn_ss) {                                                                                                  \
+      sc__ = 1.f + (g.bn_ss[(size_t)(b_) * g.bn_ldss + (c_)] + g.bn_ssb[(c_)]);                                     \
+      sh__ = g.bn_ss[(size_t)(b_) * g.bn_ldss + g.Cout + (c_)] + g.bn_ssb[g.Cout + (c_)];                           \
+    }                                                                                                               \
+    float xv__[16];                                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
+        xv__[r] = (xrow_)[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * (xstep_)];                                  \
+    float a1__ = 0.f, a2__ = 0.f;                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
+      const float xh__ = (xv__[r] - mean__) * rstd__;                                                               \
+      const float v__ = (xh__ * gm__ + bt__) * sc__ + sh__;                                                         \
+      const float sg__ = 1.f / (1.f + expf(-v__));                                                                  \
+      const float dv__ = ((acc_)[r] + (bv_)) * (sg__ * (1.f + v__ * (1.f - sg__)));                                 \
+      a1__ += dv__;                                                                                                 \
+      a2__ += dv__ * xh__;                                                                                          \
+    }                                                                                                               \
+    a1__ += __shfl_xor(a1__, 32);                                                                                   \
+    a2__ += __shfl_xor(a2__, 32);                                                                                   \
+    if (half == 0) {                                                                                                \
+      double* o__ = g.bn_part + (((size_t)(b_) * g.bn_nchunk + ((pix_in_img_) >> 5)) * g.Cout + (c_)) * 2;          \
+      o__[0] = (double)a1__;                                                                                        \
+      o__[1] = (double)a2__;                                                                                        \
+    }                                                                                                               \
+  }
 template <int KC, int NT, int AMAX, int BMAX, int KH, int KW, bool PHASED, bool PERSIST, int MT>
 __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ wp,
@@ -444,6 +477,10 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
           gs2 += v * v;
         }
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
+        if (g.bn_part) {   // plain stride-1 geometry (os == 1, output grid == x grid): the wave's pixels are consecutive in x
+          const float* xrow = g.bn_x + (((size_t)b * g.Ho + oy) * g.Wo + tx0) * g.Cout + c;
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout)
+        }
       }
     }
     }
@@ -475,6 +512,14 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         const int p0w = mt * 128 + wave * 32;
         const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
         if (b0 + img0 < g.B && img0 < g.NI) PIDM_GN_PARTIAL(gs1, gs2, b0 + img0, (vy0 + ty0) * g.Wv, c)
+      }
+      if (g.bn_part) {   // 32 % Wv == 0: the wave's 32 pixels are whole, consecutive rows of one image = 32 consecutive pixels of x
+        const int p0w = mt * 128 + wave * 32;
+        const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
+        if (b0 + img0 < g.B && img0 < g.NI) {
+          const float* xrow = g.bn_x + (((size_t)(b0 + img0) * g.Ho + (vy0 + ty0)) * g.Wo) * g.Cout + c;
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout)
+        }
       }
     }
   }
@@ -1570,7 +1615,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
 #undef PIDM_LAUNCH_PIPE
     if (prof) prof_end_launch(st);
     PIDM_CHECK_LAUNCH("conv_igemm_pipe_kernel");
-    return (g.gn_part && NT == 4) ? 1 : 0;   // 1: convolution done, the requested GroupNorm partials were NOT produced
+    return ((g.gn_part || g.bn_part) && NT == 4) ? 1 : 0;   // 1: convolution done, the requested GroupNorm partials were NOT produced
   }
   if (g.nph > 1) return fail("conv: phased 4x4/s2 geometry is not eligible for the pipelined kernel (tile too large)");
   if constexpr (NT == 4 || KC == 32) {
@@ -1597,7 +1642,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
                      tgs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out);
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv_igemm_kernel");
-  return g.gn_part ? 1 : 0;   // the generic kernel has no statistics epilogue
+  return (g.gn_part || g.bn_part) ? 1 : 0;   // the generic kernel has no statistics epilogue
   }
 }
 

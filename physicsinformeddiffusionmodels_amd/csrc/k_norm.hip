@@ -632,7 +632,8 @@ static int gn_chunks(int HW, int B) {
 size_t gn_ws_bytes(int B, int HW, int C, int G) {
   const int nchunk = gn_chunks(HW, B);
   size_t part = (size_t)B * nchunk * (C > G ? C : G) * 2 * sizeof(double);
-  const size_t epi = (size_t)B * (HW / 32 + 1) * G * 2 * sizeof(double);   // statistics from a convolution epilogue (32-pixel chunks)
+  // statistics / backward sums from a convolution epilogue (32-pixel chunks; per group resp. per channel)
+  const size_t epi = (size_t)B * (HW / 32 + 1) * (C > G ? C : G) * 2 * sizeof(double);
   if (epi > part) part = epi;
   return part + (size_t)B * 2 * C * sizeof(float) + 256;
 }
@@ -673,22 +674,27 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
 }
 
 // dx, dgamma, dbeta and (if ss) dss[b][off..off+2C) from dy
+// part_chunks > 0: the first pass (per-channel sums S1, S2) was done by the dgrad convolution that produced dy
+// (ConvGeom::bn_part): `ws` already holds part_chunks partials per (image, channel)
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
-                  void* ws, hipStream_t st, float* dgb_persist, ReduceQueue* defer) {
+                  void* ws, hipStream_t st, float* dgb_persist, ReduceQueue* defer, int part_chunks) {
   if (gn_check(C, G)) return -1;
   if (C > 1024) return fail("groupnorm bwd: C=%d > 1024", C);
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
+  const int pchunks = part_chunks > 0 ? part_chunks : nchunk;
   char* w = reinterpret_cast<char*>(ws);
   double* partial = reinterpret_cast<double*>(w);
-  w += (size_t)B * nchunk * C * 2 * sizeof(double);
+  w += (size_t)B * pchunks * C * 2 * sizeof(double);
   float* dgb = (defer && dgb_persist) ? dgb_persist : reinterpret_cast<float*>(w);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, HW, C,
-                     G, ppb, partial);
-  PIDM_CHECK_LAUNCH("gn_bwd_reduce_kernel");
+  if (part_chunks <= 0) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, HW, C,
+                       G, ppb, partial);
+    PIDM_CHECK_LAUNCH("gn_bwd_reduce_kernel");
+  }
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, dy, stats, gamma, beta, ss, ssb, ldss, partial,
-                     nchunk, dss, dgb, dx, HW, C, G, ppb);
+                     pchunks, dss, dgb, dx, HW, C, G, ppb);
   PIDM_CHECK_LAUNCH("gn_bwd_apply_kernel");
   if (defer && dgb_persist) {   // dgamma[c] = sum_b dgb[b][0][c], dbeta[c] = sum_b dgb[b][1][c]
     defer->push(dgb, dgamma, nullptr, nullptr, (size_t)2 * C, B, 1, C, 1, 1, C);

@@ -75,6 +75,17 @@ struct ConvGeom {
   // Requires Cout % 32 == 0, gn_cpg = Cout/gn_G a power of two in [4, 32], Ho*Wo % 32 == 0, channels-last output, no residual.
   double* gn_part;
   int gn_cpg, gn_G, gn_nchunk;
+  // backward twin: a dgrad convolution whose OUTPUT is the gradient dy wrt y = SiLU(FiLM(GroupNorm(x))) also leaves the sums the
+  // GroupNorm backward needs, per (image, 32-pixel chunk, channel): S1 = sum dv, S2 = sum dv*xhat with dv = dy*SiLU'(v), at
+  // bn_part[((b*bn_nchunk + chunk)*Cout + c)*2] (doubles) - the first of the two passes of launch_gn_bwd.  bn_part == null: off.
+  const float* bn_x;      // the normalised tensor x [B][Ho*Wo][Cout], channels-last
+  const float* bn_stats;  // [B][bn_G][2] (mean, rstd)
+  const float* bn_gamma;
+  const float* bn_beta;
+  const float* bn_ss;     // FiLM activations [B][bn_ldss] (scale | shift), may be null
+  const float* bn_ssb;    // their bias [2*Cout]
+  double* bn_part;
+  int bn_ldss, bn_cpg, bn_G, bn_nchunk;
 };
 
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)

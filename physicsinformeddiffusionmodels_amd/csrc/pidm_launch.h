@@ -50,7 +50,7 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
                     int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks = 0);
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
-                  void* ws, hipStream_t st, float* dgb_persist = nullptr, ReduceQueue* defer = nullptr);
+                  void* ws, hipStream_t st, float* dgb_persist = nullptr, ReduceQueue* defer = nullptr, int part_chunks = 0);
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st);
 size_t layernorm_bwd_ws_bytes(int C);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,

@@ -728,13 +728,37 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
                     U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st, dgb2, r.q()));
   if (conv_wgrad(r, m.c2, m.bact, nullptr, g_c)) return -1;
   float* g_b = r.tmp.alloc(n);
-  if (conv_dgrad(r, m.c2, g_c, nullptr, g_b)) return -1;
-  // g_c is dead on THIS stream after the two uses above, but the side-stream wgrad of c2 may still be reading it
-  float* g_a = r.overlap || r.dry ? r.tmp.alloc(n) : g_c;
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
+  // the dgrad of conv2 produces dy of GroupNorm 1: its epilogue also leaves the per-channel sums the GroupNorm backward starts
+  // with (the first of its two passes over x and dy).  Needs the deferred-reduction arena: otherwise the weight-gradient
+  // partials of conv2 live in r.scratch, where the sums go.
+  int pcb = 0;
+  {
+    static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr;
+    pidm_conv_desc d = desc_of(m.c2, r.B);
+    ConvGeom g;
+    int kind;
+    if (geom_dgrad(&d, m.c2.Cout, m.c2.C0 + m.c2.C1, &g, &kind)) return -1;
+    const int cpg = (G > 0 && Co % G == 0) ? Co / G : 0;
+    const bool ok = !off && r.defer_on && g.Cout == Co && Co % 32 == 0 && cpg >= 1 && HW % 32 == 0 && g.nz == 1 && g.nph == 1 && g.os == 1 &&
+                    g.soc == 1 && g.KH == 3 && g.Ho * g.Wo == HW;
+    if (ok) {
+      g.bn_part = reinterpret_cast<double*>(r.scratch);
+      g.bn_x = m.a; g.bn_stats = m.st1; g.bn_gamma = U->P[m.gn1w]; g.bn_beta = U->P[m.gn1b];
+      g.bn_ss = ss; g.bn_ssb = ssb; g.bn_ldss = U->ss_total;
+      g.bn_cpg = cpg; g.bn_G = G; g.bn_nchunk = HW / 32;
+    }
+    if (!r.dry) {
+      const int rc = launch_conv(g, g_c, nullptr, r.wpack + m.c2.off_d, nullptr, nullptr, g_b, 0, r.st);
+      if (rc < 0) return rc;
+      if (ok && rc == 0) pcb = HW / 32;
+    }
+  }
+  // g_c is dead on THIS stream after the two uses above, but the side-stream wgrad of c2 may still be reading it
+  float* g_a = r.overlap || r.dry ? r.tmp.alloc(n) : g_c;
   RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
-                    g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st, dgb1, r.q()));
+                    g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st, dgb1, r.q(), pcb));
   if (conv_wgrad(r, m.c1, m.x0, m.x1, g_a)) return -1;
   if (m.has_res) {
     if (conv_wgrad(r, m.cr, m.x0, m.x1, g_out)) return -1;

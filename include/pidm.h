@@ -84,6 +84,16 @@ int pidm_clip_adam_step(float* param, const float* grad, float* exp_avg, float* 
                         double beta2, double eps, long long step, double max_norm, float* total_norm_out, void* workspace,
                         void* stream);
 
+/* The same step with the parameter EMA of main.py:178-179 folded in (EMA.update, src/denoising_utils.py:174-177):
+ *   shadow = (1 - mu) * p_new + mu * shadow   with the reference's fp32 roundings (two products, one sum; no fma),
+ * so the shadow is bit-identical to the reference's per-tensor update applied to the same p_new.  ema_shadow: n floats.
+ * pidm_ema_update is the stand-alone form (one read of p and shadow, one write of shadow) for steps taken by another
+ * optimizer. */
+int pidm_clip_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_shadow, size_t n,
+                            double lr, double beta1, double beta2, double eps, long long step, double max_norm, double ema_mu,
+                            float* total_norm_out, void* workspace, void* stream);
+int pidm_ema_update(float* ema_shadow, const float* param, size_t n, double ema_mu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Mechanics residual r = K(rho) u - f, matrix-free      replaces ResidualsMechanics.compute_residual
  *   src/residuals_mechanics_K.py:198-274 (dense 8450x8450 index_put assembly + einsum) and resize_image :10-21
@@ -99,6 +109,18 @@ int pidm_mech_residual_fwd(const float* x0_pred, const float* bcs, const float* 
 int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, const float* kloc, int kloc_stride,
                            const int32_t* elem_dofs, const int32_t* dof_elems, int nel, const float* g_residual,
                            const float* g_model_out, const float* g_comp_shift, float* g_x0_pred, int B, void* stream);
+
+/* Fused mechanics training loss + its gradient wrt the network output     replaces src/denoising_utils.py:666-708 (loss
+ * algebra on top of compute_residual) for gov_eqs == 'mechanics': data term on model_out = (u resized to nn x nn, rho zero padded)
+ * against target x_0 [B,3,nn,nn], residual term, the [B,B]-broadcast inequality term (:697, only when c_ineq > 0) and the
+ * compliance term, all with injected per-sample p2_loss_weight[t_b] and 1/posterior_variance_clipped[t_b].
+ * out_scalars[8]: loss, data loss, mean |r|, mean shift (0 unless c_ineq > 0), mean compliance, 0, 0, 0.
+ * grad_x0_pred [B,3,nel,nel] = d loss / d x0_pred.  workspace: pidm_mech_loss_ws(B) bytes. */
+size_t pidm_mech_loss_ws(int B);
+int pidm_mech_loss_fwd_bwd(const float* x0_pred, const float* target, const float* bcs, const float* vf, const float* p2w,
+                           const float* inv_var, float c_data, float c_residual, float c_ineq, float lambda_opt, const float* kloc,
+                           int kloc_stride, const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* grad_x0_pred,
+                           float* out_scalars, void* workspace, int B, void* stream);
 
 /* Topology-optimisation evaluation block      replaces src/residuals_mechanics_K.py:276-347,369-380
  *   pidm_mech_apply:  residual = K_closed(rho) u - f and comp_uf = u.f for nodal displacement images u [B,2,nn,nn]

@@ -541,9 +541,113 @@ def g18():
     print("g18 linear attention:", tuple(y.shape), float(y.abs().max()), float(qkv.grad.abs().max()))
 
 
+# G19: the mechanics-shaped UNet at its FULL width (main.py:126 builds Unet3D(dim=128, channels=10, out_dim=3,
+# sigmoid_last_channel=True)): channel widths 128..1024 reach conv tile variants no dim<=32 golden exercises.
+# Large gradient tensors are stored as strided samples of the flattened tensor (stride in "gstride/<name>").
+BIG_PROBES = ["init_conv.weight", "downs.0.0.block1.proj.weight", "downs.1.0.res_conv.weight", "downs.0.2.fn.fn.to_qkv.weight",
+              "downs.0.2.fn.fn.to_out.weight", "downs.0.2.fn.norm.gamma", "downs.0.3.weight", "ups.0.3.weight",
+              "time_mlp.3.weight", "downs.0.0.mlp.1.weight", "mid_spatial_attn.fn.fn.fn.to_qkv.weight",
+              "mid_spatial_attn.fn.norm.gamma", "downs.3.1.block2.proj.weight", "downs.3.0.block1.norm.weight",
+              "final_conv.1.weight", "final_conv.0.res_conv.weight", "ups.3.0.block1.proj.weight", "ups.0.0.block1.proj.weight",
+              "mid_block1.block2.proj.weight", "downs.2.2.fn.fn.to_out.bias"]
+
+
+def g19(tag="g19_unet_dim128_mech", dim=128, P=64, tval=42):
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    x = seeded((1, 10, P, P), 71)
+    t = torch.tensor([tval], dtype=torch.long)
+    out = m(x.permute(0, 2, 3, 1).reshape(1, P * P, 10), t)
+    w = seeded(tuple(out.shape), 72)
+    (out * w).sum().backward()
+    d = {"x": npy(x), "t": npy(t), "w": npy(w), "out_probe": npy(out[:, :, ::4, ::4]),
+         "out_sum": np.array(out.double().sum().item()), "out_abs_sum": np.array(out.double().abs().sum().item())}
+    names, norms = [], []
+    params = dict(m.named_parameters())
+    for k, p in params.items():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    d["grad_names"] = np.array(names)
+    d["grad_norms"] = np.array(norms)
+    for k in BIG_PROBES:
+        gflat = params[k].grad.reshape(-1)
+        stride = max(1, gflat.numel() // 8192)
+        if stride > 1 and stride % 2 == 0:
+            stride += 1          # odd stride: the sample walks through every tap / channel residue
+        d["grad/" + k] = npy(gflat[::stride])
+        d["gstride/" + k] = np.array(stride)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "out", tuple(out.shape), "n_grads", len(names), "out_abs_sum", float(d["out_abs_sum"]))
+
+
+# G10b: the full mechanics model_estimation_loss at the reference's model width (dim=128), one sample
+def g10b():
+    import tempfile
+    from src.residuals_mechanics_K import ResidualsMechanics
+    folder = tempfile.mkdtemp() + "/"
+    write_synthetic_mesh(folder)
+    torch.manual_seed(0)
+    m = Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(100, "cpu")
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder=folder, device="cpu",
+                             topopt_eval=False)
+    B = 1
+    inp = torch.zeros(B, 10, 65, 65)
+    inp[:, 0] = 0.4
+    inp[:, 1:3] = seeded((B, 2, 65, 65), 81)
+    inp[:, 3:5] = seeded((B, 2, 65, 65), 82, 0.1)
+    inp[:, 5, :64, :64] = torch.sigmoid(seeded((B, 64, 64), 83))
+    inp[:, 6, :, 0] = 1.0
+    inp[:, 7, :, 0] = 1.0
+    inp[0, 9, 20, 64] = -1.0
+    eps = seeded((B, 3, 65, 65), 84)
+    t = torch.tensor([33], dtype=torch.long)
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda *a, **k: eps.clone()
+    try:
+        loss, data_l, res_l, ineq_l, opt_l = diff.model_estimation_loss(inp, residual_func=res, c_data=1.0, c_residual=1e-3,
+                                                                        c_ineq=0.5, lambda_opt=0.01)
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    loss.backward()
+    names, norms = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "g10b_mech_loss_dim128.npz"), inp=npy(inp), eps=npy(eps), t=npy(t), loss=np.array(loss.item()),
+                        data_loss=np.array(data_l), residual_abs_mean=np.array(res_l), ineq=np.array(ineq_l), opt=np.array(opt_l),
+                        grad_names=np.array(names), grad_norms=np.array(norms))
+    print("g10b mech loss dim128", loss.item(), data_l, res_l, ineq_l, opt_l, len(names))
+
+
+# G20: state_dict contract of the reference's Unet3D - every key in order, its shape, and float64 checksums of the DEFAULT
+# initialisation under torch.manual_seed(0) (the drop-in must build the identical module tree in the identical RNG draw order)
+def g20():
+    d = {}
+    for tag, kw in (("darcy", dict(dim=32, channels=2)),
+                    ("mech", dict(dim=32, channels=10, out_dim=3, sigmoid_last_channel=True)),
+                    ("selfcond", dict(dim=8, channels=2, self_condition=True))):
+        torch.manual_seed(0)
+        m = Unet3D(**kw)
+        sd = m.state_dict()
+        d[tag + "/names"] = np.array(list(sd.keys()))
+        d[tag + "/shapes"] = np.array([",".join(str(s) for s in v.shape) for v in sd.values()])
+        d[tag + "/sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        d[tag + "/abs_sum"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        d[tag + "/requires_grad"] = np.array([k for k, p in m.named_parameters() if p.requires_grad])
+        d[tag + "/next_rand"] = npy(torch.rand(4))       # RNG position after construction
+    np.savez_compressed(os.path.join(OUT, "g20_state_dict.npz"), **d)
+    print("g20 state_dict", {k: len(v) for k, v in d.items() if k.endswith("/names")})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"):
-        {"g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g10b", "g20"):
+        {"g19": g19, "g10b": g10b, "g20": g20, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -563,4 +667,7 @@ if __name__ == "__main__":
     g16()
     g17()
     g18()
+    g19()
+    g10b()
+    g20()
     print("golden vectors written to", OUT)

@@ -447,6 +447,44 @@ def mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs):
     return residual, compliance, shift
 
 
+def mechanics_loss_from_pred(tables, x_0, x0_pred, model_out_src, bcs, vf, t, kloc, elem_dofs, c_data=1.0, c_residual=0.0,
+                             c_ineq=0.0, lambda_opt=0.0):
+    """The loss algebra of src/denoising_utils.py:666-708 for the mechanics configuration.  x0_pred feeds residual,
+    compliance and volume shift; `model_out_src` (= x0_pred for x0_estimation 'mean', = the model's output at (x_t, t) for
+    'sample', src/residuals_mechanics_K.py:192-195,246-256) feeds the data term.  The inequality term reproduces the
+    reference's [B] against [B,1] broadcast (:697): its mean runs over a [B,B] matrix.
+    Returns (loss, data_loss, mean|r|, mean shift, mean compliance)."""
+    B = x_0.shape[0]
+    residual, compliance, shift = mechanics_residual(x0_pred, bcs, vf, kloc, elem_dofs)
+    out = mechanics_model_out(model_out_src)
+    per = ((x_0 - out) ** 2).reshape(B, -1).mean(dim=1)
+    data = c_data * (per * tables["p2_loss_weight"][t]).mean()
+    var = tables["posterior_variance_clipped"][t].reshape(B, 1)
+    loss = data + (c_residual * 0.5 * residual ** 2 / var).mean()
+    if c_ineq > 0.0:
+        loss = loss + (c_ineq * 0.5 * shift ** 2 / var).mean()        # [B] / [B,1] -> [B,B]
+    loss = loss + (lambda_opt * compliance).mean()
+    return loss, data, residual.abs().mean(), shift.mean(), compliance.mean()
+
+
+def mechanics_training_loss(p, cfg, tables, inp, t, eps, kloc, elem_dofs, c_data=1.0, c_residual=0.0, c_ineq=0.0,
+                            lambda_opt=0.0, x0_estimation="mean"):
+    """model_estimation_loss for `gov_eqs == 'mechanics'` with injected (t, eps): inp [B,10,65,65] = (vf, strain energy,
+    von Mises | u_x, u_y, E | bc_x, bc_y, load_x, load_y) (src/denoising_utils.py:629-660, src/residuals_mechanics_K.py:
+    166-196).  The network sees the 64x64 resize of cat(x_t, conditioning, bcs)."""
+    cond, x_0, bcs = inp[:, :3], inp[:, 3:6], inp[:, 6:]
+    xt = q_sample(tables, x_0, t, eps)
+    net_in = torch.cat((bilinear_resize(torch.cat((xt, cond), dim=1), 64), bilinear_resize(bcs, 64)), dim=1)
+    vf = cond[:, 0, 0, 0]
+    if x0_estimation == "sample":
+        model_out = unet_forward(p, net_in, t, cfg)
+        x0_pred = unet_forward(p, net_in, torch.zeros_like(t), cfg)
+    else:
+        model_out = x0_pred = unet_forward(p, net_in, t, cfg)
+    return mechanics_loss_from_pred(tables, x_0, x0_pred, model_out, bcs, vf, t, kloc, elem_dofs, c_data, c_residual, c_ineq,
+                                    lambda_opt)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Topology-optimisation evaluation block (reference src/residuals_mechanics_K.py:276-347,369-380), restated with a
 # DENSE float64 assembly + direct solve on the free dofs.  The reference solves the row-replaced system in fp32

@@ -139,6 +139,29 @@ class UnetEngine:
         return gx
 
 
+class _TapeLease:
+    """Lives in the autograd ctx of a training-mode forward.  When the graph is dropped WITHOUT a backward (main.py:187 runs
+    the validation loss with grad enabled and never differentiates it) the ctx dies, and with it this object: the engine's
+    tape is then free again instead of staying "busy" for good."""
+
+    __slots__ = ("engine", "generation")
+
+    def __init__(self, engine, generation):
+        self.engine, self.generation = engine, generation
+
+    def release(self):
+        eng = self.engine
+        if eng is not None and eng.tape_generation == self.generation:
+            eng.tape_busy = False
+        self.engine = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class _UnetFunction(torch.autograd.Function):
     """autograd node whose forward/backward are single C-ABI calls.  Parameter gradients are written by the
     engine into the flat gradient buffer and attached as `p.grad` views (accumulated if a grad already exists),
@@ -146,8 +169,9 @@ class _UnetFunction(torch.autograd.Function):
     Parameters that forward never reads keep `grad is None`, exactly like the reference."""
 
     @staticmethod
-    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool, cond=None):
+    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool, cond=None, primary=None):
         ctx.engine = engine
+        ctx.primary = primary if primary is not None else engine
         ctx.used_cond = cond is not None
         ctx.x_requires_grad = x_nhwc.requires_grad
         ctx.channels = x_nhwc.shape[-1]
@@ -156,6 +180,7 @@ class _UnetFunction(torch.autograd.Function):
             engine.tape_generation += 1
             engine.tape_busy = True
         ctx.generation = engine.tape_generation
+        ctx.lease = _TapeLease(engine, engine.tape_generation) if training else None
         out = engine.forward(x_nhwc, t, training=training, cond=cond)
         # the engine keeps RAW pointers to its inputs and output until backward: keep the tensors alive
         if cond is not None:
@@ -171,21 +196,34 @@ class _UnetFunction(torch.autograd.Function):
             raise PidmError("backward through a forward that ran without gradient tracking")
         if ctx.generation != eng.tape_generation:
             raise PidmError("the engine's activation tape was overwritten by a later training-mode forward of the same "
-                            "model (two differentiable UNet calls per step, e.g. x0_estimation='sample', need a second "
-                            "tape: not supported yet)")
+                            "model: only the latest differentiable UNet call can be differentiated (the two calls of "
+                            "x0_estimation='sample' get one tape each through DenoisingDiffusion.ddim_sample_x0)")
+        # Every backward of this model lands in ONE flat buffer - the primary engine's (slot 0): `p.grad` are views of it, the
+        # data-parallel all-reduce and the fused optimizer read it.  An engine of another slot (second activation tape of
+        # x0_estimation='sample') writes its own buffer, which is then copied / added into the primary one, whatever order
+        # autograd runs the two nodes in.
+        primary = ctx.primary
+        first = eng.params[0]
+        if primary.flat_grad is None:
+            primary._ensure_bound(True)
+        aliased = first.grad is not None and first.grad.data_ptr() == primary.grad_views[0].data_ptr()
         # the engine WRITES its flat gradient buffer.  If p.grad already aliases that buffer (a second backward without
         # zero_grad, or zero_grad(set_to_none=False)), torch semantics are accumulation: keep the old contents and add them
         # back afterwards (one 4-byte-per-parameter copy, only on this path - main.py's zero_grad() sets grads to None)
-        first = eng.params[0]
-        prev = None
-        if eng.grad_views is not None and first.grad is not None and first.grad.data_ptr() == eng.grad_views[0].data_ptr():
-            prev = eng.flat_grad.clone()
+        prev = primary.flat_grad.clone() if (aliased and eng is primary) else None
         gx = eng.backward(grad_out.contiguous(), ctx.x_requires_grad, ctx.channels)
         if prev is not None:
             eng.flat_grad.add_(prev)
+        if eng is not primary:
+            if aliased:
+                primary.flat_grad.add_(eng.flat_grad)
+            else:
+                primary.flat_grad.copy_(eng.flat_grad)
+        if ctx.lease is not None:
+            ctx.lease.release()
         eng.tape_busy = False
         n_plain = len(eng.params) - eng.n_cond
-        for i, (p, g) in enumerate(zip(eng.params, eng.grad_views)):
+        for i, (p, g) in enumerate(zip(eng.params, primary.grad_views)):
             if not p.requires_grad:
                 continue
             if i >= n_plain and not ctx.used_cond:
@@ -193,9 +231,9 @@ class _UnetFunction(torch.autograd.Function):
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
-                p.grad.add_(g)
-            # else: p.grad already aliases the engine buffer, which now holds this step's gradient
-        return None, gx, None, None, None, None
+                p.grad.add_(eng.grad_views[i] if eng is not primary else g)
+            # else: p.grad already aliases the primary buffer, which now holds the accumulated gradient
+        return None, gx, None, None, None, None, None
 
 
 def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0) -> UnetEngine:
@@ -256,17 +294,16 @@ def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None, x_self_con
     t = time.to(device=x.device, dtype=torch.int64).contiguous()
     if t.numel() != B:
         raise ValueError('time must have one entry per batch element')
-    eng = get_engine(model, P, lib)
+    primary = eng = get_engine(model, P, lib)
     anchor = eng.params[0]
     training = torch.is_grad_enabled() and (anchor.requires_grad or x_nhwc.requires_grad)
-    if training and eng.tape_busy and getattr(model, "_pidm_multi_tape", False):
+    slot = getattr(model, "_pidm_tape_slot", None)
+    if training and slot:
         # a second differentiable UNet call inside one step (x0_estimation: 'sample' evaluates the model at (x_t, t)
-        # and at (x_t, 0), src/denoising_utils.py:741-753): give it its own engine slot = own activation tape and own
-        # gradient buffer; the two backward passes then add up in p.grad.
-        slot = 1
-        while get_engine(model, P, lib, slot).tape_busy:
-            slot += 1
-        eng = get_engine(model, P, lib, slot)
+        # and at (x_t, 0), src/denoising_utils.py:741-753): it gets its own engine slot = own activation tape and own
+        # gradient buffer.  The slot is NAMED by the caller (ddim_sample_x0: 0 then 1), so a tape left "busy" by a loss that
+        # was never differentiated is simply overwritten - the number of engines per model is bounded by the slots in use.
+        eng = get_engine(model, P, lib, int(slot))
     if not training and eng.tape_busy:
         # an inference-mode forward while a training forward of this model still waits for its backward (evaluation inside a
         # step): run it on a sibling engine so that the activation tape and its pointers stay intact
@@ -275,7 +312,7 @@ def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None, x_self_con
         if cond.shape != (B, P * P, model.channels):
             raise ValueError(f'cond must be [B, P*P, {model.channels}], got {tuple(cond.shape)}')
         cond = cond.detach().contiguous().float()
-    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training, cond)
+    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training, cond, primary)
     if video:
         out = out.unsqueeze(2)
     return out

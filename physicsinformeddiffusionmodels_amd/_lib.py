@@ -67,6 +67,11 @@ class PidmLib:
         self._sig("pidm_clip_adam_ws_bytes", [], sz)
         self._sig("pidm_clip_adam_step", [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                           C.c_double, vp, vp, vp])
+        self._sig("pidm_clip_adam_ema_step", [vp, vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
+                                              C.c_double, C.c_double, vp, vp, vp])
+        self._sig("pidm_ema_update", [vp, vp, sz, C.c_double, vp])
+        self._sig("pidm_mech_loss_ws", [i], sz)
+        self._sig("pidm_mech_loss_fwd_bwd", [vp, vp, vp, vp, vp, vp, f, f, f, f, vp, i, vp, vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_bilinear_resize", [vp, vp, i, i, i, vp])
         self._sig("pidm_mech_residual_fwd", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_mech_residual_bwd", [vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, i, vp])
@@ -98,8 +103,10 @@ class PidmLib:
 
     def _sig(self, name, argtypes, restype=C.c_int):
         fn = getattr(self.lib, name, None)
-        if fn is None:  # tolerated only while a symbol is under construction; exports are tested
-            return
+        if fn is None:
+            # a stale / partially built library: calling through default int conversions would truncate pointers
+            raise PidmError(f"{self.path} does not export {name} (include/pidm.h): rebuild with "
+                            f"`make -C physicsinformeddiffusionmodels_amd/csrc` - there is no fallback")
         fn.argtypes = argtypes
         fn.restype = restype
 

@@ -229,6 +229,197 @@ __device__ __forceinline__ double block_sum(double v, double* red4) {   // all 2
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
+// =====================================================================================================================
+// Fused mechanics training loss (src/denoising_utils.py:666-708 with gov_eqs == 'mechanics') and its gradient with respect
+// to the network output, one workgroup per sample, nothing but the 5 partial sums and the gradient leave the chip:
+//   data  = c_data * mean_b( p2w_b * mean((x_0 - model_out)^2) )           model_out = (U, rho zero-padded)  [3,nn,nn]
+//   res   = mean( c_res * 0.5 * r^2 / var_b ),  r = K_closed(rho) U - f    [B, ndof]
+//   ineq  = mean_{i,j}( c_ineq * 0.5 * shift_j^2 / var_i )                 (the reference's [B] / [B,1] broadcast, :697)
+//   opt   = mean_b( lambda_opt * compliance_b ),  compliance = U . K_closed U
+// The upstream gradients are closed-form in the forward quantities, so forward, loss derivative and adjoint run back to back
+// on the LDS-resident U / rho: g_res = c_res r inv_var_b / (B ndof), g_model_out = 2 c_data p2w_b (model_out - x_0) / (3 nn^2 B),
+// g_compliance = lambda_opt / B, g_shift = c_ineq shift_b (sum_i inv_var_i) / B^2.
+// LDS: U[ndof] | rho[E] | Z[ndof] | GU[ndof] (the layout of mech_kernel<true>).
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) mech_loss_kernel(MechMesh ms, const float* __restrict__ x0,        // [B,3,nel,nel] network output
+                                                        const float* __restrict__ target,    // [B,3,nn,nn] data fields x_0
+                                                        const float* __restrict__ bcs,       // [B,4,nn,nn]
+                                                        const float* __restrict__ vf,        // [B]
+                                                        const float* __restrict__ p2w,       // [B]
+                                                        const float* __restrict__ inv_var,   // [B]
+                                                        float c_data, float c_res, float c_ineq, float lambda_opt, int B,
+                                                        float* __restrict__ g_x0,            // [B,3,nel,nel]
+                                                        double* __restrict__ partial) {      // [B][8]
+  HIP_DYNAMIC_SHARED(float, smem)
+  __shared__ double red4[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nel = ms.nel, nn = ms.nn, E = ms.E, ndof = ms.ndof;
+  float* sU = smem;
+  float* sR = smem + ndof;
+  float* sZ = sR + E;
+  float* sG = sZ + ndof;
+  const float* xb = x0 + (size_t)b * 3 * nel * nel;
+  const float* bb = bcs + (size_t)b * 4 * nn * nn;
+  const float* tb = target + (size_t)b * 3 * nn * nn;
+  const float dscale = 2.f * c_data * p2w[b] / ((float)B * 3.f * (float)(nn * nn));
+  // ---- phase 1: U = bilinear(u, nn), rho -> LDS; data term and its gradient at the nodes ----
+  double a_data = 0.0;
+  for (int node = tid; node < nn * nn; node += 256) {
+    const int r = node / nn, c = node - r * nn;
+    int y0, y1, x0i, x1i;
+    float ly, lx;
+    bil_src(r, nel, nn, &y0, &y1, &ly);
+    bil_src(c, nel, nn, &x0i, &x1i, &lx);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float* p = xb + (size_t)d * nel * nel;
+      const float top = p[y0 * nel + x0i] * (1.f - lx) + p[y0 * nel + x1i] * lx;
+      const float bot = p[y1 * nel + x0i] * (1.f - lx) + p[y1 * nel + x1i] * lx;
+      const float u = top * (1.f - ly) + bot * ly;
+      sU[2 * node + d] = u;
+      const float diff = u - tb[(size_t)d * nn * nn + node];
+      a_data += (double)(diff * diff);
+      sG[2 * node + d] = dscale * diff;
+    }
+    const float rho_pad = (r < nel && c < nel) ? xb[(size_t)2 * nel * nel + r * nel + c] : 0.f;
+    const float d2 = rho_pad - tb[(size_t)2 * nn * nn + node];
+    a_data += (double)(d2 * d2);
+  }
+  double rsum_l = 0.0;
+  for (int e = tid; e < E; e += 256) {
+    const float rv = xb[(size_t)2 * nel * nel + e];
+    sR[e] = rv;
+    rsum_l += rv;
+  }
+  double ivs_l = 0.0;
+  for (int i = tid; i < B; i += 256) ivs_l += (double)inv_var[i];
+  const double rsum = block_sum(rsum_l, red4);      // (publishes sU / sR / sG as well)
+  const double ivs = block_sum(ivs_l, red4);
+  const float shift = (float)(rsum / E) - vf[b];
+  const float gc = lambda_opt / (float)B;                                             // d loss / d compliance_b
+  const float gs = (c_ineq > 0.f ? c_ineq * shift * (float)ivs / ((float)B * (float)B) : 0.f) / (float)E;   // d loss / d rho_e via the shift
+  const float rscale = c_res * inv_var[b] / ((float)B * (float)ndof);
+  // ---- phase 2: per dof: (K_closed U)_i, residual, compliance; d loss / d (K U)_i and the direct d loss / d U_i ----
+  double a_r2 = 0.0, a_rabs = 0.0, a_comp = 0.0;
+  for (int i = tid; i < ndof; i += 256) {
+    float ku = 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const int e = ms.dof_elems[(i * 4 + s) * 2], a = ms.dof_elems[(i * 4 + s) * 2 + 1];
+      if (e < 0) continue;
+      const float* k = ms.kloc + (size_t)e * ms.kloc_stride + a * 8;
+      const int* D = ms.elem_dofs + (size_t)e * 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = fmaf(k[q], sU[D[q]], acc);
+      ku = fmaf(sR[e], acc, ku);
+    }
+    const int node = i >> 1, d = i & 1;
+    const bool masked = bb[(size_t)d * nn * nn + node] != 0.f;
+    const float ui = sU[i];
+    const float kbc = masked ? ui : ku;
+    const float f = masked ? 0.f : bb[(size_t)(2 + d) * nn * nn + node];
+    const float res = kbc - f;
+    a_r2 += (double)(res * res);
+    a_rabs += (double)fabsf(res);
+    a_comp += (double)(ui * kbc);
+    const float w = rscale * res + gc * ui;          // d L / d Kbc_i
+    sZ[i] = masked ? 0.f : w;                        // d L / d KU_i
+    sG[i] += gc * kbc + (masked ? w : 0.f);          // direct d L / d U_i (on top of the data term)
+  }
+  __syncthreads();
+  // ---- phase 3: gU += K^T z (gather); g_rho_e = z_e^T kloc u_e + shift term + data term ----
+  for (int i = tid; i < ndof; i += 256) {
+    float acc = 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const int e = ms.dof_elems[(i * 4 + s) * 2], bq = ms.dof_elems[(i * 4 + s) * 2 + 1];
+      if (e < 0) continue;
+      const float* k = ms.kloc + (size_t)e * ms.kloc_stride;
+      const int* D = ms.elem_dofs + (size_t)e * 8;
+      float t = 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) t = fmaf(k[a * 8 + bq], sZ[D[a]], t);
+      acc = fmaf(sR[e], t, acc);
+    }
+    sG[i] += acc;
+  }
+  float* gx = g_x0 + (size_t)b * 3 * nel * nel;
+  for (int e = tid; e < E; e += 256) {
+    const float* k = ms.kloc + (size_t)e * ms.kloc_stride;
+    const int* D = ms.elem_dofs + (size_t)e * 8;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t = fmaf(k[a * 8 + q], sU[D[q]], t);
+      acc = fmaf(sZ[D[a]], t, acc);
+    }
+    const int r = e / nel, c = e - r * nel;
+    gx[(size_t)2 * nel * nel + e] = acc + gs + dscale * (sR[e] - tb[(size_t)2 * nn * nn + r * nn + c]);
+  }
+  __syncthreads();
+  // ---- phase 4: adjoint of the bilinear up-sampling ----
+  for (int pix = tid; pix < nel * nel; pix += 256) {
+    const int y = pix / nel, x = pix - y * nel;
+    float g0 = 0.f, g1 = 0.f;
+    for (int r = y - 1; r <= y + 2; ++r) {
+      if (r < 0 || r >= nn) continue;
+      int y0, y1;
+      float ly;
+      bil_src(r, nel, nn, &y0, &y1, &ly);
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int c = x - 1; c <= x + 2; ++c) {
+        if (c < 0 || c >= nn) continue;
+        int x0i, x1i;
+        float lx;
+        bil_src(c, nel, nn, &x0i, &x1i, &lx);
+        const float wx = (x0i == x ? 1.f - lx : 0.f) + (x1i == x ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const int node = r * nn + c;
+        g0 = fmaf(wy * wx, sG[2 * node], g0);
+        g1 = fmaf(wy * wx, sG[2 * node + 1], g1);
+      }
+    }
+    gx[pix] = g0;
+    gx[(size_t)nel * nel + pix] = g1;
+  }
+  // ---- per-sample partial sums (fixed order) ----
+  const double s_data = block_sum(a_data, red4), s_r2 = block_sum(a_r2, red4), s_rabs = block_sum(a_rabs, red4),
+               s_comp = block_sum(a_comp, red4);
+  if (tid == 0) {
+    double* o = partial + (size_t)b * 8;
+    o[0] = s_data; o[1] = s_r2; o[2] = s_rabs; o[3] = s_comp; o[4] = (double)shift;
+  }
+}
+
+// out[0] = loss, out[1] = data loss, out[2] = mean |r|, out[3] = mean shift (0 unless c_ineq > 0), out[4] = mean compliance
+__global__ void mech_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w, const float* __restrict__ inv_var,
+                                   float c_data, float c_res, float c_ineq, float lambda_opt, int B, int nn, int ndof,
+                                   float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double data = 0.0, res = 0.0, rabs = 0.0, comp = 0.0, sh = 0.0, sh2 = 0.0, ivs = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double* p = partial + (size_t)b * 8;
+    data += p[0] / (3.0 * nn * nn) * (double)p2w[b];
+    res += p[1] * (double)inv_var[b];
+    rabs += p[2];
+    comp += p[3];
+    sh += p[4];
+    sh2 += p[4] * p[4];
+    ivs += (double)inv_var[b];
+  }
+  data = data / B * c_data;
+  double loss = data + 0.5 * c_res * res / ((double)B * ndof) + lambda_opt * comp / B;
+  if (c_ineq > 0.f) loss += 0.5 * c_ineq * ivs * sh2 / ((double)B * B);
+  out[0] = (float)loss;
+  out[1] = (float)data;
+  out[2] = (float)(rabs / ((double)B * ndof));
+  out[3] = c_ineq > 0.f ? (float)(sh / B) : 0.f;
+  out[4] = (float)(comp / B);
+  out[5] = out[6] = out[7] = 0.f;
+}
+
 __global__ void __launch_bounds__(256) mech_apply_kernel(MechMesh ms, const float* __restrict__ rho,     // [B][E]
                                                          const float* __restrict__ u_img,   // [B][2][nn][nn]
                                                          const float* __restrict__ bcs,     // [B][4][nn][nn]
@@ -481,6 +672,34 @@ extern "C" int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, co
   return 0;
 }
 
+
+extern "C" size_t pidm_mech_loss_ws(int B) { return (size_t)B * 8 * sizeof(double) + 256; }
+
+extern "C" int pidm_mech_loss_fwd_bwd(const float* x0_pred, const float* target, const float* bcs, const float* vf, const float* p2w,
+                                      const float* inv_var, float c_data, float c_residual, float c_ineq, float lambda_opt,
+                                      const float* kloc, int kloc_stride, const int32_t* elem_dofs, const int32_t* dof_elems, int nel,
+                                      float* grad_x0_pred, float* out_scalars, void* workspace, int B, void* stream) {
+  const int E = nel * nel, nn = nel + 1, ndof = 2 * nn * nn;
+  if (mech_args(nel, E, ndof, kloc, elem_dofs, dof_elems)) return -1;
+  if (!x0_pred || !target || !bcs || !vf || !p2w || !inv_var || !grad_x0_pred || !out_scalars || !workspace) return fail("mech_loss: null buffer");
+  if (B <= 0) return fail("mech_loss: B must be positive");
+  MechMesh ms{elem_dofs, dof_elems, kloc, kloc_stride, E, ndof, nel, nn};
+  const size_t lds = (size_t)(3 * ndof + E) * sizeof(float);
+  if (lds > 150 * 1024) return fail("mech: mesh does not fit LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mech_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  double* partial = reinterpret_cast<double*>((reinterpret_cast<size_t>(workspace) + 255) & ~(size_t)255);
+  hipLaunchKernelGGL(mech_loss_kernel, dim3(B), dim3(256), lds, as_stream(stream), ms, x0_pred, target, bcs, vf, p2w, inv_var, c_data,
+                     c_residual, c_ineq, lambda_opt, B, grad_x0_pred, partial);
+  PIDM_CHECK_LAUNCH("mech_loss_kernel");
+  hipLaunchKernelGGL(mech_loss_finalize, dim3(1), dim3(64), 0, as_stream(stream), partial, p2w, inv_var, c_data, c_residual, c_ineq,
+                     lambda_opt, B, nn, ndof, out_scalars);
+  PIDM_CHECK_LAUNCH("mech_loss_finalize");
+  return 0;
+}
 
 extern "C" int pidm_mech_apply(const float* rho, const float* u_img, const float* bcs, const float* kloc, int kloc_stride,
                                const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* residual, float* comp_uf,

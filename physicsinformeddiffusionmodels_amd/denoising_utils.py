@@ -64,16 +64,27 @@ def extract(input, t, x):
 
 
 class EMA(object):
-    """Shadow-weight EMA with the reference's swap-in/swap-out protocol (src/denoising_utils.py:163-205):
-    `update` after each optimizer step, `ema(model)` swaps the averaged weights in (keeping a backup), `restore`
-    swaps back - main.py does all three EVERY iteration (main.py:178-183,316).  Same dict-of-tensors state and
-    arithmetic ((1-mu)*p + mu*shadow), but executed as multi-tensor (`torch._foreach_*`) launches: 4 launches per
-    cycle instead of ~1600 per-tensor ops (11.7 ms -> <1 ms per iteration for the Darcy model on MI355X)."""
+    """Shadow-weight EMA with the reference's swap-in / swap-out protocol (src/denoising_utils.py:163-205): `update` after each
+    optimizer step, `ema(model)` swaps the averaged weights in, `restore` swaps back - main.py does all three EVERY iteration
+    (main.py:178-183,316).  Same dict-of-tensors state (`shadow`, what `state_dict()` returns and checkpoints hold) and the same
+    arithmetic, (1-mu)*p + mu*shadow with every product and the sum rounded to fp32, so the shadow is bit-identical to the
+    reference's.  What differs is how it is executed:
+
+    * `update`: once the model's parameters live in the engine's flat buffer (`optim.flatten_parameters`, done by
+      `FusedClipAdam`) the shadow is re-homed into one flat buffer too and the update is ONE kernel (`pidm_ema_update`); with
+      `FusedClipAdam(..., ema=this)` it rides inside the Adam kernel and `update` only acknowledges it.  Parameters outside the
+      flat buffer (the ones forward never reads) take three multi-tensor launches.
+    * `ema` / `restore`: a POINTER FLIP instead of three full copies - `param.data` is re-pointed at the shadow tensor and back
+      (the engine re-reads parameter pointers on every call).  Between `ema()` and `restore()` the parameters ARE the shadow:
+      evaluate, sample and checkpoint, but do not run an optimizer step there (`FusedClipAdam.step` refuses).
+      `ema(module, backup=False)` has no way back, so it copies, as the reference does."""
 
     def __init__(self, mu=0.999):
         self.mu = mu
         self.shadow = {}
         self.backup = {}
+        self._flat = None            # (flat shadow buffer, flat parameter buffer, names) once re-homed
+        self._fused_updates = 0      # updates already applied inside FusedClipAdam.step and not yet acknowledged
 
     @staticmethod
     def _named(module):
@@ -82,40 +93,135 @@ class EMA(object):
     def register(self, module):
         for name, param in self._named(module):
             self.shadow[name] = param.data.clone()
+        self._flat = None
+
+    # ---- flat layout ------------------------------------------------------------------------------------------
+    def _flat_layout(self, module):
+        """(flat shadow, flat params, engine) when the module's engine parameters are flat and all trainable, else None.
+        Re-homes the shadow tensors of those parameters into one buffer (same values) the first time, and again whenever
+        the shadow dict was replaced (load_state_dict) or the parameters were re-flattened."""
+        if self.backup:
+            return None               # swapped in: parameter pointers are the shadow's right now
+        pflat = module.__dict__.get("_pidm_flat_params")
+        engines = module.__dict__.get("_engines")
+        if pflat is None or not engines:
+            return None
+        eng = next(iter(engines.values()))
+        off = pflat.data_ptr()
+        for p, ne in zip(eng.params, eng.numels):
+            if p.data_ptr() != off or not p.requires_grad:
+                return None
+            off += 4 * ne
+        names = eng.names
+        if any(n not in self.shadow for n in names):
+            return None
+        sflat = self._flat[0] if self._flat is not None and self._flat[1] is pflat else None
+        ok = sflat is not None
+        if ok:
+            off = sflat.data_ptr()
+            for n, ne in zip(names, eng.numels):
+                if self.shadow[n].data_ptr() != off:
+                    ok = False
+                    break
+                off += 4 * ne
+        if not ok:
+            sflat = torch.empty_like(pflat)
+            off = 0
+            for n, p, ne in zip(names, eng.params, eng.numels):
+                view = sflat[off:off + ne].view(p.shape)
+                view.copy_(self.shadow[n].to(sflat.device))
+                self.shadow[n] = view
+                off += ne
+            self._flat = (sflat, pflat, tuple(names))
+        return sflat, pflat, eng
 
     def update(self, module):
         named = self._named(module)
-        shadows = [self.shadow[n].data for n, _ in named]
-        params = [p.data for _, p in named]
-        torch._foreach_mul_(shadows, self.mu)
-        torch._foreach_add_(shadows, params, alpha=1. - self.mu)
+        rest = named
+        lay = self._flat_layout(module)
+        if lay is not None:
+            sflat, pflat, eng = lay
+            if self._fused_updates > 0:
+                self._fused_updates -= 1          # FusedClipAdam.step already applied this update inside the Adam kernel
+            else:
+                eng.lib.check(eng.lib.pidm_ema_update(ptr(sflat), ptr(pflat), pflat.numel(), float(self.mu),
+                                                      stream_ptr(pflat.device)), 'pidm_ema_update')
+            flat_names = set(self._flat[2])
+            rest = [(n, p) for n, p in named if n not in flat_names]
+        if rest:
+            shadows = [self.shadow[n].data for n, _ in rest]
+            scaled = torch._foreach_mul([p.data for _, p in rest], 1. - self.mu)     # (1-mu)*p, rounded
+            torch._foreach_mul_(shadows, self.mu)                                     # mu*shadow, rounded
+            torch._foreach_add_(shadows, scaled)                                      # their sum, rounded
 
     def ema(self, module, backup=True):
         named = self._named(module)
         for n, _ in named:
             assert n in self.shadow
-        params = [p.data for _, p in named]
-        if backup:
-            if set(self.backup.keys()) != {n for n, _ in named}:
-                self.backup = {n: torch.empty_like(p.data) for n, p in named}
-            torch._foreach_copy_([self.backup[n] for n, _ in named], params)
-        torch._foreach_copy_(params, [self.shadow[n].data for n, _ in named])
+        if not backup:
+            torch._foreach_copy_([p.data for _, p in named], [self.shadow[n].data for n, _ in named])
+            return
+        dev = named[0][1].device if named else None
+        for n, p in named:
+            sh = self.shadow[n]
+            if sh.device != dev:
+                sh = self.shadow[n] = sh.to(dev)
+            self.backup[n] = p.data
+            p.data = sh
 
     def restore(self, module):
-        named = self._named(module)
-        for n, _ in named:
+        assert hasattr(self, 'backup')
+        for n, p in self._named(module):
             assert n in self.backup
-        torch._foreach_copy_([p.data for _, p in named], [self.backup[n] for n, _ in named])
+            p.data = self.backup[n]
+        self.backup = {}
 
     def state_dict(self):
         return self.shadow
 
     def load_state_dict(self, state_dict):
         self.shadow = state_dict
+        self._flat = None
 
 
 def image_array_to_gif(image_array, output_file, frame_duration=0.05, normalization_mode='final_pred', given_min_max=None):
-    raise NotImplementedError('GIF export needs imageio, which is outside the accelerated path (main.py: create_gif=False)')
+    """Animated GIF of a [frames, H, W] array (src/denoising_utils.py:244-271; sample.py calls it with create_gif=True by
+    default, sample.py:25,212-214,312).  Grey-level range: 'final_pred' = range of the last frame, 'global' = of the whole
+    array, 'given' = `given_min_max`, 'individual' = per frame, 'none' = frames are written as they are.  Host-side IO, not
+    on the accelerated path: written with imageio when it is installed (what the reference uses), otherwise with Pillow;
+    with neither, a warning is printed and nothing is written (the sampling results themselves are saved by the caller)."""
+    frames = np.asarray(image_array)
+    if normalization_mode == 'given' and given_min_max is None:
+        raise ValueError("Please provide min and max values for 'given' normalization mode.")
+    if normalization_mode not in ('final_pred', 'global', 'given', 'individual', 'none'):
+        raise ValueError(f'unknown normalization_mode {normalization_mode!r}')
+    if normalization_mode != 'none':
+        if normalization_mode == 'individual':
+            flat = frames.reshape(len(frames), -1)
+            lo, hi = flat.min(axis=1), flat.max(axis=1)
+            lo, hi = lo.reshape(-1, 1, 1), hi.reshape(-1, 1, 1)
+        else:
+            ref = {'final_pred': frames[-1], 'global': frames}.get(normalization_mode)
+            lo, hi = given_min_max if ref is None else (ref.min(), ref.max())
+        with np.errstate(divide='ignore', invalid='ignore'):
+            frames = ((frames - lo) / (hi - lo) * 255).astype(np.uint8)     # same arithmetic (and wrap-around) as the reference
+    try:
+        import imageio
+    except ImportError:
+        imageio = None
+    if imageio is not None:
+        with imageio.get_writer(output_file, mode='I', duration=frame_duration) as writer:
+            for frame in frames:
+                writer.append_data(frame)
+        return
+    try:
+        from PIL import Image
+    except ImportError:
+        print(f'image_array_to_gif: neither imageio nor Pillow is installed - {output_file} not written')
+        return
+    imgs = [Image.fromarray(np.ascontiguousarray(f if f.dtype == np.uint8 else np.clip(f, 0, 255).astype(np.uint8)))
+            for f in frames]
+    imgs[0].save(output_file, save_all=True, append_images=imgs[1:], duration=max(int(round(frame_duration * 1000)), 10), loop=0)
 
 
 def save_model(config, model, train_iterations, output_save_dir):
@@ -274,9 +380,13 @@ class DenoisingDiffusion(nn.Module):
 
     # ---- training loss (src/denoising_utils.py:616-710) ---------------------------------------------------------
     def _darcy_fast_path_ok(self, residual_func, c_ineq, lambda_opt, x):
-        return (isinstance(residual_func, ResidualsDarcy) and not residual_func.use_ddim_x0
-                and not residual_func.residual_grad_guidance and c_ineq <= 0.
+        return (isinstance(residual_func, ResidualsDarcy) and not residual_func.residual_grad_guidance and c_ineq <= 0.
                 and lambda_opt <= 0. and x.dtype == torch.float32 and (x.is_cuda or self._lib is not None))
+
+    def _mech_fast_path_ok(self, residual_func, x):
+        from .residuals_mechanics_K import ResidualsMechanics
+        return (isinstance(residual_func, ResidualsMechanics) and x.dtype == torch.float32
+                and (x.is_cuda or self._lib is not None))
 
     def model_estimation_loss(self, input, residual_func=None, c_data=1., c_residual=0., c_ineq=0., lambda_opt=0.):
         batch_size = len(input)
@@ -292,6 +402,8 @@ class DenoisingDiffusion(nn.Module):
 
         if self._darcy_fast_path_ok(residual_func, c_ineq, lambda_opt, x_0):
             return self._darcy_step(x_0, e, t, residual_func, c_data, c_residual)
+        if residual_func.gov_eqs == 'mechanics' and self._mech_fast_path_ok(residual_func, x_0):
+            return self._mech_step(x_0, conditioning, bcs, e, t, residual_func, c_data, c_residual, c_ineq, lambda_opt)
 
         a = extract(self.diff_dict['alphas_bar_sqrt'], t, x_0)
         am1 = extract(self.diff_dict['one_minus_alphas_bar_sqrt'], t, x_0)
@@ -345,23 +457,60 @@ class DenoisingDiffusion(nn.Module):
         xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
         lib.check(lib.pidm_qsample_nhwc(ptr(x_0), ptr(e.contiguous()), ptr(a), ptr(am1), ptr(xt), B, C, P * P,
                                         stream_ptr(dev)), 'pidm_qsample_nhwc')
-        x0_pred = residual_func.model(xt, t)
         p2w = dd['p2_loss_weight'][t].contiguous()
         inv_var = (1.0 / dd['posterior_variance_clipped'][t]).contiguous()
         if residual_func._f_s_flat.device != dev:
             residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
-        loss, scalars, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, residual_func._f_s_flat, p2w, inv_var, c_data, c_residual,
-                                                     residual_func.inv_h0, residual_func.inv_h1, lib)
+        args = (residual_func._f_s_flat, p2w, inv_var)
+        geo = (residual_func.inv_h0, residual_func.inv_h1, lib)
+        if residual_func.use_ddim_x0:
+            # x0_estimation 'sample' (src/residuals_darcy.py:127-128): the data term sees model(x_t, t), the residual term
+            # model(x_t, 0) - the same fused kernel once per tensor, with the other term's weight set to zero
+            x0_pred, model_out = self.ddim_sample_x0(xt, t, residual_func.model, xt.shape, residual_func.ddim_steps, 0.)
+            l_data, s_data, _ = _DarcyPidmLossFn.apply(model_out, x_0, *args, c_data, 0., *geo)
+            l_res, s_res, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, *args, 0., c_residual, *geo)
+            s = torch.stack((s_data, s_res)).tolist()  # single D2H sync
+            return l_data + l_res, s[0][1], s[1][2], 0., 0.
+        x0_pred = residual_func.model(xt, t)
+        loss, scalars, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, *args, c_data, c_residual, *geo)
         s = scalars.tolist()  # single D2H sync
         return loss, s[1], s[2], 0., 0.
+
+    def _mech_step(self, x_0, conditioning, bcs, e, t, residual_func, c_data, c_residual, c_ineq, lambda_opt):
+        """Mechanics configuration (main.py:102-109,139): the loss algebra of src/denoising_utils.py:666-708 on top of the
+        matrix-free residual runs as ONE fused kernel that also returns d loss / d x0_pred (csrc/k_mech.hip mech_loss_kernel);
+        one host sync for the four floats the reference API returns."""
+        from .residuals_mechanics_K import _MechLossFn, resize_image
+        lib = residual_func.lib
+        dd = self.diff_dict
+        a = extract(dd['alphas_bar_sqrt'], t, x_0)
+        am1 = extract(dd['one_minus_alphas_bar_sqrt'], t, x_0)
+        x = torch.cat((x_0 * a + e * am1, conditioning), dim=1)
+        P = residual_func.pixels_per_dim
+        net_in = torch.cat((resize_image(x, P, lib), resize_image(bcs, P, lib)), dim=1)          # 10 channels
+        vf = conditioning[:, 0, 0, 0].contiguous()
+        p2w = dd['p2_loss_weight'][t].contiguous()
+        inv_var = (1.0 / dd['posterior_variance_clipped'][t]).contiguous()
+        if residual_func.stiffs.kloc_dev.device != x_0.device:
+            residual_func.stiffs.to(x_0.device)
+        fixed = (x_0.contiguous(), bcs.contiguous(), vf, p2w, inv_var)
+        if residual_func.use_ddim_x0:
+            x0_pred, model_out = self.ddim_sample_x0(net_in, t, residual_func.model, x.shape, residual_func.ddim_steps, 0.,
+                                                     gov_eqs='mechanics')
+            l_data, s_data = _MechLossFn.apply(model_out, *fixed, c_data, 0., 0., 0., residual_func.stiffs, lib)
+            l_res, s_res = _MechLossFn.apply(x0_pred, *fixed, 0., c_residual, c_ineq, lambda_opt, residual_func.stiffs, lib)
+            s = torch.stack((s_data, s_res)).tolist()
+            return l_data + l_res, s[0][1], s[1][2], s[1][3], s[1][4]
+        x0_pred = residual_func.model(net_in, t)
+        loss, scalars = _MechLossFn.apply(x0_pred, *fixed, c_data, c_residual, c_ineq, lambda_opt, residual_func.stiffs, lib)
+        s = scalars.tolist()  # single D2H sync
+        return loss, s[1], s[2], s[3], s[4]
 
     # ---- sampling (src/denoising_utils.py:388-545) ---------------------------------------------------------------
     def p_sample(self, x, conditioning_input, t, save_output=False, surpress_noise=False, use_dynamic_threshold=False,
                  residual_func=None, eval_residuals=False, return_optimizer=False, return_inequality=False,
                  residual_correction=False, correction_mode='none'):
         assert correction_mode in ['x0', 'xt'] or not residual_correction, 'Correction mode unknown or not given.'
-        if use_dynamic_threshold:
-            raise NotImplementedError('dynamic thresholding is off in main.py/sample.py and not on the accelerated path')
         x_init = x.detach()
         if conditioning_input is not None:
             conditioning, bcs, solution = conditioning_input
@@ -404,6 +553,12 @@ class DenoisingDiffusion(nn.Module):
             if residual_correction and correction_mode == 'xt':      # CoCoGen (:457-459)
                 out, residual = residual_func.residual_correction(generalized_image_to_b_xy_c(out).contiguous())
                 out = generalized_b_xy_c_to_image(out).contiguous()
+            if use_dynamic_threshold:
+                # off in main.py / sample.py (src/denoising_utils.py:461-473): per-sample 0.9-quantile of |x|, at least 1;
+                # a sort per step, kept on torch (not on the accelerated path)
+                s_thr = torch.quantile(out.reshape(batch_size, -1).abs().float(), 0.9, dim=-1).clamp_(min=1.0)
+                s_thr = right_pad_dims_to(out, s_thr)
+                out = torch.maximum(torch.minimum(out, s_thr), -s_thr) / s_thr
         if t_int == 0 and eval_residuals:
             aux_out = {'residual': residual}
             if return_optimizer:
@@ -465,12 +620,15 @@ class DenoisingDiffusion(nn.Module):
         batch = shape[0]
         if len(t) == 1:
             t = torch.ones(batch, device=xt.device, dtype=torch.long) * t
-        model._pidm_multi_tape = True          # two live activation tapes (see _engine.unet_apply)
+        # two live activation tapes: the call at (x_t, t) records on engine slot 0, the call at (x_t, 0) on slot 1
+        # (_engine.unet_apply); named slots, so tapes of losses that are never differentiated (validation) do not pile up
         try:
+            model._pidm_tape_slot = 0
             model_out = model(xt, t)
+            model._pidm_tape_slot = 1
             x0_pred = model(xt, torch.zeros_like(t))
         finally:
-            model._pidm_multi_tape = False
+            model._pidm_tape_slot = None
         # RNG parity with :775: the same randn_like call on a tensor of the same shape AND strides as the reference's cur_x
         # (a permuted view of x_t - the CPU generator consumes differently for non-contiguous outputs); sigma is 0 for
         # eta = 0, so the values never matter

@@ -57,7 +57,10 @@ class FusedClipAdam:
     `step()` returns the pre-clip global gradient norm as a device scalar (what clip_grad_norm_ returns)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=None, image_size: int = 64,
-                 lib: PidmLib | None = None):
+                 lib: PidmLib | None = None, ema=None, ema_start: int = -1):
+        """ema (optional `denoising_utils.EMA`, already `register`ed): its update (main.py:178-179) is folded into the Adam
+        kernel for every step whose 0-based index is > ema_start (main.py:52 uses ema_start = 1000); the `ema.update(model)`
+        call main.py makes right after then only acknowledges it, so the loop body stays as it is."""
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.max_norm = None if max_norm is None else float(max_norm)
@@ -74,6 +77,7 @@ class FusedClipAdam:
         dev = self.flat.device
         self._ws = torch.empty(self.lib.pidm_clip_adam_ws_bytes(), dtype=torch.uint8, device=dev)
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ema, self.ema_start = ema, int(ema_start)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
@@ -98,14 +102,26 @@ class FusedClipAdam:
     @torch.no_grad()
     def step(self):
         if not _is_flat(self.eng, self.flat):
-            raise PidmError("FusedClipAdam: the model's parameters were re-allocated after flatten_parameters()")
+            raise PidmError("FusedClipAdam: the model's parameters do not live in the flat buffer (re-allocated after "
+                            "flatten_parameters(), or the EMA weights are swapped in: call ema.restore(model) first)")
         g = self._flat_grad()
         self.step_count += 1
         dev = self.flat.device
-        self.lib.check(self.lib.pidm_clip_adam_step(
-            ptr(self.flat), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
-            self.betas[1], self.eps, self.step_count, -1.0 if self.max_norm is None else self.max_norm, ptr(self._norm),
-            ptr(self._ws), stream_ptr(dev)), "pidm_clip_adam_step")
+        max_norm = -1.0 if self.max_norm is None else self.max_norm
+        lay = None
+        if self.ema is not None and self.step_count - 1 > self.ema_start:
+            lay = self.ema._flat_layout(self.model)
+        if lay is not None:
+            self.lib.check(self.lib.pidm_clip_adam_ema_step(
+                ptr(self.flat), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(lay[0]), self.flat.numel(), self.lr,
+                self.betas[0], self.betas[1], self.eps, self.step_count, max_norm, float(self.ema.mu), ptr(self._norm), ptr(self._ws),
+                stream_ptr(dev)), "pidm_clip_adam_ema_step")
+            self.ema._fused_updates += 1
+        else:
+            self.lib.check(self.lib.pidm_clip_adam_step(
+                ptr(self.flat), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
+                self.betas[1], self.eps, self.step_count, max_norm, ptr(self._norm), ptr(self._ws), stream_ptr(dev)),
+                "pidm_clip_adam_step")
         return self._norm[0]
 
     # checkpointing: flat tensors in the engine's canonical parameter order (names alongside for inspection)

@@ -172,6 +172,36 @@ class _MechResidualFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _MechLossFn(torch.autograd.Function):
+    """(loss, scalars[8]) of the mechanics training loss and, saved for backward, d loss / d x0_pred - one fused kernel
+    (`pidm_mech_loss_fwd_bwd`, src/denoising_utils.py:666-708).  scalars = (loss, data loss, mean |r|, mean shift, mean
+    compliance, 0, 0, 0)."""
+
+    @staticmethod
+    def forward(ctx, x0_pred, target, bcs, vf, p2w, inv_var, c_data, c_residual, c_ineq, lambda_opt, stiffs, lib):
+        x = x0_pred.contiguous().float()
+        B, _, nel, _ = x.shape
+        dev = x.device
+        if tuple(target.shape) != (B, 3, nel + 1, nel + 1) or tuple(bcs.shape) != (B, 4, nel + 1, nel + 1):
+            raise PidmError(f"mechanics loss: target / bcs must be [B,3,{nel + 1},{nel + 1}] / [B,4,{nel + 1},{nel + 1}]")
+        grad = torch.empty_like(x)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pidm_mech_loss_ws(B), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_mech_loss_fwd_bwd(ptr(x), ptr(target.contiguous().float()), ptr(bcs.contiguous().float()),
+                                             ptr(vf.contiguous().float()), ptr(p2w), ptr(inv_var), float(c_data), float(c_residual),
+                                             float(c_ineq), float(lambda_opt), ptr(stiffs.kloc_dev), stiffs.kloc_stride,
+                                             ptr(stiffs.elem_dofs32), ptr(stiffs.dof_elems32), nel, ptr(grad), ptr(out), ptr(ws), B,
+                                             stream_ptr(dev)), "pidm_mech_loss_fwd_bwd")
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        (grad,) = ctx.saved_tensors
+        return (grad * g_loss,) + (None,) * 11
+
+
 class ResidualsMechanics:
     """Drop-in for reference ResidualsMechanics (src/residuals_mechanics_K.py:105-367), matrix-free."""
 
@@ -247,20 +277,28 @@ class ResidualsMechanics:
         if pass_through:
             assert isinstance(input, torch.Tensor), 'Input is assumed to directly be given output.'
             x0_pred = input
+            mo_src = None
         else:
+            mo_src = None
             assert len(input) == 2 and isinstance(input, tuple), 'Input must be a tuple consisting of noisy signal and time.'
             noisy_in, time = input
             P = self.pixels_per_dim
             noisy_img = generalized_b_xy_c_to_image(noisy_in).detach()
             net_in = torch.cat((resize_image(noisy_img, P, lib), resize_image(bcs.detach(), P, lib)), dim=1)   # 10 channels
             if self.use_ddim_x0:
-                x0_pred, _ = ddim_func(net_in, time, self.model, noisy_img.shape, self.ddim_steps, 0., gov_eqs='mechanics')
+                # x0_pred = model(x_t, 0) feeds the residual; model_out = model(x_t, t) is what the data loss and the
+                # sampler's posterior mean see (reference :192-195, 246-256)
+                x0_pred, mo_src = ddim_func(net_in, time, self.model, noisy_img.shape, self.ddim_steps, 0., gov_eqs='mechanics')
             else:
                 x0_pred = self.model(net_in, time)
         assert x0_pred.dim() == 4, 'Model output must be a tensor shaped as an image.'
         if self.stiffs.kloc_dev.device != x0_pred.device:
             self.stiffs.to(x0_pred.device)
         residual, model_out, compliance, shift = _MechResidualFn.apply(x0_pred, bcs, vf, self.stiffs, lib)
+        if mo_src is not None and return_model_out:
+            # displacements resized to the nodal grid + zero-padded density of the FIRST model call (differentiable: the same
+            # kernel pair, only its model_out output / input gradient are used)
+            _, model_out, _, _ = _MechResidualFn.apply(mo_src, bcs, vf, self.stiffs, lib)
         output = {'residual': residual}
         if return_model_out:
             output['model_out'] = model_out

@@ -215,3 +215,52 @@ def test_mechanics_config4_step_dim128_b32_deterministic():
     n_used = sum(p.grad is not None for p in m.parameters())
     n_all = sum(1 for _ in m.parameters())
     assert n_used == 259 and n_all > n_used
+
+
+@pytest.mark.slow
+def test_darcy_step_b64_vs_oracle():
+    """BASELINE configs[1] at its real batch (64): the large-grid tile variants (persistent 3x3 walk, 256-pixel tiles, permuted
+    128-channel 1x1 tiles, fused attention - all gated on >= 512 workgroups and therefore only reached by small-shape unit
+    tests otherwise) against the oracle's autograd on the same weights, (t, eps) and data: loss, data loss, mean |residual|
+    and EVERY used gradient tensor (norm 1e-3 + element-wise on 24 probes).  ~30 s of host time for the oracle."""
+    from oracle import pidm_oracle as O
+    m, diff, res, dev = _darcy_setup()
+    B, P = 64, 64
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, 2, P, P, generator=g)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(B, 2, P, P, generator=g)
+    t = torch.randint(0, 100, (B,), generator=g)
+    orig = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.to(dev)
+    torch.randn_like = lambda *a, **k: eps.to(dev)
+    try:
+        loss, data_l, res_l, _, _ = diff.model_estimation_loss(x0.to(dev), residual_func=res, c_data=1., c_residual=1e-3)
+    finally:
+        torch.randint, torch.randn_like = orig
+    loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref, rdata, rabs, _ = O.darcy_training_loss(p, O.UnetCfg(dim=32, channels=2), O.diffusion_tables(100), x0, t, eps, 1., 1e-3)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item()), (loss.item(), ref.item())
+    assert abs(data_l - rdata.item()) < 1e-4 * abs(rdata.item())
+    assert abs(res_l - rabs.item()) < 1e-4 * abs(rabs.item())
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    n, probes, bad = 0, 0, []
+    for k, prm in m.named_parameters():
+        if p[k].grad is None:
+            assert prm.grad is None, k
+            continue
+        a = prm.grad.detach().cpu()
+        b = p[k].grad
+        if not abs(a.norm().item() - b.norm().item()) <= 1e-3 * b.norm().item() + 2e-6 * gmax:
+            bad.append((k, a.norm().item(), b.norm().item()))
+        n += 1
+        if n % 11 == 0:       # element-wise on every 11th tensor (24 of 259)
+            assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item() + 2e-6 * gmax, k
+            probes += 1
+    assert not bad, bad[:8]
+    assert n == 259 and probes >= 20

@@ -142,14 +142,14 @@ def test_sample_estimation_two_tapes(backend):
         assert abs(a - b) <= 2e-3 * b + 5e-6 * gmax, (k, a, b)
 
 
-def run_mech_loss_case(backend):
+def run_mech_loss_case(backend, tag="g10_mech_loss_dim8", dim=8):
     """Full mechanics model_estimation_loss (UNet 10->3 channels with sigmoid head, matrix-free K u residual, compliance,
     volume-shift with the reference's [B,B] broadcast) vs the reference run with the dense stiffness matrix."""
     from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
     L, dev = backend
     lib = L if dev.type == "cpu" else None
-    g = np.load(os.path.join(G, "g10_mech_loss_dim8.npz"))
-    m = Unet3D(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    g = np.load(os.path.join(G, tag + ".npz"))
+    m = Unet3D(dim=dim, channels=10, out_dim=3, sigmoid_last_channel=True)
     m.load_state_dict(O.fill_state_dict(m.state_dict()))
     m = m.to(dev)
     m._pidm_lib = lib
@@ -178,6 +178,13 @@ def run_mech_loss_case(backend):
 @pytest.mark.slow
 def test_mechanics_loss_dim8(backend):
     run_mech_loss_case(backend)
+
+
+@pytest.mark.gpu
+def test_mechanics_loss_dim128_gpu():
+    """Golden g10b: the reference's mechanics model_estimation_loss at its own model width (dim=128, main.py:126), B=1."""
+    from physicsinformeddiffusionmodels_amd._lib import get_lib
+    run_mech_loss_case((get_lib(), torch.device("cuda:0")), "g10b_mech_loss_dim128", 128)
 
 
 def test_multi_step_training_trajectory_vs_oracle(backend):
@@ -237,3 +244,89 @@ def test_ddim_sample_x0_outputs_and_rng_consumption(backend, k):
         assert (mine.cpu() - torch.from_numpy(ref)).abs().max().item() < 3e-5 * np.abs(ref).max()
     if dev.type == "cpu":
         np.testing.assert_array_equal(torch.rand(4).numpy(), g[f"next_rand_k{k}"])
+
+
+def _mech_setup(backend, dim=8):
+    from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
+    L, dev = backend
+    lib = L if dev.type == "cpu" else None
+    m = Unet3D(dim=dim, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = lib
+    diff = DenoisingDiffusion(100, dev, lib=lib)
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder="/nonexistent/", device=dev,
+                             topopt_eval=False, lib=lib)
+    return m, diff, res, dev
+
+
+def _oracle_params(m):
+    return {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+
+
+def _compare_grads(m, p, rtol=2e-3):
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    for k, prm in m.named_parameters():
+        if p[k].grad is None:
+            assert prm.grad is None, k
+            continue
+        a, b = prm.grad.cpu().norm().item(), p[k].grad.norm().item()
+        assert abs(a - b) <= rtol * b + 5e-6 * gmax, (k, a, b)
+
+
+@pytest.mark.slow
+def test_mechanics_sample_estimation_vs_oracle(backend):
+    """x0_estimation='sample' with the mechanics residual (model.yaml:6-7 wired to ResidualsMechanics in main.py:139): the data
+    loss sees model(x_t, t), residual / compliance / volume shift see model(x_t, 0) (src/residuals_mechanics_K.py:192-195,
+    246-256), both tapes get gradients and no engine tape is left busy."""
+    m, diff, res, dev = _mech_setup(backend)
+    res.use_ddim_x0 = True
+    g = np.load(os.path.join(G, "g10_mech_loss_dim8.npz"))
+    inp, eps, t = (torch.from_numpy(g[k]) for k in ("inp", "eps", "t"))
+    with patched_rng(randint=lambda *a, **k: t.to(dev), randn_like=lambda *a, **k: eps.to(dev)):
+        loss, data_l, res_l, ineq_l, opt_l = diff.model_estimation_loss(inp.to(dev), residual_func=res, c_data=1., c_residual=1e-3,
+                                                                        c_ineq=0.5, lambda_opt=0.01)
+    loss.backward()
+    p = _oracle_params(m)
+    cfg = O.UnetCfg(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    kloc, ed = O.q4_plane_stress_stiffness(1.0, 0.3, 1.0), O.synthetic_mesh_element_dofs(64)
+    ref = O.mechanics_training_loss(p, cfg, O.diffusion_tables(100), inp, t, eps, kloc, ed, 1., 1e-3, 0.5, 0.01, x0_estimation="sample")
+    ref[0].backward()
+    for got, want in zip((loss.item(), data_l, res_l, ineq_l, opt_l), ref):
+        assert abs(got - want.item()) < 2e-4 * abs(want.item()), (got, want.item())
+    # model_out is the FIRST call's output, model(x_t, t): the data term equals the genuine reference's mean-estimation value
+    # (golden g10), while the residual comes from the evaluation at time 0
+    assert abs(data_l - float(g["data_loss"])) < 2e-4 * float(g["data_loss"])
+    assert abs(res_l - float(g["residual_abs_mean"])) > 1e-3 * float(g["residual_abs_mean"])
+    _compare_grads(m, p)
+    assert not any(e.tape_busy for e in m._engines.values())
+
+
+def test_undifferentiated_losses_do_not_pile_up_engines(backend):
+    """main.py:187 evaluates the validation loss with grad enabled and never calls backward.  With two differentiable UNet
+    calls per loss (x0_estimation='sample') the engine count must stay bounded, the tapes must be released when the graph
+    is dropped, and the next training step must still be exact."""
+    import gc
+    m, diff, res, dev = setup(backend, 8, 16, 100)
+    res.use_ddim_x0 = True
+    x0 = torch.randn(2, 2, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def step(differentiate):
+        loss, *_ = diff.model_estimation_loss(x0, residual_func=res, c_data=1., c_residual=1e-3)
+        if differentiate:
+            for p in m.parameters():
+                p.grad = None
+            loss.backward()
+        return loss
+
+    for it in range(3):
+        step(True)
+        val = step(False)        # graph kept alive by `val` until the next iteration, as in main.py
+    n_engines = len(m._engines)
+    assert n_engines <= 3, sorted(m._engines)      # slot 0, slot 1 (+ at most one inference sibling)
+    del val
+    gc.collect()
+    assert not any(e.tape_busy for e in m._engines.values())
+    with torch.no_grad():
+        m(x0.permute(0, 2, 3, 1).reshape(2, 256, 2).contiguous(), torch.tensor([1, 2], device=dev))
+    assert len(m._engines) == n_engines            # inference after released tapes: no sibling engine needed

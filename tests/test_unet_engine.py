@@ -84,6 +84,48 @@ def test_unet_dim32_p64_gpu(monkeypatch, fused_min_wgs):
     run_case((get_lib(), torch.device("cuda:0")), "g6_unet_dim32_p64", 32, False)
 
 
+def run_dim128_case(L, dev):
+    """Golden g19 (genuine reference): Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True), the model main.py:126
+    builds for topology optimisation - channel widths 128..1024 on 64x64..8x8 maps, i.e. the conv / wgrad tile variants that
+    no dim<=32 golden reaches.  Output probes and sum, the exact 259-tensor used set, every gradient norm, 20 strided gradient
+    samples."""
+    lib = L if dev.type == "cpu" else None
+    g = np.load(os.path.join(G, "g19_unet_dim128_mech.npz"))
+    m = Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    t = torch.from_numpy(g["t"]).to(dev)
+    out = unet_apply(m, x.permute(0, 2, 3, 1).reshape(1, 64 * 64, 10), t, lib=lib)
+    o = out.detach().cpu().numpy()
+    assert rel(o[:, :, ::4, ::4], g["out_probe"]) < 3e-5
+    assert abs(float(o.astype(np.float64).sum()) - float(g["out_sum"])) < 1e-4 * float(g["out_abs_sum"])
+    (out * torch.from_numpy(g["w"]).to(dev)).sum().backward()
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(m.named_parameters())
+    assert sorted(k for k, p in params.items() if p.grad is not None) == sorted(names)
+    gmax = float(np.max(g["grad_norms"]))
+    bad = []
+    for k, ref in zip(names, g["grad_norms"]):
+        got = params[k].grad.double().norm().item()
+        if not abs(got - ref) <= 5e-4 * ref + 2e-6 * gmax:
+            bad.append((k, got, float(ref)))
+    assert not bad, bad[:8]
+    n = 0
+    for f in g.files:
+        if f.startswith("grad/"):
+            k = f[5:]
+            assert rel(params[k].grad.reshape(-1)[::int(g["gstride/" + k])].cpu().numpy(), g[f]) < 1e-3, k
+            n += 1
+    assert n == 20
+
+
+@pytest.mark.gpu
+def test_unet_dim128_mechanics_shape_gpu():
+    from physicsinformeddiffusionmodels_amd._lib import get_lib
+    run_dim128_case(get_lib(), torch.device("cuda:0"))
+
+
 def test_self_conditioning_vs_reference(backend):
     """Unet3D(self_condition=True) (golden g15, genuine reference): init_conv reads cat(x_self_cond, x); a missing
     x_self_cond means zeros; gradients of all used parameters."""

@@ -1,4 +1,5 @@
-"""bench.py - headline benchmark: training samples/sec of the UNet + PDE-residual step, Darcy 64x64.
+"""bench.py - headline benchmark: training samples/sec of the UNet + PDE-residual step, Darcy 64x64 (default workload),
+plus the two other BASELINE.json single-GPU workloads behind --workload {darcy,mechanics,sampling}.
 
 A step is the reference's training-loop body (main.py:157-166): model_estimation_loss (q-sample, UNet forward,
 Darcy residual, PIDM loss) -> zero_grad -> backward -> [gradient all-reduce when N>1] -> clip_grad_norm_(1.0) ->
@@ -8,6 +9,11 @@ Workload = BASELINE.json configs[1] (batch 64 per GPU; configs[2] = 8 x 64 under
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+--workload mechanics = BASELINE configs[3] per-GPU share (Unet3D dim=128, 10->3 channels, K.u residual, batch 32 per GPU:
+main.py:102-109,126,139); --workload sampling = configs[4] (sample.py:145-150: DDPM ancestral chain, 1000-step schedule,
+batch 1024; a step = ONE p_sample step of the whole batch: UNet forward + residual + ancestral update, `value` in
+sample-steps/s).  Same JSON schema, roofline and cpu_baseline for all three.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     - the dominant kernel class (implicit-GEMM conv fwd/dgrad + wgrad on the fp32 matrix cores):
@@ -30,6 +36,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 FLOPS_PER_SAMPLE_FWD_BWD = 11.916e9   # SURVEY 8(d), FlopCounterMode on the reference, Darcy dim=32 64x64
 BYTES_PER_SAMPLE = 148.5e6            # SURVEY 8(d) compulsory-traffic contract at per-GPU batch 256
+FLOPS_PER_SAMPLE_FWD = 3.98e9         # Darcy dim=32 forward only (sampling)
+FLOPS_PER_SAMPLE_MECH = 141.39e9      # mechanics dim=128, 10->3 channels, fwd+bwd (FlopCounterMode on the reference)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -37,9 +45,13 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (configs[1] = 64)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("darcy", "mechanics", "sampling"), default="darcy")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 64 darcy = configs[1], 32 mechanics = configs[3] "
+                                                         "per GPU, 1024 sampling = configs[4])")
+    ap.add_argument("--ema", action="store_true", help="darcy/mechanics: include the EMA update of main.py:178-179 in the step "
+                                                       "(folded into the Adam kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true",
@@ -49,48 +61,89 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch=8, steps=2):
-    """Time the oracle's full training step (fwd + autograd bwd + clip + Adam) on the host cores."""
+def _oracle_params(m):
+    trainable = {k for k, v in m.named_parameters() if v.requires_grad}
+    return {k: v.detach().clone().requires_grad_(k in trainable) for k, v in m.state_dict().items()}
+
+
+def cpu_baseline(workload, batch, steps, threads):
+    """Time the CPU oracle (the restatement of the reference pinned by tests/golden) on this box's host cores: the same
+    workload at the same per-GPU batch where that fits the time budget (Darcy: B=64), a bounded sample of it otherwise."""
     from oracle import pidm_oracle as O
     from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
-    from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch
+    from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch, synthetic_mechanics_batch
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
-    m = Unet3D(dim=32, channels=2)
-    trainable = {k for k, v in m.named_parameters() if v.requires_grad}
-    p = {k: v.detach().clone().requires_grad_(k in trainable) for k, v in m.state_dict().items()}
-    used = None
-    cfg = O.UnetCfg(dim=32, channels=2)
     tables = O.diffusion_tables(100)
-    x0 = synthetic_darcy_batch(batch, 64, seed=1)
     g = torch.Generator().manual_seed(2)
     t = torch.randint(0, 100, (batch,), generator=g)
-    eps = torch.randn(batch, 2, 64, 64, generator=g)
-    opt = None
+    if workload == "sampling":
+        m = Unet3D(dim=32, channels=2)
+        p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        cfg = O.UnetCfg(dim=32, channels=2)
+        tab = O.diffusion_tables(1000)
+        x = torch.randn(batch, 2, 64, 64, generator=g)
+
+        def one(it):
+            nonlocal x
+            with torch.no_grad():
+                i = 999 - it
+                x0p = O.unet_forward(p, x, torch.full((batch,), i, dtype=torch.long), cfg)
+                O.darcy_residual(x0p)
+                x = O.p_sample_update(tab, x0p, x, i, torch.randn(batch, 2, 64, 64, generator=g))
+        what = "p_sample steps (UNet dim=32 forward, Darcy residual, ancestral update)"
+        unit = "sample-steps/s"
+    else:
+        if workload == "darcy":
+            m = Unet3D(dim=32, channels=2)
+            cfg = O.UnetCfg(dim=32, channels=2)
+            x0 = synthetic_darcy_batch(batch, 64, seed=1)
+            eps = torch.randn(batch, 2, 64, 64, generator=g)
+            what = "Darcy 64x64 training steps (UNet dim=32 fwd+bwd, residual, loss, clip, Adam)"
+        else:
+            m = Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True)
+            cfg = O.UnetCfg(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True)
+            inp = synthetic_mechanics_batch(batch, seed=1)
+            eps = torch.randn(batch, 3, 65, 65, generator=g)
+            kloc, ed = O.q4_plane_stress_stiffness(1.0, 0.3, 1.0), O.synthetic_mesh_element_dofs(64)
+            what = "mechanics 64x64 training steps (UNet dim=128 fwd+bwd, matrix-free K.u residual, loss, clip, Adam)"
+        p = _oracle_params(m)
+        state = {"used": None, "opt": None}
+        unit = "samples/s"
+
+        def one(it):
+            if workload == "darcy":
+                loss = O.darcy_training_loss(p, cfg, tables, x0, t, eps, 1.0, 1e-3)[0]
+            else:
+                loss = O.mechanics_training_loss(p, cfg, tables, inp, t, eps, kloc, ed, 1.0, 1e-3, 0.1, 0.01)[0]
+            for v in p.values():
+                v.grad = None
+            loss.backward()
+            if state["used"] is None:
+                state["used"] = [v for v in p.values() if v.grad is not None]
+                state["opt"] = torch.optim.Adam(state["used"], lr=1e-4)
+            torch.nn.utils.clip_grad_norm_(state["used"], 1.0)
+            state["opt"].step()
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
-        loss, _, _, _ = O.darcy_training_loss(p, cfg, tables, x0, t, eps, 1.0, 1e-3)
-        for v in p.values():
-            v.grad = None
-        loss.backward()
-        if used is None:
-            used = [v for v in p.values() if v.grad is not None]
-            opt = torch.optim.Adam(used, lr=1e-4)
-        torch.nn.utils.clip_grad_norm_(used, 1.0)
-        opt.step()
+        one(it)
         if it > 0:
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
-    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (1 warm-up) of the oracle's Darcy 64x64 training step (UNet dim=32 fwd+bwd, "
-                      f"residual, loss, clip, Adam) at batch {batch}, {dt:.2f} s/step"}
+    torch.set_num_threads(prev_threads)
+    return {"value": round(batch / dt, 3), "unit": unit, "cores": threads, "kind": "port",
+            "sample": f"{steps} timed (1 warm-up) oracle {what} at batch {batch} on {threads} threads "
+                      f"(host has {os.cpu_count()} logical cores), {dt:.2f} s/step"}
 
 
-def pmc_traffic(batch):
+def pmc_traffic(workload, batch):
     """HBM bytes per launch of the conv class from the committed PMC passes (tools/pmc_traffic.sh -> profiles/): the
-    counters need rocprofv3 around the process, so they cannot be read live; null when no pass exists for this batch."""
+    counters need rocprofv3 around the process, so they cannot be read live; null when no pass exists for this workload."""
     import json as _json
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_b{batch}.json")
+    tag = f"pmc_traffic_b{batch}.json" if workload == "darcy" else f"pmc_traffic_{workload}_b{batch}.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tag)
     try:
         with open(path) as f:
             return round(float(_json.load(f)["conv"]["hbm_bytes_per_launch"]), 0)
@@ -123,37 +176,66 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from physicsinformeddiffusionmodels_amd._lib import get_lib
-    from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch
-    from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion
-    from physicsinformeddiffusionmodels_amd.parallel import allreduce_gradients
+    from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch, synthetic_mechanics_batch
+    from physicsinformeddiffusionmodels_amd.denoising_utils import EMA, DenoisingDiffusion
+    from physicsinformeddiffusionmodels_amd.parallel import GradientExchange
     from physicsinformeddiffusionmodels_amd.residuals_darcy import ResidualsDarcy
+    from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
     from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
 
     lib = get_lib()
-    B = args.batch
+    wl = args.workload
+    B = args.batch or {"darcy": 64, "mechanics": 32, "sampling": 1024}[wl]
     torch.manual_seed(0)                      # identical initial weights on every rank
-    model = Unet3D(dim=32, channels=2).to(dev)
-    diffusion = DenoisingDiffusion(100, dev)
-    residuals = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=64, pixels_at_boundary=True, reverse_d1=True,
-                               device=dev, bcs='none', domain_length=1.)
-    if args.torch_optimizer:
-        optimizer = torch.optim.Adam(model.parameters(), lr=1.e-4)
+    train = wl != "sampling"
+    if wl == "mechanics":
+        model = Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True).to(dev)
+        diffusion = DenoisingDiffusion(100, dev)
+        residuals = ResidualsMechanics(model=model, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder="/nonexistent/",
+                                       device=dev, topopt_eval=False)
+        batch = synthetic_mechanics_batch(B, seed=100 + rank, device=dev)
+        loss_kw = dict(c_data=1., c_residual=1e-3, c_ineq=0.1, lambda_opt=0.01)
+        flops_per_unit, n_lr = FLOPS_PER_SAMPLE_MECH, 1.e-4
     else:
-        from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
-        optimizer = FusedClipAdam(model, lr=1.e-4, max_norm=1., image_size=64)   # clip_grad_norm_(1.) + Adam, 2 launches
-    batch = synthetic_darcy_batch(B, 64, seed=100 + rank, device=dev)   # resident in HBM; each rank its own shard
+        model = Unet3D(dim=32, channels=2).to(dev)
+        diffusion = DenoisingDiffusion(100 if train else 1000, dev)
+        residuals = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=64, pixels_at_boundary=True, reverse_d1=True,
+                                   device=dev, bcs='none', domain_length=1.)
+        batch = synthetic_darcy_batch(B, 64, seed=100 + rank, device=dev)   # resident in HBM; each rank its own shard
+        loss_kw = dict(c_data=1., c_residual=1e-3, c_ineq=0., lambda_opt=0.)
+        flops_per_unit, n_lr = (FLOPS_PER_SAMPLE_FWD_BWD if train else FLOPS_PER_SAMPLE_FWD), 1.e-4
+    ema = None
+    optimizer = exchange = None
+    if train:
+        if args.ema:
+            ema = EMA(0.99)
+            ema.register(model)
+        if args.torch_optimizer:
+            optimizer = torch.optim.Adam(model.parameters(), lr=n_lr)
+        else:
+            from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
+            optimizer = FusedClipAdam(model, lr=n_lr, max_norm=1., image_size=64, ema=ema, ema_start=-1)   # clip_grad_norm_(1.) + Adam
+        exchange = GradientExchange(model, world, diffusion=diffusion) if world > 1 else None
     torch.manual_seed(1234 + rank)
+    chain = {"x": torch.randn(B, 2, 64, 64, device=dev), "i": 999} if not train else None
 
     def step():
-        loss, data_loss, residual_loss, _, _ = diffusion.model_estimation_loss(
-            batch, residual_func=residuals, c_data=1., c_residual=1e-3, c_ineq=0., lambda_opt=0.)
+        if not train:
+            # one ancestral step of the whole batch (src/denoising_utils.py:388-455); the chain restarts at t = 999 when it ends
+            (nx, _), _ = diffusion.p_sample(chain["x"], None, chain["i"], save_output=False, surpress_noise=True, residual_func=residuals)
+            chain["x"] = nx
+            chain["i"] = chain["i"] - 1 if chain["i"] > 0 else 999
+            return nx
+        loss, *_ = diffusion.model_estimation_loss(batch, residual_func=residuals, **loss_kw)
         optimizer.zero_grad()
         loss.backward()
-        if world > 1:
-            allreduce_gradients(model, world)
+        if exchange is not None:
+            exchange.allreduce()
         if args.torch_optimizer:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
         optimizer.step()
+        if ema is not None:
+            ema.update(model)
         return loss
 
     def fence():
@@ -197,10 +279,10 @@ def main():
         lib.pidm_prof_collect(ms, cnt, work)
         conv_ms, conv_fl, conv_n = ms[0] + ms[1], work[0] + work[1], cnt[0] + cnt[1]
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        step_flops = B * FLOPS_PER_SAMPLE_FWD_BWD
+        step_flops = B * flops_per_unit
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(wl, B),
             "kernel": "conv_igemm_kernel + conv_wgrad_kernel (fp32 MFMA implicit GEMM: fwd, dgrad, wgrad)",
             "timing": "HIP events per launch in extra steps after the timed region; the library keeps the weight-gradient "
                       "side-stream overlap OFF while these hooks are on (a kernel that shares the chip has no duration of its own); "
@@ -210,24 +292,40 @@ def main():
             "fwd_dgrad": {"ms_per_step": round(ms[0] / nprof, 3), "tflops": round(work[0] / max(ms[0], 1e-9) / 1e9, 2)},
             "wgrad": {"ms_per_step": round(ms[1] / nprof, 3), "tflops": round(work[1] / max(ms[1], 1e-9) / 1e9, 2)},
             "step_flop_fraction": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "step_hbm_fraction": round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
         }
+        if wl == "darcy":
+            roofline["step_hbm_fraction"] = round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        threads = max(1, min(32, os.cpu_count() or 1))
+        cpu_b, cpu_steps = {"darcy": (64, 2), "mechanics": (2, 1), "sampling": (32, 3)}[wl]
+        cpu = cpu_baseline(wl, cpu_b, cpu_steps, threads)
 
     if rank == 0:
+        if wl == "darcy":
+            metric, unit = "training samples/sec (UNet+PDE-residual step), 64x64 Darcy", "samples/s"
+            workload = ("Darcy 64x64 2-ch (K,p), PIDM loss on (c_residual=1e-3), Unet3D dim=32, 100 diffusion steps, "
+                        "loss+backward+clip+Adam (main.py:157-166)")
+        elif wl == "mechanics":
+            metric, unit = "training samples/sec (UNet+PDE-residual step), 64x64 topology optimisation (mechanics)", "samples/s"
+            workload = ("topology optimisation 64x64 elements (65x65 nodes), 10-ch input / 3-ch output, Unet3D dim=128 with sigmoid "
+                        "density head, matrix-free K.u residual + volume + compliance terms, loss+backward+clip+Adam "
+                        "(main.py:102-109,126,157-166)")
+        else:
+            metric, unit = "sample-steps/sec (DDPM ancestral sampling: UNet forward + residual + update per step), 64x64 Darcy", "sample-steps/s"
+            workload = ("sample.py DDPM sampling, Darcy 64x64, 1000-step schedule, Unet3D dim=32; a step = one p_sample step of the "
+                        "whole batch (a full chain = 1000 steps; sample.py:145-150)")
+        cfg = {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"}
+        if train:
+            cfg["optimizer"] = "torch clip_grad_norm_+Adam" if args.torch_optimizer else "fused flat clip+Adam (k_optim.hip)"
+            cfg["ema_in_step"] = bool(args.ema)
+        else:
+            cfg["seconds_per_1000_step_chain"] = round(ms_per_step, 2)
         out = {
-            "metric": "training samples/sec (UNet+PDE-residual step), 64x64 Darcy", "value": round(value, 2),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Darcy 64x64 2-ch (K,p), PIDM loss on (c_residual=1e-3), Unet3D dim=32, 100 diffusion "
-                                   "steps, loss+backward+clip+Adam (main.py:157-166)", "per_gpu_batch": B,
-                       "optimizer": "torch clip_grad_norm_+Adam" if args.torch_optimizer else "fused flat clip+Adam (k_optim.hip)",
-                       "global_batch": B * world, "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

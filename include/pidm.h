@@ -114,13 +114,16 @@ int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, const float* 
  * algebra on top of compute_residual) for gov_eqs == 'mechanics': data term on model_out = (u resized to nn x nn, rho zero padded)
  * against target x_0 [B,3,nn,nn], residual term, the [B,B]-broadcast inequality term (:697, only when c_ineq > 0) and the
  * compliance term, all with injected per-sample p2_loss_weight[t_b] and 1/posterior_variance_clipped[t_b].
+ * inv_var_sum (device float, may be NULL): value to use for sum_i inv_var_i in the inequality term instead of the local sum -
+ * under data parallelism the caller passes the all-rank sum divided by the number of ranks (it depends on t only), which makes
+ * the rank-averaged loss and gradient equal to the single-process global-batch ones.
  * out_scalars[8]: loss, data loss, mean |r|, mean shift (0 unless c_ineq > 0), mean compliance, 0, 0, 0.
  * grad_x0_pred [B,3,nel,nel] = d loss / d x0_pred.  workspace: pidm_mech_loss_ws(B) bytes. */
 size_t pidm_mech_loss_ws(int B);
 int pidm_mech_loss_fwd_bwd(const float* x0_pred, const float* target, const float* bcs, const float* vf, const float* p2w,
-                           const float* inv_var, float c_data, float c_residual, float c_ineq, float lambda_opt, const float* kloc,
-                           int kloc_stride, const int32_t* elem_dofs, const int32_t* dof_elems, int nel, float* grad_x0_pred,
-                           float* out_scalars, void* workspace, int B, void* stream);
+                           const float* inv_var, const float* inv_var_sum, float c_data, float c_residual, float c_ineq,
+                           float lambda_opt, const float* kloc, int kloc_stride, const int32_t* elem_dofs, const int32_t* dof_elems,
+                           int nel, float* grad_x0_pred, float* out_scalars, void* workspace, int B, void* stream);
 
 /* Topology-optimisation evaluation block      replaces src/residuals_mechanics_K.py:276-347,369-380
  *   pidm_mech_apply:  residual = K_closed(rho) u - f and comp_uf = u.f for nodal displacement images u [B,2,nn,nn]
@@ -187,6 +190,15 @@ int pidm_unet_set_condition(pidm_unet* h, const float* cond_nhwc);
 /* grad_out: [B,out_dim,P,P] NCHW.  grad_x (may be NULL): [B,P*P,C].  Writes all bound grads. */
 int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, float* grad_x_nhwc, int B, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* Data-parallel overlap (no reference counterpart: the reference is single-process).  The deferred gradient
+ * reduction of pidm_unet_backward runs in n_phases (1..3) launches - after the decoder half (ups.*, final_conv.*), after the
+ * encoder half (downs.*, mid_*), at the end (everything else) - and records events[k] (hipEvent_t, may be NULL) on the
+ * backward's stream after phase k, so the caller can start the collective over that phase's gradients while the rest of
+ * backward is still running.  pidm_unet_grad_phase_range: canonical parameter index range [first, end) finalised by a phase;
+ * the LAST phase additionally finalises every parameter outside the earlier phases' ranges. */
+int pidm_unet_set_grad_events(pidm_unet* h, int n_phases, void* const* events);
+int pidm_unet_grad_phase_range(const pidm_unet* h, int n_phases, int phase, int* first_param, int* end_param);
 
 /* ---------------------------------------------------------------------------------------------
  * Unit-level kernel entry points (used by the parity tests; the engine calls the same launchers)

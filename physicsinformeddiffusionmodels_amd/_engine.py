@@ -55,6 +55,7 @@ class UnetEngine:
         self._bound_key = None
         self.workspace = None
         self._ws_key = None
+        self.backward_calls = 0      # backward passes since the last gradient exchange (parallel.GradientExchange)
         self.tape_generation = 0
         self.tape_busy = False   # a training-mode forward whose backward has not run yet owns the tape
 
@@ -222,6 +223,8 @@ class _UnetFunction(torch.autograd.Function):
         if ctx.lease is not None:
             ctx.lease.release()
         eng.tape_busy = False
+        # the phase events of the overlapped exchange describe the buffer only if this was the step's one plain backward
+        primary.backward_calls += 1 if (eng is primary and prev is None) else 2
         n_plain = len(eng.params) - eng.n_cond
         for i, (p, g) in enumerate(zip(eng.params, primary.grad_views)):
             if not p.requires_grad:

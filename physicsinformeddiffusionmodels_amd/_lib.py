@@ -71,7 +71,7 @@ class PidmLib:
                                               C.c_double, C.c_double, vp, vp, vp])
         self._sig("pidm_ema_update", [vp, vp, sz, C.c_double, vp])
         self._sig("pidm_mech_loss_ws", [i], sz)
-        self._sig("pidm_mech_loss_fwd_bwd", [vp, vp, vp, vp, vp, vp, f, f, f, f, vp, i, vp, vp, i, vp, vp, vp, i, vp])
+        self._sig("pidm_mech_loss_fwd_bwd", [vp, vp, vp, vp, vp, vp, vp, f, f, f, f, vp, i, vp, vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_bilinear_resize", [vp, vp, i, i, i, vp])
         self._sig("pidm_mech_residual_fwd", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp, i, vp])
         self._sig("pidm_mech_residual_bwd", [vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, i, vp])
@@ -84,6 +84,8 @@ class PidmLib:
         self._sig("pidm_unet_bind", [vp, C.POINTER(vp), C.POINTER(vp)])
         self._sig("pidm_unet_forward", [vp, vp, vp, vp, i, i, i, vp, sz, vp])
         self._sig("pidm_unet_backward", [vp, vp, vp, i, vp, sz, vp])
+        self._sig("pidm_unet_set_grad_events", [vp, i, C.POINTER(vp)])
+        self._sig("pidm_unet_grad_phase_range", [vp, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int)])
         self._sig("pidm_conv_packed_weight_floats", [C.POINTER(ConvDesc)], sz)
         self._sig("pidm_conv_pack_weights", [C.POINTER(ConvDesc), vp, vp, i, vp])
         self._sig("pidm_conv_forward", [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])

@@ -1289,10 +1289,10 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradGeo
 
 // all deferred reductions of one backward pass in ONE launch (descriptor table on the device, binary search per block
 // like pack_multi_kernel); same arithmetic as wgrad_reduce_kernel with 4 independent chains per split lane
-__global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __restrict__ table, int ndesc) {
+__global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __restrict__ table, int ndesc, unsigned blk_base) {
   __shared__ float red[8][32];
   int lo = 0, hi = ndesc - 1;
-  const unsigned bid = blockIdx.x;
+  const unsigned bid = blockIdx.x + blk_base;   // descriptors carry absolute block offsets; a launch may cover a sub-range
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (table[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
@@ -1489,9 +1489,9 @@ int launch_split_reduce(const float* partial, float* dst, const float* bias_part
   return 0;
 }
 
-int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st) {
+int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st, unsigned blk_base) {
   if (ndesc <= 0 || nblocks == 0) return 0;
-  hipLaunchKernelGGL(reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc, blk_base);
   PIDM_CHECK_LAUNCH("reduce_multi_kernel");
   return 0;
 }

@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(256) mech_loss_kernel(MechMesh ms, const float
                                                         const float* __restrict__ vf,        // [B]
                                                         const float* __restrict__ p2w,       // [B]
                                                         const float* __restrict__ inv_var,   // [B]
+                                                        const float* __restrict__ ivs_dev,   // null, or 1 float: sum_i inv_var_i to use
                                                         float c_data, float c_res, float c_ineq, float lambda_opt, int B,
                                                         float* __restrict__ g_x0,            // [B,3,nel,nel]
                                                         double* __restrict__ partial) {      // [B][8]
@@ -294,7 +295,9 @@ __global__ void __launch_bounds__(256) mech_loss_kernel(MechMesh ms, const float
   double ivs_l = 0.0;
   for (int i = tid; i < B; i += 256) ivs_l += (double)inv_var[i];
   const double rsum = block_sum(rsum_l, red4);      // (publishes sU / sR / sG as well)
-  const double ivs = block_sum(ivs_l, red4);
+  // data parallel: the caller passes (sum over ALL ranks' samples of inv_var) / world instead of the local sum, which makes the
+  // rank-averaged loss and gradient of the [B,B] term equal to the single-process global-batch values
+  const double ivs = ivs_dev ? (double)ivs_dev[0] : block_sum(ivs_l, red4);
   const float shift = (float)(rsum / E) - vf[b];
   const float gc = lambda_opt / (float)B;                                             // d loss / d compliance_b
   const float gs = (c_ineq > 0.f ? c_ineq * shift * (float)ivs / ((float)B * (float)B) : 0.f) / (float)E;   // d loss / d rho_e via the shift
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) mech_loss_kernel(MechMesh ms, const float
 
 // out[0] = loss, out[1] = data loss, out[2] = mean |r|, out[3] = mean shift (0 unless c_ineq > 0), out[4] = mean compliance
 __global__ void mech_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w, const float* __restrict__ inv_var,
-                                   float c_data, float c_res, float c_ineq, float lambda_opt, int B, int nn, int ndof,
+                                   const float* __restrict__ ivs_dev, float c_data, float c_res, float c_ineq, float lambda_opt, int B, int nn, int ndof,
                                    float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double data = 0.0, res = 0.0, rabs = 0.0, comp = 0.0, sh = 0.0, sh2 = 0.0, ivs = 0.0;
@@ -409,6 +412,7 @@ __global__ void mech_loss_finalize(const double* __restrict__ partial, const flo
     sh2 += p[4] * p[4];
     ivs += (double)inv_var[b];
   }
+  if (ivs_dev) ivs = (double)ivs_dev[0];
   data = data / B * c_data;
   double loss = data + 0.5 * c_res * res / ((double)B * ndof) + lambda_opt * comp / B;
   if (c_ineq > 0.f) loss += 0.5 * c_ineq * ivs * sh2 / ((double)B * B);
@@ -676,9 +680,10 @@ extern "C" int pidm_mech_residual_bwd(const float* x0_pred, const float* bcs, co
 extern "C" size_t pidm_mech_loss_ws(int B) { return (size_t)B * 8 * sizeof(double) + 256; }
 
 extern "C" int pidm_mech_loss_fwd_bwd(const float* x0_pred, const float* target, const float* bcs, const float* vf, const float* p2w,
-                                      const float* inv_var, float c_data, float c_residual, float c_ineq, float lambda_opt,
-                                      const float* kloc, int kloc_stride, const int32_t* elem_dofs, const int32_t* dof_elems, int nel,
-                                      float* grad_x0_pred, float* out_scalars, void* workspace, int B, void* stream) {
+                                      const float* inv_var, const float* inv_var_sum, float c_data, float c_residual, float c_ineq,
+                                      float lambda_opt, const float* kloc, int kloc_stride, const int32_t* elem_dofs,
+                                      const int32_t* dof_elems, int nel, float* grad_x0_pred, float* out_scalars, void* workspace,
+                                      int B, void* stream) {
   const int E = nel * nel, nn = nel + 1, ndof = 2 * nn * nn;
   if (mech_args(nel, E, ndof, kloc, elem_dofs, dof_elems)) return -1;
   if (!x0_pred || !target || !bcs || !vf || !p2w || !inv_var || !grad_x0_pred || !out_scalars || !workspace) return fail("mech_loss: null buffer");
@@ -692,11 +697,11 @@ extern "C" int pidm_mech_loss_fwd_bwd(const float* x0_pred, const float* target,
     attr = true;
   }
   double* partial = reinterpret_cast<double*>((reinterpret_cast<size_t>(workspace) + 255) & ~(size_t)255);
-  hipLaunchKernelGGL(mech_loss_kernel, dim3(B), dim3(256), lds, as_stream(stream), ms, x0_pred, target, bcs, vf, p2w, inv_var, c_data,
-                     c_residual, c_ineq, lambda_opt, B, grad_x0_pred, partial);
+  hipLaunchKernelGGL(mech_loss_kernel, dim3(B), dim3(256), lds, as_stream(stream), ms, x0_pred, target, bcs, vf, p2w, inv_var, inv_var_sum,
+                     c_data, c_residual, c_ineq, lambda_opt, B, grad_x0_pred, partial);
   PIDM_CHECK_LAUNCH("mech_loss_kernel");
-  hipLaunchKernelGGL(mech_loss_finalize, dim3(1), dim3(64), 0, as_stream(stream), partial, p2w, inv_var, c_data, c_residual, c_ineq,
-                     lambda_opt, B, nn, ndof, out_scalars);
+  hipLaunchKernelGGL(mech_loss_finalize, dim3(1), dim3(64), 0, as_stream(stream), partial, p2w, inv_var, inv_var_sum, c_data, c_residual,
+                     c_ineq, lambda_opt, B, nn, ndof, out_scalars);
   PIDM_CHECK_LAUNCH("mech_loss_finalize");
   return 0;
 }

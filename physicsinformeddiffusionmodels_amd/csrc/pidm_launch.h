@@ -22,7 +22,7 @@ struct ReduceQueue {
     v.push_back(d);
   }
 };
-int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st);
+int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st, unsigned blk_base = 0);
 int launch_split_reduce(const float* partial, float* dst, const float* bias_partial, float* dbias, int nsplit, int M, int N, int T,
                         int MP, int NP, hipStream_t st);
 // k_conv.hip

@@ -113,6 +113,12 @@ struct pidm_unet {
   std::map<int, size_t> defer_cache;                     // B -> bytes of the deferred-reduction arena (training)
   std::vector<ReduceDesc> red_table;                     // host copy of the last uploaded reduction table
   const void* red_table_dev = nullptr;
+  // data-parallel overlap (pidm_unet_set_grad_events): the deferred gradient reduction runs in up to 3 phases - after the
+  // decoder half, after the encoder half, at the end - and an event is recorded after each, so the caller's collective of
+  // the parameters that phase finalises can start while the rest of backward still runs
+  int n_phases = 1;
+  hipEvent_t phase_ev[3] = {nullptr, nullptr, nullptr};
+  int idx_downs_first = 0, idx_ups_first = 0;            // canonical parameter indices that bound the phases
 };
 
 namespace pidm {
@@ -279,6 +285,7 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
   U->down.resize(n);
   U->up.resize(n);
   int irb = 0, iat = 0;
+  U->idx_downs_first = (int)U->names.size();
   for (int i = 0; i < n; ++i) {
     const std::string pre = "downs." + std::to_string(i) + ".";
     const int din = U->dims[i], dout = U->dims[i + 1];
@@ -294,6 +301,7 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
   make_resblock(U, U->rb[irb], "mid_block1.", U->dims[n], 0, U->dims[n], res[n - 1], true); U->rb[irb++].ss_off = ss_off["mid_block1."];
   make_attn(U, U->attn[iat++], "mid_spatial_attn.", U->dims[n], res[n - 1], true);
   make_resblock(U, U->rb[irb], "mid_block2.", U->dims[n], 0, U->dims[n], res[n - 1], true); U->rb[irb++].ss_off = ss_off["mid_block2."];
+  U->idx_ups_first = (int)U->names.size();
   for (int j = 0; j < n; ++j) {
     const std::string pre = "ups." + std::to_string(j) + ".";
     const int lvl = n - 1 - j;
@@ -853,6 +861,49 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
   return mx;
 }
 
+// Runs the fixed-order reductions queued since the previous flush (weight / bias / norm-parameter gradients) in one launch.
+// `phase` >= 0: also record that phase's event (data-parallel overlap).  The descriptor table lives at the head of the deferred
+// arena; only the part that differs from what the device already holds is uploaded (steady state: nothing).
+static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase) {
+  pidm_unet* U = r.U;
+  if (r.dry) return 0;
+  if (join_side(r)) return -1;
+  const size_t n = r.rq.v.size(), first = *done;
+  if (n > kMaxReduceDesc) return fail("backward: reduction table overflow (%zu)", n);
+  if (n > first) {
+    if (U->red_table.capacity() < kMaxReduceDesc) U->red_table.reserve(kMaxReduceDesc);   // never reallocates afterwards: async uploads read it
+    const bool same = U->red_table_dev == red_dev && U->red_table.size() >= n &&
+                      memcmp(U->red_table.data() + first, r.rq.v.data() + first, (n - first) * sizeof(ReduceDesc)) == 0;
+    if (!same) {
+      if (getenv("PIDM_REDUCE_STATS")) {   // one line per table change: what the deferred reduction reads
+        double bytes = 0, outs = 0;
+        for (size_t i = first; i < n; ++i) {
+          const ReduceDesc& d = r.rq.v[i];
+          bytes += (double)d.nsplit * d.sstride * 4;
+          outs += (double)d.M * d.N * d.T;
+          if ((double)d.nsplit * d.sstride * 4 > 8e6)
+            fprintf(stderr, "[pidm]   nsplit=%d M=%d N=%d T=%d: %.1f MB\n", d.nsplit, d.M, d.N, d.T, (double)d.nsplit * d.sstride * 4 / 1e6);
+        }
+        fprintf(stderr, "[pidm] deferred reduction (phase %d): %zu tensors, %.1f MB of partials -> %.2f M outputs\n", phase, n - first,
+                bytes / 1e6, outs / 1e6);
+      }
+      if (U->red_table_dev != red_dev) U->red_table.clear();
+      U->red_table.resize(n > U->red_table.size() ? n : U->red_table.size());
+      memcpy(U->red_table.data() + first, r.rq.v.data() + first, (n - first) * sizeof(ReduceDesc));
+      if (hipMemcpyAsync(red_dev + first, U->red_table.data() + first, (n - first) * sizeof(ReduceDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
+        return fail("backward: reduction table upload failed");
+      U->red_table_dev = red_dev;
+    }
+    const unsigned blk0 = r.rq.v[first].blk0;
+    RUN(launch_reduce_multi(red_dev + first, (int)(n - first), r.rq.nblocks - blk0, r.st, blk0));
+    *done = n;
+  }
+  if (phase >= 0 && phase < 3 && U->phase_ev[phase]) {
+    if (hipEventRecord(U->phase_ev[phase], r.st) != hipSuccess) return fail("backward: phase event record failed");
+  }
+  return 0;
+}
+
 static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc) {
   pidm_unet* U = r.U;
   const int B = r.B, P = U->cfg.image_size, dim = U->cfg.dim, n = U->n_lv, td = U->tdim, od = U->cfg.out_dim;
@@ -861,6 +912,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   r.rq.v.clear();
   r.rq.nblocks = 0;
   ReduceDesc* red_dev = reinterpret_cast<ReduceDesc*>(r.defer.alloc(kMaxReduceDesc * sizeof(ReduceDesc) / 4));
+  size_t red_done = 0;
+  const int n_phases = U->n_phases;
   float* dss = r.tmp.alloc((size_t)B * U->ss_total);
   float* g_o = r.tmp.alloc((size_t)B * HW * od);
   RUN(launch_nchw_to_nhwc(grad_out_nchw, g_o, B, od, (int)HW, U->cfg.sigmoid_last_channel ? U->out_nchw : nullptr, r.st));
@@ -907,6 +960,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     RUN(launch_copy_add(g_x, dout, gc, 2 * dout, nullptr, 0, npix, dout, r.st));
     RUN(launch_copy_add(g_skip[lvl], dout, gc + dout, 2 * dout, nullptr, 0, npix, dout, r.st));
   }
+  // decoder half done: every gradient of ups.* / final_conv.* is final after this flush
+  if (n_phases >= 2 && flush_reductions(r, red_dev, &red_done, 0)) return -1;
   {
     const int C = U->dims[n], H = P >> (n - 1);
     const size_t nn = (size_t)B * H * H * C;
@@ -937,6 +992,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (resblock_bwd(r, U->rb[irb--], g2, g3, dss)) return -1;
     g_x = g3;
   }
+  // encoder half done: downs.* / mid_* gradients are final after this flush
+  if (n_phases >= 3 && flush_reductions(r, red_dev, &red_done, 1)) return -1;
   // h0 feeds both the first resblock and the final concat
   float* g_h0 = r.tmp.alloc((size_t)B * HW * dim);
   RUN(launch_copy_add(g_h0, dim, g_x, dim, g_r, dim, (size_t)B * HW, dim, r.st));
@@ -988,34 +1045,8 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     RUN(launch_act_bwd(U->h1, d_h1g, d_h1, (size_t)B * td, 1, r.st));
     if (conv_wgrad(r, U->lin1, U->emb, nullptr, d_h1)) return -1;
   }
-  // ---- every queued fixed-order reduction (weight/bias/norm-parameter gradients) in one launch ----
-  if (join_side(r)) return -1;
-  if (!r.dry && !r.rq.v.empty()) {
-    if (r.rq.v.size() > kMaxReduceDesc) return fail("backward: reduction table overflow (%zu)", r.rq.v.size());
-    const bool same = U->red_table_dev == red_dev && U->red_table.size() == r.rq.v.size() &&
-                      memcmp(U->red_table.data(), r.rq.v.data(), r.rq.v.size() * sizeof(ReduceDesc)) == 0;
-    if (!same) {
-      if (getenv("PIDM_REDUCE_STATS")) {   // one line per table change: what the single deferred reduction reads
-        double bytes = 0, outs = 0;
-        int big = 0;
-        for (const ReduceDesc& d : r.rq.v) {
-          bytes += (double)d.nsplit * d.sstride * 4;
-          outs += (double)d.M * d.N * d.T;
-          if ((double)d.nsplit * d.sstride * 4 > 16e6) ++big;
-        }
-        fprintf(stderr, "[pidm] deferred reduction: %zu tensors, %.1f MB of partials -> %.2f M outputs, %u blocks, %d tensors > 16 MB\n",
-                r.rq.v.size(), bytes / 1e6, outs / 1e6, r.rq.nblocks, big);
-        for (const ReduceDesc& d : r.rq.v)
-          if ((double)d.nsplit * d.sstride * 4 > 8e6)
-            fprintf(stderr, "[pidm]   nsplit=%d M=%d N=%d T=%d: %.1f MB\n", d.nsplit, d.M, d.N, d.T, (double)d.nsplit * d.sstride * 4 / 1e6);
-      }
-      U->red_table = r.rq.v;   // persistent host copy (source of the async upload)
-      if (hipMemcpyAsync(red_dev, U->red_table.data(), U->red_table.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
-        return fail("backward: reduction table upload failed");
-      U->red_table_dev = red_dev;
-    }
-    RUN(launch_reduce_multi(red_dev, (int)r.rq.v.size(), r.rq.nblocks, r.st));
-  }
+  // ---- every remaining queued fixed-order reduction (weight/bias/norm-parameter gradients) in one launch ----
+  if (flush_reductions(r, red_dev, &red_done, n_phases - 1)) return -1;
   return 0;
 }
 
@@ -1127,6 +1158,29 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   r.overlap = h->side_ok && !prof_enabled();
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
+  return 0;
+}
+
+extern "C" int pidm_unet_set_grad_events(pidm_unet* h, int n_phases, void* const* events) {
+  if (!h) return fail("unet_set_grad_events: null handle");
+  if (n_phases < 1 || n_phases > 3) return fail("unet_set_grad_events: n_phases must be 1..3 (got %d)", n_phases);
+  h->n_phases = n_phases;
+  for (int i = 0; i < 3; ++i) h->phase_ev[i] = (events && i < n_phases) ? reinterpret_cast<hipEvent_t>(events[i]) : nullptr;
+  return 0;
+}
+
+extern "C" int pidm_unet_grad_phase_range(const pidm_unet* h, int n_phases, int phase, int* first_param, int* end_param) {
+  if (!h || !first_param || !end_param) return fail("unet_grad_phase_range: null argument");
+  if (n_phases < 1 || n_phases > 3 || phase < 0 || phase >= n_phases) return fail("unet_grad_phase_range: bad phase %d of %d", phase, n_phases);
+  const int n = (int)h->names.size();
+  // canonical order: [FiLM + init + time | downs + mid | ups + final | conditioning]; the last phase finalises whatever the
+  // earlier ones did not (head and conditioning tail): it is reported as ONE range only when it is contiguous (n_phases == 1),
+  // otherwise as the head range - the caller treats "everything not covered by earlier phases" as the last bucket
+  if (n_phases == 1) { *first_param = 0; *end_param = n; return 0; }
+  if (phase == 0) { *first_param = h->idx_ups_first; *end_param = h->cond_first_param; return 0; }
+  if (n_phases == 3 && phase == 1) { *first_param = h->idx_downs_first; *end_param = h->idx_ups_first; return 0; }
+  *first_param = 0;
+  *end_param = (n_phases == 3) ? h->idx_downs_first : h->idx_ups_first;
   return 0;
 }
 

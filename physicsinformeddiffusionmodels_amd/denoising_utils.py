@@ -314,6 +314,9 @@ class DenoisingDiffusion(nn.Module):
         self.diff_dict = self.create_diff_dict()
         self.residual_grad_guidance = residual_grad_guidance
         self._lib = lib
+        # data parallelism (parallel.GradientExchange sets these): number of ranks that average their gradients
+        self.data_parallel_world = 1
+        self.data_parallel_group = None
 
     @property
     def lib(self):
@@ -493,7 +496,16 @@ class DenoisingDiffusion(nn.Module):
         inv_var = (1.0 / dd['posterior_variance_clipped'][t]).contiguous()
         if residual_func.stiffs.kloc_dev.device != x_0.device:
             residual_func.stiffs.to(x_0.device)
-        fixed = (x_0.contiguous(), bcs.contiguous(), vf, p2w, inv_var)
+        ivs = None
+        if c_ineq > 0. and self.data_parallel_world > 1:
+            # the inequality term couples the samples of a batch through its [B,B] broadcast (:697).  Its only cross-sample
+            # factor that involves other ranks' data is sum_i 1/var_i, which depends on t alone: one scalar all-reduce (issued
+            # before the UNet forward, it never waits) makes the rank-averaged loss and gradients exactly the global-batch ones
+            import torch.distributed as dist
+            ivs = inv_var.sum().reshape(1)
+            dist.all_reduce(ivs, op=dist.ReduceOp.SUM, group=self.data_parallel_group)
+            ivs = ivs / float(self.data_parallel_world)
+        fixed = (x_0.contiguous(), bcs.contiguous(), vf, p2w, inv_var, ivs)
         if residual_func.use_ddim_x0:
             x0_pred, model_out = self.ddim_sample_x0(net_in, t, residual_func.model, x.shape, residual_func.ddim_steps, 0.,
                                                      gov_eqs='mechanics')

@@ -1,26 +1,53 @@
-"""Data-parallel gradient exchange: one process per GPU, one collective per step.
+"""Data-parallel gradient exchange: one process per GPU, batch sharded, parameters replicated.
 
 The reference has no distributed code; `north_star` shards the batch over the 8 MI355X of a node.
 Every sample's forward/residual/loss/backward is independent (GroupNorm/LayerNorm/attention are per-sample), so
-the only exchange is the gradient average.  The engine already writes all 259 used gradients into ONE flat fp32
-buffer (35.7 MB for the Darcy model), so the exchange is a single RCCL all-reduce over xGMI - no bucketing of
-small tensors, no per-parameter hooks.  RNG: each rank seeds its own (t, eps) stream; equivalence with the
-single-process global-batch step is tested with injected (t, eps) in tests/test_data_parallel.py.
+the only exchange is the gradient average.  The engine writes all used gradients into ONE flat fp32 buffer in its
+canonical parameter order (35.7 MB for the Darcy model, 521 MB for the mechanics model), so there is no bucketing
+of small tensors and no per-parameter hook.  `GradientExchange` overlaps the exchange with backward:
+
+* the engine runs its deferred gradient reduction in three phases - after the decoder half (`ups.*`, `final_conv.*`),
+  after the encoder half (`downs.*`, `mid_*`), at the end (time MLP, FiLM linears, `init_conv`) - and records a HIP
+  event after each (`pidm_unet_set_grad_events`); in the flat buffer those are three contiguous ranges;
+* `allreduce()` (called right after `loss.backward()`, which only ENQUEUES the backward kernels) issues one RCCL
+  all-reduce per range on a side stream that waits for that range's event, so the decoder's gradients travel over
+  xGMI while the encoder half of backward is still computing; the caller's stream then waits for the side stream.
+  xGMI is point-to-point (ring collectives are per-link bound): three large messages, not many small ones.
+
+Fallbacks that keep the result identical: more than one backward per step (two activation tapes of
+x0_estimation='sample', gradient accumulation) or a non-GPU backend (the gloo tests) -> one all-reduce per range on
+the caller's stream after backward.  RNG: each rank seeds its own (t, eps) stream; equivalence with the single-process
+global-batch step is tested with injected (t, eps) in tests/test_data_parallel.py.
 """
 from __future__ import annotations
+
+import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
 
+from ._engine import get_engine
+from ._lib import vp
+
 
 def flat_gradient_buffers(model):
-    """The engine-owned flat gradient buffer(s) of a Unet3D (one per engine instance / image size)."""
-    # slot 0 owns the buffer p.grad aliases; further slots (second activation tape) are added INTO it by backward
+    """The flat gradient buffer(s) `p.grad` alias: the primary engine's (slot 0), one per image size.  Engines of other
+    slots (second activation tape) add their result INTO it during backward (_engine._UnetFunction.backward)."""
     return [e.flat_grad for k, e in model.__dict__.get("_engines", {}).items() if e.flat_grad is not None and k[2] == 0]
 
 
+def _allreduce_avg(buf, world, group):
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)     # RCCL over xGMI
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        buf.mul_(1.0 / world)
+
+
 def allreduce_gradients(model, world_size: int | None = None, group=None):
-    """Average the gradients over all ranks (in place).  Call between loss.backward() and clip_grad_norm_."""
+    """Average the gradients over all ranks (in place), one collective on the caller's stream.  Call between
+    loss.backward() and clip_grad_norm_.  (`GradientExchange` is the overlapped form.)"""
     if not dist.is_initialized():
         return
     world = world_size or dist.get_world_size(group)
@@ -30,11 +57,88 @@ def allreduce_gradients(model, world_size: int | None = None, group=None):
     if not bufs:
         raise RuntimeError("allreduce_gradients: no engine gradient buffer - run loss.backward() first")
     for buf in bufs:
-        if dist.get_backend(group) == "nccl":
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)     # RCCL: one collective over xGMI
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            buf.mul_(1.0 / world)
+        _allreduce_avg(buf, world, group)
+
+
+class GradientExchange:
+    """Overlapped, bucketed gradient average for a `Unet3D` driven by the gfx950 engine.
+
+        ex = GradientExchange(model, world, diffusion=diffusion_utils)     # once, after model.to(device)
+        loss.backward(); ex.allreduce(); clip / optimizer.step()
+
+    buckets: 1..3 phases of the engine's deferred reduction (PIDM_DP_BUCKETS overrides; 1 = a single collective after
+    backward, the round-1 behaviour).  diffusion: the DenoisingDiffusion whose mechanics inequality term should be made
+    data-parallel exact (it needs the world size for one scalar all-reduce)."""
+
+    def __init__(self, model, world_size: int | None = None, image_size: int = 64, buckets: int = 3, group=None, lib=None,
+                 diffusion=None):
+        self.model, self.group = model, group
+        self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.eng = get_engine(model, image_size, lib)
+        self.buckets = max(1, min(3, int(os.environ.get("PIDM_DP_BUCKETS", buckets))))
+        if diffusion is not None:
+            diffusion.data_parallel_world = self.world
+            diffusion.data_parallel_group = group
+        eng = self.eng
+        # element ranges of the flat buffer per phase; the last phase takes everything the earlier ones do not cover
+        offs = [0]
+        for ne in eng.numels:
+            offs.append(offs[-1] + ne)
+        self.ranges = []
+        covered = []
+        a, b = C.c_int(), C.c_int()
+        for k in range(self.buckets - 1):
+            eng.lib.check(eng.lib.pidm_unet_grad_phase_range(eng.handle, self.buckets, k, C.byref(a), C.byref(b)), "pidm_unet_grad_phase_range")
+            self.ranges.append([(offs[a.value], offs[b.value])])
+            covered.append((offs[a.value], offs[b.value]))
+        rest, pos = [], 0
+        for lo, hi in sorted(covered):
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < offs[-1]:
+            rest.append((pos, offs[-1]))
+        self.ranges.append(rest)
+        dev = eng.params[0].device
+        self.on_gpu = dev.type == "cuda"
+        self.events, self.stream = None, None
+        handles = None
+        if self.on_gpu and self.world > 1 and os.environ.get("PIDM_DP_NO_OVERLAP") != "1":
+            try:
+                self.stream = torch.cuda.Stream(device=dev)
+                self.events = [torch.cuda.Event(enable_timing=False) for _ in range(self.buckets)]
+                for ev in self.events:
+                    ev.record(torch.cuda.current_stream(dev))      # creates the underlying hipEvent_t
+                handles = (vp * 3)(*[vp(ev.cuda_event) for ev in self.events], *([vp(0)] * (3 - self.buckets)))
+            except (AttributeError, RuntimeError) as e:            # no raw event handle on this torch build: exchange after backward
+                print(f"GradientExchange: overlapped exchange disabled ({e})")
+                self.events = self.stream = handles = None
+        eng.lib.check(eng.lib.pidm_unet_set_grad_events(eng.handle, self.buckets, handles), "pidm_unet_set_grad_events")
+        eng.backward_calls = 0
+
+    def allreduce(self):
+        """Average the gradients over all ranks (in place).  Call right after loss.backward()."""
+        eng = self.eng
+        calls, eng.backward_calls = eng.backward_calls, 0
+        if self.world == 1:
+            return
+        flat = eng.flat_grad
+        if flat is None:
+            raise RuntimeError("GradientExchange.allreduce: no engine gradient buffer - run loss.backward() first")
+        overlapped = self.events is not None and calls == 1
+        if not overlapped:
+            # several backward passes wrote / accumulated into the buffer after the phase events: exchange once everything is in
+            for rs in self.ranges:
+                for lo, hi in rs:
+                    _allreduce_avg(flat[lo:hi], self.world, self.group)
+            return
+        cur = torch.cuda.current_stream(flat.device)
+        for k, rs in enumerate(self.ranges):
+            self.stream.wait_event(self.events[k])
+            with torch.cuda.stream(self.stream):
+                for lo, hi in rs:
+                    _allreduce_avg(flat[lo:hi], self.world, self.group)
+        cur.wait_stream(self.stream)
 
 
 def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:

@@ -178,7 +178,7 @@ class _MechLossFn(torch.autograd.Function):
     compliance, 0, 0, 0)."""
 
     @staticmethod
-    def forward(ctx, x0_pred, target, bcs, vf, p2w, inv_var, c_data, c_residual, c_ineq, lambda_opt, stiffs, lib):
+    def forward(ctx, x0_pred, target, bcs, vf, p2w, inv_var, inv_var_sum, c_data, c_residual, c_ineq, lambda_opt, stiffs, lib):
         x = x0_pred.contiguous().float()
         B, _, nel, _ = x.shape
         dev = x.device
@@ -188,7 +188,7 @@ class _MechLossFn(torch.autograd.Function):
         out = torch.empty(8, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.pidm_mech_loss_ws(B), dtype=torch.uint8, device=dev)
         lib.check(lib.pidm_mech_loss_fwd_bwd(ptr(x), ptr(target.contiguous().float()), ptr(bcs.contiguous().float()),
-                                             ptr(vf.contiguous().float()), ptr(p2w), ptr(inv_var), float(c_data), float(c_residual),
+                                             ptr(vf.contiguous().float()), ptr(p2w), ptr(inv_var), ptr(inv_var_sum), float(c_data), float(c_residual),
                                              float(c_ineq), float(lambda_opt), ptr(stiffs.kloc_dev), stiffs.kloc_stride,
                                              ptr(stiffs.elem_dofs32), ptr(stiffs.dof_elems32), nel, ptr(grad), ptr(out), ptr(ws), B,
                                              stream_ptr(dev)), "pidm_mech_loss_fwd_bwd")
@@ -199,7 +199,7 @@ class _MechLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         (grad,) = ctx.saved_tensors
-        return (grad * g_loss,) + (None,) * 11
+        return (grad * g_loss,) + (None,) * 12
 
 
 class ResidualsMechanics:

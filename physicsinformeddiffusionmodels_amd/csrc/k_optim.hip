@@ -36,7 +36,13 @@ __global__ void __launch_bounds__(256) sqsum_partial_kernel(const float* __restr
 // reference EMA.update (src/denoising_utils.py:176): (1. - mu) * param + mu * shadow - two fp32 products and one sum, each
 // rounded (no contraction into an fma), so the shadow matches the reference bit for bit
 __device__ __forceinline__ float ema_mix(float p, float s, float one_minus_mu, float mu) {
-  return __fadd_rn(__fmul_rn(one_minus_mu, p), __fmul_rn(mu, s));
+  // HIP's __fmul_rn / __fadd_rn are plain operators and -ffp-contract=fast fuses across them (and across a contract(off)
+  // pragma: the back end fuses on its own): the products are made opaque so that each is rounded before the sum
+  float a = one_minus_mu * p;
+  float b = mu * s;
+  PIDM_OPAQUE_F32(a);
+  PIDM_OPAQUE_F32(b);
+  return a + b;
 }
 
 // p, m, v updated in place.  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (computed on the host in double,

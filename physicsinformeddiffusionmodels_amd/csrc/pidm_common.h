@@ -29,6 +29,12 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // exact n / d for small operands via one mulhi (d == 1 handled by the caller's magic == 0 convention)
 __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
 
+// value barrier: the compiler may not look through it (used where a product must be ROUNDED before it is added - no fma).
+// The host emulator's shadow <hip/hip_runtime.h> provides its own definition.
+#ifndef PIDM_OPAQUE_F32
+#define PIDM_OPAQUE_F32(x) asm volatile("" : "+v"(x))
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -220,8 +220,7 @@ static inline float hipemu_fast_expf(float x) { return exp2f(x * 1.4426950408889
 #define __expf(x) hipemu_fast_expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
-static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }   // rounded product, never contracted
-static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+#define PIDM_OPAQUE_F32(x) do { volatile float t__ = (x); (x) = t__; } while (0)   // value barrier (pidm_common.h)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __ldg(const float* p) { return *p; }
 

@@ -256,6 +256,21 @@ int pidm_linear_attention_out_backward(const float* qkv, const float* kstat, con
                                        const float* d_y, int ld_dy, const float* w_out, int Cout, float* dqkv, float* dw_out,
                                        int B, int N, int heads, void* workspace, void* stream);
 
+/* Linear attention WITHOUT a qkv tensor (csrc/k_attn_proj.hip)      replaces Residual(PreNorm(SpatialLinearAttention)) between the
+ * LayerNorm and the residual add, src/unet_model.py:281-299 + :139-145, and its autograd.
+ * xn [B,N,C] = LayerNorm output (channels-last); w_qkv [3*heads*32, C] and w_out [C, heads*32] in the reference layouts
+ * (to_qkv.weight, to_out.weight); bias [C]; resid [B,N,C] = the block input x; y [B,N,C] = to_out(attention) + bias + x.
+ * The forward keeps `saved` (pidm_lap_saved_floats floats: k-softmax statistics, M, ctx, P per image and head) and
+ * qstat [B,N,heads,2] (q-softmax max, 1/sum) for the backward.  The backward takes dY = d loss / d y and WRITES d_xn (without
+ * the residual's own dY -> dx share), d_w_qkv, d_w_out.  C in {32, 64}, N % 32 == 0, heads <= 8.  workspace: pidm_lap_ws bytes. */
+size_t pidm_lap_ws(int B, int N, int heads, int C);
+size_t pidm_lap_saved_floats(int B, int heads, int C);
+int pidm_lap_forward(const float* xn, const float* w_qkv, const float* w_out, const float* bias, const float* resid, float* y,
+                     float* saved, float* qstat, int C, int B, int N, int heads, void* workspace, void* stream);
+int pidm_lap_backward(const float* xn, const float* dy, const float* w_qkv, const float* w_out, const float* saved,
+                      const float* qstat, float* d_xn, float* d_w_qkv, float* d_w_out, int C, int B, int N, int heads,
+                      void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

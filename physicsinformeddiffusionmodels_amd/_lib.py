@@ -100,6 +100,10 @@ class PidmLib:
         self._sig("pidm_linear_attention_out_forward", [vp, vp, vp, vp, vp, i, vp, vp, vp, i, i, i, vp, vp])
         self._sig("pidm_linear_attention_out_backward_ws", [i, i, i, i], sz)
         self._sig("pidm_linear_attention_out_backward", [vp, vp, vp, vp, vp, i, vp, i, vp, vp, i, i, i, vp, vp])
+        self._sig("pidm_lap_ws", [i, i, i, i], sz)
+        self._sig("pidm_lap_saved_floats", [i, i, i], sz)
+        self._sig("pidm_lap_forward", [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
+        self._sig("pidm_lap_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
         if L.pidm_version() != 1:
             raise PidmError(f"{path}: ABI version {L.pidm_version()} != 1")
 

@@ -1,0 +1,786 @@
+// Linear attention WITHOUT a qkv tensor ("projected" form), forward + backward, for the full-resolution levels.
+//
+// Replaces Residual(PreNorm(SpatialLinearAttention)) between the LayerNorm and the residual add (reference
+// src/unet_model.py:281-299 + 139-145) and everything autograd replays through it.  The reference materialises
+// qkv = to_qkv(xn): 3*heads*32 channels per pixel (805 MB per 64x64 instance at batch 64), written once and read five
+// times forward + backward, plus its gradient.  Here q and k are 32x32 (pixel x head-channel) tiles rebuilt on the
+// matrix cores from the 32..64-channel xn tile wherever a kernel needs them (C/2 MFMAs per tile and head), and v is never
+// formed per pixel at all - linearity moves the to_v projection (and to_out) out of the pixel sums:
+//
+//   ks[n][d] = softmax_n( xn[n][:] . Wk[d][:] )                      M[d][c]   = sum_n ks[n][d] xn[n][c]
+//   ctx[d][e] = 1/N sum_c M[d][c] Wv[e][c]    (= sum_n ks v / N)     P[d][c']  = sum_e ctx[d][e] Wout[c'][h*32+e]
+//   qs[n][d] = scale * softmax_d( xn[n][:] . Wq[d][:] )              y[n][c']  = bias[c'] + x[n][c'] + sum_h sum_d qs_h[n][d] P_h[d][c']
+//
+// and backward (dY = d loss / d y; the residual's own share dY -> dx is added by the LayerNorm backward kernel):
+//   G_h[d][c']  = sum_n qs_h[n][d] dY[n][c']        (= dP_h)          dctx = G Wout_h, dWout += G^T ctx, dM = dctx Wv / N,
+//   dWv += dctx^T M / N,  rowdot[d] = sum_c dM[d][c] M[d][c]          (= sum_n ks[n][d] dks[n][d]: closed form, no extra pass)
+//   dqs[n][d] = sum_c' dY[n][c'] P[d][c'],  dq = qs (dqs - <qs, dqs>/scale)
+//   dks[n][d] = sum_c xn[n][c] dM[d][c],    dk = ks (dks - rowdot[d])
+//   d_xn[n][c] = sum_h sum_d ( dq Wq + dk Wk + ks dM ),   dWq += dq^T xn,  dWk += dk^T xn        (pixel sums)
+//
+// Matrix-core layouts (v_mfma_f32_32x32x2_f32: D[i][j] with j = lane & 31, rows i = (r&3) + 8(r>>2) + 4(lane>>5), r < 16):
+//   * pixel sums (M, G, dWq, dWk) contract over pixels, so their left operand needs lane = d: the k / q tile is built as
+//     D[px][d] (A = xn rows, B = W^T) and fed back as the A operand in its own accumulator-row order ("transposed chaining");
+//   * per-pixel work (softmax over d, Jacobians, y, d_xn) wants one pixel per lane: tiles are built as D[d][px] (A = W, B = xn^T),
+//     reductions over d are in-lane plus one cross-half exchange, and results chain into the next product as B operands;
+//   * dq / dk are needed in both roles: they are produced with lane = px and turned through a wave-private 32x33 LDS tile.
+// Kernels: lap_kctx (+ _final), lap_out (forward); lap_g, lap_mid, lap_bwd (backward).  One workgroup = one image's pixel
+// range, one wave per head in the pixel-sum kernels (8 waves), one wave per 32-pixel tile in lap_out.
+// Supported: C = Cout in {32, 64}, N % 32 == 0, heads <= 8, dim_head = 32.  Everything else keeps the qkv form (k_attn.hip).
+#include "pidm_launch.h"
+
+namespace pidm {
+
+static const int kLapDH = 32;
+static const int kLapTileLd = 33;    // row stride of a wave's 32x32 transposition tile (conflict-free in both directions)
+
+__device__ __forceinline__ float lap_exp(float x) { return __expf(x); }
+__device__ __forceinline__ int lap_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// pixels per workgroup of the pixel-sum kernels: the xn (and dY) slab of the range lives in LDS, rows padded to C + 4 floats
+static int lap_nper(int N, int C, int slabs) {
+  int n = (slabs == 1 ? 512 : 256) * 32 / C;
+  if (slabs == 3) n /= 2;
+  while (n > 32 && N % n) n >>= 1;
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward 1: per (image, pixel range, head): running column max m[d], Z[d] = sum_n exp(k - m), Mt[d][c] = sum_n exp(k - m) xn[n][c]
+// part layout per (b, ns, h): [32][C] Mt rows, then m[32], then Z[32]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__ xn, const float* __restrict__ wqkv,
+                                                       float* __restrict__ part, int N, int heads, int nper) {
+  constexpr int C = 32 * CB, CP = C + 4;
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* xs = smem;                          // [nper][CP]
+  float* fs = smem + (size_t)nper * CP;      // [8][32] rescale factors (wave private)
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NS = N / nper;
+  const int b = blockIdx.x / NS, ns = blockIdx.x % NS;
+  const int HD = heads * kLapDH;
+  const float* xb = xn + ((size_t)b * N + (size_t)ns * nper) * C;
+  for (int e = tid; e < nper * (C / 4); e += 512) {
+    const int px = e / (C / 4), q = e - px * (C / 4);
+    *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(xb + (size_t)px * C + 4 * q);
+  }
+  __syncthreads();
+  const int h = wave;
+  if (h >= heads) return;
+  // B operand of the k tile: W_k^T[c][d], lane = d; k-slots permuted so that one 16-byte fetch feeds four MFMAs
+  f32x4 wk[C / 8];
+  const float* wrow = wqkv + ((size_t)HD + h * kLapDH + l31) * C + 4 * half;
+#pragma unroll
+  for (int g8 = 0; g8 < C / 8; ++g8) wk[g8] = *reinterpret_cast<const f32x4*>(wrow + 8 * g8);
+  f32x16 M[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+    for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
+  float mrun = -3.0e38f, zp = 0.f;
+  float* fw = fs + wave * 32;
+  for (int t = 0; t < nper / 32; ++t) {
+    f32x16 kt;
+    for (int r = 0; r < 16; ++r) kt[r] = 0.f;
+    const float* arow = xs + (size_t)(t * 32 + l31) * CP + 4 * half;
+#pragma unroll
+    for (int g8 = 0; g8 < C / 8; ++g8) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kt = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], wk[g8][s], kt, 0, 0, 0);
+    }
+    // kt[px][d]: lane = d, registers = 16 of the tile's pixels.  Online softmax over pixels: column max of the tile first
+    float tm = kt[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    if (__any(tm > mrun)) {     // wave-uniform: the max of some column grew - rescale what has been accumulated (rare after the first tiles)
+      const float mn = fmaxf(mrun, tm);
+      const float f = lap_exp(mrun - mn);
+      zp *= f;
+      mrun = mn;
+      if (half == 0) fw[l31] = f;
+      __builtin_amdgcn_wave_barrier();
+      // Mt rows live across registers: row d = lap_row(r, half) needs factor f[d]
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f4 = *reinterpret_cast<const f32x4*>(fw + 8 * q4 + 4 * half);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) M[cb][4 * q4 + i] *= f4[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      kt[r] = lap_exp(kt[r] - mrun);
+      zp += kt[r];
+    }
+    // Mt[d][c] += sum_px e[px][d] xn[px][c]: A = the exponentials in their own accumulator-row order, B = xn rows from LDS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* brow = xs + (size_t)(t * 32 + lap_row(r, half)) * CP + l31;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], brow[32 * cb], M[cb], 0, 0, 0);
+    }
+  }
+  const float z = zp + __shfl_xor(zp, 32);
+  float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C + 64);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)lap_row(r, half) * C + 32 * cb + l31] = M[cb][r];
+  if (half == 0) {
+    o[32 * C + l31] = mrun;
+    o[32 * C + 32 + l31] = z;
+  }
+}
+
+// forward 1b, per (image, head): merge the pixel ranges; M = Mt / Z, kst = (m, 1/Z), ctx = M Wv^T / N, P = ctx Wout_h^T
+__global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __restrict__ part, const float* __restrict__ wqkv,
+                                                             const float* __restrict__ wout, float* __restrict__ kst,
+                                                             float* __restrict__ Mmat, float* __restrict__ ctx,
+                                                             float* __restrict__ P, int N, int heads, int C, int NS) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* sM = smem;                 // [32][C]
+  float* sW = sM + 32 * C;          // [32][C+1] Wv_h rows, later Wout[:, h*32 .. +32] as [C][33]
+  float* sC = sW + 32 * (C + 1) + C;   // [32][33] ctx
+  float* sw = sC + 32 * 33;         // [NS][32] merge weights
+  __shared__ float sm_[32], siz[32];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+  const int HD = heads * kLapDH;
+  const size_t pstride = (size_t)(32 * C + 64);
+  const float* p0 = part + ((size_t)b * NS * heads + h) * pstride;
+  if (tid < 32) {
+    float m = -3.0e38f;
+    for (int k = 0; k < NS; ++k) m = fmaxf(m, p0[(size_t)k * heads * pstride + 32 * C + tid]);
+    float z = 0.f;
+    for (int k = 0; k < NS; ++k) {
+      const float w = lap_exp(p0[(size_t)k * heads * pstride + 32 * C + tid] - m);
+      sw[k * 32 + tid] = w;
+      z += p0[(size_t)k * heads * pstride + 32 * C + 32 + tid] * w;
+    }
+    sm_[tid] = m;
+    siz[tid] = 1.f / z;
+    kst[((size_t)blockIdx.x * 32 + tid) * 2] = m;
+    kst[((size_t)blockIdx.x * 32 + tid) * 2 + 1] = 1.f / z;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int d = e / C;
+    float v = 0.f;
+    for (int k = 0; k < NS; ++k) v += p0[(size_t)k * heads * pstride + e] * sw[k * 32 + d];
+    v *= siz[d];
+    sM[e] = v;
+    Mmat[(size_t)blockIdx.x * 32 * C + e] = v;
+    const int c = e - d * C;
+    sW[d * (C + 1) + c] = wqkv[((size_t)2 * HD + h * kLapDH + d) * C + c];     // Wv_h[e = d][c]
+  }
+  __syncthreads();
+  const float invN = 1.f / (float)N;
+  for (int e = tid; e < 1024; e += 256) {
+    const int d = e >> 5, ee = e & 31;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) v = fmaf(sM[d * C + c], sW[ee * (C + 1) + c], v);
+    v *= invN;
+    sC[d * 33 + ee] = v;
+    ctx[(size_t)blockIdx.x * 1024 + e] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * C; e += 256) {     // sW <- Wout[c'][h*32 + e] as [c'][33]
+    const int cc = e >> 5, ee = e & 31;
+    sW[cc * 33 + ee] = wout[(size_t)cc * HD + h * kLapDH + ee];
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int d = e / C, cc = e - d * C;
+    float v = 0.f;
+#pragma unroll
+    for (int ee = 0; ee < 32; ++ee) v = fmaf(sC[d * 33 + ee], sW[cc * 33 + ee], v);
+    P[(size_t)blockIdx.x * 32 * C + e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward 2: y = bias + x + sum_h qs_h P_h, one wave per 32-pixel tile, heads in a loop; also leaves qstat = (max, 1/sum) of the
+// q softmax per (pixel, head) for the backward pixel sums.  LDS: W_q of all heads [HD][C+4] | P of this image [heads*32][C]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(256) lap_out_kernel(const float* __restrict__ xn, const float* __restrict__ wqkv,
+                                                      const float* __restrict__ P, const float* __restrict__ bias,
+                                                      const float* __restrict__ resid, float* __restrict__ y,
+                                                      float* __restrict__ qstat, int N, int heads, int tiles_per_wg, float scale) {
+  constexpr int C = 32 * CB, CP = C + 4;
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int HD = heads * kLapDH;
+  float* sWq = smem;                        // [HD][CP]
+  float* sP = smem + (size_t)HD * CP;       // [HD][C]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgs_per_img = (N / 32 + tiles_per_wg - 1) / tiles_per_wg;
+  const int b = blockIdx.x / wgs_per_img, wg = blockIdx.x % wgs_per_img;
+  for (int e = tid; e < HD * (C / 4); e += 256) {
+    const int row = e / (C / 4), q = e - row * (C / 4);
+    *reinterpret_cast<f32x4*>(sWq + (size_t)row * CP + 4 * q) = *reinterpret_cast<const f32x4*>(wqkv + (size_t)row * C + 4 * q);
+    *reinterpret_cast<f32x4*>(sP + (size_t)row * C + 4 * q) = *reinterpret_cast<const f32x4*>(P + ((size_t)b * HD + row) * C + 4 * q);
+  }
+  __syncthreads();
+  const int t_end = (wg + 1) * tiles_per_wg < N / 32 ? (wg + 1) * tiles_per_wg : N / 32;
+  for (int t = wg * tiles_per_wg + wave; t < t_end; t += 4) {
+    const size_t pix = (size_t)b * N + (size_t)t * 32 + l31;
+    // B operand of every head's q tile: xn^T[c][px], lane = px
+    f32x4 xt[C / 8];
+#pragma unroll
+    for (int g8 = 0; g8 < C / 8; ++g8) xt[g8] = *reinterpret_cast<const f32x4*>(xn + pix * C + 8 * g8 + 4 * half);
+    f32x16 yacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      for (int r = 0; r < 16; ++r) yacc[cb][r] = 0.f;
+    for (int h = 0; h < heads; ++h) {
+      f32x16 qt;
+      for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+      const float* wrow = sWq + (size_t)(h * kLapDH + l31) * CP + 4 * half;
+#pragma unroll
+      for (int g8 = 0; g8 < C / 8; ++g8) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + 8 * g8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], xt[g8][s], qt, 0, 0, 0);
+      }
+      // qt[d][px]: lane = pixel, registers = 16 of the 32 head channels; softmax over d = in-lane + the other half
+      float mx = qt[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qt[r] = lap_exp(qt[r] - mx);
+        sm += qt[r];
+      }
+      sm += __shfl_xor(sm, 32);
+      const float inv = 1.f / sm;
+      if (half == 0) *reinterpret_cast<float2*>(qstat + (pix * heads + h) * 2) = make_float2(mx, inv);
+      const float sc = inv * scale;
+      // y^T[c'][px] += P_h^T[c'][d] qs^T[d][px]: B = the softmax tile in its own row order, A = P_h rows read in that order
+      const float* prow = sP + (size_t)(h * kLapDH) * C + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float qv = qt[r] * sc;
+        const float* pr = prow + (size_t)lap_row(r, half) * C;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) yacc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[32 * cb], qv, yacc[cb], 0, 0, 0);
+      }
+    }
+    // yacc[cb][r] = y[px][32 cb + lap_row(r, half)]: four consecutive channels per register quad -> 16-byte accesses
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int c0 = 32 * cb + 8 * q4 + 4 * half;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + pix * C + c0);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = yacc[cb][4 * q4 + i] + bv[i] + rv[i];
+        *reinterpret_cast<f32x4*>(y + pix * C + c0) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward 1: G_h[d][c'] = sum_n qs_h[n][d] dY[n][c'] per (image, pixel range, head); part layout [32][C] per (b, ns, h)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(512) lap_g_kernel(const float* __restrict__ xn, const float* __restrict__ dy,
+                                                    const float* __restrict__ wqkv, const float* __restrict__ qstat,
+                                                    float* __restrict__ part, int N, int heads, int nper, float scale) {
+  constexpr int C = 32 * CB, CP = C + 4;
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* xs = smem;                           // [nper][CP]
+  float* ys = smem + (size_t)nper * CP;       // [nper][CP]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NS = N / nper;
+  const int b = blockIdx.x / NS, ns = blockIdx.x % NS;
+  const size_t pix0 = (size_t)b * N + (size_t)ns * nper;
+  for (int e = tid; e < nper * (C / 4); e += 512) {
+    const int px = e / (C / 4), q = e - px * (C / 4);
+    *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
+    *reinterpret_cast<f32x4*>(ys + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+  }
+  __syncthreads();
+  const int h = wave;
+  if (h >= heads) return;
+  f32x4 wq[C / 8];
+  const float* wrow = wqkv + ((size_t)h * kLapDH + l31) * C + 4 * half;
+#pragma unroll
+  for (int g8 = 0; g8 < C / 8; ++g8) wq[g8] = *reinterpret_cast<const f32x4*>(wrow + 8 * g8);
+  f32x16 G[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+    for (int r = 0; r < 16; ++r) G[cb][r] = 0.f;
+  for (int t = 0; t < nper / 32; ++t) {
+    f32x16 qt;
+    for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+    const float* arow = xs + (size_t)(t * 32 + l31) * CP + 4 * half;
+#pragma unroll
+    for (int g8 = 0; g8 < C / 8; ++g8) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qt = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], wq[g8][s], qt, 0, 0, 0);
+    }
+    // qt[px][d] (lane = d): the per-pixel softmax constants come from the forward (same address across a lane half: broadcast)
+    const float* st = qstat + ((pix0 + (size_t)t * 32) * heads + h) * 2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = lap_row(r, half);
+      const float2 s2 = *reinterpret_cast<const float2*>(st + (size_t)px * heads * 2);
+      const float qv = lap_exp(qt[r] - s2.x) * s2.y * scale;
+      const float* brow = ys + (size_t)(t * 32 + px) * CP + l31;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) G[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, brow[32 * cb], G[cb], 0, 0, 0);
+    }
+  }
+  float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)lap_row(r, half) * C + 32 * cb + l31] = G[cb][r];
+}
+
+// backward 1b, per (image, head): G = sum of the ranges; dctx = G Wout_h; dWout share of this image; dM = dctx Wv / N;
+// dWv share of this image; rowdot[d] = sum_c dM[d][c] M[d][c]
+__global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ gpart, const float* __restrict__ wqkv,
+                                                      const float* __restrict__ wout, const float* __restrict__ ctx,
+                                                      const float* __restrict__ Mmat, float* __restrict__ dMmat,
+                                                      float* __restrict__ rowdot, float* __restrict__ dwout_part,
+                                                      float* __restrict__ dwv_part, int N, int heads, int C, int NS) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* sG = smem;                       // [32][C+1]
+  float* sW = sG + 32 * (C + 1);          // [C][33] Wout[c'][h*32+e], later Wv_h [32][C+1]
+  float* sD = sW + (C > 33 ? C : 33) * 33 + 32 * (C + 1);   // [32][33] dctx
+  float* sM = sD + 32 * 33;               // [32][C+1] M, later dM
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+  const int HD = heads * kLapDH;
+  const float* g0 = gpart + ((size_t)b * NS * heads + h) * (size_t)(32 * C);
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int d = e / C, c = e - d * C;
+    float v = 0.f;
+    for (int k = 0; k < NS; ++k) v += g0[(size_t)k * heads * 32 * C + e];
+    sG[d * (C + 1) + c] = v;
+    sM[d * (C + 1) + c] = Mmat[(size_t)blockIdx.x * 32 * C + e];
+    const int cc = e >> 5, ee = e & 31;
+    sW[cc * 33 + ee] = wout[(size_t)cc * HD + h * kLapDH + ee];
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {           // dctx[d][e] = sum_c' G[d][c'] Wout[c'][h*32+e]
+    const int d = e >> 5, ee = e & 31;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) v = fmaf(sG[d * (C + 1) + c], sW[c * 33 + ee], v);
+    sD[d * 33 + ee] = v;
+  }
+  // dWout[c'][h*32+e] share of this image = sum_d G[d][c'] ctx[d][e]
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int cc = e >> 5, ee = e & 31;
+    float v = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 32; ++d) v = fmaf(sG[d * (C + 1) + cc], ctx[(size_t)blockIdx.x * 1024 + d * 32 + ee], v);
+    dwout_part[((size_t)b * C + cc) * HD + h * kLapDH + ee] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * C; e += 256) {         // sW <- Wv_h[e][c] as [32][C+1]
+    const int ee = e / C, c = e - ee * C;
+    sW[ee * (C + 1) + c] = wqkv[((size_t)2 * HD + h * kLapDH + ee) * C + c];
+  }
+  __syncthreads();
+  const float invN = 1.f / (float)N;
+  // dWv[h*32+e][c] share of this image = sum_d dctx[d][e] M[d][c] / N
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int ee = e / C, c = e - ee * C;
+    float v = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 32; ++d) v = fmaf(sD[d * 33 + ee], sM[d * (C + 1) + c], v);
+    dwv_part[((size_t)b * HD + h * kLapDH + ee) * C + c] = v * invN;
+  }
+  __syncthreads();
+  // dM[d][c] = sum_e dctx[d][e] Wv[e][c] / N; rowdot[d] = sum_c dM[d][c] M[d][c]
+  for (int e = tid; e < 32 * C; e += 256) {
+    const int d = e / C, c = e - d * C;
+    float v = 0.f;
+#pragma unroll 8
+    for (int ee = 0; ee < 32; ++ee) v = fmaf(sD[d * 33 + ee], sW[ee * (C + 1) + c], v);
+    v *= invN;
+    dMmat[(size_t)blockIdx.x * 32 * C + e] = v;
+    sG[d * (C + 1) + c] = v * sM[d * (C + 1) + c];
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) v += sG[tid * (C + 1) + c];
+    rowdot[(size_t)blockIdx.x * 32 + tid] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward 2: per (image, pixel range): d_xn of the range (all heads, summed across the 8 waves through LDS) and this range's
+// share of dWq, dWk (one head per wave, accumulated over the range's tiles).  dw part layout: [b*NS+ns][2*HD][C] (q rows, k rows)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ dy,
+                                                      const float* __restrict__ wqkv, const float* __restrict__ P,
+                                                      const float* __restrict__ kst, const float* __restrict__ dMmat,
+                                                      const float* __restrict__ rowdot, float* __restrict__ dxn,
+                                                      float* __restrict__ dw_part, int N, int heads, int nper, int nsub,
+                                                      float scale) {
+  constexpr int C = 32 * CB, CP = C + 4;
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* xs = smem;                                   // [nper][CP]
+  float* ys = xs + (size_t)nper * CP;                 // [nper][CP]
+  float* tiles = ys + (size_t)nper * CP;              // [8][CB][32][33]: transposition tile / d_xn share of each wave
+  float* cst = tiles + (size_t)8 * CB * 32 * kLapTileLd;   // [8][96]: k max, k 1/Z, rowdot of each wave's head
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NW = N / (nper * nsub);                  // workgroups per image: each walks nsub consecutive pixel ranges
+  const int b = blockIdx.x / NW, nw = blockIdx.x % NW;
+  const int HD = heads * kLapDH;
+  const int h = wave;
+  const bool act = h < heads;
+  float* tw = tiles + (size_t)wave * CB * 32 * kLapTileLd;
+  float* cw = cst + wave * 96;
+  if (act && half == 0) {
+    cw[l31] = kst[(((size_t)b * heads + h) * 32 + l31) * 2];
+    cw[32 + l31] = kst[(((size_t)b * heads + h) * 32 + l31) * 2 + 1];
+    cw[64 + l31] = rowdot[((size_t)b * heads + h) * 32 + l31];
+  }
+  // A operands with lane = d (rows of Wq_h, Wk_h, P_h, dM_h; 16 bytes per lane and 8-channel group) are re-fetched per tile
+  // through L1 instead of living in registers for the whole range: with them resident the kernel needs > 256 registers
+  // (two waves per SIMD in a 512-thread workgroup: 256 is the ceiling) and spills into the MFMA loops
+  f32x16 dWq[CB], dWk[CB];
+  const size_t bh = (size_t)b * heads + (act ? h : 0);
+  const float* wq_p = wqkv + ((size_t)(act ? h : 0) * kLapDH + l31) * C + 4 * half;
+  const float* wk_p = wq_p + (size_t)HD * C;
+  const float* pp_p = P + (bh * 32 + l31) * C + 4 * half;
+  const float* dm_p = dMmat + (bh * 32 + l31) * C + 4 * half;
+  if (act) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      for (int r = 0; r < 16; ++r) { dWq[cb][r] = 0.f; dWk[cb][r] = 0.f; }
+  }
+  const float* wqT = wqkv + (size_t)h * kLapDH * C + l31;                 // Wq_h[d][c = l31 + 32 cb] for the d_xn products (A, lane = c)
+  const float* wkT = wqkv + ((size_t)HD + h * kLapDH) * C + l31;
+  const float* dmT = dMmat + ((size_t)b * heads + h) * 32 * C + l31;
+  const float rscale = 1.f / scale;
+  for (int sub = 0; sub < nsub; ++sub) {
+  const size_t pix0 = (size_t)b * N + ((size_t)nw * nsub + sub) * nper;
+  // (re)stage the range's xn and dY slabs; the loop below ends on a barrier, so nobody still reads the previous range
+  for (int e = tid; e < nper * (C / 4); e += 512) {
+    const int px = e / (C / 4), q = e - px * (C / 4);
+    *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
+    *reinterpret_cast<f32x4*>(ys + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+  }
+  __syncthreads();
+  for (int t = 0; t < nper / 32; ++t) {
+    f32x16 dx[CB];
+    if (act) {
+      int z0 = 0;
+      PIDM_OPAQUE_I32(z0);      // keeps the operand fetches below inside the tile loop
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
+      // B operands with lane = px: xn^T and dY^T rows of the tile, fetched from the LDS slabs where they are used (holding them
+      // across the whole tile costs C/2 registers each)
+      const float* xrow = xs + (size_t)(t * 32 + l31) * CP + 4 * half;
+      const float* yrow = ys + (size_t)(t * 32 + l31) * CP + 4 * half;
+      // ---- q: qs^T[d][px], dqs^T[d][px] = P_h dY^T, softmax Jacobian per pixel (in-lane + other half) ----
+      f32x16 qt, dq;
+      for (int r = 0; r < 16; ++r) { qt[r] = 0.f; dq[r] = 0.f; }
+#pragma unroll
+      for (int g8 = 0; g8 < C / 8; ++g8) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wq_p + z0 + 8 * g8);
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(pp_p + z0 + 8 * g8);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xrow + 8 * g8);
+        const f32x4 y4 = *reinterpret_cast<const f32x4*>(yrow + 8 * g8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], x4[s], qt, 0, 0, 0);
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(p4[s], y4[s], dq, 0, 0, 0);
+        }
+      }
+      float mx = qt[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qt[r] = lap_exp(qt[r] - mx);
+        sm += qt[r];
+      }
+      sm += __shfl_xor(sm, 32);
+      const float sc = scale / sm;
+      float jd = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qt[r] *= sc;                     // qs
+        jd += qt[r] * dq[r];
+      }
+      jd = (jd + __shfl_xor(jd, 32)) * rscale;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = qt[r] * (dq[r] - jd);
+      // d_xn^T[c][px] += Wq_h^T[c][d] dq^T[d][px]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* wr = wqT + (size_t)lap_row(r, half) * C;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
+      }
+      // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dq[r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = tw[l31 * kLapTileLd + 2 * s + half];
+        const float* brow = xs + (size_t)(t * 32 + 2 * s + half) * CP + l31;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dWq[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWq[cb], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
+      f32x16 kt, dk;
+      for (int r = 0; r < 16; ++r) { kt[r] = 0.f; dk[r] = 0.f; }
+#pragma unroll
+      for (int g8 = 0; g8 < C / 8; ++g8) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk_p + z0 + 8 * g8);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(dm_p + z0 + 8 * g8);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xrow + 8 * g8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          kt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], x4[s], kt, 0, 0, 0);
+          dk = __builtin_amdgcn_mfma_f32_32x32x2f32(m4[s], x4[s], dk, 0, 0, 0);
+        }
+      }
+      // per-head column constants in accumulator-row order (row d = lap_row(r, half)): k max, k 1/Z, rowdot from the wave's LDS block
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 mx4 = *reinterpret_cast<const f32x4*>(cw + 8 * q4 + 4 * half);
+        const f32x4 iz4 = *reinterpret_cast<const f32x4*>(cw + 32 + 8 * q4 + 4 * half);
+        const f32x4 rd4 = *reinterpret_cast<const f32x4*>(cw + 64 + 8 * q4 + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q4 + i;
+          kt[r] = lap_exp(kt[r] - mx4[i]) * iz4[i];     // ks
+          dk[r] = kt[r] * (dk[r] - rd4[i]);
+        }
+      }
+      // d_xn^T[c][px] += Wk_h^T[c][d] dk^T[d][px] + dM_h^T[c][d] ks^T[d][px]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* wr = wkT + (size_t)lap_row(r, half) * C;
+        const float* mr = dmT + (size_t)lap_row(r, half) * C;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dk[r], dx[cb], 0, 0, 0);
+          dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[32 * cb], kt[r], dx[cb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dk[r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = tw[l31 * kLapTileLd + 2 * s + half];
+        const float* brow = xs + (size_t)(t * 32 + 2 * s + half) * CP + l31;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dWk[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWk[cb], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tw[(cb * 32 + lap_row(r, half)) * kLapTileLd + l31] = dx[cb][r];
+    }
+    __syncthreads();
+    // sum over the heads (waves) and store d_xn rows: thread -> (pixel, 4 consecutive channels)
+    for (int e = tid; e < 32 * (C / 4); e += 512) {
+      const int px = e / (C / 4), c0 = 4 * (e - px * (C / 4));
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < heads; ++w) {
+        const float* tp = tiles + (size_t)w * CB * 32 * kLapTileLd + (size_t)c0 * kLapTileLd + px;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += tp[i * kLapTileLd];
+      }
+      *reinterpret_cast<f32x4*>(dxn + (pix0 + (size_t)t * 32 + px) * C + c0) = o;
+    }
+    __syncthreads();
+  }
+  }
+  if (act) {
+    float* oq = dw_part + ((size_t)blockIdx.x * 2 * HD + h * kLapDH) * C;
+    float* ok = oq + (size_t)HD * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        oq[(size_t)lap_row(r, half) * C + 32 * cb + l31] = dWq[cb][r];
+        ok[(size_t)lap_row(r, half) * C + 32 * cb + l31] = dWk[cb][r];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------------
+bool lap_ok(int N, int heads, int C, int Cout) {
+  return Cout == C && (C == 32 || C == 64) && N % 32 == 0 && N >= 32 && heads >= 1 && heads <= 8;
+}
+
+// floats of caller scratch (partials of the pixel-range kernels; the larger of forward and backward needs)
+size_t lap_scratch_floats(int B, int N, int heads, int C) {
+  const size_t fw = (size_t)B * (N / lap_nper(N, C, 1)) * heads * (32 * C + 64);
+  const size_t bw = (size_t)B * (N / lap_nper(N, C, 2)) * heads * 32 * C;
+  return (fw > bw ? fw : bw) + 64;
+}
+// floats of the saved statistics block: kst | M | ctx | P  (qstat is separate: B*N*heads*2)
+size_t lap_saved_floats(int B, int heads, int C) { return (size_t)B * heads * (64 + 32 * C + 1024 + 32 * C); }
+// partial weight-gradient buffers of one backward: dWq|dWk per pixel range, dWv per image, dWout per image
+// ranges one lap_bwd workgroup walks (its dWq / dWk share is written once): keeps the partial buffers small while the
+// launch still has >= 8 workgroups per image
+static int lap_nsub(int N, int C) {
+  const int ns = N / lap_nper(N, C, 3);
+  int k = 1;
+  while (k < 4 && ns % (2 * k) == 0 && ns / (2 * k) >= 8) k *= 2;
+  return k;
+}
+size_t lap_dw_ranges(int N, int C) { return (size_t)(N / lap_nper(N, C, 3) / lap_nsub(N, C)); }
+
+template <int CB>
+static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, const float* bias, const float* resid, float* y,
+                         float* saved, float* qstat, int B, int N, int heads, float* scratch, hipStream_t st) {
+  constexpr int C = 32 * CB;
+  const int nper = lap_nper(N, C, 1), NS = N / nper;
+  float* kst = saved;
+  float* Mmat = kst + (size_t)B * heads * 64;
+  float* ctx = Mmat + (size_t)B * heads * 32 * C;
+  float* P = ctx + (size_t)B * heads * 1024;
+  const size_t lds1 = ((size_t)nper * (C + 4) + 8 * 32) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kctx_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_out_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kctx_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_kernel<CB>), dim3(B * NS), dim3(512), lds1, st, xn, wqkv, scratch, N, heads, nper);
+  PIDM_CHECK_LAUNCH("lap_kctx_kernel");
+  const size_t lds2 = ((size_t)32 * C + 32 * (C + 1) + C + 32 * 33 + (size_t)NS * 32 + 64) * sizeof(float);
+  hipLaunchKernelGGL(lap_kctx_final_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, kst, Mmat, ctx, P, N, heads, C, NS);
+  PIDM_CHECK_LAUNCH("lap_kctx_final_kernel");
+  const int HD = heads * kLapDH;
+  const size_t lds3 = ((size_t)HD * (C + 4) + (size_t)HD * C) * sizeof(float);
+  // tiles per workgroup: enough workgroups to fill the chip twice, at least one tile per wave
+  int tpw = 4;
+  while ((long)B * ((N / 32 + tpw - 1) / tpw) > 2048 && tpw < 64) tpw *= 2;
+  const int wgs = B * ((N / 32 + tpw - 1) / tpw);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_out_kernel<CB>), dim3(wgs), dim3(256), lds3, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tpw,
+                     0.17677669529663687f);
+  PIDM_CHECK_LAUNCH("lap_out_kernel");
+  return 0;
+}
+
+int launch_lap_forward(const float* xn, const float* wqkv, const float* wout, const float* bias, const float* resid, float* y,
+                       float* saved, float* qstat, int C, int B, int N, int heads, float* scratch, hipStream_t st) {
+  if (!lap_ok(N, heads, C, C)) return fail("projected linear attention: unsupported shape (N=%d heads=%d C=%d)", N, heads, C);
+  if (!bias || !resid) return fail("projected linear attention: bias and residual are required");
+  if (C == 32) return lap_forward_t<1>(xn, wqkv, wout, bias, resid, y, saved, qstat, B, N, heads, scratch, st);
+  return lap_forward_t<2>(xn, wqkv, wout, bias, resid, y, saved, qstat, B, N, heads, scratch, st);
+}
+
+template <int CB>
+static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, const float* wout, const float* saved, const float* qstat,
+                          float* dxn, float* dwqk_part, float* dwv_part, float* dwout_part, float* tmp, int B, int N, int heads,
+                          float* scratch, hipStream_t st) {
+  constexpr int C = 32 * CB;
+  const float scale = 0.17677669529663687f;
+  const float* kst = saved;
+  const float* Mmat = kst + (size_t)B * heads * 64;
+  const float* ctx = Mmat + (size_t)B * heads * 32 * C;
+  const float* P = ctx + (size_t)B * heads * 1024;
+  float* dMmat = tmp;                                    // [B][heads][32][C]
+  float* rowdot = tmp + (size_t)B * heads * 32 * C;      // [B][heads][32]
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_g_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_bwd_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  const int np2 = lap_nper(N, C, 2), NS2 = N / np2;
+  const size_t lds1 = (size_t)2 * np2 * (C + 4) * sizeof(float);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_kernel<CB>), dim3(B * NS2), dim3(512), lds1, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
+  PIDM_CHECK_LAUNCH("lap_g_kernel");
+  const size_t lds2 = ((size_t)32 * (C + 1) + (size_t)(C > 33 ? C : 33) * 33 + 32 * (C + 1) + 32 * 33 + 32 * (C + 1) + 64) * sizeof(float);
+  hipLaunchKernelGGL(lap_mid_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, ctx, Mmat, dMmat, rowdot, dwout_part, dwv_part, N,
+                     heads, C, NS2);
+  PIDM_CHECK_LAUNCH("lap_mid_kernel");
+  const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;
+  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96) * sizeof(float);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
+                     N, heads, np3, nsub, scale);
+  PIDM_CHECK_LAUNCH("lap_bwd_kernel");
+  return 0;
+}
+
+size_t lap_bwd_tmp_floats(int B, int heads, int C) { return (size_t)B * heads * (32 * C + 32) + 64; }
+
+// dwqk_part: [B * lap_dw_ranges(N, C)][2*HD][C]; dwv_part: [B][HD][C]; dwout_part: [B][C][HD]; tmp: lap_bwd_tmp_floats
+int launch_lap_backward(const float* xn, const float* dy, const float* wqkv, const float* wout, const float* saved, const float* qstat,
+                        float* dxn, float* dwqk_part, float* dwv_part, float* dwout_part, float* tmp, int C, int B, int N, int heads,
+                        float* scratch, hipStream_t st) {
+  if (!lap_ok(N, heads, C, C)) return fail("projected linear attention: unsupported shape (N=%d heads=%d C=%d)", N, heads, C);
+  if (C == 32)
+    return lap_backward_t<1>(xn, dy, wqkv, wout, saved, qstat, dxn, dwqk_part, dwv_part, dwout_part, tmp, B, N, heads, scratch, st);
+  return lap_backward_t<2>(xn, dy, wqkv, wout, saved, qstat, dxn, dwqk_part, dwv_part, dwout_part, tmp, B, N, heads, scratch, st);
+}
+
+}  // namespace pidm
+
+using namespace pidm;
+
+// ---- unit-level C ABI (parity tests, tools/bench_attn.py) ---------------------------------------------------------------------
+extern "C" size_t pidm_lap_ws(int B, int N, int heads, int C) {
+  // scratch | backward tmp | dWq,dWk ranges | dWv per image | dWout per image
+  const size_t HD = (size_t)heads * kLapDH;
+  return (lap_scratch_floats(B, N, heads, C) + lap_bwd_tmp_floats(B, heads, C) + (size_t)B * lap_dw_ranges(N, C) * 2 * HD * C +
+          (size_t)B * HD * C * 2 + 256) * sizeof(float);
+}
+extern "C" size_t pidm_lap_saved_floats(int B, int heads, int C) { return lap_saved_floats(B, heads, C); }
+
+extern "C" int pidm_lap_forward(const float* xn, const float* w_qkv, const float* w_out, const float* bias, const float* resid, float* y,
+                                float* saved, float* qstat, int C, int B, int N, int heads, void* workspace, void* stream) {
+  if (!xn || !w_qkv || !w_out || !y || !saved || !qstat || !workspace) return fail("lap_forward: null buffer");
+  return launch_lap_forward(xn, w_qkv, w_out, bias, resid, y, saved, qstat, C, B, N, heads, reinterpret_cast<float*>(workspace), as_stream(stream));
+}
+
+// d_w_qkv [3*HD][C], d_w_out [C][HD] are WRITTEN (fixed-order sums over images / pixel ranges); d_xn [B][N][C]
+extern "C" int pidm_lap_backward(const float* xn, const float* dy, const float* w_qkv, const float* w_out, const float* saved,
+                                 const float* qstat, float* d_xn, float* d_w_qkv, float* d_w_out, int C, int B, int N, int heads,
+                                 void* workspace, void* stream) {
+  if (!xn || !dy || !w_qkv || !w_out || !saved || !qstat || !d_xn || !d_w_qkv || !d_w_out || !workspace) return fail("lap_backward: null buffer");
+  if (!lap_ok(N, heads, C, C)) return fail("projected linear attention: unsupported shape (N=%d heads=%d C=%d)", N, heads, C);
+  hipStream_t st = as_stream(stream);
+  const int HD = heads * kLapDH;
+  float* scratch = reinterpret_cast<float*>(workspace);
+  float* tmp = scratch + lap_scratch_floats(B, N, heads, C);
+  float* dwqk = tmp + lap_bwd_tmp_floats(B, heads, C);
+  const int nr = (int)lap_dw_ranges(N, C);
+  float* dwv = dwqk + (size_t)B * nr * 2 * HD * C;
+  float* dwo = dwv + (size_t)B * HD * C;
+  if (launch_lap_backward(xn, dy, w_qkv, w_out, saved, qstat, d_xn, dwqk, dwv, dwo, tmp, C, B, N, heads, scratch, st)) return -1;
+  if (launch_split_reduce(dwqk, d_w_qkv, nullptr, nullptr, B * nr, 2 * HD, C, 1, 2 * HD, C, st)) return -1;
+  if (launch_split_reduce(dwv, d_w_qkv + (size_t)2 * HD * C, nullptr, nullptr, B, HD, C, 1, HD, C, st)) return -1;
+  return launch_split_reduce(dwo, d_w_out, nullptr, nullptr, B, C, HD, 1, C, HD, st);
+}

@@ -35,6 +35,13 @@ namespace pidm {
 
 static const int kBM = 128;  // pixels per workgroup tile
 
+// Measurement aid (tools/conv_probe.py builds variant libraries with -DPIDM_ABLATE_FLAGS=n; the product build has 0 and the
+// branches below fold away): 1 = operand tiles are not fetched from memory, 2 = the epilogue does not store, 4 = no MFMAs.
+#ifndef PIDM_ABLATE_FLAGS
+#define PIDM_ABLATE_FLAGS 0
+#endif
+static constexpr int kAblate = PIDM_ABLATE_FLAGS;
+
 // ---------------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------------------------------
@@ -317,7 +324,10 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
   f32x4 ra[AMAX], rb[BMAX];  // native vectors: stay in VGPRs across the loop back-edge
 
 #define PIDM_PREFETCH(c0_)                                                                                         \
-  {                                                                                                                \
+  if (kAblate & 1) {                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < AMAX; ++k) ra[k] = f32x4{1.f, 0.f, 0.f, 0.f};                            \
+    _Pragma("unroll") for (int k = 0; k < BMAX; ++k) rb[k] = f32x4{1.f, 0.f, 0.f, 0.f};                            \
+  } else {                                                                                                         \
     const int kk__ = (c0_);                 /* position along the packed K axis */                                 \
     const int ph__ = PHASED ? kk__ / g.Cin : 0;                                                                    \
     const int c0__ = PHASED ? kk__ - ph__ * g.Cin : kk__;                                                          \
@@ -395,8 +405,10 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt * NT + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][g8][s], fb[cur][g8][ni][s], acc[mt * NT + ni], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+              if (kAblate & 4) acc[mt * NT + ni][(g8 * 4 + s) & 15] += fa[cur][mt][g8][s] * fb[cur][g8][ni][s];
+              else acc[mt * NT + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mt][g8][s], fb[cur][g8][ni][s], acc[mt * NT + ni], 0, 0, 0);
+            }
         }
       }
       // pin the order hipcc otherwise undoes (it sinks the next tap's ds_reads below this tap's MFMAs):
@@ -472,7 +484,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
           float v = acc[mt * NT + ni][r] + bv;
           if (rp) v += rp[rowc * rrstep];
           if (sig) v = 1.f / (1.f + expf(-v));
-          op[rowc * rstep] = v;
+          if (!(kAblate & 2) || v == 1.2345e30f) op[rowc * rstep] = v;
           gs1 += v;
           gs2 += v * v;
         }
@@ -1663,6 +1675,12 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
                 const float* residual, float* out, int sigmoid_last, hipStream_t st) {
   const int KC = pick_kc(g.Cin), NT = pick_nt(g.Cout, g.tiles_m * g.nz);
   const bool nt4 = conv_nt4_ok(g, KC);
+  if (prof_enabled()) {
+    char lab[160];
+    snprintf(lab, sizeof(lab), "conv B%d %dx%d Cin%d Cout%d k%dx%d nph%d nz%d%s%s%s", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH, g.KW, g.nph,
+             g.nz, g.gn_part ? " +gnstats" : "", g.bn_part ? " +bnsums" : "", residual ? " +res" : "");
+    prof_set_label(lab);
+  }
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
@@ -1783,7 +1801,12 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     attr_done = true;
   }
   const bool prof = prof_enabled();
-  if (prof) prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
+  if (prof) {
+    char lab[160];
+    snprintf(lab, sizeof(lab), "wgrad B%d %dx%d Cin%d Cout%d k%dx%d nph%d", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH, g.KW, g.nph);
+    prof_set_label(lab);
+    prof_begin_launch(1, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T, st);
+  }
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
                        ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
   const int smode = wgrad_stream_mode(g, ld_dy);

@@ -36,15 +36,20 @@ extern "C" const char* pidm_backend(void) {
 // ---------------------------------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline figures)
 // ---------------------------------------------------------------------------------------------------------
+#include <map>
+#include <string>
 #include <vector>
+#include <stdlib.h>
 namespace pidm {
-struct ProfRec { hipEvent_t a, b; int cls; double work; };
+struct ProfRec { hipEvent_t a, b; int cls; double work; std::string label; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::string g_prof_label;
 bool prof_enabled() { return g_prof_on; }
+void prof_set_label(const char* label) { g_prof_label = label ? label : ""; }
 void prof_begin_launch(int cls, double work, hipStream_t st) {
   ProfRec r;
-  r.cls = cls; r.work = work;
+  r.cls = cls; r.work = work; r.label = g_prof_label;
   (void)hipEventCreate(&r.a);
   (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, st);
@@ -60,14 +65,27 @@ extern "C" int pidm_prof_enable(int on) {
 // sums since the last collect: ms[c], launches[c], work[c] (flops or bytes as declared by the launcher), c < 4
 extern "C" int pidm_prof_collect(double* ms, long long* launches, double* work) {
   for (int c = 0; c < 4; ++c) { ms[c] = 0.0; launches[c] = 0; work[c] = 0.0; }
+  struct Agg { double ms = 0, work = 0; long n = 0; int cls = 0; };
+  std::map<std::string, Agg> by_label;
+  const char* dump = getenv("PIDM_PROF_DUMP");   // per-shape table of the timed launches (tools/, A/B measurements)
   for (auto& r : pidm::g_prof) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.a, r.b);
     if (r.cls >= 0 && r.cls < 4) { ms[r.cls] += t; launches[r.cls] += 1; work[r.cls] += r.work; }
+    if (dump) { Agg& a = by_label[r.label]; a.ms += t; a.work += r.work; a.n += 1; a.cls = r.cls; }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
   pidm::g_prof.clear();
+  if (dump && !by_label.empty()) {
+    if (FILE* f = fopen(dump, "a")) {
+      fprintf(f, "# class launches total_ms avg_us TFLOP/s label\n");
+      for (auto& kv : by_label)
+        fprintf(f, "%d %ld %.3f %.1f %.1f %s\n", kv.second.cls, kv.second.n, kv.second.ms, kv.second.ms * 1e3 / kv.second.n,
+                kv.second.work / (kv.second.ms * 1e-3) / 1e12, kv.first.c_str());
+      fclose(f);
+    }
+  }
   return 0;
 }

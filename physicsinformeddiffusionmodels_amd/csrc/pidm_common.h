@@ -15,6 +15,7 @@ int fail(const char* fmt, ...);  // sets the error, returns -1
 
 // bench-only per-launch timing (pidm_api.cpp).  classes: 0 conv fwd/dgrad (flops), 1 conv wgrad (flops)
 bool prof_enabled();
+void prof_set_label(const char* label);   // attached to the next prof_begin_launch records (per-shape tables)
 void prof_begin_launch(int cls, double work, hipStream_t st);
 void prof_end_launch(hipStream_t st);
 
@@ -33,6 +34,7 @@ __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d
 // The host emulator's shadow <hip/hip_runtime.h> provides its own definition.
 #ifndef PIDM_OPAQUE_F32
 #define PIDM_OPAQUE_F32(x) asm volatile("" : "+v"(x))
+#define PIDM_OPAQUE_I32(x) asm volatile("" : "+v"(x))   // e.g. a zero the optimiser cannot see: keeps loop-invariant loads inside the loop
 #endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -74,5 +74,16 @@ int launch_la_backward_fused(const float* qkv, const float* kstat, const float* 
                              int heads, float* scratch, hipStream_t st);
 int launch_la_backward(const float* qkv, const float* kstat, const float* qstat, const float* ctx, const float* dA, float* dctx,
                        float* rowdot, float* dqkv, int B, int N, int heads, float* scratch, hipStream_t st);
+// k_attn_proj.hip: linear attention without a qkv tensor (q / k tiles rebuilt from xn on the matrix cores, v never formed)
+bool lap_ok(int N, int heads, int C, int Cout);
+size_t lap_scratch_floats(int B, int N, int heads, int C);
+size_t lap_saved_floats(int B, int heads, int C);
+size_t lap_dw_ranges(int N, int C);
+size_t lap_bwd_tmp_floats(int B, int heads, int C);
+int launch_lap_forward(const float* xn, const float* wqkv, const float* wout, const float* bias, const float* resid, float* y,
+                       float* saved, float* qstat, int C, int B, int N, int heads, float* scratch, hipStream_t st);
+int launch_lap_backward(const float* xn, const float* dy, const float* wqkv, const float* wout, const float* saved, const float* qstat,
+                        float* dxn, float* dwqk_part, float* dwv_part, float* dwout_part, float* tmp, int C, int B, int N, int heads,
+                        float* scratch, hipStream_t st);
 int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N, int heads, bool bwd, hipStream_t st);
 }  // namespace pidm

@@ -57,6 +57,7 @@ struct AttnBlock {
   ConvLayer qkv, out;
   const float* x = nullptr;
   float *xn = nullptr, *qkvb = nullptr, *kstat = nullptr, *qstat = nullptr, *ctx = nullptr, *attn = nullptr;
+  float* lsaved = nullptr;   // projected form (k_attn_proj.hip): k statistics | M | ctx | P; qstat as above; no qkv tensor
 };
 
 }  // namespace pidm
@@ -552,6 +553,18 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
   return 0;
 }
 
+// Linear attention without the qkv tensor (k_attn_proj.hip) where the level is large enough for the recomputation to beat the
+// 768-channel round trips: the 64x64 and 32x32 levels of the Darcy model.  PIDM_NO_LAP=1 keeps the qkv form everywhere (A/B
+// measurements); PIDM_LAP_MIN_N lowers the gate (the unit tests reach the path with small images).
+static bool attn_projected(const AttnBlock& a, int heads) {
+  const char* e = getenv("PIDM_NO_LAP");       // read per call (a handful of calls per step): tests and A/B runs flip it
+  const bool off = e && atoi(e);
+  const char* m = getenv("PIDM_LAP_MIN_N");
+  const int min_n = m ? atoi(m) : 1024;
+  const int N = a.H * a.H;
+  return !off && !a.mid && a.out.b >= 0 && N >= min_n && lap_ok(N, heads, a.C, a.C);
+}
+
 static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   pidm_unet* U = r.U;
   const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
@@ -561,6 +574,15 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   a.x = x;
   a.xn = act_alloc(r, npix * C);
   RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
+  if (attn_projected(a, heads)) {
+    a.qkvb = nullptr;
+    a.lsaved = act_alloc(r, lap_saved_floats(B, heads, C));
+    a.qstat = act_alloc(r, npix * heads * 2);
+    RUN(launch_lap_forward(a.xn, U->P[a.qkv.w], U->P[a.out.w], U->P[a.out.b], x, out, a.lsaved, a.qstat, C, B, N, heads, r.scratch, r.st));
+    r.tmp.release(mk);
+    *out_p = out;
+    return 0;
+  }
   a.qkvb = act_alloc(r, npix * 3 * HD);
   if (conv_fwd(r, a.qkv, a.xn, nullptr, nullptr, a.qkvb)) return -1;
   if (!a.mid && (la_fused_ok(N, heads, C, C) && la_fused_pays(B, N))) {
@@ -789,6 +811,36 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   const size_t mk = r.tmp.mark();
   float* g_qkv = nullptr;
   float* g_xn = nullptr;
+  if (attn_projected(a, heads)) {
+    // no qkv tensor, no dqkv tensor: d_xn and the to_qkv / to_out weight-gradient shares come straight from (xn, dY)
+    const size_t nr = (size_t)B * lap_dw_ranges(N, C);
+    const size_t n_qk = nr * 2 * HD * C, n_v = (size_t)B * HD * C, n_o = (size_t)B * C * HD;
+    float* dwqk = r.defer_on ? r.defer.alloc(n_qk) : r.tmp.alloc(n_qk);
+    float* dwv = r.defer_on ? r.defer.alloc(n_v) : r.tmp.alloc(n_v);
+    float* dwo = r.defer_on ? r.defer.alloc(n_o) : r.tmp.alloc(n_o);
+    float* cpart = r.part_alloc(colsum_ws_bytes(npix, C));
+    float* ltmp = r.tmp.alloc(lap_bwd_tmp_floats(B, heads, C));
+    g_xn = r.tmp.alloc(npix * C);
+    RUN(launch_lap_backward(a.xn, g_out, U->P[a.qkv.w], U->P[a.out.w], a.lsaved, a.qstat, g_xn, dwqk, dwv, dwo, ltmp, C, B, N, heads, r.scratch,
+                            r.st));
+    if (U->have_grads && !r.dry) {
+      float* gw = U->G[a.qkv.w];
+      if (r.q()) {
+        r.q()->push(dwqk, gw, nullptr, nullptr, (size_t)2 * HD * C, (int)nr, 2 * HD, C, 1, 2 * HD, C);
+        r.q()->push(dwv, gw + (size_t)2 * HD * C, nullptr, nullptr, (size_t)HD * C, B, HD, C, 1, HD, C);
+        r.q()->push(dwo, U->G[a.out.w], nullptr, nullptr, (size_t)C * HD, B, C, HD, 1, C, HD);
+      } else {
+        RUN(launch_split_reduce(dwqk, gw, nullptr, nullptr, (int)nr, 2 * HD, C, 1, 2 * HD, C, r.st));
+        RUN(launch_split_reduce(dwv, gw + (size_t)2 * HD * C, nullptr, nullptr, B, HD, C, 1, HD, C, r.st));
+        RUN(launch_split_reduce(dwo, U->G[a.out.w], nullptr, nullptr, B, C, HD, 1, C, HD, r.st));
+      }
+      RUN(launch_colsum(g_out, npix, C, C, U->G[a.out.b], cpart, r.st, r.q()));
+    }
+    float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
+    RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
+    if (!(r.overlap || r.dry)) r.tmp.release(mk);
+    return 0;
+  }
   if (!a.mid && (la_fused_ok(N, heads, C, C) && la_fused_pays(B, N))) {
     // attention backward fused with the to_out projection: the gradient of the attention output (npix*HD floats), the
     // projection's dgrad and its wgrad over the materialised attention output are all replaced (k_attn.hip)
@@ -855,6 +907,7 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
     conv_ws(a.qkv); conv_ws(a.out);
     upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
     upd(la_scratch_floats(B, a.H * a.H, U->heads) * sizeof(float));
+    if (attn_projected(a, U->heads)) upd(lap_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
     if (!a.mid && la_fused_ok(a.H * a.H, U->heads, a.C, a.C) && la_fused_pays(B, a.H * a.H)) upd(la_fused_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
   }
   for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }

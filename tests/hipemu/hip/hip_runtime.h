@@ -136,6 +136,13 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
   return hipemu::shfl_any(v, s);
 }
 
+// wave vote: non-zero when the predicate holds on any lane of the wave
+static inline int __any(int pred) {
+  int v = pred != 0;
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off);
+  return v;
+}
+
 // ---- MFMA (f32 in / f32 acc), lane layouts per cdna_hip_programming.md section 3 -----------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
@@ -221,6 +228,7 @@ static inline float hipemu_fast_expf(float x) { return exp2f(x * 1.4426950408889
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 #define PIDM_OPAQUE_F32(x) do { volatile float t__ = (x); (x) = t__; } while (0)   // value barrier (pidm_common.h)
+#define PIDM_OPAQUE_I32(x) do { volatile int t__ = (x); (x) = t__; } while (0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __ldg(const float* p) { return *p; }
 

@@ -113,8 +113,10 @@ def test_training_step_determinism_and_shard_average_b64():
     assert (avg - g1).abs().max().item() < 2e-4 * scale
 
 
-def test_attention_projection_fusion_equals_separate_kernels_b64(monkeypatch):
-    """The engine's fused attention x to_out kernels (64x64 and 32x32 levels at batch 64: the heads*32-channel attention output
+def test_attention_forms_agree_b64(monkeypatch):
+    """Three executions of the same attention blocks at batch 64: without a qkv tensor (k_attn_proj.hip, the default of the 64x64
+    and 32x32 levels), with the qkv tensor and the attention fused into the to_out projection, and with separate kernels.
+    The engine's fused attention x to_out kernels (64x64 and 32x32 levels at batch 64: the heads*32-channel attention output
     and its gradient are never stored; dctx and dW_out come from one q x dY reduction) give the same loss and the same
     gradient - every parameter, in particular to_out.weight / to_out.bias / to_qkv.weight - as the separate attention and
     projection kernels, up to fp32 reassociation."""
@@ -125,9 +127,12 @@ def test_attention_projection_fusion_equals_separate_kernels_b64(monkeypatch):
     eps = torch.randn(64, 2, 64, 64, generator=g).to(dev)
     t = torch.randint(0, 100, (64,), generator=g).to(dev)
 
-    def grads(min_wgs):
+    def grads(env):
         # one engine per setting (same seed-0 parameters): the activation arena is sized for the path chosen at first use
-        monkeypatch.setenv("PIDM_LA_FUSED_MIN_WGS", min_wgs)
+        for k in ("PIDM_NO_LAP", "PIDM_LA_FUSED_MIN_WGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         m, diff, res, _ = _darcy_setup()
         orig = torch.randint, torch.randn_like
         torch.randint = lambda *a, **k: t.clone()
@@ -143,14 +148,16 @@ def test_attention_projection_fusion_equals_separate_kernels_b64(monkeypatch):
         per = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and ("to_out" in n or "to_qkv" in n)}
         return loss.item(), eng.flat_grad.clone(), per
 
-    lf, gf, pf = grads("1")              # fused wherever eligible (64x64, 32x32, 16x16 levels)
-    ls, gs, ps = grads("1000000000")     # never
-    assert abs(lf - ls) < 1e-5 * abs(ls)
+    ls, gs, ps = grads({"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1000000000"})     # qkv tensor, separate kernels
     scale = gs.abs().max().item()
-    assert (gf - gs).abs().max().item() < 1e-4 * scale
-    assert len(pf) >= 16
-    for n in ps:                         # the tensors the fusion computes differently, each against its own scale
-        assert (pf[n] - ps[n]).abs().max().item() < 2e-4 * max(ps[n].abs().max().item(), 1e-12), n
+    for env in ({"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1"},       # qkv tensor, fused wherever eligible (64x64, 32x32, 16x16)
+                {}):                                                         # default: no qkv tensor at 64x64 / 32x32
+        lf, gf, pf = grads(env)
+        assert abs(lf - ls) < 1e-5 * abs(ls), env
+        assert (gf - gs).abs().max().item() < 1e-4 * scale, env
+        assert len(pf) >= 16
+        for n in ps:                     # the tensors the forms compute differently, each against its own scale
+            assert (pf[n] - ps[n]).abs().max().item() < 2e-4 * max(ps[n].abs().max().item(), 1e-12), (env, n)
 
 
 def test_sampling_b1024_two_steps_finite_and_deterministic():

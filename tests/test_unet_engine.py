@@ -68,19 +68,28 @@ def test_unet_dim16_p32(backend):
     run_case(backend, "g5b_unet_dim16_p32", 16, True)
 
 
-def test_unet_dim32_p64_emulated(monkeypatch):
+# attention forms of the 64x64 / 32x32 levels: "proj" = no qkv tensor (k_attn_proj.hip, the default), "fused" = qkv tensor with the
+# attention fused into the to_out projection, "separate" = qkv tensor, separate projection kernels
+ATTN_FORMS = {"proj": {}, "fused": {"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1"},
+              "separate": {"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1000000"}}
+
+
+@pytest.mark.parametrize("form", ["proj", "fused"])
+def test_unet_dim32_p64_emulated(monkeypatch, form):
     """The full Darcy model (dim=32, 64x64: golden g6 from the genuine reference) through the host emulator, ~15 s
     (the same golden runs on the real GPU in test_unet_dim32_p64_gpu)."""
     from tests.emu_util import emu_lib
-    monkeypatch.setenv("PIDM_LA_FUSED_MIN_WGS", "1")     # batch 2: take the attention+projection fused kernels as the full-size step does
+    for k, v in ATTN_FORMS[form].items():
+        monkeypatch.setenv(k, v)
     run_case((emu_lib(), torch.device("cpu")), "g6_unet_dim32_p64", 32, False)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused_min_wgs", ["1", "1000000"])      # attention fused with the to_out projection / separate kernels
-def test_unet_dim32_p64_gpu(monkeypatch, fused_min_wgs):
+@pytest.mark.parametrize("form", sorted(ATTN_FORMS))
+def test_unet_dim32_p64_gpu(monkeypatch, form):
     from physicsinformeddiffusionmodels_amd._lib import get_lib
-    monkeypatch.setenv("PIDM_LA_FUSED_MIN_WGS", fused_min_wgs)
+    for k, v in ATTN_FORMS[form].items():
+        monkeypatch.setenv(k, v)
     run_case((get_lib(), torch.device("cuda:0")), "g6_unet_dim32_p64", 32, False)
 
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ int lap_row(int r, int half) { return (r & 3) + 8 * (
 // pixels per workgroup of the pixel-sum kernels: the xn (and dY) slab of the range lives in LDS, rows padded to C + 4 floats
 static int lap_nper(int N, int C, int slabs) {
   int n = (slabs == 1 ? 512 : 256) * 32 / C;
-  if (slabs == 3) n /= 2;
+  if (slabs == 3) n = (C == 32) ? 32 : n / 2;   // lap_bwd: C = 32 keeps Wq | Wk | dM of all heads in LDS as well (one tile per staging)
   while (n > 32 && N % n) n >>= 1;
   return n;
 }
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
       zp *= f;
       mrun = mn;
       if (half == 0) fw[l31] = f;
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
       // Mt rows live across registers: row d = lap_row(r, half) needs factor f[d]
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
 #pragma unroll
           for (int i = 0; i < 4; ++i) M[cb][4 * q4 + i] *= f4[i];
       }
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -440,11 +440,24 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   float* ys = xs + (size_t)nper * CP;                 // [nper][CP]
   float* tiles = ys + (size_t)nper * CP;              // [8][CB][32][33]: transposition tile / d_xn share of each wave
   float* cst = tiles + (size_t)8 * CB * 32 * kLapTileLd;   // [8][96]: k max, k 1/Z, rowdot of each wave's head
+  // C = 32: the operand matrices that are read row-wise (lane = c) 48 times per tile and head - Wq, Wk (all heads) and this image's
+  // dM - live in LDS, rows padded to CP: fetched through L1 with the register file full, every one of those MFMAs waited for its
+  // own load (measured: 52 % of the matrix-core rate for the whole kernel)
+  constexpr bool WLDS = (CB == 1);
+  float* wl = cst + 8 * 96;                           // [3][8*32][CP] when WLDS
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = N / (nper * nsub);                  // workgroups per image: each walks nsub consecutive pixel ranges
   const int b = blockIdx.x / NW, nw = blockIdx.x % NW;
   const int HD = heads * kLapDH;
+  if (WLDS) {
+    for (int e = tid; e < 3 * HD * (C / 4); e += 512) {
+      const int m = e / (HD * (C / 4)), rem = e - m * (HD * (C / 4));
+      const int row = rem / (C / 4), q = rem - row * (C / 4);
+      const float* src = (m < 2) ? wqkv + ((size_t)m * HD + row) * C : dMmat + ((size_t)b * HD + row) * C;
+      *reinterpret_cast<f32x4*>(wl + ((size_t)m * 256 + row) * CP + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    }
+  }
   const int h = wave;
   const bool act = h < heads;
   float* tw = tiles + (size_t)wave * CB * 32 * kLapTileLd;
@@ -459,18 +472,22 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // (two waves per SIMD in a 512-thread workgroup: 256 is the ceiling) and spills into the MFMA loops
   f32x16 dWq[CB], dWk[CB];
   const size_t bh = (size_t)b * heads + (act ? h : 0);
-  const float* wq_p = wqkv + ((size_t)(act ? h : 0) * kLapDH + l31) * C + 4 * half;
-  const float* wk_p = wq_p + (size_t)HD * C;
+  const int hrow = (act ? h : 0) * kLapDH + l31;
+  const float* wq_p = WLDS ? wl + (size_t)hrow * CP + 4 * half : wqkv + (size_t)hrow * C + 4 * half;
+  const float* wk_p = WLDS ? wl + (size_t)(256 + hrow) * CP + 4 * half : wqkv + ((size_t)HD + hrow) * C + 4 * half;
+  const float* dm_p = WLDS ? wl + (size_t)(512 + hrow) * CP + 4 * half : dMmat + (bh * 32 + l31) * C + 4 * half;
   const float* pp_p = P + (bh * 32 + l31) * C + 4 * half;
-  const float* dm_p = dMmat + (bh * 32 + l31) * C + 4 * half;
   if (act) {
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
       for (int r = 0; r < 16; ++r) { dWq[cb][r] = 0.f; dWk[cb][r] = 0.f; }
   }
-  const float* wqT = wqkv + (size_t)h * kLapDH * C + l31;                 // Wq_h[d][c = l31 + 32 cb] for the d_xn products (A, lane = c)
-  const float* wkT = wqkv + ((size_t)HD + h * kLapDH) * C + l31;
-  const float* dmT = dMmat + ((size_t)b * heads + h) * 32 * C + l31;
+  // Wq_h[d][c = l31 + 32 cb] etc. for the d_xn products (A operand, lane = c); row stride ldT
+  const int ldT = WLDS ? CP : C;
+  const float* wqT = WLDS ? wl + (size_t)(h * kLapDH) * CP + l31 : wqkv + (size_t)h * kLapDH * C + l31;
+  const float* wkT = WLDS ? wl + (size_t)(256 + h * kLapDH) * CP + l31 : wqkv + ((size_t)HD + h * kLapDH) * C + l31;
+  const float* dmT = WLDS ? wl + (size_t)(512 + h * kLapDH) * CP + l31 : dMmat + ((size_t)b * heads + h) * 32 * C + l31;
+
   const float rscale = 1.f / scale;
   for (int sub = 0; sub < nsub; ++sub) {
   const size_t pix0 = (size_t)b * N + ((size_t)nw * nsub + sub) * nper;
@@ -485,7 +502,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     f32x16 dx[CB];
     if (act) {
       int z0 = 0;
-      PIDM_OPAQUE_I32(z0);      // keeps the operand fetches below inside the tile loop
+      if (!WLDS) PIDM_OPAQUE_I32(z0);      // keeps the operand fetches below inside the tile loop
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
         for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
@@ -529,17 +546,29 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       jd = (jd + __shfl_xor(jd, 32)) * rscale;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = qt[r] * (dq[r] - jd);
-      // d_xn^T[c][px] += Wq_h^T[c][d] dq^T[d][px]
+      // d_xn^T[c][px] += Wq_h^T[c][d] dq^T[d][px]  (operand rows fetched as one batch, then the MFMAs)
+      if constexpr (WLDS) {
+        float wa[16][CB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* wr = wqT + (size_t)lap_row(r, half) * C;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
+          for (int cb = 0; cb < CB; ++cb) wa[r][cb] = (wqT + (size_t)lap_row(r, half) * ldT)[32 * cb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[r][cb], dq[r], dx[cb], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* wr = wqT + (size_t)lap_row(r, half) * ldT;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
+        }
       }
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dq[r];
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const float a = tw[l31 * kLapTileLd + 2 * s + half];
@@ -547,7 +576,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) dWq[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWq[cb], 0, 0, 0);
       }
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
       f32x16 kt, dk;
       for (int r = 0; r < 16; ++r) { kt[r] = 0.f; dk[r] = 0.f; }
@@ -576,19 +605,37 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         }
       }
       // d_xn^T[c][px] += Wk_h^T[c][d] dk^T[d][px] + dM_h^T[c][d] ks^T[d][px]
+      if constexpr (WLDS) {
+        float wa[16][CB], ma[16][CB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* wr = wkT + (size_t)lap_row(r, half) * C;
-        const float* mr = dmT + (size_t)lap_row(r, half) * C;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-          dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dk[r], dx[cb], 0, 0, 0);
-          dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[32 * cb], kt[r], dx[cb], 0, 0, 0);
+          for (int cb = 0; cb < CB; ++cb) {
+            wa[r][cb] = (wkT + (size_t)lap_row(r, half) * ldT)[32 * cb];
+            ma[r][cb] = (dmT + (size_t)lap_row(r, half) * ldT)[32 * cb];
+          }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[r][cb], dk[r], dx[cb], 0, 0, 0);
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[r][cb], kt[r], dx[cb], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* wr = wkT + (size_t)lap_row(r, half) * ldT;
+          const float* mr = dmT + (size_t)lap_row(r, half) * ldT;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dk[r], dx[cb], 0, 0, 0);
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[32 * cb], kt[r], dx[cb], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dk[r];
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const float a = tw[l31 * kLapTileLd + 2 * s + half];
@@ -596,7 +643,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) dWk[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWk[cb], 0, 0, 0);
       }
-      __builtin_amdgcn_wave_barrier();
+      PIDM_WAVE_LDS_SYNC();
       // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
@@ -652,7 +699,7 @@ size_t lap_saved_floats(int B, int heads, int C) { return (size_t)B * heads * (6
 static int lap_nsub(int N, int C) {
   const int ns = N / lap_nper(N, C, 3);
   int k = 1;
-  while (k < 4 && ns % (2 * k) == 0 && ns / (2 * k) >= 8) k *= 2;
+  while (k < 16 && ns % (2 * k) == 0 && ns / (2 * k) >= 8) k *= 2;
   return k;
 }
 size_t lap_dw_ranges(int N, int C) { return (size_t)(N / lap_nper(N, C, 3) / lap_nsub(N, C)); }
@@ -727,7 +774,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
                      heads, C, NS2);
   PIDM_CHECK_LAUNCH("lap_mid_kernel");
   const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;
-  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96) * sizeof(float);
+  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * 256 * (C + 4) : 0)) * sizeof(float);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
                      N, heads, np3, nsub, scale);
   PIDM_CHECK_LAUNCH("lap_bwd_kernel");

@@ -546,6 +546,220 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Streaming 3x3 / stride-1 convolution (forward and dgrad of every resblock conv with Cin % 32 == 0, Cout % 32 == 0).
+//
+// Why a second kernel: conv_igemm_pipe_kernel runs a workgroup as load -> barrier -> MFMAs -> store, and the two workgroups
+// that fit a CU start together and stay in lock-step, so the chip alternates between a load burst and a compute phase
+// (tools/conv_probe.py, 64x64 32->32 at batch 64: 62 us per launch; 43 us with neither loads nor stores, 42 us with no MFMAs at
+// all, 31 us MFMA-only floor).  Here ONE persistent workgroup per CU walks its (m-tile, 32-channel chunk) stages as a single
+// software pipeline over two LDS buffers:
+//   stage s:  MFMAs read buffer s&1 | tap t's slot of stage s+1 (already in registers) is written to buffer (s+1)&1 right
+//             after tap t's MFMAs | the same registers are re-loaded with stage s+2's slot | ONE barrier per stage
+// so operand fetch (a whole stage = 9216 matrix-pipe cycles ahead), LDS staging and the MFMAs of a wave overlap instead of
+// taking turns, across chunks AND across tiles.  The stage body is branch-free (out-of-image pixels: clamped address +
+// select; slots beyond the halo tile: a dump location in the row padding), which lets the scheduler interleave it.
+// Tile: 128 pixels x 32 output channels, K chunk 32 channels x 9 taps (144 MFMAs per wave and stage), LDS rows of 36 floats.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
+                                                             const float* __restrict__ src1, const float* __restrict__ wp,
+                                                             const float* __restrict__ bias, const float* __restrict__ residual,
+                                                             float* __restrict__ out, int n_items, int items_per_wg) {
+  constexpr int KCP = 36, T = 9;
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int z = 0;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  const int bufsz = (npixA + T * 32) * KCP;          // floats per buffer: halo tile | 9 x 32 weight rows
+  const int tpi = g.Hv / g.TH;
+  const int NCH = g.Cin >> 5;
+  const int CinP = g.Kw;
+  const int item0 = blockIdx.x * items_per_wg;
+  const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
+  const int nst = my_items * NCH;
+
+  // fragment base of this lane's A row (pixel) inside the halo tile
+  const int pm = wave * 32 + l31;
+  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
+
+  // staging slots: slot k of a thread = halo element tid + 256 k (pixel (tid >> 3) + 32 k, channel quad tid & 7) and weight row
+  // tid >> 3 of tap k
+  const int aq = tid & 7;
+  int a_lds[T], a_dec[T];
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const int hp = (tid >> 3) + 32 * k;
+    if (hp < npixA) {
+      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;
+      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
+      a_lds[k] = hp * KCP + 4 * aq;
+      a_dec[k] = (img << 20) | (hy << 10) | hx;
+    } else {
+      a_lds[k] = ((tid >> 3) % npixA) * KCP + 32;    // the 16 bytes of row padding: never read
+      a_dec[k] = -1;
+    }
+  }
+  const int b_lds0 = npixA * KCP + (tid >> 3) * KCP + 4 * aq;     // + k * 32 * KCP
+  const int b_glb0 = (tid >> 3) * T * CinP + 4 * aq;              // + k * CinP (+ n0 * T * CinP + c0)
+
+  f32x4 ra[T], rb[T];
+  unsigned amask = 0;
+  // stage geometry of the loads in flight
+  const float* l_sp = src0;
+  const float* l_wn = wp;
+  int l_ld = g.ld0, l_b0 = 0, l_iy0 = 0;
+#define PIDM_ST_STAGE(s_)                                                                                          \
+  {                                                                                                                \
+    int ss__ = (s_);                                                                                               \
+    if (ss__ >= nst) ss__ = nst - 1;                                                                               \
+    const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
+    const int tn__ = it__ / g.tiles_m, tm__ = it__ - tn__ * g.tiles_m;                                             \
+    const int c0__ = ch__ * 32;                                                                                    \
+    l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
+    l_iy0 = (tm__ % tpi) * g.TH - g.pad_y[z];                                                                      \
+    l_sp = (c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0);                                                     \
+    l_ld = (c0__ < g.C0) ? g.ld0 : g.ld1;                                                                          \
+    l_wn = wp + (size_t)tn__ * 32 * T * CinP + c0__;                                                               \
+  }
+#define PIDM_ST_LOAD(k_)                                                                                           \
+  {                                                                                                                \
+    const int d__ = a_dec[k_];                                                                                     \
+    const int b__ = l_b0 + (d__ >> 20), iy__ = l_iy0 + ((d__ >> 10) & 1023), ix__ = (d__ & 1023) - g.pad_x[z];     \
+    const bool ok__ = d__ >= 0 && b__ < g.B && iy__ >= 0 && iy__ < g.Hi && ix__ >= 0 && ix__ < g.Wi;              \
+    const int pix__ = ok__ ? (b__ * g.Hi + iy__) * g.Wi + ix__ : 0;                                                \
+    ra[k_] = *reinterpret_cast<const f32x4*>(l_sp + (size_t)pix__ * l_ld + 4 * aq);                                \
+    amask = (amask & ~(1u << (k_))) | ((ok__ ? 1u : 0u) << (k_));                                                  \
+    rb[k_] = *reinterpret_cast<const f32x4*>(l_wn + b_glb0 + (k_)*CinP);                                           \
+  }
+#define PIDM_ST_WRITE(k_, buf_)                                                                                    \
+  {                                                                                                                \
+    const f32x4 zero4__ = {0.f, 0.f, 0.f, 0.f};                                                                    \
+    *reinterpret_cast<f32x4*>((buf_) + a_lds[k_]) = ((amask >> (k_)) & 1u) ? ra[k_] : zero4__;                     \
+    *reinterpret_cast<f32x4*>((buf_) + b_lds0 + (k_)*32 * KCP) = rb[k_];                                           \
+  }
+
+  float* bufc = smem;              // buffer the MFMAs read
+  float* bufn = smem + bufsz;      // buffer being filled
+  PIDM_ST_STAGE(0)
+#pragma unroll
+  for (int k = 0; k < T; ++k) PIDM_ST_LOAD(k)
+#pragma unroll
+  for (int k = 0; k < T; ++k) PIDM_ST_WRITE(k, bufc)
+  PIDM_ST_STAGE(1)
+#pragma unroll
+  for (int k = 0; k < T; ++k) PIDM_ST_LOAD(k)
+  __syncthreads();
+
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int s = 0; s < nst; ++s) {
+    PIDM_ST_STAGE(s + 2)          // geometry of the loads issued during this stage
+    const float* As = bufc;
+    const float* abase_p = As + (size_t)abase * KCP + 4 * half;
+    const float* bbase_p = As + (size_t)npixA * KCP + (size_t)l31 * KCP + 4 * half;
+    f32x4 fa[2][4], fb[2][4];
+#define PIDM_ST_FRAGS(set_, t_)                                                                                    \
+  {                                                                                                                \
+    const float* arow = abase_p + (size_t)(((t_) / 3) * g.IWt + ((t_) % 3)) * KCP;                                 \
+    const float* brow = bbase_p + (size_t)((t_)*32) * KCP;                                                         \
+    _Pragma("unroll") for (int g8 = 0; g8 < 4; ++g8) {                                                             \
+      fa[set_][g8] = *reinterpret_cast<const f32x4*>(arow + 8 * g8);                                               \
+      fb[set_][g8] = *reinterpret_cast<const f32x4*>(brow + 8 * g8);                                               \
+    }                                                                                                              \
+  }
+    PIDM_ST_FRAGS(0, 0)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < T) PIDM_ST_FRAGS(cur ^ 1, t + 1)
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          if (kAblate & 4) acc[(g8 * 4 + q4) & 15] += fa[cur][g8][q4] * fb[cur][g8][q4];
+          else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][q4], fb[cur][g8][q4], acc, 0, 0, 0);
+        }
+      // slot t of the NEXT stage goes to the other buffer, then its registers take the slot of the stage after that
+      PIDM_ST_WRITE(t, bufn)
+      PIDM_ST_LOAD(t)
+    }
+#undef PIDM_ST_FRAGS
+    // ---- last chunk of a tile: epilogue (bias, residual, sigmoid, store, GroupNorm partial sums), accumulator restarts ----
+    const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
+    if (ch == NCH - 1) {
+      const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
+      const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
+      const int c = n0 + l31;
+      const float bv = bias ? bias[c] : 0.f;
+      const bool sig = sigmoid_last && c == g.Cout - 1;
+      if (g.Wv >= 32) {
+        const int p0 = wave * 32;
+        const int tx0 = p0 & (g.Wv - 1), ty = (p0 >> g.wsh) & (g.TH - 1), img = p0 >> (g.wsh + g.tsh);
+        const int b = b0 + img;
+        if (b < g.B && img < g.NI) {
+          const int oy = vy0 + ty;
+          const long rstep = g.sox, rrstep = g.ldr;
+          const long opix = (long)b * g.sob + (long)oy * g.soy + (long)tx0 * g.sox + 4 * half * rstep;
+          const long rpix = (((long)b * g.Ho + oy) * g.Wo + tx0) * g.ldr + 4 * half * rrstep;
+          float* op = out + opix + (long)c * g.soc;
+          const float* rp = residual ? residual + rpix + c : nullptr;
+          float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rowc = (r & 3) + 8 * (r >> 2);
+            float v = acc[r] + bv;
+            if (rp) v += rp[rowc * rrstep];
+            if (sig) v = 1.f / (1.f + expf(-v));
+            if (!(kAblate & 2) || v == 1.2345e30f) op[rowc * rstep] = v;
+            gs1 += v;
+            gs2 += v * v;
+          }
+          if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
+          if (g.bn_part) {
+            const float* xrow = g.bn_x + (((size_t)b * g.Ho + oy) * g.Wo + tx0) * g.Cout + c;
+            PIDM_BN_PARTIAL(acc, bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout)
+          }
+        }
+      } else {
+        float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int p = wave * 32 + row;
+          const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+          const int b = b0 + img;
+          if (b >= g.B || img >= g.NI) continue;
+          const int oy = vy0 + ty;
+          float v = acc[r] + bv;
+          if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + tx) * g.ldr + c];
+          if (sig) v = 1.f / (1.f + expf(-v));
+          out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)tx * g.sox + (size_t)c * g.soc] = v;
+          gs1 += v;
+          gs2 += v * v;
+        }
+        const int p0w = wave * 32;
+        const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
+        if (b0 + img0 < g.B && img0 < g.NI) {
+          if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b0 + img0, (vy0 + ty0) * g.Wv, c)
+          if (g.bn_part) {
+            const float* xrow = g.bn_x + (((size_t)(b0 + img0) * g.Ho + (vy0 + ty0)) * g.Wo) * g.Cout + c;
+            PIDM_BN_PARTIAL(acc, bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout)
+          }
+        }
+      }
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    float* tswap = bufc; bufc = bufn; bufn = tswap;
+  }
+#undef PIDM_ST_STAGE
+#undef PIDM_ST_LOAD
+#undef PIDM_ST_WRITE
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: reference layout -> [nz][Np][T][Kp] (zero padded)
 //   kind 0: fwd, normal conv        src [N=Cout][K=Cin][KH][KW]
 //   kind 1: fwd, transposed 4x4s2   src [K=Cin][N=Cout][4][4], 4 parity classes of 2x2 taps
@@ -1684,6 +1898,39 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
+  {
+    // streaming persistent 3x3 kernel (PIDM_CONV_STREAM=0: off, for A/B measurements and to reach the older tilings in tests)
+    const char* se = getenv("PIDM_CONV_STREAM");
+    const bool on = !(se && !atoi(se));
+    const int npixA = g.NI * g.IHt * g.IWt;
+    const size_t lds = (size_t)2 * (npixA + 9 * 32) * 36 * sizeof(float);
+    if (on && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.os == 1 && g.soc == 1 && (g.Cin % 32 == 0) &&
+        (g.C0 % 32 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.Cout % 32 == 0) && npixA <= 9 * 32 && lds <= 160 * 1024 - 256 &&
+        g.pad_y[0] == 1 && g.pad_x[0] == 1) {
+      const bool prof = prof_enabled();
+      static bool attr_s = false;
+      if (!attr_s) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_s = true;
+      }
+      ConvGeom gs = g;
+      gs.w_off[0] = 0;
+      const int n_items = g.tiles_m * (g.Cout / 32);
+      static int n_cu = 0;
+      if (!n_cu) {
+        const char* ce = getenv("PIDM_STREAM_WGS");      // persistent workgroups (default: one per CU of an MI355X)
+        n_cu = ce ? atoi(ce) : 256;
+        if (n_cu < 1) n_cu = 256;
+      }
+      const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
+      if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
+      hipLaunchKernelGGL(conv3x3_stream_kernel, dim3(wgs), dim3(256), lds, st, gs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out,
+                         n_items, ipw);
+      if (prof) prof_end_launch(st);
+      PIDM_CHECK_LAUNCH("conv3x3_stream_kernel");
+      return 0;
+    }
+  }
   if (nt4) {
     // K == 32 (the qkv projections of the 64x64 level, to_out dgrad): one 32-channel chunk = ONE dependent load round per
     // workgroup instead of two (PIDM_KC32=0 disables, for A/B measurements)

@@ -37,6 +37,12 @@ __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d
 #define PIDM_OPAQUE_I32(x) asm volatile("" : "+v"(x))   // e.g. a zero the optimiser cannot see: keeps loop-invariant loads inside the loop
 #endif
 
+// Data handed between the lanes of ONE wave through LDS: the hardware executes a wave's LDS operations in order, so only the
+// compiler has to be kept from reordering the accesses (the host emulator runs lanes as fibers and needs a real rendezvous).
+#ifndef PIDM_WAVE_LDS_SYNC
+#define PIDM_WAVE_LDS_SYNC() asm volatile("" ::: "memory")
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -229,6 +229,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 #define PIDM_OPAQUE_F32(x) do { volatile float t__ = (x); (x) = t__; } while (0)   // value barrier (pidm_common.h)
 #define PIDM_OPAQUE_I32(x) do { volatile int t__ = (x); (x) = t__; } while (0)
+#define PIDM_WAVE_LDS_SYNC() hipemu::wave_sync()
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __ldg(const float* p) { return *p; }
 

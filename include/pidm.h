@@ -271,6 +271,9 @@ int pidm_lap_backward(const float* xn, const float* dy, const float* w_qkv, cons
                       const float* qstat, float* d_xn, float* d_w_qkv, float* d_w_out, int C, int B, int N, int heads,
                       void* workspace, void* stream);
 
+/* measurement aid (tools/conv_trace.py): cycle stamps of the streaming 3x3 convolution kernel, written when PIDM_STREAM_TRACE is set */
+int pidm_debug_stream_trace(unsigned long long* out256);
+
 #ifdef __cplusplus
 }
 #endif

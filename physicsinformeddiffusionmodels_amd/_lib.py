@@ -104,6 +104,7 @@ class PidmLib:
         self._sig("pidm_lap_saved_floats", [i, i, i], sz)
         self._sig("pidm_lap_forward", [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
         self._sig("pidm_lap_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
+        self._sig("pidm_debug_stream_trace", [vp])
         if L.pidm_version() != 1:
             raise PidmError(f"{path}: ABI version {L.pidm_version()} != 1")
 

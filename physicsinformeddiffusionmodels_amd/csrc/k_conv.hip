@@ -560,10 +560,14 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
 // select; slots beyond the halo tile: a dump location in the row padding), which lets the scheduler interleave it.
 // Tile: 128 pixels x 32 output channels, K chunk 32 channels x 9 taps (144 MFMAs per wave and stage), LDS rows of 36 floats.
 // ---------------------------------------------------------------------------------------------------
+// cycle stamps of workgroup 0 / wave 0 (tools/conv_trace.py; PIDM_STREAM_TRACE=1): [stage][0..3] = stage top, first MFMA issued,
+// tap loop done, after the barrier
+__device__ unsigned long long g_stream_trace[4 * 64];
+
 __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sigmoid_last, const float* __restrict__ src0,
                                                              const float* __restrict__ src1, const float* __restrict__ wp,
                                                              const float* __restrict__ bias, const float* __restrict__ residual,
-                                                             float* __restrict__ out, int n_items, int items_per_wg) {
+                                                             float* __restrict__ out, int n_items, int items_per_wg, int trace) {
   constexpr int KCP = 36, T = 9;
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x;
@@ -584,32 +588,48 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
   const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
 
-  // staging slots: slot k of a thread = halo element tid + 256 k (pixel (tid >> 3) + 32 k, channel quad tid & 7) and weight row
-  // tid >> 3 of tap k
+  // Staging.  The fp32 MFMA runs on the SIMD's vector ALUs (tools/mfma_overlap.hip: every VALU instruction of a wave ADDS its
+  // issue time to the wave's MFMA chain, with one or two waves per SIMD alike), so the staging path carries no per-element
+  // vector arithmetic: the halo COLUMNS (x = -1, x = W) are zero for every tile - written once, never staged again - and
+  // the staged part of the halo tile is whole image rows, 8 pixels (one row segment) per wave and slot, so that row validity
+  // (top / bottom padding, images past the batch) and the row's global base are wave-uniform scalars.  A slot's global
+  // address is scalar base + a per-thread constant byte offset; LDS addresses are per-thread constants as well.
   const int aq = tid & 7;
-  int a_lds[T], a_dec[T];
+  const int SEG = g.NI * g.IHt * g.Wv;               // staged pixels per tile (multiple of 32), slot k = pixels 32k .. 32k+31
+  const int AS = SEG >> 5;                           // <= 8 slots
+  const int wv8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+  int a_lds[8];
+  unsigned a_vo[2];                                  // byte offset of (x, channel quad) inside a row, by slot parity
+  int s_img[8], s_hy[8];                             // wave-uniform: image and halo row of this wave's segment in slot k
 #pragma unroll
-  for (int k = 0; k < T; ++k) {
-    const int hp = (tid >> 3) + 32 * k;
-    if (hp < npixA) {
-      const int hrow = fast_div(hp, g.IWt, g.mIWt), hx = hp - hrow * g.IWt;
-      const int img = fast_div(hrow, g.IHt, g.mIHt), hy = hrow - img * g.IHt;
-      a_lds[k] = hp * KCP + 4 * aq;
-      a_dec[k] = (img << 20) | (hy << 10) | hx;
-    } else {
-      a_lds[k] = ((tid >> 3) % npixA) * KCP + 32;    // the 16 bytes of row padding: never read
-      a_dec[k] = -1;
-    }
+  for (int k = 0; k < 8; ++k) {
+    const int sp = (tid >> 3) + 32 * k;
+    const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
+    const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
+    // slots past the tile (k >= AS) are loaded and written like the others - no branch in the stage body, exact vmcnt
+    // bookkeeping - but land in the 16 bytes of row padding, which nothing reads
+    a_lds[k] = (k < AS) ? ((img * g.IHt + hy) * g.IWt + x + 1) * KCP + 4 * aq : ((tid >> 3) % npixA) * KCP + 32;
+    if (k < 2) a_vo[k] = (unsigned)(x * g.ld0 + 4 * aq) * 4u;
+    const int srw = (wv8 + 32 * k) >> g.wsh;
+    s_img[k] = fast_div(srw, g.IHt, g.mIHt);
+    s_hy[k] = srw - s_img[k] * g.IHt;
   }
   const int b_lds0 = npixA * KCP + (tid >> 3) * KCP + 4 * aq;     // + k * 32 * KCP
-  const int b_glb0 = (tid >> 3) * T * CinP + 4 * aq;              // + k * CinP (+ n0 * T * CinP + c0)
+  const unsigned b_vo = (unsigned)((tid >> 3) * T * CinP + 4 * aq) * 4u;   // + (k * CinP + n0 * T * CinP + c0) * 4 as a scalar
 
-  f32x4 ra[T], rb[T];
-  unsigned amask = 0;
-  // stage geometry of the loads in flight
-  const float* l_sp = src0;
-  const float* l_wn = wp;
-  int l_ld = g.ld0, l_b0 = 0, l_iy0 = 0;
+  // zero halo columns of both buffers (and the whole pad region of unused rows stays untouched: never read)
+  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 8; e += 256) {
+    const int q = e & 7, side = (e >> 3) & 1, row = (e >> 4) % (g.NI * g.IHt), bufi = (e >> 4) / (g.NI * g.IHt);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * KCP + 4 * q) = zero4;
+  }
+
+  f32x4 ra[8], rb[T];
+  unsigned amask = 0;          // wave-uniform: bit k = slot k of the loads in flight is a real image row
+  // stage geometry of the loads in flight (all scalar)
+  const char* l_sp = reinterpret_cast<const char*>(src0);
+  const char* l_wn = reinterpret_cast<const char*>(wp);
+  int l_b0 = 0, l_iy0 = 0;
 #define PIDM_ST_STAGE(s_)                                                                                          \
   {                                                                                                                \
     int ss__ = (s_);                                                                                               \
@@ -619,42 +639,52 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
     const int c0__ = ch__ * 32;                                                                                    \
     l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
     l_iy0 = (tm__ % tpi) * g.TH - g.pad_y[z];                                                                      \
-    l_sp = (c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0);                                                     \
-    l_ld = (c0__ < g.C0) ? g.ld0 : g.ld1;                                                                          \
-    l_wn = wp + (size_t)tn__ * 32 * T * CinP + c0__;                                                               \
+    l_sp = reinterpret_cast<const char*>((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0));                      \
+    l_wn = reinterpret_cast<const char*>(wp + (size_t)tn__ * 32 * T * CinP + c0__);                                \
   }
-#define PIDM_ST_LOAD(k_)                                                                                           \
+#define PIDM_ST_LOAD_A(k_)                                                                                         \
   {                                                                                                                \
-    const int d__ = a_dec[k_];                                                                                     \
-    const int b__ = l_b0 + (d__ >> 20), iy__ = l_iy0 + ((d__ >> 10) & 1023), ix__ = (d__ & 1023) - g.pad_x[z];     \
-    const bool ok__ = d__ >= 0 && b__ < g.B && iy__ >= 0 && iy__ < g.Hi && ix__ >= 0 && ix__ < g.Wi;              \
-    const int pix__ = ok__ ? (b__ * g.Hi + iy__) * g.Wi + ix__ : 0;                                                \
-    ra[k_] = *reinterpret_cast<const f32x4*>(l_sp + (size_t)pix__ * l_ld + 4 * aq);                                \
+    /* unconditional load (a branch around it makes the compiler's vmcnt bookkeeping wait for this stage's loads): */ \
+    /* padding rows read row 0 of the source and are zeroed with a scalar-conditioned select when they go to LDS */  \
+    const int b__ = l_b0 + s_img[k_], iy__ = l_iy0 + s_hy[k_];                                                     \
+    const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < g.Hi);        /* wave-uniform */                         \
+    const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + iy__) * g.Wi : 0;                                            \
+    ra[k_] = *reinterpret_cast<const f32x4*>(l_sp + row__ * (size_t)g.ld0 * 4 + a_vo[(k_) & 1]);                   \
     amask = (amask & ~(1u << (k_))) | ((ok__ ? 1u : 0u) << (k_));                                                  \
-    rb[k_] = *reinterpret_cast<const f32x4*>(l_wn + b_glb0 + (k_)*CinP);                                           \
   }
-#define PIDM_ST_WRITE(k_, buf_)                                                                                    \
+#define PIDM_ST_LOAD_B(k_) rb[k_] = *reinterpret_cast<const f32x4*>(l_wn + (size_t)(k_)*CinP * 4 + b_vo);
+#define PIDM_ST_WRITE_A(k_, buf_)                                                                                  \
   {                                                                                                                \
-    const f32x4 zero4__ = {0.f, 0.f, 0.f, 0.f};                                                                    \
-    *reinterpret_cast<f32x4*>((buf_) + a_lds[k_]) = ((amask >> (k_)) & 1u) ? ra[k_] : zero4__;                     \
-    *reinterpret_cast<f32x4*>((buf_) + b_lds0 + (k_)*32 * KCP) = rb[k_];                                           \
+    const float keep__ = ((amask >> (k_)) & 1u) ? 1.f : 0.f;        /* scalar */                                   \
+    *reinterpret_cast<f32x4*>((buf_) + a_lds[k_]) = ra[k_] * keep__;                                               \
   }
+#define PIDM_ST_WRITE_B(k_, buf_) *reinterpret_cast<f32x4*>((buf_) + b_lds0 + (k_)*32 * KCP) = rb[k_];
 
   float* bufc = smem;              // buffer the MFMAs read
   float* bufn = smem + bufsz;      // buffer being filled
   PIDM_ST_STAGE(0)
 #pragma unroll
-  for (int k = 0; k < T; ++k) PIDM_ST_LOAD(k)
+  for (int k = 0; k < 8; ++k) PIDM_ST_LOAD_A(k)
 #pragma unroll
-  for (int k = 0; k < T; ++k) PIDM_ST_WRITE(k, bufc)
+  for (int k = 0; k < T; ++k) PIDM_ST_LOAD_B(k)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) PIDM_ST_WRITE_A(k, bufc)
+#pragma unroll
+  for (int k = 0; k < T; ++k) PIDM_ST_WRITE_B(k, bufc)
   PIDM_ST_STAGE(1)
 #pragma unroll
-  for (int k = 0; k < T; ++k) PIDM_ST_LOAD(k)
+  for (int k = 0; k < 8; ++k) PIDM_ST_LOAD_A(k)
+#pragma unroll
+  for (int k = 0; k < T; ++k) PIDM_ST_LOAD_B(k)
   __syncthreads();
 
-  f32x16 acc;
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // two accumulator chains (even / odd MFMA of a tap): a single dependent chain issues every 69.5 cycles, two alternate at the
+  // pipe's 64 (tools/mfma_overlap.hip); they are added once per tile in the epilogue
+  f32x16 acc, acc1;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
+  const bool tr_on = trace && blockIdx.x == 0 && tid == 0;
   for (int s = 0; s < nst; ++s) {
+    if (tr_on && s < 64) g_stream_trace[4 * s + 0] = clock64();
     PIDM_ST_STAGE(s + 2)          // geometry of the loads issued during this stage
     const float* As = bufc;
     const float* abase_p = As + (size_t)abase * KCP + 4 * half;
@@ -670,93 +700,98 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
     }                                                                                                              \
   }
     PIDM_ST_FRAGS(0, 0)
+    if (tr_on && s < 64) g_stream_trace[4 * s + 1] = clock64();
+    // One wave per SIMD: nothing but this wave's own instruction stream feeds the matrix pipe, and an in-order wave parks at the
+    // next MFMA until the pipe frees (64 cycles) - whatever else it has to do is free only if it sits BETWEEN two MFMAs in
+    // small pieces.  So each tap is 16 pinned steps "MFMA j; piece j" (sched_barrier(0): nothing crosses): pieces 0..7 = the 8
+    // fragment reads of the next tap, 8/9 = this tap's slots of the next stage to LDS, 10/11 = reload of those registers.
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int cur = t & 1;
-      if (t + 1 < T) PIDM_ST_FRAGS(cur ^ 1, t + 1)
+      const float* arow_n = abase_p + (size_t)(((t + 1) / 3) * g.IWt + ((t + 1) % 3)) * KCP;
+      const float* brow_n = bbase_p + (size_t)((t + 1) * 32) * KCP;
 #pragma unroll
-      for (int g8 = 0; g8 < 4; ++g8)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          if (kAblate & 4) acc[(g8 * 4 + q4) & 15] += fa[cur][g8][q4] * fb[cur][g8][q4];
-          else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][q4], fb[cur][g8][q4], acc, 0, 0, 0);
-        }
-      // slot t of the NEXT stage goes to the other buffer, then its registers take the slot of the stage after that
-      PIDM_ST_WRITE(t, bufn)
-      PIDM_ST_LOAD(t)
+      for (int j = 0; j < 16; ++j) {
+        const int g8 = j >> 2, q4 = j & 3;
+        if (kAblate & 4) acc[j] += fa[cur][g8][q4] * fb[cur][g8][q4];
+        else if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][q4], fb[cur][g8][q4], acc1, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][g8][q4], fb[cur][g8][q4], acc, 0, 0, 0);
+        if (t + 1 < T && j < 4) fa[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(arow_n + 8 * j);
+        if (t + 1 < T && j >= 4 && j < 8) fb[cur ^ 1][j - 4] = *reinterpret_cast<const f32x4*>(brow_n + 8 * (j - 4));
+        if (j == 8 && t < 8) PIDM_ST_WRITE_A(t, bufn)
+        if (j == 9) PIDM_ST_WRITE_B(t, bufn)
+        if (j == 10 && t < 8) PIDM_ST_LOAD_A(t)
+        if (j == 11) PIDM_ST_LOAD_B(t)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #undef PIDM_ST_FRAGS
-    // ---- last chunk of a tile: epilogue (bias, residual, sigmoid, store, GroupNorm partial sums), accumulator restarts ----
+    if (tr_on && s < 64) g_stream_trace[4 * s + 2] = clock64();
+    // ---- last chunk of a tile: epilogue (bias, residual, store, GroupNorm partial sums), accumulators restart ----
+    // A lane holds ONE channel of 16 pixels; stored like that, every store instruction moves 4 bytes per lane and the wave spends
+    // ~2700 cycles issuing its 16 stores (measured with PIDM_STREAM_TRACE; nothing overlaps them here).  Each 4x4 block (4 lanes
+    // x 4 registers) is transposed in registers - two DPP exchange stages - so that a lane holds 4 consecutive channels of one
+    // pixel and a store instruction writes 8 whole 128-byte pixel rows.
     const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
     if (ch == NCH - 1) {
       const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
       const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
       const int c = n0 + l31;
       const float bv = bias ? bias[c] : 0.f;
-      const bool sig = sigmoid_last && c == g.Cout - 1;
-      if (g.Wv >= 32) {
-        const int p0 = wave * 32;
-        const int tx0 = p0 & (g.Wv - 1), ty = (p0 >> g.wsh) & (g.TH - 1), img = p0 >> (g.wsh + g.tsh);
-        const int b = b0 + img;
-        if (b < g.B && img < g.NI) {
-          const int oy = vy0 + ty;
-          const long rstep = g.sox, rrstep = g.ldr;
-          const long opix = (long)b * g.sob + (long)oy * g.soy + (long)tx0 * g.sox + 4 * half * rstep;
-          const long rpix = (((long)b * g.Ho + oy) * g.Wo + tx0) * g.ldr + 4 * half * rrstep;
-          float* op = out + opix + (long)c * g.soc;
-          const float* rp = residual ? residual + rpix + c : nullptr;
-          float gs1 = 0.f, gs2 = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rowc = (r & 3) + 8 * (r >> 2);
-            float v = acc[r] + bv;
-            if (rp) v += rp[rowc * rrstep];
-            if (sig) v = 1.f / (1.f + expf(-v));
-            if (!(kAblate & 2) || v == 1.2345e30f) op[rowc * rstep] = v;
-            gs1 += v;
-            gs2 += v * v;
-          }
-          if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
-          if (g.bn_part) {
-            const float* xrow = g.bn_x + (((size_t)b * g.Ho + oy) * g.Wo + tx0) * g.Cout + c;
-            PIDM_BN_PARTIAL(acc, bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout)
-          }
-        }
-      } else {
+      // the wave's 32 pixels are consecutive pixels of ONE image (tiles are whole image rows)
+      const int p0 = wave * 32;
+      const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
+      const int b = b0 + img0;
+      if (b < g.B && img0 < g.NI) {        // wave-uniform
+        const int pin = (vy0 + ty0) * g.Wv + tx0;                      // first pixel of the wave inside its image
+        float v[16];
         float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int p = wave * 32 + row;
-          const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
-          const int b = b0 + img;
-          if (b >= g.B || img >= g.NI) continue;
-          const int oy = vy0 + ty;
-          float v = acc[r] + bv;
-          if (residual) v += residual[(((size_t)b * g.Ho + oy) * g.Wo + tx) * g.ldr + c];
-          if (sig) v = 1.f / (1.f + expf(-v));
-          out[(size_t)b * g.sob + (size_t)oy * g.soy + (size_t)tx * g.sox + (size_t)c * g.soc] = v;
-          gs1 += v;
-          gs2 += v * v;
+          v[r] = (acc[r] + acc1[r]) + bv;
+          gs1 += v[r];
+          gs2 += v[r] * v[r];
         }
-        const int p0w = wave * 32;
-        const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
-        if (b0 + img0 < g.B && img0 < g.NI) {
-          if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b0 + img0, (vy0 + ty0) * g.Wv, c)
-          if (g.bn_part) {
-            const float* xrow = g.bn_x + (((size_t)(b0 + img0) * g.Ho + (vy0 + ty0)) * g.Wo) * g.Cout + c;
-            PIDM_BN_PARTIAL(acc, bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout)
-          }
+        if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
+        if (g.bn_part) {
+          const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
+          f32x16 accs;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[r] = acc[r] + acc1[r];
+          PIDM_BN_PARTIAL(accs, bv, b, pin, c, xrow, g.Cout)
+        }
+        const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+        const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
+        const size_t rpix = ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + n0 + 4 * (l31 >> 2);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float x0 = v[4 * q4], x1 = v[4 * q4 + 1], x2 = v[4 * q4 + 2], x3 = v[4 * q4 + 3];
+          // stage 1: 2x2 blocks across lane bit 0
+          const float r01 = pidm_quad_xor1(odd1 ? x0 : x1), r23 = pidm_quad_xor1(odd1 ? x2 : x3);
+          x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+          x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+          // stage 2: across lane bit 1, registers (0,2) and (1,3)
+          const float r02 = pidm_quad_xor2(odd2 ? x0 : x2), r13 = pidm_quad_xor2(odd2 ? x1 : x3);
+          x0 = odd2 ? r02 : x0; x2 = odd2 ? x2 : r02;
+          x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
+          // lane (l31 & 3) = pixel 8 q4 + 4 half + (l31 & 3) of the wave, channels n0 + 4 (l31 >> 2) .. + 3
+          const int prow = 8 * q4 + 4 * half + (l31 & 3);
+          f32x4 o = {x0, x1, x2, x3};
+          if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);
+          if (!(kAblate & 2) || x0 == 1.2345e30f) *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
         }
       }
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     }
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    if (tr_on && s < 64) g_stream_trace[4 * s + 3] = clock64();
     float* tswap = bufc; bufc = bufn; bufn = tswap;
   }
 #undef PIDM_ST_STAGE
-#undef PIDM_ST_LOAD
-#undef PIDM_ST_WRITE
+#undef PIDM_ST_LOAD_A
+#undef PIDM_ST_LOAD_B
+#undef PIDM_ST_WRITE_A
+#undef PIDM_ST_WRITE_B
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1905,8 +1940,10 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
     const int npixA = g.NI * g.IHt * g.IWt;
     const size_t lds = (size_t)2 * (npixA + 9 * 32) * 36 * sizeof(float);
     if (on && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.os == 1 && g.soc == 1 && (g.Cin % 32 == 0) &&
-        (g.C0 % 32 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.Cout % 32 == 0) && npixA <= 9 * 32 && lds <= 160 * 1024 - 256 &&
-        g.pad_y[0] == 1 && g.pad_x[0] == 1) {
+        (g.C0 % 32 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.C1 == 0 || g.ld1 == g.ld0) && (g.Cout % 32 == 0) && g.Wv >= 8 &&
+        g.Wv == g.Wi && (g.NI * g.IHt * g.Wv) % 32 == 0 && g.NI * g.IHt * g.Wv <= 256 && lds <= 160 * 1024 - 256 &&
+        g.pad_y[0] == 1 && g.pad_x[0] == 1 && !sigmoid_last && (g.sox & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0))) {
       const bool prof = prof_enabled();
       static bool attr_s = false;
       if (!attr_s) {
@@ -1916,16 +1953,13 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       ConvGeom gs = g;
       gs.w_off[0] = 0;
       const int n_items = g.tiles_m * (g.Cout / 32);
-      static int n_cu = 0;
-      if (!n_cu) {
-        const char* ce = getenv("PIDM_STREAM_WGS");      // persistent workgroups (default: one per CU of an MI355X)
-        n_cu = ce ? atoi(ce) : 256;
-        if (n_cu < 1) n_cu = 256;
-      }
+      const char* ce = getenv("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
+      int n_cu = ce ? atoi(ce) : 256;                      // (the unit tests lower it to get several work items per workgroup)
+      if (n_cu < 1) n_cu = 256;
       const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
       if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
       hipLaunchKernelGGL(conv3x3_stream_kernel, dim3(wgs), dim3(256), lds, st, gs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out,
-                         n_items, ipw);
+                         n_items, ipw, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
       if (prof) prof_end_launch(st);
       PIDM_CHECK_LAUNCH("conv3x3_stream_kernel");
       return 0;
@@ -2280,4 +2314,9 @@ extern "C" int pidm_conv_wgrad(const pidm_conv_desc* d, const float* src0, const
     return launch_colsum(dy, dy_rows, d->Cout, ld_dy, dbias, ws2, st);
   }
   return 0;
+}
+
+// measurement aid: the cycle stamps conv3x3_stream_kernel left (PIDM_STREAM_TRACE=1): 4 per stage, up to 64 stages
+extern "C" int pidm_debug_stream_trace(unsigned long long* out256) {
+  return hipMemcpyFromSymbol(out256, HIP_SYMBOL(pidm::g_stream_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
 }

@@ -43,6 +43,17 @@ __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d
 #define PIDM_WAVE_LDS_SYNC() asm volatile("" ::: "memory")
 #endif
 
+// value of the lane whose index differs in bit 0 / bit 1 (within a group of four lanes): one DPP move on the GPU; the host
+// emulator's shadow header supplies shuffle-based versions
+#ifndef PIDM_HAVE_QUAD_XOR
+__device__ __forceinline__ float pidm_quad_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pidm_quad_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+}
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -143,6 +143,10 @@ static inline int __any(int pred) {
   return v;
 }
 
+#define PIDM_HAVE_QUAD_XOR 1
+static inline float pidm_quad_xor1(float v) { return __shfl_xor(v, 1); }
+static inline float pidm_quad_xor2(float v) { return __shfl_xor(v, 2); }
+
 // ---- MFMA (f32 in / f32 acc), lane layouts per cdna_hip_programming.md section 3 -----------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
@@ -265,6 +269,9 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
+static inline long long clock64() { return 0; }
+#define HIP_SYMBOL(x) x
+template <typename T> static inline hipError_t hipMemcpyFromSymbol(void* dst, const T& sym, size_t n) { memcpy(dst, &sym, n); return hipSuccess; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)

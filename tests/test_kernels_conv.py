@@ -67,6 +67,30 @@ PERSIST_CASES = [   # 3x3 convs walked persistently (several m-tiles per workgro
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", PERSIST_CASES)
 def test_conv_3x3_persistent(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     monkeypatch.setenv("PIDM_PERSIST_SLOTS", "3")
+    monkeypatch.setenv("PIDM_CONV_STREAM", "0")          # the streaming kernel would take the eligible shapes
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+STREAM3_CASES = [   # the streaming persistent 3x3 kernel (two LDS buffers, one barrier per (tile, chunk) stage)
+    (6, 16, 32, 32, 64, 3, 1, 1, 0),     # concat source = 2 chunks, 2 n-tiles, 24 work items over 5 workgroups (ragged last one)
+    (3, 8, 64, 0, 32, 3, 1, 1, 0),       # two 8x8 images per tile, ragged batch (3 images), single work item per workgroup
+    (1, 64, 32, 0, 32, 3, 1, 1, 0),      # full-width 64 tile, single chunk: cross-tile pipeline only
+    (2, 32, 96, 0, 32, 3, 1, 1, 0),      # three chunks per tile
+    (1, 4, 32, 0, 32, 3, 1, 1, 0),       # one 4x4 image: 16 valid pixels in the tile, everything else padding
+]
+
+
+@pytest.mark.parametrize("wgs", ["5", "256"])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM3_CASES)
+def test_conv_3x3_streaming(backend, monkeypatch, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM3_CASES[:2])
+def test_conv_3x3_streaming_off_matches(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """PIDM_CONV_STREAM=0 keeps the older tilings reachable (A/B measurements)."""
+    monkeypatch.setenv("PIDM_CONV_STREAM", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
@@ -81,6 +105,7 @@ MT2_CASES = [   # 3x3 convs on the 256-pixel workgroup tile (two m-tiles per wav
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", MT2_CASES)
 def test_conv_3x3_two_mtiles_per_wave(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     monkeypatch.setenv("PIDM_MT2_MIN_WGS", "1")
+    monkeypatch.setenv("PIDM_CONV_STREAM", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 

@@ -1559,6 +1559,32 @@ __global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __r
     if (table[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
   }
   const ReduceDesc d = table[lo];
+  if (d.mode == 1) {
+    // block = (row m, 64 columns): T partial rows of 64 floats per split are read as whole lines, summed in split order, turned
+    // through LDS and written as ONE contiguous run of 64*T floats of the [m][n][t] result
+    __shared__ float tile[64 * 16];
+    const int nb = (d.N + 63) / 64;
+    const int m = (int)((bid - d.blk0) / nb), n0 = (int)((bid - d.blk0) % nb) * 64;
+    const int nn = (d.N - n0 < 64) ? d.N - n0 : 64;
+    for (int e = threadIdx.x; e < 64 * d.T; e += 256) {
+      const int t = e >> 6, nl = e & 63;
+      float a = 0.f;
+      if (nl < nn) {
+        const float* p = d.src + ((size_t)m * d.T + t) * d.NP + n0 + nl;
+        for (int sp = 0; sp < d.nsplit; ++sp) a += p[(size_t)sp * d.sstride];
+      }
+      tile[nl * d.T + t] = a;
+    }
+    __syncthreads();
+    float* o = d.dst + ((size_t)m * d.N + n0) * d.T;
+    for (int e = threadIdx.x; e < nn * d.T; e += 256) o[e] = tile[e];
+    if (d.bdst && n0 == 0 && threadIdx.x == 0) {       // the row's bias gradient rides with its first column block
+      float a = 0.f;
+      for (int sp = 0; sp < d.nsplit; ++sp) a += d.bsrc[(size_t)sp * d.MP + m];
+      d.bdst[m] = a;
+    }
+    return;
+  }
   const int tid = threadIdx.x, ol = tid & 31, sl = tid >> 5;
   const long nw = (long)d.M * d.T * d.N;
   const long o = (long)(bid - d.blk0) * 32 + ol;

@@ -17,7 +17,8 @@ struct ReduceQueue {
     d.nsplit = nsplit; d.M = M; d.N = N; d.T = T; d.MP = MP; d.NP = NP;
     const size_t total = (size_t)M * N * T + (bdst ? M : 0);
     d.blk0 = nblocks;
-    d.nblk = (unsigned)((total + 31) / 32);
+    d.mode = (nsplit <= 8 && T <= 16 && (size_t)M * N * T >= 32768) ? 1 : 0;
+    d.nblk = d.mode ? (unsigned)M * (unsigned)((N + 63) / 64) : (unsigned)((total + 31) / 32);
     nblocks += d.nblk;
     v.push_back(d);
   }

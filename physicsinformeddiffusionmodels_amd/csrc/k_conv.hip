@@ -1034,7 +1034,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const flo
 // accumulators) resp. 4 (1x1) workgroups share a CU and hide each other's barrier / staging phases
 // WIDE: the wave's 32 pixels are consecutive in x inside one image row (Wv >= 32): pointer bumps instead of a per-step
 // decode.  A compile-time switch: as a runtime branch the two loops made the register allocator copy all accumulators.
-template <int KH, int KW, bool PHASED, bool WIDE, int MINW>
+// ROWST (3x3, stride 1, full-width tiles): the staging path without vector arithmetic of conv3x3_stream_kernel - halo columns
+// zeroed once, whole image rows staged with wave-uniform validity and scalar row bases, per-thread constant offsets.  The fp32
+// MFMA shares the SIMD's vector ALUs, so the ~350 VALU instructions of the per-tile slot decode cost a quarter of a tile's 144
+// MFMAs (measured: 75 TFLOP/s on the 3x3 weight gradients before).
+template <int KH, int KW, bool PHASED, bool WIDE, int MINW, bool ROWST = false>
 __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg, const float* __restrict__ src0,
                                                               const float* __restrict__ src1, const float* __restrict__ dy,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial) {
@@ -1066,6 +1070,53 @@ __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg
   // the (halo pixel) -> (image, row, column) decode of a staging slot is recomputed per tile (a few VALU ops against
   // 144 MFMAs) instead of being kept in registers: the accumulators leave no room for it at 2 waves per SIMD
   f32x4 rx[XMAX], ry[YMAX];
+  // ---- ROWST state: per-thread constants and wave-uniform row descriptors ----
+  int rs_lds[8];
+  unsigned rs_xvo[2], rs_yvo = 0, rs_xmask = 0, rs_ymask = 0;
+  int rs_img[8], rs_hy[8], rs_yimg[4];
+  int rs_AS = 0;
+  if constexpr (ROWST) {
+    rs_AS = (g.NI * g.IHt * g.Wv) >> 5;
+    const int wv8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int sp = (tid >> 3) + 32 * k;
+      const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
+      const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
+      rs_lds[k] = (k < rs_AS) ? ((img * g.IHt + hy) * g.IWt + x + 1) * 32 + 4 * q : -1;
+      if (k < 2) rs_xvo[k] = (unsigned)(x * xld + 4 * q) * 4u;
+      const int srw = (wv8 + 32 * k) >> g.wsh;
+      rs_img[k] = fast_div(srw, g.IHt, g.mIHt);
+      rs_hy[k] = srw - rs_img[k] * g.IHt;
+    }
+    rs_yvo = (unsigned)((tid >> 3) * wg.ld_dy + cy) * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rs_yimg[k] = (wv8 + 32 * k) >> (g.wsh + g.tsh);
+    // halo columns of the X tile: zero for every tile, written once
+    for (int e = tid; e < g.NI * g.IHt * 2 * 8; e += 256) {
+      const int qq = e & 7, side = (e >> 3) & 1, row = e >> 4;
+      *reinterpret_cast<f32x4*>(Xs + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * 32 + 4 * qq) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const char* rs_xsrc = reinterpret_cast<const char*>((n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0));   // n-tile = one source (C0 % 32 == 0)
+#define PIDM_WG_PREFETCH_ROWS(tile_)                                                                              \
+  {                                                                                                               \
+    const int tile__ = (tile_);                                                                                   \
+    const int b0__ = (tile__ / tpi) * g.NI, vy0__ = (tile__ % tpi) * g.TH;                                        \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                               \
+      const int b__ = b0__ + rs_img[k], iy__ = vy0__ - g.pad_y[0] + rs_hy[k];                                     \
+      const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < g.Hi) & cx_ok;                                         \
+      const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + iy__) * g.Wi : 0;                                         \
+      rx[k] = *reinterpret_cast<const f32x4*>(rs_xsrc + row__ * (size_t)xld * 4 + rs_xvo[k & 1]);                 \
+      rs_xmask = (rs_xmask & ~(1u << k)) | ((ok__ ? 1u : 0u) << k);                                               \
+    }                                                                                                             \
+    const char* yb__ = reinterpret_cast<const char*>(dy) + (((size_t)b0__ * g.Hv + vy0__) * g.Wv) * (size_t)wg.ld_dy * 4; \
+    _Pragma("unroll") for (int k = 0; k < YMAX; ++k) {                                                            \
+      const bool ok__ = (b0__ + rs_yimg[k] < g.B) & (rs_yimg[k] < g.NI) & cy_ok;                                   \
+      ry[k] = *reinterpret_cast<const f32x4*>(yb__ + (ok__ ? (size_t)k * 32 * wg.ld_dy * 4 + rs_yvo : (size_t)0)); \
+      rs_ymask = (rs_ymask & ~(1u << k)) | ((ok__ ? 1u : 0u) << k);                                               \
+    }                                                                                                             \
+  }
 
 #define PIDM_WG_PREFETCH(tile_)                                                                                   \
   {                                                                                                               \
@@ -1105,21 +1156,36 @@ __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg
 
   const int tile_lo = split * wg.tiles_per_split;
   const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
-  if (tile_lo < tile_hi) PIDM_WG_PREFETCH(tile_lo)
+  if (tile_lo < tile_hi) {
+    if constexpr (ROWST) PIDM_WG_PREFETCH_ROWS(tile_lo)
+    else PIDM_WG_PREFETCH(tile_lo)
+  }
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     __syncthreads();
+    if constexpr (ROWST) {
 #pragma unroll
-    for (int k = 0; k < XMAX; ++k) {
-      const int hp = (tid + k * 256) >> 3;
-      if (hp < npixA) *reinterpret_cast<f32x4*>(Xs + (size_t)hp * 32 + 4 * q) = rx[k];
-    }
+      for (int k = 0; k < 8; ++k)
+        if (k < rs_AS) *reinterpret_cast<f32x4*>(Xs + rs_lds[k]) = rx[k] * (((rs_xmask >> k) & 1u) ? 1.f : 0.f);
 #pragma unroll
-    for (int k = 0; k < YMAX; ++k) {
-      const int p = (tid + k * 256) >> 3;
-      *reinterpret_cast<f32x4*>(Ys + (size_t)p * 32 + 4 * q) = ry[k];
+      for (int k = 0; k < YMAX; ++k)
+        *reinterpret_cast<f32x4*>(Ys + (size_t)((tid >> 3) + 32 * k) * 32 + 4 * q) = ry[k] * (((rs_ymask >> k) & 1u) ? 1.f : 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < XMAX; ++k) {
+        const int hp = (tid + k * 256) >> 3;
+        if (hp < npixA) *reinterpret_cast<f32x4*>(Xs + (size_t)hp * 32 + 4 * q) = rx[k];
+      }
+#pragma unroll
+      for (int k = 0; k < YMAX; ++k) {
+        const int p = (tid + k * 256) >> 3;
+        *reinterpret_cast<f32x4*>(Ys + (size_t)p * 32 + 4 * q) = ry[k];
+      }
     }
     __syncthreads();
-    if (tile + 1 < tile_hi) PIDM_WG_PREFETCH(tile + 1)
+    if (tile + 1 < tile_hi) {
+      if constexpr (ROWST) PIDM_WG_PREFETCH_ROWS(tile + 1)
+      else PIDM_WG_PREFETCH(tile + 1)
+    }
     if (do_bias) {
       const int o = tid & 31, part = tid >> 5;
 #pragma unroll
@@ -1174,6 +1240,7 @@ __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg
     }
   }
 #undef PIDM_WG_PREFETCH
+#undef PIDM_WG_PREFETCH_ROWS
   float* red = smem;  // [4][1024]
 #pragma unroll
   for (int tl = 0; tl < MAXT; ++tl) {
@@ -2136,17 +2203,18 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   } else if (g.nph > 1) {
     if (!aligned || g.NI * g.IHt * g.IWt * 8 > 9 * 256) return fail("wgrad: phased 4x4/s2 geometry not eligible for the pipelined kernel");
     const dim3 gridp(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 4);
-#define PIDM_LAUNCH_WG(KH_, KW_, PH_, WIDE_, MINW_, grid_)                                                                 \
+#define PIDM_LAUNCH_WG6(KH_, KW_, PH_, WIDE_, MINW_, ROWST_, grid_)                                                        \
   {                                                                                                                        \
     static bool attr_ = false;                                                                                             \
     if (!attr_) {                                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_>),        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_, ROWST_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
       attr_ = true;                                                                                                        \
     }                                                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_>), grid_, dim3(256), lds, st, wg, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_, ROWST_>), grid_, dim3(256), lds, st, wg, \
                        src0, src1 ? src1 : src0, dy, partial, bias_partial);                                              \
   }
+#define PIDM_LAUNCH_WG(KH_, KW_, PH_, WIDE_, MINW_, grid_) PIDM_LAUNCH_WG6(KH_, KW_, PH_, WIDE_, MINW_, false, grid_)
     if (g.Wv >= 32) PIDM_LAUNCH_WG(2, 2, true, true, 2, gridp)
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
   } else if (smode == 1) {
@@ -2163,10 +2231,22 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
     } else {
-      if (g.Wv >= 32) PIDM_LAUNCH_WG(3, 3, false, true, 1, grid)
-      else PIDM_LAUNCH_WG(3, 3, false, false, 1, grid)
+      // row-aligned staging without vector arithmetic where the geometry allows it (PIDM_WGRAD_ROWST=0: off, for A/B runs)
+      const char* re = getenv("PIDM_WGRAD_ROWST");
+      const int seg = g.NI * g.IHt * g.Wv;
+      const bool rowst = !(re && !atoi(re)) && g.stride == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi && g.Wv >= 8 &&
+                         seg % 32 == 0 && seg <= 256 && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) &&
+                         (g.C1 == 0 || g.ld1 == g.ld0) && (ld_dy & 3) == 0;
+      if (rowst) {
+        if (g.Wv >= 32) PIDM_LAUNCH_WG6(3, 3, false, true, 1, true, grid)
+        else PIDM_LAUNCH_WG6(3, 3, false, false, 1, true, grid)
+      } else {
+        if (g.Wv >= 32) PIDM_LAUNCH_WG(3, 3, false, true, 1, grid)
+        else PIDM_LAUNCH_WG(3, 3, false, false, 1, grid)
+      }
     }
 #undef PIDM_LAUNCH_WG
+#undef PIDM_LAUNCH_WG6
   } else if (wg.tgs == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else

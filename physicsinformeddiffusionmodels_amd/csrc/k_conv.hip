@@ -795,6 +795,256 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same convolutions on the bf16 matrix pipe, fp32-faithful ("split" form, pidm_common.h).
+//
+// The fp32 MFMA tops out at ~143 TFLOP/s in practice and shares the vector ALUs with everything else a wave does
+// (tools/mfma_overlap.hip); 6 bf16 MFMAs on round-to-nearest 3-piece operands give the same product to within the fp32 MFMA's own
+// rounding error in 2.3x less matrix-pipe time (tools/mfma_bf16_probe.hip), and the VALU work of ONE wave runs under the MFMAs of
+// the OTHER wave of its SIMD.  So: 8 waves (two per SIMD), a 256-pixel x 32-channel tile (one 32x32 accumulator per wave), K
+// chunks of 16 channels x 9 taps = 54 MFMAs per wave and stage.  Activations are split on their way from global memory into
+// LDS (36 VALU per 8 channels); the weights arrive pre-split from the weight re-pack (pack_kernel: split_store), one contiguous
+// 27 KB slab per (32 output channels, 16 input channels).
+// LDS row (pixel of the halo tile, or weight row of a tap) = 112 bytes = [half h: piece 0 | piece 1 | piece 2][h = 1: ...][16 pad],
+// 16 bytes = 8 channels of one piece = one MFMA operand; 7 slots per row is odd, so the 16 lanes ds_read_b128 serves per cycle
+// (consecutive pixels / output channels) hit 16 different 16-byte bank groups.
+// The pipeline is the one of conv3x3_stream_kernel: stage s computes from buffer s&1 while the registers loaded during stage
+// s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
+// ---------------------------------------------------------------------------------------------------
+static constexpr int kSplitRow = 112;                 // bytes per LDS row
+static constexpr int kSplitSlab = 9 * 32 * 96;        // bytes of pre-split weights per stage
+
+__global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                            const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, float* __restrict__ out, int n_items,
+                                                            int items_per_wg) {
+  constexpr int RB = kSplitRow, T = 9;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int z = 0;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  const int bufsz = (npixA + T * 32) * RB;             // bytes per buffer: halo tile | 9 x 32 weight rows
+  const int tpi = g.Hv / g.TH;
+  const int NCH = g.Cin >> 4;
+  const int item0 = blockIdx.x * items_per_wg;
+  const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
+  const int nst = my_items * NCH;
+
+  // operand fragments of this lane: A row = pixel wave*32 + l31 of the tile, B row = output channel l31 of the tap
+  const int pm = wave * 32 + l31;
+  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
+  const int a_frag = abase * RB + 48 * half;
+  const int b_frag = (npixA + l31) * RB + 48 * half;
+
+  // Activation staging: a unit = 8 channels of one pixel (32 bytes in, 3 x 16 bytes out); whole image rows, the halo columns
+  // are zero for every tile and written once.  Units tid and tid + 512; the second exists for the first nA1 waves.
+  const int SEG = g.NI * g.IHt * g.Wv;                 // staged pixels per tile
+  const int nA1 = (2 * SEG - 512) >> 6;
+  const int hh = tid & 1;
+  int a_lds[2], a_im[2], a_hy[2];
+  unsigned a_vo[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int sp = (tid + 512 * k) >> 1;
+    if (sp >= SEG) sp = SEG - 1;
+    const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
+    const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
+    a_lds[k] = ((img * g.IHt + hy) * g.IWt + x + 1) * RB + 48 * hh;
+    a_vo[k] = (unsigned)(x * g.ld0 + 8 * hh) * 4u;
+    a_im[k] = img;
+    a_hy[k] = hy;
+  }
+  // Weight staging: the stage's slab is 1728 16-byte pieces, row r = q / 6; pieces tid + 512 k, the fourth for 192 threads
+  int b_lds[4];
+  unsigned b_vo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int q = tid + 512 * k;
+    if (q > 1727) q = 1727;
+    b_lds[k] = (npixA + q / 6) * RB + 16 * (q % 6);
+    b_vo[k] = 16u * q;
+  }
+
+  // zero halo columns of both buffers
+  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 512) {
+    const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * RB + 16 * q) = zero4;
+  }
+
+  f32x4 ra[2][2];
+  u32x4 rb[4];
+  float akeep[2] = {0.f, 0.f};
+  const char* l_sp = reinterpret_cast<const char*>(src0);
+  const char* l_wn = reinterpret_cast<const char*>(ws);
+  int l_b0 = 0, l_iy0 = 0;
+#define PIDM_SP_STAGE(s_)                                                                                          \
+  {                                                                                                                \
+    int ss__ = (s_);                                                                                               \
+    if (ss__ >= nst) ss__ = nst - 1;                                                                               \
+    const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
+    const int tn__ = it__ / g.tiles_m, tm__ = it__ - tn__ * g.tiles_m;                                             \
+    const int c0__ = ch__ * 16;                                                                                    \
+    l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
+    l_iy0 = (tm__ % tpi) * g.TH - g.pad_y[z];                                                                      \
+    l_sp = reinterpret_cast<const char*>((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0));                      \
+    l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tn__ * NCH + ch__) * kSplitSlab;                           \
+  }
+  // unconditional loads (rows outside the image read row 0 and are zeroed on their way to LDS)
+#define PIDM_SP_LOAD_A(k_)                                                                                         \
+  {                                                                                                                \
+    const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
+    const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < g.Hi);                                                   \
+    const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + iy__) * g.Wi : 0;                                            \
+    const f32x4* p__ = reinterpret_cast<const f32x4*>(l_sp + row__ * (size_t)g.ld0 * 4 + a_vo[k_]);                \
+    ra[k_][0] = p__[0];                                                                                            \
+    ra[k_][1] = p__[1];                                                                                            \
+    akeep[k_] = ok__ ? 1.f : 0.f;                                                                                  \
+  }
+#define PIDM_SP_LOAD_B(k_) rb[k_] = *reinterpret_cast<const u32x4*>(l_wn + b_vo[k_]);
+#define PIDM_SP_WRITE_A(k_, buf_)                                                                                  \
+  {                                                                                                                \
+    const f32x4 v0__ = ra[k_][0] * akeep[k_], v1__ = ra[k_][1] * akeep[k_];                                        \
+    unsigned q0__[4], q1__[4], q2__[4];                                                                            \
+    pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
+    pidm_split3_pk(v0__[2], v0__[3], q0__[1], q1__[1], q2__[1]);                                                   \
+    pidm_split3_pk(v1__[0], v1__[1], q0__[2], q1__[2], q2__[2]);                                                   \
+    pidm_split3_pk(v1__[2], v1__[3], q0__[3], q1__[3], q2__[3]);                                                   \
+    u32x4* d__ = reinterpret_cast<u32x4*>((buf_) + a_lds[k_]);                                                     \
+    d__[0] = u32x4{q0__[0], q0__[1], q0__[2], q0__[3]};                                                            \
+    d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \
+    d__[2] = u32x4{q2__[0], q2__[1], q2__[2], q2__[3]};                                                            \
+  }
+#define PIDM_SP_WRITE_B(k_, buf_) *reinterpret_cast<u32x4*>((buf_) + b_lds[k_]) = rb[k_];
+
+  char* bufc = smem;               // buffer the MFMAs read
+  char* bufn = smem + bufsz;       // buffer being filled
+  PIDM_SP_STAGE(0)
+  PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) PIDM_SP_LOAD_B(k)
+  PIDM_SP_WRITE_A(0, bufc)
+  if (wave < nA1) PIDM_SP_WRITE_A(1, bufc)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) PIDM_SP_WRITE_B(k, bufc)
+  if (wave < 3) PIDM_SP_WRITE_B(3, bufc)
+  PIDM_SP_STAGE(1)
+  PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) PIDM_SP_LOAD_B(k)
+  __syncthreads();
+
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int s = 0; s < nst; ++s) {
+    PIDM_SP_STAGE(s + 2)           // geometry of the loads issued during this stage
+    const char* afp = bufc + a_frag;
+    const char* bfp = bufc + b_frag;
+    u32x4 fa[2][3], fb[2][3];
+#define PIDM_SP_FRAGS(set_, t_)                                                                                    \
+  {                                                                                                                \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)(((t_) / 3) * g.IWt + ((t_) % 3)) * RB);      \
+    const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
+      fa[set_][p] = ar__[p];                                                                                       \
+      fb[set_][p] = br__[p];                                                                                       \
+    }                                                                                                              \
+  }
+    PIDM_SP_FRAGS(0, 0)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < T) PIDM_SP_FRAGS(cur ^ 1, t + 1)
+      // small terms first
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], acc);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
+      if (t == 0) PIDM_SP_WRITE_A(0, bufn)
+      if (t == 1) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) }
+      if (t == 2) { PIDM_SP_WRITE_B(0, bufn) PIDM_SP_WRITE_B(1, bufn) }
+      if (t == 3) { PIDM_SP_WRITE_B(2, bufn) if (wave < 3) PIDM_SP_WRITE_B(3, bufn) }
+      if (t == 4) { PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1) }
+      if (t == 5) { PIDM_SP_LOAD_B(0) PIDM_SP_LOAD_B(1) PIDM_SP_LOAD_B(2) PIDM_SP_LOAD_B(3) }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PIDM_SP_FRAGS
+    // ---- last chunk of a tile: epilogue as in conv3x3_stream_kernel (bias, GroupNorm partial sums, 4x4 register transposes,
+    //      residual, 16-byte stores), accumulator restarts ----
+    const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
+    if (ch == NCH - 1) {
+      const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
+      const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
+      const int c = n0 + l31;
+      const float bv = bias ? bias[c] : 0.f;
+      const int p0 = wave * 32;
+      const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
+      const int b = b0 + img0;
+      if (b < g.B && img0 < g.NI) {        // wave-uniform
+        const int pin = (vy0 + ty0) * g.Wv + tx0;
+        float v[16];
+        float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = acc[r] + bv;
+          gs1 += v[r];
+          gs2 += v[r] * v[r];
+        }
+        if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
+        if (g.bn_part) {
+          const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
+          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout)
+        }
+        const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+        const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
+        const size_t rpix = ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + n0 + 4 * (l31 >> 2);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float x0 = v[4 * q4], x1 = v[4 * q4 + 1], x2 = v[4 * q4 + 2], x3 = v[4 * q4 + 3];
+          const float r01 = pidm_quad_xor1(odd1 ? x0 : x1), r23 = pidm_quad_xor1(odd1 ? x2 : x3);
+          x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+          x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+          const float r02 = pidm_quad_xor2(odd2 ? x0 : x2), r13 = pidm_quad_xor2(odd2 ? x1 : x3);
+          x0 = odd2 ? r02 : x0; x2 = odd2 ? x2 : r02;
+          x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
+          const int prow = 8 * q4 + 4 * half + (l31 & 3);
+          f32x4 o = {x0, x1, x2, x3};
+          if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);
+          *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
+        }
+      }
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    char* tswap = bufc; bufc = bufn; bufn = tswap;
+  }
+#undef PIDM_SP_STAGE
+#undef PIDM_SP_LOAD_A
+#undef PIDM_SP_LOAD_B
+#undef PIDM_SP_WRITE_A
+#undef PIDM_SP_WRITE_B
+}
+
+// pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
+// fp32 packing of the same tensor (packed_floats counts both).  Shape-only condition: the launcher may still take another kernel.
+static bool split_shape_ok(const ConvGeom& g) {
+  return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && (g.Cin % 32 == 0) && (g.Cout % 32 == 0);
+}
+__device__ __forceinline__ void split_store(unsigned short* ws, int nch, int n, int t, int k, float v) {
+  unsigned p0, p1, p2;
+  pidm_split3_pk(v, 0.f, p0, p1, p2);
+  const size_t o = ((((size_t)(n >> 5) * nch + (k >> 4)) * 9 + t) * 32 + (n & 31)) * 48 + ((k >> 3) & 1) * 24 + (k & 7);
+  ws[o] = (unsigned short)(p0 & 0xffffu);
+  ws[o + 8] = (unsigned short)(p1 & 0xffffu);
+  ws[o + 16] = (unsigned short)(p2 & 0xffffu);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: reference layout -> [nz][Np][T][Kp] (zero padded)
 //   kind 0: fwd, normal conv        src [N=Cout][K=Cin][KH][KW]
 //   kind 1: fwd, transposed 4x4s2   src [K=Cin][N=Cout][4][4], 4 parity classes of 2x2 taps
@@ -807,7 +1057,7 @@ __device__ __forceinline__ int parity_tap(int par, int j) { return par == 0 ? 3 
 // iterates over the SOURCE-valid elements (n < N, k < K) only; padding is zero-filled once by the caller.
 // (n_off, k_off) place a source tensor inside a larger packed matrix (concatenated time-MLP linears).
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int nz, int N, int K,
-                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off) {
+                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off, unsigned short* __restrict__ split, int nch) {
   const size_t total = (size_t)nz * N * T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % K);
@@ -836,6 +1086,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
       v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
     }
     dst[(((size_t)z * Np + n_off + n) * T + t) * Kp + k_off + k] = v;
+    if (split) split_store(split, nch, n_off + n, t, k_off + k, v);
   }
 }
 
@@ -875,6 +1126,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
       v = d.src[(((size_t)k * d.N + n) * 4 + ky) * 4 + kx];
     }
     d.dst[(((size_t)z * d.Np + d.n_off + n) * d.T + t) * d.Kp + d.k_off + k] = v;
+    if (d.split) split_store(d.split, d.nch, d.n_off + n, t, d.k_off + k, v);
   }
 }
 
@@ -1796,10 +2048,17 @@ static int pick_nt(int Cout, int tiles_m) {
 // packed weights always pad Cout to a multiple of 64 so that either tile width can read them
 static int packed_np(int Cout) { return cdiv(Cout, 64) * 64; }
 
-size_t packed_floats(const ConvGeom& g) {
+static size_t packed_fp32_floats(const ConvGeom& g) {
   const int KC = pick_kc(g.Cin);
   const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Kw, KC) * KC;
   return (size_t)g.nz * Np * g.KH * g.KW * Kp;
+}
+// fp32 packing, followed by the bf16 pieces (3 x 2 bytes per weight) where conv3x3_split_kernel can take the tensor
+size_t packed_floats(const ConvGeom& g) {
+  return packed_fp32_floats(g) + (split_shape_ok(g) ? (size_t)g.Cout * g.Cin * 9 * 3 / 2 : 0);
+}
+static unsigned short* split_part(const ConvGeom& g, float* w_packed) {
+  return split_shape_ok(g) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
 }
 
 // w_ref -> packed.  The packed matrix is sized by g (g.Cout rows, g.Cin columns); the source tensor covers rows
@@ -1814,8 +2073,9 @@ int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed
   const size_t total = (size_t)g.nz * N * T * K * g.nph;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  unsigned short* split = (kind == 0 || kind == 2) ? split_part(g, w_packed) : nullptr;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nph > 1 ? 4 : g.nz, N, K, Np, Kp, srcKH,
-                     srcKW, T, n_off, k_off);
+                     srcKW, T, n_off, k_off, split, g.Cin / 16);
   PIDM_CHECK_LAUNCH("pack_kernel");
   return 0;
 }
@@ -1828,6 +2088,8 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->N = n_src > 0 ? n_src : g.Cout; d->K = k_src > 0 ? k_src : g.Cin;
   d->Np = packed_np(g.Cout); d->Kp = cdiv(g.Kw, KC) * KC; d->KH = srcKH; d->KW = srcKW; d->T = g.KH * g.KW;
   d->n_off = n_off; d->k_off = k_off;
+  d->split = (kind == 0 || kind == 2) ? split_part(g, w_packed) : nullptr;
+  d->nch = g.Cin / 16;
   if (g.nph > 1) { d->kind = (kind == 4) ? 6 : 5; d->nz = 4; }   // nz doubles as the phase count for kinds 5/6
   const size_t total = (size_t)d->nz * d->N * d->T * d->K;
   d->nblk = (unsigned)((total + 2047) / 2048);
@@ -2026,6 +2288,42 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
+  {
+    // bf16 matrix pipe, fp32-faithful split operands (PIDM_CONV_SPLIT=0: off -> the fp32-MFMA kernels below; read per launch)
+    const char* se = getenv("PIDM_CONV_SPLIT");
+    const bool on = !(se && !atoi(se));
+    ConvGeom gs = g;
+    if (on && split_shape_ok(g) && g.soc == 1 && (g.C0 % 16 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.C1 == 0 || g.ld1 == g.ld0) &&
+        g.Wv >= 8 && g.Wv == g.Wi && g.pad_y[0] == 1 && g.pad_x[0] == 1 && !sigmoid_last && (g.sox & 3) == 0 &&
+        (reinterpret_cast<size_t>(out) & 15) == 0 && (reinterpret_cast<size_t>(src0) & 15) == 0 &&
+        (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) && retile_bm(&gs, 256)) {
+      const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
+      const size_t lds = (size_t)2 * (npixA + 9 * 32) * kSplitRow;
+      if (SEG % 32 == 0 && 2 * SEG >= 512 && 2 * SEG <= 1024 && lds <= 160 * 1024 - 256) {
+        const bool prof = prof_enabled();
+        static bool attr_p = false;
+        if (!attr_p) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          attr_p = true;
+        }
+        gs.w_off[0] = 0;
+        const int n_items = gs.tiles_m * (g.Cout / 32);
+        const char* ce = getenv("PIDM_STREAM_WGS");
+        int n_cu = ce ? atoi(ce) : 256;
+        if (n_cu < 1) n_cu = 256;
+        const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
+        const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
+        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel, %d items over %d workgroups, %zu B LDS\n", n_items, wgs, lds);
+        if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
+        hipLaunchKernelGGL(conv3x3_split_kernel, dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
+                           n_items, ipw);
+        if (prof) prof_end_launch(st);
+        PIDM_CHECK_LAUNCH("conv3x3_split_kernel");
+        return 0;
+      }
+    }
+  }
   {
     // streaming persistent 3x3 kernel (PIDM_CONV_STREAM=0: off, for A/B measurements and to reach the older tilings in tests)
     const char* se = getenv("PIDM_CONV_STREAM");

@@ -62,6 +62,7 @@ struct Fiber {
 struct BlockRunner {
   std::vector<Fiber> fibers;
   std::vector<uint64_t> xa, xb;  // cross-lane exchange slots
+  std::vector<uint32_t> xw;      // 8 dwords per lane: the 128-bit operand pairs of the bf16 MFMA
   void* sched_sp = nullptr;
   int cur = 0;
   int nthreads = 0;
@@ -205,6 +206,38 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
       float fa, fb;
       memcpy(&fa, &xa, 4);
       memcpy(&fb, &xb, 4);
+      acc = fmaf(fa, fb, acc);
+    }
+    c[reg] = acc;
+  }
+  hipemu::wave_sync();
+  return c;
+}
+// ---- bf16 operands (pidm_common.h: split form of the fp32 contraction) ---------------------------------------------------------
+#define PIDM_HAVE_BF16_OPS 1
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+static inline unsigned hipemu_bf16_rne(float f) {   // v_cvt_pk_bf16_f32 rounds to nearest even
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned pidm_cvt_pk_bf16(float lo, float hi) { return hipemu_bf16_rne(lo) | (hipemu_bf16_rne(hi) << 16); }
+// v_mfma_f32_32x32x16_bf16: lane l holds row / column l & 31, k = 8 (l >> 5) + 0..7; D as the fp32 32x32 MFMAs
+static inline hipemu_f32x16 pidm_mfma_bf16_32x32x16(hipemu_u32x4 a, hipemu_u32x4 b, hipemu_f32x16 c, int line = __builtin_LINE()) {
+  hipemu::BlockRunner* r = hipemu::g_runner;
+  int t = hipemu::flat_tid(), lane = t & 63, wb = t & ~63;
+  r->xa[t] = (uint64_t)(uint32_t)line << 32;
+  for (int i = 0; i < 4; ++i) { r->xw[8 * t + i] = a[i]; r->xw[8 * t + 4 + i] = b[i]; }
+  hipemu::wave_sync();
+  hipemu_mfma_check(r, wb, lane, line);
+  for (int reg = 0; reg < 16; ++reg) {
+    int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t wa = r->xw[8 * (wb + (k >> 3) * 32 + row) + ((k & 7) >> 1)], wbv = r->xw[8 * (wb + (k >> 3) * 32 + col) + 4 + ((k & 7) >> 1)];
+      const float fa = __uint_as_float((k & 1) ? (wa & 0xffff0000u) : (wa << 16)), fb = __uint_as_float((k & 1) ? (wbv & 0xffff0000u) : (wbv << 16));
       acc = fmaf(fa, fb, acc);
     }
     c[reg] = acc;

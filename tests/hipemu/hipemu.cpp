@@ -69,6 +69,7 @@ static void run_block(BlockRunner* r, dim3 block, size_t shmem) {
   }
   r->xa.assign(((n + 63) / 64) * 64, 0);
   r->xb.assign(((n + 63) / 64) * 64, 0);
+  r->xw.assign(((n + 63) / 64) * 64 * 8, 0);
   if (shmem > r->dyn_cap) {
     free(r->dyn);
     r->dyn = (char*)aligned_alloc(64, (shmem + 63) / 64 * 64);

@@ -816,7 +816,7 @@ static constexpr int kSplitSlab = 9 * 32 * 96;        // bytes of pre-split weig
 __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                             const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, float* __restrict__ out, int n_items,
-                                                            int items_per_wg) {
+                                                            int items_per_wg, int trace) {
   constexpr int RB = kSplitRow, T = 9;
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
@@ -939,8 +939,13 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
 
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // PIDM_STREAM_TRACE=1: cycle stamps of workgroup 0, waves 0 and 4 (one SIMD): [wave][stage < 32][top, taps done, epilogue done, past barrier]
+  const int tr_base = (trace && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) ? (wave >> 2) * 128 : -1;
   for (int s = 0; s < nst; ++s) {
+    if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 0] = clock64();
     PIDM_SP_STAGE(s + 2)           // geometry of the loads issued during this stage
+    // the epilogue's bias, fetched a stage ahead of its use (unconditional load, any valid address when there is no bias)
+    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[((item0 + s / NCH) / g.tiles_m) * 32 + l31];
     const char* afp = bufc + a_frag;
     const char* bfp = bufc + b_frag;
     u32x4 fa[2][3], fb[2][3];
@@ -954,6 +959,10 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
     }                                                                                                              \
   }
     PIDM_SP_FRAGS(0, 0)
+    // Measured and left out (tools/split_variants.py, profiles/r02_split_conv_notes.txt): staggering the staging pieces between
+    // the two waves of a SIMD (either as two copies of the tap loop or only the two VALU-heavy pieces) and alternating
+    // s_setprio per tap - all within +-3 % or slower.  The stage is bound by the LDS (54 ds_read_b128 + ~10 ds_write_b128 per
+    // wave = ~2800 LDS-array cycles of the 3780 matrix-pipe cycles), not by VALU issue.
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int cur = t & 1;
@@ -974,6 +983,7 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_SP_FRAGS
+    if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 1] = clock64();
     // ---- last chunk of a tile: epilogue as in conv3x3_stream_kernel (bias, GroupNorm partial sums, 4x4 register transposes,
     //      residual, 16-byte stores), accumulator restarts ----
     const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
@@ -981,7 +991,7 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
       const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
       const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
       const int c = n0 + l31;
-      const float bv = bias ? bias[c] : 0.f;
+      const float bv = bias ? bv_pre : 0.f;
       const int p0 = wave * 32;
       const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
       const int b = b0 + img0;
@@ -1020,7 +1030,9 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
       }
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
+    if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 2] = clock64();
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 3] = clock64();
     char* tswap = bufc; bufc = bufn; bufn = tswap;
   }
 #undef PIDM_SP_STAGE
@@ -2317,7 +2329,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel, %d items over %d workgroups, %zu B LDS\n", n_items, wgs, lds);
         if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
         hipLaunchKernelGGL(conv3x3_split_kernel, dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
-                           n_items, ipw);
+                           n_items, ipw, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
         if (prof) prof_end_launch(st);
         PIDM_CHECK_LAUNCH("conv3x3_split_kernel");
         return 0;

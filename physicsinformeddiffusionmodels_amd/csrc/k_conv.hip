@@ -813,11 +813,13 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 static constexpr int kSplitSlab = 9 * 32 * 96;        // bytes of pre-split weights per stage
 
-__global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                             const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, float* __restrict__ out, int n_items,
                                                             int items_per_wg, int trace) {
-  constexpr int RB = kSplitRow, T = 9;
+  constexpr int RB = kSplitRow, T = 9, NT = 64 * NW;        // NW waves: 8 (256-pixel tile, two waves per SIMD) or 4 (128 pixels)
+  constexpr int NB = (1728 + NT - 1) / NT;                  // 16-byte pieces of the weight slab per thread: 4 / 7, the last for 3 waves
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
@@ -840,15 +842,15 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
   const int b_frag = (npixA + l31) * RB + 48 * half;
 
   // Activation staging: a unit = 8 channels of one pixel (32 bytes in, 3 x 16 bytes out); whole image rows, the halo columns
-  // are zero for every tile and written once.  Units tid and tid + 512; the second exists for the first nA1 waves.
+  // are zero for every tile and written once.  Units tid and tid + NT; the second exists for the first nA1 waves.
   const int SEG = g.NI * g.IHt * g.Wv;                 // staged pixels per tile
-  const int nA1 = (2 * SEG - 512) >> 6;
+  const int nA1 = (2 * SEG - NT) >> 6;
   const int hh = tid & 1;
   int a_lds[2], a_im[2], a_hy[2];
   unsigned a_vo[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    int sp = (tid + 512 * k) >> 1;
+    int sp = (tid + NT * k) >> 1;
     if (sp >= SEG) sp = SEG - 1;
     const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
     const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
@@ -857,26 +859,26 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
     a_im[k] = img;
     a_hy[k] = hy;
   }
-  // Weight staging: the stage's slab is 1728 16-byte pieces, row r = q / 6; pieces tid + 512 k, the fourth for 192 threads
-  int b_lds[4];
-  unsigned b_vo[4];
+  // Weight staging: the stage's slab is 1728 16-byte pieces, row r = q / 6; pieces tid + NT k, the last one for 192 threads
+  int b_lds[NB];
+  unsigned b_vo[NB];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int q = tid + 512 * k;
+  for (int k = 0; k < NB; ++k) {
+    int q = tid + NT * k;
     if (q > 1727) q = 1727;
     b_lds[k] = (npixA + q / 6) * RB + 16 * (q % 6);
     b_vo[k] = 16u * q;
   }
 
   // zero halo columns of both buffers
-  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 512) {
+  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += NT) {
     const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * RB + 16 * q) = zero4;
   }
 
   f32x4 ra[2][2];
-  u32x4 rb[4];
+  u32x4 rb[NB];
   float akeep[2] = {0.f, 0.f};
   const char* l_sp = reinterpret_cast<const char*>(src0);
   const char* l_wn = reinterpret_cast<const char*>(ws);
@@ -925,16 +927,16 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
   PIDM_SP_STAGE(0)
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) PIDM_SP_LOAD_B(k)
+  for (int k = 0; k < NB; ++k) PIDM_SP_LOAD_B(k)
   PIDM_SP_WRITE_A(0, bufc)
   if (wave < nA1) PIDM_SP_WRITE_A(1, bufc)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) PIDM_SP_WRITE_B(k, bufc)
-  if (wave < 3) PIDM_SP_WRITE_B(3, bufc)
+  for (int k = 0; k < NB - 1; ++k) PIDM_SP_WRITE_B(k, bufc)
+  if (wave < 3) PIDM_SP_WRITE_B(NB - 1, bufc)
   PIDM_SP_STAGE(1)
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) PIDM_SP_LOAD_B(k)
+  for (int k = 0; k < NB; ++k) PIDM_SP_LOAD_B(k)
   __syncthreads();
 
   f32x16 acc;
@@ -974,12 +976,17 @@ __global__ void __launch_bounds__(512) conv3x3_split_kernel(ConvGeom g, const fl
       acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
       acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
       acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
-      if (t == 0) PIDM_SP_WRITE_A(0, bufn)
-      if (t == 1) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) }
-      if (t == 2) { PIDM_SP_WRITE_B(0, bufn) PIDM_SP_WRITE_B(1, bufn) }
-      if (t == 3) { PIDM_SP_WRITE_B(2, bufn) if (wave < 3) PIDM_SP_WRITE_B(3, bufn) }
-      if (t == 4) { PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1) }
-      if (t == 5) { PIDM_SP_LOAD_B(0) PIDM_SP_LOAD_B(1) PIDM_SP_LOAD_B(2) PIDM_SP_LOAD_B(3) }
+      // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
+      if (t == 0) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
+      if (t == 1) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
+      if (t >= 2) {
+#pragma unroll
+        for (int k = 2 * (t - 2); k < 2 * (t - 2) + 2; ++k) {
+          if (k < NB - 1) PIDM_SP_WRITE_B(k, bufn)
+          if (k == NB - 1) { if (wave < 3) PIDM_SP_WRITE_B(k, bufn) }
+          if (k < NB) PIDM_SP_LOAD_B(k)
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_SP_FRAGS
@@ -2309,27 +2316,43 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         g.Wv >= 8 && g.Wv == g.Wi && g.pad_y[0] == 1 && g.pad_x[0] == 1 && !sigmoid_last && (g.sox & 3) == 0 &&
         (reinterpret_cast<size_t>(out) & 15) == 0 && (reinterpret_cast<size_t>(src0) & 15) == 0 &&
         (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
-        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) && retile_bm(&gs, 256)) {
-      const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
-      const size_t lds = (size_t)2 * (npixA + 9 * 32) * kSplitRow;
-      if (SEG % 32 == 0 && 2 * SEG >= 512 && 2 * SEG <= 1024 && lds <= 160 * 1024 - 256) {
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0))) {
+      // 8 waves on a 256-pixel tile, or - when that leaves CUs without a work item - 4 waves on 128 pixels (PIDM_SPLIT_NW forces one)
+      const char* fe = getenv("PIDM_SPLIT_NW");
+      const int force = fe ? atoi(fe) : 0;
+      ConvGeom g8 = g;
+      const char* ce = getenv("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
+      int n_cu = ce ? atoi(ce) : 256;
+      if (n_cu < 1) n_cu = 256;
+      const bool small = !retile_bm(&g8, 256) || g8.tiles_m * (g.Cout / 32) < n_cu;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int nw = (small != (pass == 1)) ? 4 : 8;
+        if (force && force != nw) continue;
+        gs = g;
+        if (!retile_bm(&gs, 32 * nw)) continue;
+        const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
+        const size_t lds = (size_t)2 * (npixA + 9 * 32) * kSplitRow;
+        if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
+        const int n_items = gs.tiles_m * (g.Cout / 32);
         const bool prof = prof_enabled();
         static bool attr_p = false;
         if (!attr_p) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
           attr_p = true;
         }
         gs.w_off[0] = 0;
-        const int n_items = gs.tiles_m * (g.Cout / 32);
-        const char* ce = getenv("PIDM_STREAM_WGS");
-        int n_cu = ce ? atoi(ce) : 256;
-        if (n_cu < 1) n_cu = 256;
         const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
         const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
-        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel, %d items over %d workgroups, %zu B LDS\n", n_items, wgs, lds);
+        const int trace = getenv("PIDM_STREAM_TRACE") ? 1 : 0;
+        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
-        hipLaunchKernelGGL(conv3x3_split_kernel, dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
-                           n_items, ipw, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
+        if (nw == 8)
+          hipLaunchKernelGGL(conv3x3_split_kernel<8>, dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
+                             n_items, ipw, trace);
+        else
+          hipLaunchKernelGGL(conv3x3_split_kernel<4>, dim3(wgs), dim3(256), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
+                             n_items, ipw, trace);
         if (prof) prof_end_launch(st);
         PIDM_CHECK_LAUNCH("conv3x3_split_kernel");
         return 0;

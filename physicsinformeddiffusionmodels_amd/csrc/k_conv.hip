@@ -1547,6 +1547,201 @@ __global__ void __launch_bounds__(256, MINW) conv_wgrad_pipe_kernel(WgradGeom wg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 weight gradient in the split form (bf16 matrix pipe, fp32-faithful 3-piece operands; pidm_common.h).
+//   dW[m][tap][n] = sum_p dY[p][m] X[p + tap][n]: the contraction runs over PIXELS, so the 32x32x16 MFMA wants, per lane, 8
+//   consecutive pixels of one channel in 4 registers - the transpose of the channels-last tensors.  Staging does it in registers:
+//   a thread loads 4 channels of one pixel, v_permlane32_swap / v_permlane16_swap (2 + 2 instructions) turn 4 lanes x 4
+//   registers into 4 pixels of one channel, the values are split into their 3 bf16 pieces and land in LDS as [piece][channel][pixel].
+//   Rows of X are stored with one halo element on either side of an 8-element-aligned body, so the centre tap (kx = 1) is an
+//   aligned 16-byte read and the taps kx = 0 / 2 are the same registers moved by one element (v_alignbit with the dword before /
+//   after: 5 VALU per piece and k-step for both).
+// Workgroup = 12 waves = 3 kernel rows (ky) x 4 pixel quarters of a P-pixel tile: a wave owns the 3 accumulators (kx) of its ky
+// for a 32 (dY channels) x 32 (X channels) block and walks its quarter of every tile of the split; the quarters are summed
+// through LDS at the end and the result goes to the split's partial slab like the other wgrad kernels (fixed-order reduction).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wgs_xrow_bytes(const ConvGeom& g) {
+  int xr = ((g.NI * g.IHt * (g.Wv + 8) + 8) * 2 + 15) & ~15;
+  if (((xr >> 4) & 1) == 0) xr += 16;       // odd number of 16-byte slots: conflict-free ds_read_b128 across channels
+  return xr;
+}
+template <int P>
+__global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                               const float* __restrict__ dy, float* __restrict__ partial,
+                                                               float* __restrict__ bias_partial) {
+  constexpr int NQ = 4, KS = P / (16 * NQ), NSLOT = (P == 256) ? 7 : 4, NWV = 12;
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = wg.NP / 32;
+  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int split = blockIdx.x;
+  const int RW = g.Wv + 8;
+  const int XROW = wgs_xrow_bytes(g), YROW = P * 2 + 16;
+  char* Xs = smem;
+  char* Ys = smem + 96 * XROW;
+  const int tpi = g.Hv / g.TH;
+  const int SEG8 = (g.NI * g.IHt * g.Wv) >> 3;       // 8-pixel groups of the X halo tile (whole rows), then P / 8 groups of dY
+
+  // ---- staging slots: wave-slot j = wave + 12 k is an 8-pixel x 32-channel group of X (j < SEG8) or of dY ----
+  const int q = lane & 7, pb = (lane >> 3) & 1, la = lane >> 4;      // channel quad, pixel bit 2, pixel bits 0-1
+  const char* xbase = reinterpret_cast<const char*>((n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0));   // n-tile = one source (C0 % 32 == 0)
+  const char* ybase = reinterpret_cast<const char*>(dy + m0);
+  int s_kind[NSLOT], s_img[NSLOT], s_row[NSLOT];     // wave-uniform: 0 none, 1 X, 2 dY; image and (halo / tile) row of the group
+  int lds_off[NSLOT];
+  unsigned g_vo[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int j = wave + NWV * k;
+    if (j < SEG8) {
+      const int sp = 8 * j, sr = sp >> g.wsh, x0 = sp & (g.Wv - 1);
+      s_kind[k] = 1;
+      s_img[k] = fast_div(sr, g.IHt, g.mIHt);
+      s_row[k] = sr - s_img[k] * g.IHt;
+      lds_off[k] = (4 * q + la) * XROW + (sr * RW + 8 + x0 + 4 * pb) * 2;
+      g_vo[k] = (unsigned)((x0 + 4 * pb + la) * g.ld0 + 4 * q) * 4u;
+    } else if (j < SEG8 + P / 8) {
+      const int p0 = 8 * (j - SEG8);
+      s_kind[k] = 2;
+      s_img[k] = p0 >> (g.wsh + g.tsh);
+      s_row[k] = (p0 >> g.wsh) & (g.TH - 1);
+      lds_off[k] = 96 * XROW + (4 * q + la) * YROW + (p0 + 4 * pb) * 2;
+      g_vo[k] = (unsigned)(((p0 & (g.Wv - 1)) + 4 * pb + la) * wg.ld_dy + 4 * q) * 4u;
+    } else {
+      s_kind[k] = 0; s_img[k] = 0; s_row[k] = 0; lds_off[k] = 0; g_vo[k] = 0;
+    }
+  }
+  // X region zeroed once: the halo elements of every row stay zero, the bodies are rewritten per tile
+  for (int e = tid; e < (96 * XROW) >> 4; e += 768) reinterpret_cast<u32x4*>(Xs)[e] = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- fragment offsets of this wave: kernel row ky, pixel quarter pq; per k-step the lane's 8 pixels (one row segment) ----
+  const int ky = wave >> 2, pq = wave & 3;
+  int xo[KS], yo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int p = pq * (P / NQ) + 16 * ks + 8 * half;
+    const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+    xo[ks] = l31 * XROW + (((img * g.IHt + ty + ky) * RW) + 8 + tx) * 2;
+    yo[ks] = 96 * XROW + l31 * YROW + p * 2;
+  }
+
+  f32x4 rr[NSLOT];
+  unsigned keep = 0;           // wave-uniform: bit k = slot k of the loads in flight is inside the batch / image
+#define PIDM_WS_PREFETCH(tile_)                                                                                    \
+  {                                                                                                                \
+    const int b0__ = ((tile_) / tpi) * g.NI, vy0__ = ((tile_) % tpi) * g.TH;                                       \
+    _Pragma("unroll") for (int k = 0; k < NSLOT; ++k) {                                                            \
+      const int b__ = b0__ + s_img[k];                                                                             \
+      const int iy__ = vy0__ + s_row[k] - (s_kind[k] == 1 ? 1 : 0);                                                \
+      const bool ok__ = (s_kind[k] != 0) & (b__ < g.B) & (iy__ >= 0) & (iy__ < g.Hi);                              \
+      const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + iy__) * g.Wi : 0;                                          \
+      const char* base__ = (s_kind[k] == 2) ? ybase + row__ * (size_t)wg.ld_dy * 4 : xbase + row__ * (size_t)g.ld0 * 4; \
+      rr[k] = *reinterpret_cast<const f32x4*>(base__ + g_vo[k]);                                                   \
+      keep = (keep & ~(1u << k)) | ((ok__ ? 1u : 0u) << k);                                                        \
+    }                                                                                                              \
+  }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0);
+  float bacc = 0.f;
+
+  const int tile_lo = split * wg.tiles_per_split;
+  const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
+  if (tile_lo < tile_hi) PIDM_WS_PREFETCH(tile_lo)
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    __syncthreads();
+    // ---- registers -> LDS: 4x4 transpose across lane bits 4-5, split, three 8-byte stores ----
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      if (s_kind[k] != 0) {       // wave-uniform
+        const f32x4 v = rr[k] * (((keep >> k) & 1u) ? 1.f : 0.f);
+        unsigned t0 = __float_as_uint(v[0]), t1 = __float_as_uint(v[1]), t2 = __float_as_uint(v[2]), t3 = __float_as_uint(v[3]);
+        {
+          const auto s02 = __builtin_amdgcn_permlane32_swap(t0, t2, false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(t1, t3, false, false);
+          const auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+          const auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+          t0 = s01[0]; t1 = s01[1]; t2 = s23[0]; t3 = s23[1];
+        }
+        // now: channel 4 q + la, pixels 4 pb + 0..3 of the group
+        const float f0 = __uint_as_float(t0), f1 = __uint_as_float(t1), f2 = __uint_as_float(t2), f3 = __uint_as_float(t3);
+        if (do_bias && s_kind[k] == 2) bacc += (f0 + f1) + (f2 + f3);
+        unsigned a0, a1, a2, b0, b1, b2;
+        pidm_split3_pk(f0, f1, a0, a1, a2);
+        pidm_split3_pk(f2, f3, b0, b1, b2);
+        const int ps = 32 * (s_kind[k] == 1 ? XROW : YROW);
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        char* d = smem + lds_off[k];
+        *reinterpret_cast<u32x2_t*>(d) = u32x2_t{a0, b0};
+        *reinterpret_cast<u32x2_t*>(d + ps) = u32x2_t{a1, b1};
+        *reinterpret_cast<u32x2_t*>(d + 2 * ps) = u32x2_t{a2, b2};
+      }
+    }
+    __syncthreads();
+    if (tile + 1 < tile_hi) PIDM_WS_PREFETCH(tile + 1)
+    // ---- the wave's k-steps: 3 dY fragments, 3 x (aligned X chunk + dword before + dword after), 18 MFMAs ----
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 ya[3], xc[3], xl[3], xr[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        ya[pc] = *reinterpret_cast<const u32x4*>(smem + yo[ks] + pc * 32 * YROW);
+        const char* xp = smem + xo[ks] + pc * 32 * XROW;
+        xc[pc] = *reinterpret_cast<const u32x4*>(xp);
+        const unsigned prev = *reinterpret_cast<const unsigned*>(xp - 4), next = *reinterpret_cast<const unsigned*>(xp + 16);
+        const unsigned m01 = __builtin_amdgcn_alignbit(xc[pc][1], xc[pc][0], 16), m12 = __builtin_amdgcn_alignbit(xc[pc][2], xc[pc][1], 16),
+                       m23 = __builtin_amdgcn_alignbit(xc[pc][3], xc[pc][2], 16);
+        xl[pc] = u32x4{__builtin_amdgcn_alignbit(xc[pc][0], prev, 16), m01, m12, m23};
+        xr[pc] = u32x4{m01, m12, m23, __builtin_amdgcn_alignbit(next, xc[pc][3], 16)};
+      }
+#define PIDM_WS_SIX(acc_, xb_)                                                                                     \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[2], xb_[0], acc_);                                                             \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[0], xb_[2], acc_);                                                             \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[1], xb_[1], acc_);                                                             \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[1], xb_[0], acc_);                                                             \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[0], xb_[1], acc_);                                                             \
+  acc_ = pidm_mfma_bf16_32x32x16(ya[0], xb_[0], acc_);
+      PIDM_WS_SIX(acc[0], xl)
+      PIDM_WS_SIX(acc[1], xc)
+      PIDM_WS_SIX(acc[2], xr)
+#undef PIDM_WS_SIX
+    }
+  }
+#undef PIDM_WS_PREFETCH
+  // ---- sum of the 4 pixel quarters through LDS, then the split's partial slab ----
+  __syncthreads();
+  float* red = smemf;      // [12 waves][3 kx][1024]
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 3 + kx) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[kx][r];
+  __syncthreads();
+  for (int e = tid; e < 9 * 1024; e += 768) {
+    const int tap = e >> 10, el = e & 1023, kyo = tap / 3, kxo = tap - 3 * kyo;
+    const float* rp = red + ((kyo * 4) * 3 + kxo) * 1024 + el;
+    const float sv = (rp[0] + rp[3 * 1024]) + (rp[6 * 1024] + rp[9 * 1024]);
+    partial[(((size_t)split * wg.MP + (m0 + (el >> 5))) * 9 + tap) * wg.NP + n0 + (el & 31)] = sv;
+  }
+  if (do_bias) {
+    __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (tid < 32) {        // channel c = 4 q + la: lanes (q, pb, la) of every wave
+      float sb = 0.f;
+      const int cq = tid >> 2, ca = tid & 3;
+      for (int w = 0; w < 12; ++w)
+        for (int b = 0; b < 2; ++b) sb += red[w * 64 + ca * 16 + b * 8 + cq];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
 // wgrad for convolutions with very few input channels (the 7x7 init conv: Cin = 2 or 10): the GEMM N dimension is
 // the flattened (tap, channel) index - 98 columns for 7x7x2 instead of 49 taps x a 32-channel tile that is 94 % padding.
 // Wave w owns n-tiles {w, w+4, ...} (<= MAXN) and walks the whole 128-pixel tile; lane j of an n-tile reads
@@ -2487,6 +2682,55 @@ size_t wgrad_ws_bytes(const ConvGeom& g) {
   return ns * wg.MP * wgrad_taps(g) * wg.NP * sizeof(float) + ns * wg.MP * sizeof(float) + 256;
 }
 
+// 3x3 / stride 1 on the bf16 pipe (conv_wgrad_split_kernel) when the geometry allows it; PIDM_WGRAD_SPLIT=0: off.  On success *used
+// holds the tiling and split actually launched (never more splits than the plan the workspace was sized for).
+static int wgs_xrow_bytes_host(const ConvGeom& g) {
+  int xr = ((g.NI * g.IHt * (g.Wv + 8) + 8) * 2 + 15) & ~15;
+  if (((xr >> 4) & 1) == 0) xr += 16;
+  return xr;
+}
+static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
+                               float* bias_partial, hipStream_t st, WgradGeom* used) {
+  const ConvGeom& g = plan.g;
+  const char* se = getenv("PIDM_WGRAD_SPLIT");
+  if (se && !atoi(se)) return false;
+  if (!(g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi &&
+        g.Hv == g.Hi && g.Wv >= 8 && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) && (g.C1 == 0 || g.ld1 == g.ld0) &&
+        (g.ld0 & 3) == 0 && (ld_dy & 3) == 0 && (reinterpret_cast<size_t>(src0) & 15) == 0 &&
+        (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) && (reinterpret_cast<size_t>(dy) & 15) == 0))
+    return false;
+  const char* pe = getenv("PIDM_WGRAD_SPLIT_P");      // tests: force the 128-pixel tile
+  for (int P = (pe && atoi(pe) == 128) ? 128 : 256; P >= 128; P >>= 1) {
+    WgradGeom wg = plan;
+    if (!retile_bm(&wg.g, P)) continue;
+    const ConvGeom& gp = wg.g;
+    const int seg = gp.NI * gp.IHt * gp.Wv, nslot = (P == 256) ? 7 : 4;
+    const size_t stage = (size_t)96 * (wgs_xrow_bytes_host(gp) + P * 2 + 16);
+    const size_t lds = stage > 12 * 3 * 4096 ? stage : 12 * 3 * 4096;
+    if (gp.NI * gp.TH * gp.Wv != P || seg % 8 || seg / 8 + P / 8 > 12 * nslot || lds > 160 * 1024 - 512) continue;
+    int ns = plan.nsplit < gp.tiles_m ? plan.nsplit : gp.tiles_m;
+    const char* me = getenv("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several tiles per split on small problems
+    if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+    wg.tiles_per_split = cdiv(gp.tiles_m, ns);
+    wg.nsplit = cdiv(gp.tiles_m, wg.tiles_per_split);
+    const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
+    static bool attr_ = false;
+    if (!attr_) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      attr_ = true;
+    }
+    if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv_wgrad_split_kernel<%d>, %d splits x %d blocks, %d tiles each, %zu B LDS\n", P, wg.nsplit, grid.y, wg.tiles_per_split, lds);
+    if (P == 256)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<128>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    *used = wg;
+    return true;
+  }
+  return false;
+}
+
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
 // dbias (may be null) = column sums of dy, fused into the same two launches
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
@@ -2563,6 +2807,8 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
+    } else if (launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
+      // taken by the bf16-pipe kernel (wg now holds its tiling / split)
     } else {
       // row-aligned staging without vector arithmetic where the geometry allows it (PIDM_WGRAD_ROWST=0: off, for A/B runs)
       const char* re = getenv("PIDM_WGRAD_ROWST");

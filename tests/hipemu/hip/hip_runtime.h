@@ -245,6 +245,24 @@ static inline hipemu_f32x16 pidm_mfma_bf16_32x32x16(hipemu_u32x4 a, hipemu_u32x4
   hipemu::wave_sync();
   return c;
 }
+// v_permlane32_swap / v_permlane16_swap (gfx950): rows (16 lanes) 2,3 of the first operand <-> rows 0,1 of the second; odd rows
+// of the first <-> even rows of the second.  Returns {new first, new second}.
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2 hipemu_permlane_swap(unsigned a, unsigned b, int dist) {
+  const int l = hipemu::lane_id();
+  const bool upper = (l & dist) != 0;
+  const uint64_t mine = (uint64_t)a | ((uint64_t)b << 32);
+  const uint64_t other = hipemu::exchange(mine, l ^ dist);
+  hipemu_u32x2 r;
+  if (upper) { r[0] = (unsigned)(other >> 32); r[1] = b; }      // first operand's upper part receives the partner's second operand
+  else { r[0] = a; r[1] = (unsigned)(other & 0xffffffffu); }    // second operand's lower part receives the partner's first operand
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu_permlane_swap((a), (b), 32)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane_swap((a), (b), 16)
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+  return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
+}
 // v_readfirstlane_b32: lane 0's value for the whole wave (kernels use it to tell the compiler a value is wave-uniform)
 static inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)

@@ -67,7 +67,8 @@ PERSIST_CASES = [   # 3x3 convs walked persistently (several m-tiles per workgro
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", PERSIST_CASES)
 def test_conv_3x3_persistent(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     monkeypatch.setenv("PIDM_PERSIST_SLOTS", "3")
-    monkeypatch.setenv("PIDM_CONV_STREAM", "0")          # the streaming kernel would take the eligible shapes
+    monkeypatch.setenv("PIDM_CONV_STREAM", "0")          # the streaming / split kernels would take the eligible shapes
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
@@ -83,7 +84,28 @@ STREAM3_CASES = [   # the streaming persistent 3x3 kernel (two LDS buffers, one 
 @pytest.mark.parametrize("wgs", ["5", "256"])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM3_CASES)
 def test_conv_3x3_streaming(backend, monkeypatch, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """The fp32-MFMA streaming kernel and the row-staged fp32 wgrad (the split forms off)."""
     monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
+    monkeypatch.setenv("PIDM_WGRAD_SPLIT", "0")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+SPLIT_CASES = STREAM3_CASES[:4] + [
+    (5, 8, 32, 0, 64, 3, 1, 1, 0),       # 8x8 images, ragged batch, two n-tiles
+    (2, 16, 64, 32, 32, 3, 1, 1, 0),     # concat source with unequal parts, 6 chunks of 16 channels
+]
+
+
+@pytest.mark.parametrize("nw,wgs,p,maxns", [("8", "3", "256", "2"), ("4", "256", "128", "1"), ("4", "2", "256", "3")])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", SPLIT_CASES)
+def test_conv_3x3_split_forms(backend, monkeypatch, nw, wgs, p, maxns, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """3x3 forward / dgrad / wgrad on the bf16 matrix pipe with 3-piece operands: both tile sizes of each kernel, several work
+    items per workgroup (forward) and several tiles per split (wgrad); same tolerance as the fp32-MFMA kernels."""
+    monkeypatch.setenv("PIDM_SPLIT_NW", nw)
+    monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
+    monkeypatch.setenv("PIDM_WGRAD_SPLIT_P", p)
+    monkeypatch.setenv("PIDM_WGRAD_SPLIT_MAXNS", maxns)
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
@@ -91,6 +113,8 @@ def test_conv_3x3_streaming(backend, monkeypatch, wgs, B, H, C0, C1, Cout, K, st
 def test_conv_3x3_streaming_off_matches(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     """PIDM_CONV_STREAM=0 keeps the older tilings reachable (A/B measurements)."""
     monkeypatch.setenv("PIDM_CONV_STREAM", "0")
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
+    monkeypatch.setenv("PIDM_WGRAD_SPLIT", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
@@ -106,6 +130,7 @@ MT2_CASES = [   # 3x3 convs on the 256-pixel workgroup tile (two m-tiles per wav
 def test_conv_3x3_two_mtiles_per_wave(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     monkeypatch.setenv("PIDM_MT2_MIN_WGS", "1")
     monkeypatch.setenv("PIDM_CONV_STREAM", "0")
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 

@@ -1568,7 +1568,7 @@ __device__ __forceinline__ int wgs_xrow_bytes(const ConvGeom& g) {
 template <int P>
 __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
                                                                const float* __restrict__ dy, float* __restrict__ partial,
-                                                               float* __restrict__ bias_partial) {
+                                                               float* __restrict__ bias_partial, int trace) {
   constexpr int NQ = 4, KS = P / (16 * NQ), NSLOT = (P == 256) ? 7 : 4, NWV = 12;
   const ConvGeom& g = wg.g;
   HIP_DYNAMIC_SHARED(float, smemf)
@@ -1587,6 +1587,10 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
   const int SEG8 = (g.NI * g.IHt * g.Wv) >> 3;       // 8-pixel groups of the X halo tile (whole rows), then P / 8 groups of dY
 
   // ---- staging slots: wave-slot j = wave + 12 k is an 8-pixel x 32-channel group of X (j < SEG8) or of dY ----
+  // Channel c = 4 q + la of a tile lives in LDS row q + 8 la: the 16 lanes a ds_write_b64 serves per cycle have one la and all 8 q,
+  // i.e. 8 consecutive rows (rows of 16 x odd bytes: every bank once), where rows 4 q + la would put them on two bank groups
+  // (4-way conflict).  The MFMA operands are read by LDS row, so the accumulator's row / column r stands for channel
+  // 4 (r & 7) + (r >> 3); the final write to the partial slab undoes the permutation.
   const int q = lane & 7, pb = (lane >> 3) & 1, la = lane >> 4;      // channel quad, pixel bit 2, pixel bits 0-1
   const char* xbase = reinterpret_cast<const char*>((n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0));   // n-tile = one source (C0 % 32 == 0)
   const char* ybase = reinterpret_cast<const char*>(dy + m0);
@@ -1601,14 +1605,14 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
       s_kind[k] = 1;
       s_img[k] = fast_div(sr, g.IHt, g.mIHt);
       s_row[k] = sr - s_img[k] * g.IHt;
-      lds_off[k] = (4 * q + la) * XROW + (sr * RW + 8 + x0 + 4 * pb) * 2;
+      lds_off[k] = (q + 8 * la) * XROW + (sr * RW + 8 + x0 + 4 * pb) * 2;
       g_vo[k] = (unsigned)((x0 + 4 * pb + la) * g.ld0 + 4 * q) * 4u;
     } else if (j < SEG8 + P / 8) {
       const int p0 = 8 * (j - SEG8);
       s_kind[k] = 2;
       s_img[k] = p0 >> (g.wsh + g.tsh);
       s_row[k] = (p0 >> g.wsh) & (g.TH - 1);
-      lds_off[k] = 96 * XROW + (4 * q + la) * YROW + (p0 + 4 * pb) * 2;
+      lds_off[k] = 96 * XROW + (q + 8 * la) * YROW + (p0 + 4 * pb) * 2;
       g_vo[k] = (unsigned)(((p0 & (g.Wv - 1)) + 4 * pb + la) * wg.ld_dy + 4 * q) * 4u;
     } else {
       s_kind[k] = 0; s_img[k] = 0; s_row[k] = 0; lds_off[k] = 0; g_vo[k] = 0;
@@ -1654,8 +1658,15 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
   const int tile_lo = split * wg.tiles_per_split;
   const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
   if (tile_lo < tile_hi) PIDM_WS_PREFETCH(tile_lo)
+  // PIDM_STREAM_TRACE=1: cycle stamps of workgroup (0,0), wave 0: [0] kernel entry, then per tile 5 stamps (top, past barrier 1,
+  // staged, past barrier 2, k-steps done), then the end of the kernel
+  const bool tr_on = trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  int tr_n = 1;
+  if (tr_on) g_stream_trace[0] = clock64();
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
     __syncthreads();
+    if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
     // ---- registers -> LDS: 4x4 transpose across lane bits 4-5, split, three 8-byte stores ----
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
@@ -1683,7 +1694,9 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
         *reinterpret_cast<u32x2_t*>(d + 2 * ps) = u32x2_t{a2, b2};
       }
     }
+    if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
     __syncthreads();
+    if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
     if (tile + 1 < tile_hi) PIDM_WS_PREFETCH(tile + 1)
     // ---- the wave's k-steps: 3 dY fragments, 3 x (aligned X chunk + dword before + dword after), 18 MFMAs ----
 #pragma unroll
@@ -1712,6 +1725,7 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
       PIDM_WS_SIX(acc[2], xr)
 #undef PIDM_WS_SIX
     }
+    if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
   }
 #undef PIDM_WS_PREFETCH
   // ---- sum of the 4 pixel quarters through LDS, then the split's partial slab ----
@@ -1726,7 +1740,8 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
     const int tap = e >> 10, el = e & 1023, kyo = tap / 3, kxo = tap - 3 * kyo;
     const float* rp = red + ((kyo * 4) * 3 + kxo) * 1024 + el;
     const float sv = (rp[0] + rp[3 * 1024]) + (rp[6 * 1024] + rp[9 * 1024]);
-    partial[(((size_t)split * wg.MP + (m0 + (el >> 5))) * 9 + tap) * wg.NP + n0 + (el & 31)] = sv;
+    const int rr_ = el >> 5, cc_ = el & 31;
+    partial[(((size_t)split * wg.MP + (m0 + 4 * (rr_ & 7) + (rr_ >> 3))) * 9 + tap) * wg.NP + n0 + 4 * (cc_ & 7) + (cc_ >> 3)] = sv;
   }
   if (do_bias) {
     __syncthreads();
@@ -1740,6 +1755,7 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
       bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
     }
   }
+  if (tr_on) { g_stream_trace[tr_n] = clock64(); g_stream_trace[255] = (unsigned long long)tr_n; }
 }
 
 // wgrad for convolutions with very few input channels (the 7x7 init conv: Cin = 2 or 10): the GEMM N dimension is
@@ -2722,9 +2738,9 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
     }
     if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv_wgrad_split_kernel<%d>, %d splits x %d blocks, %d tiles each, %zu B LDS\n", P, wg.nsplit, grid.y, wg.tiles_per_split, lds);
     if (P == 256)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<128>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<128>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
     *used = wg;
     return true;
   }

@@ -7,6 +7,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; B=${1:-64}
 export TMPDIR=/tmp PYTHONPATH=$R; out=$R/gpurun_out/pmc_traffic; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 180 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o p -- \
-      python $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --calib-copy > $out/$c.log 2>&1)
+      python $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-roofline --no-alt --calib-copy > $out/$c.log 2>&1)
 done
 python $R/tools/pmc_traffic_report.py $out $B | tee $out/summary.txt

@@ -6,7 +6,7 @@ printed next to the result so the correction can be judged on this very run."""
 import collections, csv, glob, json, sys
 
 d, batch = sys.argv[1], int(sys.argv[2])
-CLASSES = [("conv_igemm", "conv"), ("conv3x3_stream", "conv"), ("conv_wgrad", "conv"), ("lap_", "attn"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
+CLASSES = [("conv_igemm", "conv"), ("conv3x3_stream", "conv"), ("conv3x3_split", "conv"), ("conv_wgrad", "conv"), ("lap_", "attn"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
            ("pack_", "conv_aux"), ("clip_adam", "optimizer"), ("sqsum", "optimizer"),
            ("colsum", "conv_aux"), ("gn_", "norm"), ("layernorm", "norm"), ("la_", "attn"), ("mid_attn", "attn"),
            ("darcy", "darcy"), ("qsample", "darcy")]

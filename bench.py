@@ -41,6 +41,7 @@ FLOPS_PER_SAMPLE_FWD = 3.98e9         # Darcy dim=32 forward only (sampling)
 FLOPS_PER_SAMPLE_MECH = 141.39e9      # mechanics dim=128, 10->3 channels, fwd+bwd (FlopCounterMode on the reference)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+LOG_FREQ = 20                         # main.py:153
 
 
 def parse():
@@ -55,6 +56,8 @@ def parse():
                                                        "(folded into the Adam kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-scalars", action="store_true", help="model_estimation_loss returns python floats every step (the "
+                    "reference's types: one host sync per step) instead of floats that synchronise when read")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra run with the 3x3 convolutions on the fp32 MFMA")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused flat clip+Adam kernel (same math)")
@@ -221,6 +224,9 @@ def main():
     torch.manual_seed(1234 + rank)
     chain = {"x": torch.randn(B, 2, 64, 64, device=dev), "i": 999} if not train else None
 
+    diffusion.deferred_scalars = not args.eager_scalars
+    counter = {"it": 0, "last": None}
+
     def step():
         if not train:
             # one ancestral step of the whole batch (src/denoising_utils.py:388-455); the chain restarts at t = 999 when it ends
@@ -228,7 +234,10 @@ def main():
             chain["x"] = nx
             chain["i"] = chain["i"] - 1 if chain["i"] > 0 else 999
             return nx
-        loss, *_ = diffusion.model_estimation_loss(batch, residual_func=residuals, **loss_kw)
+        loss, *tracked = diffusion.model_estimation_loss(batch, residual_func=residuals, **loss_kw)
+        counter["it"] += 1
+        if counter["it"] % LOG_FREQ == 0:      # main.py:167-175: the tracked loss terms are read every log_freq = 20 iterations
+            counter["last"] = [float(v) for v in tracked]
         optimizer.zero_grad()
         loss.backward()
         if exchange is not None:
@@ -351,6 +360,9 @@ def main():
         if train:
             cfg["optimizer"] = "torch clip_grad_norm_+Adam" if args.torch_optimizer else "fused flat clip+Adam (k_optim.hip)"
             cfg["ema_in_step"] = bool(args.ema)
+            cfg["loss_scalars"] = ("python floats every step (host sync per step)" if args.eager_scalars else
+                                   "computed and copied to the host every step, read every 20 steps as main.py:167-175 does "
+                                   "(DenoisingDiffusion.deferred_scalars)")
         else:
             cfg["seconds_per_1000_step_chain"] = round(ms_per_step, 2)
         out = {

@@ -108,6 +108,7 @@ def main():
     ema.register(model)
     optimizer = FusedClipAdam(model, lr=args.lr, max_norm=1., image_size=64, ema=ema, ema_start=args.ema_start)
     exchange = GradientExchange(model, world, diffusion=diffusion)
+    diffusion.deferred_scalars = True       # the tracked loss terms synchronise when they are printed (every log_freq iterations)
     torch.manual_seed(args.seed + 1000 * (rank + 1))        # per-rank (t, eps) streams
     out_dir = f'./trained_models/{args.name}'
     loss_kw = dict(c_data=config['c_data'], c_residual=config['c_residual'], c_ineq=config['c_ineq'], lambda_opt=config['lambda_opt'])

@@ -330,3 +330,49 @@ def test_undifferentiated_losses_do_not_pile_up_engines(backend):
     with torch.no_grad():
         m(x0.permute(0, 2, 3, 1).reshape(2, 256, 2).contiguous(), torch.tensor([1, 2], device=dev))
     assert len(m._engines) == n_engines            # inference after released tapes: no sibling engine needed
+
+
+def test_deferred_float_behaves_like_a_float():
+    """DenoisingDiffusion.deferred_scalars: the tracked loss terms are objects that synchronise when first used."""
+    from physicsinformeddiffusionmodels_amd.denoising_utils import DeferredFloat
+
+    class Src:
+        def __init__(self):
+            self.calls = 0
+
+        def values(self):
+            self.calls += 1
+            return [[1.5, 2.5], [3.0, -4.0]]
+
+    src = Src()
+    d = DeferredFloat(src, (1, 1))
+    assert src.calls == 0                       # nothing is read at construction
+    assert float(d) == -4.0 and f"{d:.1e}" == "-4.0e+00" and abs(d) == 4.0 and d + 1 == -3.0 and 2 * d == -8.0
+    assert d < 0 and d == -4.0 and d.item() == -4.0 and repr(d) == "-4.0"
+    assert DeferredFloat(src, (0, 0)) * 2 == 3.0
+
+
+@pytest.mark.gpu
+def test_deferred_scalars_equal_eager_scalars():
+    """Same step twice (same seed): python floats (reference types) and deferred floats carry the same values; the loss tensor is
+    identical."""
+    import torch
+    from oracle import pidm_oracle as O
+    from physicsinformeddiffusionmodels_amd.denoising_utils import DeferredFloat, DenoisingDiffusion
+    from physicsinformeddiffusionmodels_amd.residuals_darcy import ResidualsDarcy
+    from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+    dev = torch.device("cuda:0")
+    m = Unet3D(dim=8, channels=2)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    diff = DenoisingDiffusion(100, dev)
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=16, pixels_at_boundary=True, reverse_d1=True, device=dev)
+    x0 = torch.randn(4, 2, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    outs = []
+    for deferred in (False, True):
+        diff.deferred_scalars = deferred
+        torch.manual_seed(11)
+        loss, d, r, q, o = diff.model_estimation_loss(x0, residual_func=res, c_data=1., c_residual=1e-3)
+        assert isinstance(d, DeferredFloat) == deferred and isinstance(r, DeferredFloat) == deferred
+        outs.append((loss.item(), float(d), float(r)))
+    assert outs[0] == outs[1]

@@ -939,8 +939,11 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   for (int k = 0; k < NB; ++k) PIDM_SP_LOAD_B(k)
   __syncthreads();
 
-  f32x16 acc;
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // two accumulators (even / odd taps), added once per tile: every MFMA rounds its sum into the accumulator, so the error grows
+  // with the number of additions into ONE register - two chains keep it at the level of the fp32-MFMA kernels
+  // (tests/test_kernels_conv.py: test_split_form_is_as_accurate_as_the_fp32_mfma)
+  f32x16 acc, accb;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
   // PIDM_STREAM_TRACE=1: cycle stamps of workgroup 0, waves 0 and 4 (one SIMD): [wave][stage < 32][top, taps done, epilogue done, past barrier]
   const int tr_base = (trace && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) ? (wave >> 2) * 128 : -1;
   for (int s = 0; s < nst; ++s) {
@@ -970,12 +973,21 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       const int cur = t & 1;
       if (t + 1 < T) PIDM_SP_FRAGS(cur ^ 1, t + 1)
       // small terms first
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], acc);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
+      if (t & 1) {
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
+      } else {
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
+      }
       // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
       if (t == 0) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
       if (t == 1) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
@@ -995,6 +1007,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     //      residual, 16-byte stores), accumulator restarts ----
     const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
     if (ch == NCH - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += accb[r];
       const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
       const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
       const int c = n0 + l31;
@@ -1035,7 +1049,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
           *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
         }
       }
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
     }
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 2] = clock64();
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free

@@ -238,3 +238,42 @@ def test_conv_epilogue_groupnorm_partials(backend, B, H, C0, C1, Cout, groups):
     # per chunk: 32 consecutive pixels of one image
     ck = rg.reshape(B, groups, cpg, chunks_max, 32).sum(dim=(2, 4)).permute(0, 2, 1)
     assert (pc[..., 0] - ck).abs().max().item() < 1e-4 * ck.abs().max().item()
+
+
+def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
+    """The 3-piece / 6-term bf16 form against a float64 convolution, next to the fp32-MFMA kernels on the same data (K = 576):
+    forward, input-gradient and weight-gradient errors of the split form stay within 1.25x of the fp32-MFMA kernels' and below
+    2e-6 of the result's scale (measured on an MI355X: see profiles/r02_split_conv_notes.txt)."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(99)
+    B, H, Cin, Cout = 2, 32, 64, 64
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=1)
+    ref.backward(dy.double())
+    x0, dyn, wd_ = nhwc(x).to(dev), nhwc(dy).to(dev), w.to(dev)
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=Cout)
+    errs = {}
+    for form in ("split", "fp32"):
+        monkeypatch.setenv("PIDM_CONV_SPLIT", "1" if form == "split" else "0")
+        monkeypatch.setenv("PIDM_WGRAD_SPLIT", "1" if form == "split" else "0")
+        wp = torch.empty(L.pidm_conv_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wp), 0, st))
+        out = torch.empty(B, H, H, Cout, device=dev)
+        L.check(L.pidm_conv_forward(d, ptr(x0), None, ptr(wp), None, None, ptr(out), st))
+        wdg = torch.empty(L.pidm_conv_dgrad_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wdg), 1, st))
+        dx = torch.empty(B, H, H, Cin, device=dev)
+        L.check(L.pidm_conv_dgrad(d, ptr(dyn), Cout, ptr(wdg), None, ptr(dx), Cin, st))
+        ws = torch.empty(L.pidm_conv_wgrad_ws(d), dtype=torch.uint8, device=dev)
+        dw = torch.empty_like(wd_)
+        L.check(L.pidm_conv_wgrad(d, ptr(x0), None, ptr(dyn), Cout, ptr(dw), None, ptr(ws), st))
+        errs[form] = [float((a.double().cpu() - b).abs().max() / b.abs().max()) for a, b in
+                      ((out, nhwc(ref.detach())), (dx, nhwc(xr.grad)), (dw, wr.grad))]
+    print("max error / max |reference| (forward, dgrad, wgrad):", errs)
+    for e_split, e_fp32, what in zip(errs["split"], errs["fp32"], ("forward", "dgrad", "wgrad")):
+        assert e_split < 1.25 * e_fp32 + 1e-8, (what, errs)
+        assert e_split < 2e-6, (what, errs)

@@ -810,6 +810,9 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 // The pipeline is the one of conv3x3_stream_kernel: stage s computes from buffer s&1 while the registers loaded during stage
 // s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
 // ---------------------------------------------------------------------------------------------------
+#ifndef PIDM_SPLIT_ABLATE
+#define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging
+#endif
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 static constexpr int kSplitSlab = 9 * 32 * 96;        // bytes of pre-split weights per stage
 
@@ -959,8 +962,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)(((t_) / 3) * g.IWt + ((t_) % 3)) * RB);      \
     const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
-      fa[set_][p] = ar__[p];                                                                                       \
-      fb[set_][p] = br__[p];                                                                                       \
+      if (!(PIDM_SPLIT_ABLATE & 2) || (t_) == 0) fa[set_][p] = ar__[p]; else fa[set_][p] = fa[(set_) ^ 1][p];      \
+      if (!(PIDM_SPLIT_ABLATE & 1) || (t_) == 0) fb[set_][p] = br__[p]; else fb[set_][p] = fb[(set_) ^ 1][p];      \
     }                                                                                                              \
   }
     PIDM_SP_FRAGS(0, 0)
@@ -989,9 +992,9 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
         acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
       }
       // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
-      if (t == 0) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
-      if (t == 1) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
-      if (t >= 2) {
+      if (t == 0 && !(PIDM_SPLIT_ABLATE & 4)) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
+      if (t == 1 && !(PIDM_SPLIT_ABLATE & 4)) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
+      if (t >= 2 && !(PIDM_SPLIT_ABLATE & 8)) {
 #pragma unroll
         for (int k = 2 * (t - 2); k < 2 * (t - 2) + 2; ++k) {
           if (k < NB - 1) PIDM_SP_WRITE_B(k, bufn)

@@ -969,8 +969,9 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     PIDM_SP_FRAGS(0, 0)
     // Measured and left out (tools/split_variants.py, profiles/r02_split_conv_notes.txt): staggering the staging pieces between
     // the two waves of a SIMD (either as two copies of the tap loop or only the two VALU-heavy pieces) and alternating
-    // s_setprio per tap - all within +-3 % or slower.  The stage is bound by the LDS (54 ds_read_b128 + ~10 ds_write_b128 per
-    // wave = ~2800 LDS-array cycles of the 3780 matrix-pipe cycles), not by VALU issue.
+    // s_setprio per tap or around the MFMAs - all within +-3 % or slower.  Ablation (tools/split_ablate.py): without the staging a
+    // stage runs at the matrix pipe's 3780 cycles, with it ~5800 - fragment reads, barrier and arbitration are free, the staging
+    // (loads, split arithmetic, LDS writes) is what the hardware does not hide under the other wave's MFMAs.
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int cur = t & 1;

@@ -171,10 +171,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("PIDM_BENCH_FORCE_EXCHANGE") == "1"    # debug: one rank, but the RCCL exchange path runs
+    if world > 1 or force_dp:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dp and world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group(backend="gloo")
         else:
@@ -220,7 +225,7 @@ def main():
         else:
             from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
             optimizer = FusedClipAdam(model, lr=n_lr, max_norm=1., image_size=64, ema=ema, ema_start=-1)   # clip_grad_norm_(1.) + Adam
-        exchange = GradientExchange(model, world, diffusion=diffusion) if world > 1 else None
+        exchange = GradientExchange(model, world, diffusion=diffusion, force=force_dp) if (world > 1 or force_dp) else None
     torch.manual_seed(1234 + rank)
     chain = {"x": torch.randn(B, 2, 64, 64, device=dev), "i": 999} if not train else None
 
@@ -371,9 +376,16 @@ def main():
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
             "fp32_mfma_only": alt,
         }
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its banner through C stdio (block-buffered when stdout is a pipe): flush it first so that the JSON line is
+        # the last line of the output
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

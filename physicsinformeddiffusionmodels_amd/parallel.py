@@ -71,9 +71,11 @@ class GradientExchange:
     data-parallel exact (it needs the world size for one scalar all-reduce)."""
 
     def __init__(self, model, world_size: int | None = None, image_size: int = 64, buckets: int = 3, group=None, lib=None,
-                 diffusion=None):
+                 diffusion=None, force: bool = False):
         self.model, self.group = model, group
         self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
+        # force: run the collectives even with one rank (exercises RCCL, the side stream and the phase events on a single-GPU box)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.eng = get_engine(model, image_size, lib)
         self.buckets = max(1, min(3, int(os.environ.get("PIDM_DP_BUCKETS", buckets))))
         if diffusion is not None:
@@ -103,7 +105,7 @@ class GradientExchange:
         self.on_gpu = dev.type == "cuda"
         self.events, self.stream = None, None
         handles = None
-        if self.on_gpu and self.world > 1 and os.environ.get("PIDM_DP_NO_OVERLAP") != "1":
+        if self.on_gpu and self.active and os.environ.get("PIDM_DP_NO_OVERLAP") != "1":
             try:
                 self.stream = torch.cuda.Stream(device=dev)
                 self.events = [torch.cuda.Event(enable_timing=False) for _ in range(self.buckets)]
@@ -120,7 +122,7 @@ class GradientExchange:
         """Average the gradients over all ranks (in place).  Call right after loss.backward()."""
         eng = self.eng
         calls, eng.backward_calls = eng.backward_calls, 0
-        if self.world == 1:
+        if not self.active:
             return
         flat = eng.flat_grad
         if flat is None:

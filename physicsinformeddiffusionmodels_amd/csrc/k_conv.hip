@@ -1924,6 +1924,58 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// out[m][n] = sum_k A[m][k] W[n][k] for FEW rows m and a very long k (the input gradient of the concatenated FiLM linears:
+// M = batch, N = time dimension, K = sum of 2 Cout over all resblocks = 3968 / 15872): as an implicit GEMM that is 4 workgroups
+// walking 124 chunks each (134 us for 65 MFLOP).  Here K is split over workgroups of 128 columns each; partial[split][M][N] is
+// summed in fixed order by wgrad_reduce_kernel.  grid = (k splits, N / 32, ceil(M / 32)); the 4 waves take a quarter of the
+// 128 columns each (k-slots permuted: one 16-byte LDS read feeds four MFMAs) and are summed through LDS.
+__global__ void __launch_bounds__(256) smallm_splitk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                            float* __restrict__ partial, int M, int N, int K, int MP, int NP) {
+  constexpr int KC = 128, KP = KC + 4;
+  __shared__ float As[32 * KP], Ws[32 * KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int k0 = blockIdx.x * KC, n0 = blockIdx.y * 32, m0 = blockIdx.z * 32;
+  for (int e = tid; e < 32 * (KC / 4); e += 256) {
+    const int row = e / (KC / 4), q = e - row * (KC / 4), k = k0 + 4 * q;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {       // K % 4 == 0
+      if (m0 + row < M) a = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + row) * lda + k);
+      if (n0 + row < N) w = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + row) * ldw + k);
+    }
+    *reinterpret_cast<f32x4*>(As + row * KP + 4 * q) = a;
+    *reinterpret_cast<f32x4*>(Ws + row * KP + 4 * q) = w;
+  }
+  __syncthreads();
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g8 = 0; g8 < 4; ++g8) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(As + l31 * KP + 32 * wave + 8 * g8 + 4 * half);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(Ws + l31 * KP + 32 * wave + 8 * g8 + 4 * half);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], w4[i], acc, 0, 0, 0);
+  }
+  __syncthreads();
+  float* red = As;       // [4][1024] needs 4096 floats: As (4224) suffices
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) {
+    const float sv = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    partial[((size_t)blockIdx.x * MP + m0 + (e >> 5)) * NP + n0 + (e & 31)] = sv;
+  }
+}
+size_t smallm_splitk_ws_floats(int M, int N, int K) { return (size_t)cdiv(K, 128) * (cdiv(M, 32) * 32) * (cdiv(N, 32) * 32) + 64; }
+bool smallm_splitk_ok(int M, int N, int K, int lda, int ldw) {
+  return M <= 512 && K >= 1024 && (K % 4) == 0 && (lda % 4) == 0 && (ldw % 4) == 0 && (N % 32) == 0;
+}
+int launch_smallm_splitk(const float* A, int lda, const float* W, int ldw, float* out, int M, int N, int K, float* scratch, hipStream_t st) {
+  const int ks = cdiv(K, 128), MP = cdiv(M, 32) * 32, NP = cdiv(N, 32) * 32;
+  hipLaunchKernelGGL(smallm_splitk_kernel, dim3(ks, NP / 32, MP / 32), dim3(256), 0, st, A, lda, W, ldw, scratch, M, N, K, MP, NP);
+  PIDM_CHECK_LAUNCH("smallm_splitk_kernel");
+  return launch_split_reduce(scratch, out, nullptr, nullptr, ks, M, N, 1, MP, NP, st);
+}
+
 // 1x1 (stride 1) weight gradient without LDS and without barriers: dW[m][n] = sum_p dY[p][m] X[p][n] is a pure stream over
 // the pixels - a wave reads its own MFMA fragments straight from global memory (32 consecutive channels = one 128-byte
 // line per pixel and operand; every dY element is used exactly once per n-tile) and keeps UNR independent loads per
@@ -2296,6 +2348,11 @@ static int pick_nt(int Cout, int tiles_m) {
 // packed weights always pad Cout to a multiple of 64 so that either tile width can read them
 static int packed_np(int Cout) { return cdiv(Cout, 64) * 64; }
 
+// K columns of one packed weight row (the leading dimension of the fp32 packing)
+int packed_kp(const ConvGeom& g) {
+  const int KC = pick_kc(g.Cin);
+  return cdiv(g.Kw, KC) * KC;
+}
 static size_t packed_fp32_floats(const ConvGeom& g) {
   const int KC = pick_kc(g.Cin);
   const size_t Np = (size_t)packed_np(g.Cout), Kp = (size_t)cdiv(g.Kw, KC) * KC;

@@ -31,6 +31,7 @@ int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int 
               int stride, int pad, int out_nchw, int ldo, int ldr);
 int geom_dgrad(const pidm_conv_desc* d, int ld_dy, int ld_dx, ConvGeom* g, int* pack_kind);
 size_t packed_floats(const ConvGeom& g);
+int packed_kp(const ConvGeom& g);
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,
                 int n_src, int k_src, hipStream_t st);
 unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off,
@@ -38,6 +39,10 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
 int launch_pack_multi(const PackDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st);
 int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias,
                 const float* residual, float* out, int sigmoid_last, hipStream_t st);
+// out[m][n] = sum_k A[m][k] W[n][k], few rows, very long k: split-K over workgroups + fixed-order reduction (k_conv.hip)
+size_t smallm_splitk_ws_floats(int M, int N, int K);
+bool smallm_splitk_ok(int M, int N, int K, int lda, int ldw);
+int launch_smallm_splitk(const float* A, int lda, const float* W, int ldw, float* out, int M, int N, int K, float* scratch, hipStream_t st);
 size_t wgrad_ws_bytes(const ConvGeom& g);
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
                  float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer = nullptr);

@@ -1088,7 +1088,20 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     float* part = r.part_alloc(wgrad_ws_bytes(g));
     RUN(launch_wgrad(g, U->st, nullptr, dss, U->ss_total, U->G[0], U->G[nf], part, r.st, r.q()));
     float* d_st = r.tmp.alloc((size_t)B * td);
-    if (conv_dgrad(r, U->lincat, dss, nullptr, d_st)) return -1;
+    {
+      // d_st[b][n] = sum_k dss[b][k] W[n][k] with k over all FiLM outputs (3968 / 15872) and only B rows: split-K kernel
+      pidm_conv_desc dd = desc_of(U->lincat, B);
+      ConvGeom gd;
+      int kind;
+      if (geom_dgrad(&dd, U->lincat.Cout, U->lincat.C0, &gd, &kind)) return -1;
+      const int Kp = packed_kp(gd);
+      if (smallm_splitk_ok(B, td, U->ss_total, U->ss_total, Kp)) {
+        float* sc = r.tmp.alloc(smallm_splitk_ws_floats(B, td, U->ss_total));
+        RUN(launch_smallm_splitk(dss, U->ss_total, r.wpack + U->lincat.off_d, Kp, d_st, B, td, U->ss_total, sc, r.st));
+      } else if (conv_dgrad(r, U->lincat, dss, nullptr, d_st)) {
+        return -1;
+      }
+    }
     float* d_temb = r.tmp.alloc((size_t)B * td);
     RUN(launch_act_bwd(U->temb, d_st, d_temb, (size_t)B * td, 0, r.st));
     if (conv_wgrad(r, U->lin2, U->h1g, nullptr, d_temb)) return -1;

@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 #define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging
 #endif
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
-static constexpr int kSplitSlab = 9 * 32 * 96;        // bytes of pre-split weights per stage
+static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
                                                             const float* __restrict__ residual, float* __restrict__ out, int n_items,
                                                             int items_per_wg, int trace) {
   constexpr int RB = kSplitRow, T = 9, NT = 64 * NW;        // NW waves: 8 (256-pixel tile, two waves per SIMD) or 4 (128 pixels)
-  constexpr int NB = (1728 + NT - 1) / NT;                  // 16-byte pieces of the weight slab per thread: 4 / 7, the last for 3 waves
+  constexpr int NB = 32 / NW;                               // 1 KB pieces of the weight slab per wave (31.5 KB: the last one is half)
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const int half = lane >> 5, l31 = lane & 31;
   const int z = 0;
   const int npixA = g.NI * g.IHt * g.IWt;
-  const int bufsz = (npixA + T * 32) * RB;             // bytes per buffer: halo tile | 9 x 32 weight rows
+  const int bufsz = (npixA + T * 32) * RB + 512;       // bytes per buffer: halo tile | 9 x 32 weight rows | spill of the last 1 KB piece
   const int tpi = g.Hv / g.TH;
   const int NCH = g.Cin >> 4;
   const int item0 = blockIdx.x * items_per_wg;
@@ -862,16 +862,11 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     a_im[k] = img;
     a_hy[k] = hy;
   }
-  // Weight staging: the stage's slab is 1728 16-byte pieces, row r = q / 6; pieces tid + NT k, the last one for 192 threads
-  int b_lds[NB];
-  unsigned b_vo[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    int q = tid + NT * k;
-    if (q > 1727) q = 1727;
-    b_lds[k] = (npixA + q / 6) * RB + 16 * (q % 6);
-    b_vo[k] = 16u * q;
-  }
+  // Weight staging: the stage's slab (pre-split, rows already padded to 112 bytes: an image of the LDS rows) is copied by
+  // global_load_lds_dwordx4 - 1 KB per wave and instruction straight into the buffer being filled, no registers, no ds_write;
+  // the __syncthreads() at the end of the stage drains it (vmcnt) together with everything else
+  const int b_reg = npixA * RB;                          // byte offset of the weight rows inside a buffer
+  const unsigned b_lane = 16u * lane;
 
   // zero halo columns of both buffers
   for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += NT) {
@@ -881,7 +876,6 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   }
 
   f32x4 ra[2][2];
-  u32x4 rb[NB];
   float akeep[2] = {0.f, 0.f};
   const char* l_sp = reinterpret_cast<const char*>(src0);
   const char* l_wn = reinterpret_cast<const char*>(ws);
@@ -909,7 +903,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     ra[k_][1] = p__[1];                                                                                            \
     akeep[k_] = ok__ ? 1.f : 0.f;                                                                                  \
   }
-#define PIDM_SP_LOAD_B(k_) rb[k_] = *reinterpret_cast<const u32x4*>(l_wn + b_vo[k_]);
+#define PIDM_SP_COPY_B(k_, wn_, buf_) pidm_glds_b128((wn_) + 1024 * (wave + NW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (wave + NW * (k_)));
 #define PIDM_SP_WRITE_A(k_, buf_)                                                                                  \
   {                                                                                                                \
     const f32x4 v0__ = ra[k_][0] * akeep[k_], v1__ = ra[k_][1] * akeep[k_];                                        \
@@ -923,23 +917,17 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \
     d__[2] = u32x4{q2__[0], q2__[1], q2__[2], q2__[3]};                                                            \
   }
-#define PIDM_SP_WRITE_B(k_, buf_) *reinterpret_cast<u32x4*>((buf_) + b_lds[k_]) = rb[k_];
 
   char* bufc = smem;               // buffer the MFMAs read
   char* bufn = smem + bufsz;       // buffer being filled
   PIDM_SP_STAGE(0)
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
 #pragma unroll
-  for (int k = 0; k < NB; ++k) PIDM_SP_LOAD_B(k)
+  for (int k = 0; k < NB; ++k) PIDM_SP_COPY_B(k, l_wn, bufc)
   PIDM_SP_WRITE_A(0, bufc)
   if (wave < nA1) PIDM_SP_WRITE_A(1, bufc)
-#pragma unroll
-  for (int k = 0; k < NB - 1; ++k) PIDM_SP_WRITE_B(k, bufc)
-  if (wave < 3) PIDM_SP_WRITE_B(NB - 1, bufc)
   PIDM_SP_STAGE(1)
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
-#pragma unroll
-  for (int k = 0; k < NB; ++k) PIDM_SP_LOAD_B(k)
   __syncthreads();
 
   // two accumulators (even / odd taps), added once per tile: every MFMA rounds its sum into the accumulator, so the error grows
@@ -951,7 +939,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const int tr_base = (trace && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) ? (wave >> 2) * 128 : -1;
   for (int s = 0; s < nst; ++s) {
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 0] = clock64();
-    PIDM_SP_STAGE(s + 2)           // geometry of the loads issued during this stage
+    const char* wn1 = l_wn;        // weight slab of stage s+1 (copied during this stage)
+    PIDM_SP_STAGE(s + 2)           // geometry of the activation loads issued during this stage
     // the epilogue's bias, fetched a stage ahead of its use (unconditional load, any valid address when there is no bias)
     const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[((item0 + s / NCH) / g.tiles_m) * 32 + l31];
     const char* afp = bufc + a_frag;
@@ -995,13 +984,9 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
       if (t == 0 && !(PIDM_SPLIT_ABLATE & 4)) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
       if (t == 1 && !(PIDM_SPLIT_ABLATE & 4)) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
-      if (t >= 2 && !(PIDM_SPLIT_ABLATE & 8)) {
+      if (t >= 2 && t < 6 && !(PIDM_SPLIT_ABLATE & 8)) {    // the weight copies of stage s+1, spread over taps 2..5
 #pragma unroll
-        for (int k = 2 * (t - 2); k < 2 * (t - 2) + 2; ++k) {
-          if (k < NB - 1) PIDM_SP_WRITE_B(k, bufn)
-          if (k == NB - 1) { if (wave < 3) PIDM_SP_WRITE_B(k, bufn) }
-          if (k < NB) PIDM_SP_LOAD_B(k)
-        }
+        for (int k = NB * (t - 2) / 4; k < NB * (t - 1) / 4; ++k) PIDM_SP_COPY_B(k, wn1, bufn)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1062,9 +1047,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   }
 #undef PIDM_SP_STAGE
 #undef PIDM_SP_LOAD_A
-#undef PIDM_SP_LOAD_B
+#undef PIDM_SP_COPY_B
 #undef PIDM_SP_WRITE_A
-#undef PIDM_SP_WRITE_B
 }
 
 // pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
@@ -1075,7 +1059,7 @@ static bool split_shape_ok(const ConvGeom& g) {
 __device__ __forceinline__ void split_store(unsigned short* ws, int nch, int n, int t, int k, float v) {
   unsigned p0, p1, p2;
   pidm_split3_pk(v, 0.f, p0, p1, p2);
-  const size_t o = ((((size_t)(n >> 5) * nch + (k >> 4)) * 9 + t) * 32 + (n & 31)) * 48 + ((k >> 3) & 1) * 24 + (k & 7);
+  const size_t o = ((((size_t)(n >> 5) * nch + (k >> 4)) * 9 + t) * 32 + (n & 31)) * (kSplitRow / 2) + ((k >> 3) & 1) * 24 + (k & 7);
   ws[o] = (unsigned short)(p0 & 0xffffu);
   ws[o + 8] = (unsigned short)(p1 & 0xffffu);
   ws[o + 16] = (unsigned short)(p2 & 0xffffu);
@@ -2360,7 +2344,7 @@ static size_t packed_fp32_floats(const ConvGeom& g) {
 }
 // fp32 packing, followed by the bf16 pieces (3 x 2 bytes per weight) where conv3x3_split_kernel can take the tensor
 size_t packed_floats(const ConvGeom& g) {
-  return packed_fp32_floats(g) + (split_shape_ok(g) ? (size_t)g.Cout * g.Cin * 9 * 3 / 2 : 0);
+  return packed_fp32_floats(g) + (split_shape_ok(g) ? (size_t)(g.Cout / 32) * (g.Cin / 16) * (kSplitSlab / 4) + 128 : 0);
 }
 static unsigned short* split_part(const ConvGeom& g, float* w_packed) {
   return split_shape_ok(g) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
@@ -2617,7 +2601,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         gs = g;
         if (!retile_bm(&gs, 32 * nw)) continue;
         const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
-        const size_t lds = (size_t)2 * (npixA + 9 * 32) * kSplitRow;
+        const size_t lds = (size_t)2 * ((npixA + 9 * 32) * kSplitRow + 512);
         if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
         const int n_items = gs.tiles_m * (g.Cout / 32);
         const bool prof = prof_enabled();

@@ -77,6 +77,14 @@ __device__ __forceinline__ pidm_f32x16 pidm_mfma_bf16_32x32x16(u32x4 a, u32x4 b,
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pidm_bf16x8, a), __builtin_bit_cast(pidm_bf16x8, b), c, 0, 0, 0);
 }
 #endif
+// Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is wave-uniform base +
+// 16 * lane, the global source is per lane; completion is counted by vmcnt (a following __syncthreads() drains it).
+#ifndef PIDM_HAVE_GLDS
+__device__ __forceinline__ void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+#endif
 // the three pieces of two floats, as bf16 pairs (element 0 in the low half)
 __device__ __forceinline__ void pidm_split3_pk(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
   p0 = pidm_cvt_pk_bf16(x0, x1);

@@ -248,6 +248,11 @@ static inline hipemu_f32x16 pidm_mfma_bf16_32x32x16(hipemu_u32x4 a, hipemu_u32x4
   hipemu::wave_sync();
   return c;
 }
+// global_load_lds_dwordx4 (pidm_common.h): synchronous here
+#define PIDM_HAVE_GLDS 1
+static inline void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {
+  memcpy(static_cast<char*>(lds_base_uniform) + 16 * hipemu::lane_id(), gsrc_lane, 16);
+}
 // v_permlane32_swap / v_permlane16_swap (gfx950): rows (16 lanes) 2,3 of the first operand <-> rows 0,1 of the second; odd rows
 // of the first <-> even rows of the second.  Returns {new first, new second}.
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));

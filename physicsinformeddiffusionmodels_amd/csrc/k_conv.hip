@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 // s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
 // ---------------------------------------------------------------------------------------------------
 #ifndef PIDM_SPLIT_ABLATE
-#define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging
+#define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging, 32 = no split arithmetic
 #endif
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
@@ -908,10 +908,16 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   {                                                                                                                \
     const f32x4 v0__ = ra[k_][0] * akeep[k_], v1__ = ra[k_][1] * akeep[k_];                                        \
     unsigned q0__[4], q1__[4], q2__[4];                                                                            \
+    if (PIDM_SPLIT_ABLATE & 32) {                                                                                  \
+      _Pragma("unroll") for (int i__ = 0; i__ < 4; ++i__) {                                                        \
+        q0__[i__] = __float_as_uint(v0__[i__]); q1__[i__] = __float_as_uint(v1__[i__]); q2__[i__] = q0__[i__];     \
+      }                                                                                                            \
+    } else {                                                                                                       \
     pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
     pidm_split3_pk(v0__[2], v0__[3], q0__[1], q1__[1], q2__[1]);                                                   \
     pidm_split3_pk(v1__[0], v1__[1], q0__[2], q1__[2], q2__[2]);                                                   \
     pidm_split3_pk(v1__[2], v1__[3], q0__[3], q1__[3], q2__[3]);                                                   \
+    }                                                                                                              \
     u32x4* d__ = reinterpret_cast<u32x4*>((buf_) + a_lds[k_]);                                                     \
     d__[0] = u32x4{q0__[0], q0__[1], q0__[2], q0__[3]};                                                            \
     d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \

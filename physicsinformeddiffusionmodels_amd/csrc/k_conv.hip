@@ -799,16 +799,17 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 //
 // The fp32 MFMA tops out at ~143 TFLOP/s in practice and shares the vector ALUs with everything else a wave does
 // (tools/mfma_overlap.hip); 6 bf16 MFMAs on round-to-nearest 3-piece operands give the same product to within the fp32 MFMA's own
-// rounding error in 2.3x less matrix-pipe time (tools/mfma_bf16_probe.hip), and the VALU work of ONE wave runs under the MFMAs of
-// the OTHER wave of its SIMD.  So: 8 waves (two per SIMD), a 256-pixel x 32-channel tile (one 32x32 accumulator per wave), K
-// chunks of 16 channels x 9 taps = 54 MFMAs per wave and stage.  Activations are split on their way from global memory into
-// LDS (36 VALU per 8 channels); the weights arrive pre-split from the weight re-pack (pack_kernel: split_store), one contiguous
-// 27 KB slab per (32 output channels, 16 input channels).
+// rounding error in 2.3x less matrix-pipe time (tools/mfma_bf16_probe.hip), and the VALU work of ONE wave can run under the MFMAs
+// of the OTHER wave of its SIMD (in this kernel about 40 % of it does: tools/split_ablate.py).  So: 8 waves (two per SIMD), a
+// 256-pixel x 32-channel tile (one 32x32 accumulator pair per wave), K chunks of 16 channels x 9 taps = 54 MFMAs per wave and
+// stage.  Activations are split on their way from global memory into LDS (36 VALU per 8 channels); the weights arrive pre-split
+// from the weight re-pack (pack_kernel: split_store), one contiguous 31.5 KB slab per (32 output channels, 16 input channels)
+// that is an image of its LDS rows and is copied by global_load_lds_dwordx4.
 // LDS row (pixel of the halo tile, or weight row of a tap) = 112 bytes = [half h: piece 0 | piece 1 | piece 2][h = 1: ...][16 pad],
 // 16 bytes = 8 channels of one piece = one MFMA operand; 7 slots per row is odd, so the 16 lanes ds_read_b128 serves per cycle
 // (consecutive pixels / output channels) hit 16 different 16-byte bank groups.
-// The pipeline is the one of conv3x3_stream_kernel: stage s computes from buffer s&1 while the registers loaded during stage
-// s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
+// The pipeline is the one of conv3x3_stream_kernel: stage s computes from buffer s&1 while the activation registers loaded
+// during stage s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
 // ---------------------------------------------------------------------------------------------------
 #ifndef PIDM_SPLIT_ABLATE
 #define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging, 32 = no split arithmetic

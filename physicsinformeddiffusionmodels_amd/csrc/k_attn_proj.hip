@@ -138,6 +138,179 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
   }
 }
 
+// forward 1 in the split form (pidm_common.h: fp32 operands as three bf16 pieces, 6 bf16 MFMAs per fp32 product): the two products
+// of a tile and head are 24 MFMAs on the bf16 pipe instead of 32 on the fp32 MFMA, which runs on the vector ALUs and serialises
+// with the softmax arithmetic.  The xn slab is staged ONCE per workgroup in both operand layouts (shared by the 8 heads):
+//   XA[px][piece][c]   (c contiguous: A operand of k = xn Wk^T, lane = pixel)
+//   XT[piece][c][px]   (pixels contiguous: B operand of Mt += e^T xn, lane = channel; 4x4 register transposes at staging)
+// The exponentials leave the first product as D[px][d] with lane = d and 16 pixels per lane in accumulator-row order; they are
+// the A operand of the second product in exactly that order - k-step s takes rows 8s..8s+7, i.e. pixels 16s + 4 half + {0..3, 8..11}
+// - and the B operand follows with two 8-byte reads of XT per piece.
+static int lap_nper_split(int N, int C) {
+  int n = 256 * 32 / C;
+  while (n > 32 && N % n) n >>= 1;
+  return n;
+}
+template <int CB>
+__global__ void __launch_bounds__(512) lap_kctx_split_kernel(const float* __restrict__ xn, const float* __restrict__ wqkv,
+                                                             float* __restrict__ part, int N, int heads, int nper) {
+  constexpr int C = 32 * CB, RA = 6 * C + 16;     // bytes per XA row (pixel)
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int RT = nper * 2 + 16;                   // bytes per XT row (piece, channel)
+  char* XA = smem;
+  char* XT = smem + (size_t)nper * RA;
+  float* fs = reinterpret_cast<float*>(XT + (size_t)3 * C * RT);     // [8][32] rescale factors (wave private)
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NS = N / nper;
+  const int b = blockIdx.x / NS, ns = blockIdx.x % NS;
+  const int HD = heads * kLapDH;
+  const float* xb = xn + ((size_t)b * N + (size_t)ns * nper) * C;
+  {
+    // staging: a wave-slot = (64 / (C/4)) groups of 4 pixels x all channel quads; lane = (quad, group bit, pixel bits 4-5)
+    constexpr int QN = C / 4, GP = 16 / QN;       // quads per pixel, 4-pixel groups per wave-slot (2 for C = 32, 1 for C = 64)
+    const int q = lane & (QN - 1), pb = (lane & 15) / QN, la = lane >> 4;
+    for (int sl = wave; sl < nper / (4 * GP); sl += 8) {
+      const int px = (sl * GP + pb) * 4 + la;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)px * C + 4 * q);
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      unsigned a0, a1, a2, b0, b1, b2;
+      pidm_split3_pk(v[0], v[1], a0, a1, a2);
+      pidm_split3_pk(v[2], v[3], b0, b1, b2);
+      char* da = XA + (size_t)px * RA + 8 * q;
+      *reinterpret_cast<u32x2_t*>(da) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(da + 2 * C) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(da + 4 * C) = u32x2_t{a2, b2};
+      unsigned t0 = __float_as_uint(v[0]), t1 = __float_as_uint(v[1]), t2 = __float_as_uint(v[2]), t3 = __float_as_uint(v[3]);
+      {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(t0, t2, false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(t1, t3, false, false);
+        const auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        t0 = s01[0]; t1 = s01[1]; t2 = s23[0]; t3 = s23[1];
+      }
+      // now: channel 4 q + la, pixels (sl GP + pb) 4 + 0..3
+      pidm_split3_pk(__uint_as_float(t0), __uint_as_float(t1), a0, a1, a2);
+      pidm_split3_pk(__uint_as_float(t2), __uint_as_float(t3), b0, b1, b2);
+      char* dt = XT + (size_t)(4 * q + la) * RT + (size_t)((sl * GP + pb) * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(dt) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)C * RT) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)2 * C * RT) = u32x2_t{a2, b2};
+    }
+  }
+  __syncthreads();
+  const int h = wave;
+  if (h >= heads) return;
+  // B operand of the k tile: Wk_h[d][c], lane = d, k-step s = channels 16 s + 8 half .. + 7; pre-split once
+  u32x4 wk[C / 16][3];
+  {
+    const float* wrow = wqkv + ((size_t)HD + h * kLapDH + l31) * C + 8 * half;
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + 16 * s), w1 = *reinterpret_cast<const f32x4*>(wrow + 16 * s + 4);
+      unsigned p0[4], p1[4], p2[4];
+      pidm_split3_pk(w0[0], w0[1], p0[0], p1[0], p2[0]);
+      pidm_split3_pk(w0[2], w0[3], p0[1], p1[1], p2[1]);
+      pidm_split3_pk(w1[0], w1[1], p0[2], p1[2], p2[2]);
+      pidm_split3_pk(w1[2], w1[3], p0[3], p1[3], p2[3]);
+      wk[s][0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+      wk[s][1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      wk[s][2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    }
+  }
+  f32x16 M[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+    for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
+  float mrun = -3.0e38f, zp = 0.f;
+  float* fw = fs + wave * 32;
+#define PIDM_LAP_SIX(acc_, a_, b_)                                                                                 \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[2], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[2], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[0], acc_);
+  for (int t = 0; t < nper / 32; ++t) {
+    f32x16 kt;
+    for (int r = 0; r < 16; ++r) kt[r] = 0.f;
+    const char* arow = XA + (size_t)(t * 32 + l31) * RA + 16 * half;
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) {
+      u32x4 xa[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xa[pc] = *reinterpret_cast<const u32x4*>(arow + pc * 2 * C + 32 * s);
+      PIDM_LAP_SIX(kt, xa, wk[s])
+    }
+    // kt[px][d]: lane = d, registers = 16 of the tile's pixels.  Online softmax over pixels: column max of the tile first
+    float tm = kt[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    if (__any(tm > mrun)) {
+      const float mn = fmaxf(mrun, tm);
+      const float f = lap_exp(mrun - mn);
+      zp *= f;
+      mrun = mn;
+      if (half == 0) fw[l31] = f;
+      PIDM_WAVE_LDS_SYNC();
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f4 = *reinterpret_cast<const f32x4*>(fw + 8 * q4 + 4 * half);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) M[cb][4 * q4 + i] *= f4[i];
+      }
+      PIDM_WAVE_LDS_SYNC();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      kt[r] = lap_exp(kt[r] - mrun);
+      zp += kt[r];
+    }
+    // Mt[d][c] += sum_px e[px][d] xn[px][c]: A = the exponentials (rows 8 s .. 8 s + 7 of the accumulator = pixels
+    // 16 s + 4 half + {0..3, 8..11}), B = XT rows read in the same pixel order
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 ea[3];
+      {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pidm_split3_pk(kt[8 * s + 2 * j], kt[8 * s + 2 * j + 1], p0[j], p1[j], p2[j]);
+        ea[0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+        ea[1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+        ea[2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        u32x4 xb4[3];
+        const char* brow = XT + (size_t)(32 * cb + l31) * RT + (size_t)(t * 32 + 16 * s + 4 * half) * 2;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(brow + (size_t)pc * C * RT);
+          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(brow + (size_t)pc * C * RT + 16);
+          xb4[pc] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        PIDM_LAP_SIX(M[cb], ea, xb4)
+      }
+    }
+  }
+#undef PIDM_LAP_SIX
+  const float z = zp + __shfl_xor(zp, 32);
+  float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C + 64);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)lap_row(r, half) * C + 32 * cb + l31] = M[cb][r];
+  if (half == 0) {
+    o[32 * C + l31] = mrun;
+    o[32 * C + 32 + l31] = z;
+  }
+}
+
 // forward 1b, per (image, head): merge the pixel ranges; M = Mt / Z, kst = (m, 1/Z), ctx = M Wv^T / N, P = ctx Wout_h^T
 __global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __restrict__ part, const float* __restrict__ wqkv,
                                                              const float* __restrict__ wout, float* __restrict__ kst,
@@ -687,7 +860,7 @@ bool lap_ok(int N, int heads, int C, int Cout) {
 
 // floats of caller scratch (partials of the pixel-range kernels; the larger of forward and backward needs)
 size_t lap_scratch_floats(int B, int N, int heads, int C) {
-  const size_t fw = (size_t)B * (N / lap_nper(N, C, 1)) * heads * (32 * C + 64);
+  const size_t fw = (size_t)B * (N / lap_nper_split(N, C)) * heads * (32 * C + 64);   // the split kernel's ranges are the smaller ones
   const size_t bw = (size_t)B * (N / lap_nper(N, C, 2)) * heads * 32 * C;
   return (fw > bw ? fw : bw) + 64;
 }
@@ -708,7 +881,9 @@ template <int CB>
 static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, const float* bias, const float* resid, float* y,
                          float* saved, float* qstat, int B, int N, int heads, float* scratch, hipStream_t st) {
   constexpr int C = 32 * CB;
-  const int nper = lap_nper(N, C, 1), NS = N / nper;
+  const char* spe = getenv("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
+  const bool split1 = !(spe && !atoi(spe));
+  const int nper = split1 ? lap_nper_split(N, C) : lap_nper(N, C, 1), NS = N / nper;
   float* kst = saved;
   float* Mmat = kst + (size_t)B * heads * 64;
   float* ctx = Mmat + (size_t)B * heads * 32 * C;
@@ -721,7 +896,17 @@ static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kctx_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_kernel<CB>), dim3(B * NS), dim3(512), lds1, st, xn, wqkv, scratch, N, heads, nper);
+  if (split1) {
+    const size_t ldss = (size_t)nper * (6 * C + 16) + (size_t)3 * C * (nper * 2 + 16) + 8 * 32 * sizeof(float);
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kctx_split_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr_s = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_split_kernel<CB>), dim3(B * NS), dim3(512), ldss, st, xn, wqkv, scratch, N, heads, nper);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_kernel<CB>), dim3(B * NS), dim3(512), lds1, st, xn, wqkv, scratch, N, heads, nper);
+  }
   PIDM_CHECK_LAUNCH("lap_kctx_kernel");
   const size_t lds2 = ((size_t)32 * C + 32 * (C + 1) + C + 32 * 33 + (size_t)NS * 32 + 64) * sizeof(float);
   hipLaunchKernelGGL(lap_kctx_final_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, kst, Mmat, ctx, P, N, heads, C, NS);

@@ -68,8 +68,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", ["split", "fp32"])
 @pytest.mark.parametrize("B,H,heads,C", CASES)
-def test_projected_attention_vs_oracle(backend, B, H, heads, C):
+def test_projected_attention_vs_oracle(backend, monkeypatch, form, B, H, heads, C):
+    """form: the k / context pixel sums of the forward on the bf16 matrix pipe with 3-piece operands (default) or on the fp32 MFMA"""
+    monkeypatch.setenv("PIDM_LAP_SPLIT", "1" if form == "split" else "0")
     L, dev = backend
     HD = heads * 32
     g = torch.Generator().manual_seed(5 + H + C)

@@ -523,6 +523,136 @@ __global__ void __launch_bounds__(512) lap_g_kernel(const float* __restrict__ xn
     for (int r = 0; r < 16; ++r) o[(size_t)lap_row(r, half) * C + 32 * cb + l31] = G[cb][r];
 }
 
+// backward 1 in the split form (same scheme as lap_kctx_split_kernel): xn is staged as [px][piece][c] (A operand of q = xn Wq^T),
+// dY as [piece][c'][px] (B operand of G += qs^T dY); qs leaves the first product with lane = d and chains into the second.
+template <int CB>
+__global__ void __launch_bounds__(512) lap_g_split_kernel(const float* __restrict__ xn, const float* __restrict__ dy,
+                                                          const float* __restrict__ wqkv, const float* __restrict__ qstat,
+                                                          float* __restrict__ part, int N, int heads, int nper, float scale) {
+  constexpr int C = 32 * CB, RA = 6 * C + 16;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int RT = nper * 2 + 16;
+  char* XA = smem;
+  char* YT = smem + (size_t)nper * RA;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NS = N / nper;
+  const int b = blockIdx.x / NS, ns = blockIdx.x % NS;
+  const size_t pix0 = (size_t)b * N + (size_t)ns * nper;
+  {
+    constexpr int QN = C / 4, GP = 16 / QN;
+    const int q = lane & (QN - 1), pb = (lane & 15) / QN, la = lane >> 4;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    for (int sl = wave; sl < nper / (4 * GP); sl += 8) {
+      const int px = (sl * GP + pb) * 4 + la;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+      unsigned a0, a1, a2, b0, b1, b2;
+      pidm_split3_pk(v[0], v[1], a0, a1, a2);
+      pidm_split3_pk(v[2], v[3], b0, b1, b2);
+      char* da = XA + (size_t)px * RA + 8 * q;
+      *reinterpret_cast<u32x2_t*>(da) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(da + 2 * C) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(da + 4 * C) = u32x2_t{a2, b2};
+      unsigned t0 = __float_as_uint(w[0]), t1 = __float_as_uint(w[1]), t2 = __float_as_uint(w[2]), t3 = __float_as_uint(w[3]);
+      {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(t0, t2, false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(t1, t3, false, false);
+        const auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        t0 = s01[0]; t1 = s01[1]; t2 = s23[0]; t3 = s23[1];
+      }
+      pidm_split3_pk(__uint_as_float(t0), __uint_as_float(t1), a0, a1, a2);
+      pidm_split3_pk(__uint_as_float(t2), __uint_as_float(t3), b0, b1, b2);
+      char* dt = YT + (size_t)(4 * q + la) * RT + (size_t)((sl * GP + pb) * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(dt) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)C * RT) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)2 * C * RT) = u32x2_t{a2, b2};
+    }
+  }
+  __syncthreads();
+  const int h = wave;
+  if (h >= heads) return;
+  u32x4 wq[C / 16][3];
+  {
+    const float* wrow = wqkv + ((size_t)h * kLapDH + l31) * C + 8 * half;
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + 16 * s), w1 = *reinterpret_cast<const f32x4*>(wrow + 16 * s + 4);
+      unsigned p0[4], p1[4], p2[4];
+      pidm_split3_pk(w0[0], w0[1], p0[0], p1[0], p2[0]);
+      pidm_split3_pk(w0[2], w0[3], p0[1], p1[1], p2[1]);
+      pidm_split3_pk(w1[0], w1[1], p0[2], p1[2], p2[2]);
+      pidm_split3_pk(w1[2], w1[3], p0[3], p1[3], p2[3]);
+      wq[s][0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+      wq[s][1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      wq[s][2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    }
+  }
+  f32x16 G[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+    for (int r = 0; r < 16; ++r) G[cb][r] = 0.f;
+#define PIDM_LAP_SIX(acc_, a_, b_)                                                                                 \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[2], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[2], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[0], acc_);
+  for (int t = 0; t < nper / 32; ++t) {
+    f32x16 qt;
+    for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+    const char* arow = XA + (size_t)(t * 32 + l31) * RA + 16 * half;
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) {
+      u32x4 xa[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xa[pc] = *reinterpret_cast<const u32x4*>(arow + pc * 2 * C + 32 * s);
+      PIDM_LAP_SIX(qt, xa, wq[s])
+    }
+    // qt[px][d] (lane = d): the per-pixel softmax constants come from the forward (same address across a lane half: broadcast)
+    const float* st = qstat + ((pix0 + (size_t)t * 32) * heads + h) * 2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 s2 = *reinterpret_cast<const float2*>(st + (size_t)lap_row(r, half) * heads * 2);
+      qt[r] = lap_exp(qt[r] - s2.x) * s2.y * scale;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 ea[3];
+      {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pidm_split3_pk(qt[8 * s + 2 * j], qt[8 * s + 2 * j + 1], p0[j], p1[j], p2[j]);
+        ea[0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+        ea[1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+        ea[2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        u32x4 yb4[3];
+        const char* brow = YT + (size_t)(32 * cb + l31) * RT + (size_t)(t * 32 + 16 * s + 4 * half) * 2;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(brow + (size_t)pc * C * RT);
+          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(brow + (size_t)pc * C * RT + 16);
+          yb4[pc] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        PIDM_LAP_SIX(G[cb], ea, yb4)
+      }
+    }
+  }
+#undef PIDM_LAP_SIX
+  float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)lap_row(r, half) * C + 32 * cb + l31] = G[cb][r];
+}
+
 // backward 1b, per (image, head): G = sum of the ranges; dctx = G Wout_h; dWout share of this image; dM = dctx Wv / N;
 // dWv share of this image; rowdot[d] = sum_c dM[d][c] M[d][c]
 __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ gpart, const float* __restrict__ wqkv,
@@ -952,7 +1082,18 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   }
   const int np2 = lap_nper(N, C, 2), NS2 = N / np2;
   const size_t lds1 = (size_t)2 * np2 * (C + 4) * sizeof(float);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_kernel<CB>), dim3(B * NS2), dim3(512), lds1, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
+  const char* spe = getenv("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
+  if (!(spe && !atoi(spe))) {
+    const size_t ldss = (size_t)np2 * (6 * C + 16) + (size_t)3 * C * (np2 * 2 + 16);
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_g_split_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr_s = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_split_kernel<CB>), dim3(B * NS2), dim3(512), ldss, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_kernel<CB>), dim3(B * NS2), dim3(512), lds1, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
+  }
   PIDM_CHECK_LAUNCH("lap_g_kernel");
   const size_t lds2 = ((size_t)32 * (C + 1) + (size_t)(C > 33 ? C : 33) * 33 + 32 * (C + 1) + 32 * 33 + 32 * (C + 1) + 64) * sizeof(float);
   hipLaunchKernelGGL(lap_mid_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, ctx, Mmat, dMmat, rowdot, dwout_part, dwv_part, N,

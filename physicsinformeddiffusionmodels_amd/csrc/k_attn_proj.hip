@@ -462,6 +462,145 @@ __global__ void __launch_bounds__(256) lap_out_kernel(const float* __restrict__ 
   }
 }
 
+// forward 2 in the split form (C = 32): Wq of all heads as [row][piece][c] and this image's P transposed as [piece][c'][d] live in
+// LDS as bf16 pieces (staged once per workgroup); a wave splits its tile's xn rows once for all heads; the softmax tile chains
+// into y^T += P_h^T qs^T as the B operand in accumulator-row order, the A operand follows with two 8-byte reads per piece.
+__global__ void __launch_bounds__(512) lap_out_split_kernel(const float* __restrict__ xn, const float* __restrict__ wqkv,
+                                                            const float* __restrict__ P, const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, float* __restrict__ y,
+                                                            float* __restrict__ qstat, int N, int heads, int tiles_per_wg, float scale) {
+  constexpr int C = 32, RA = 6 * C + 16;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int HD = heads * kLapDH;
+  const int RT = HD * 2 + 16;               // bytes per PT row (piece, c')
+  char* WA = smem;                          // [HD][piece][C]
+  char* PT = smem + (size_t)HD * RA;        // [piece][C][HD]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgs_per_img = (N / 32 + tiles_per_wg - 1) / tiles_per_wg;
+  const int b = blockIdx.x / wgs_per_img, wg = blockIdx.x % wgs_per_img;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  {
+    const int q = lane & 7, pb = (lane >> 3) & 1, la = lane >> 4;
+    for (int sl = wave; sl < HD / 8; sl += 8) {          // 8 rows d x 32 channels per wave-slot
+      const int d = (sl * 2 + pb) * 4 + la;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wqkv + (size_t)d * C + 4 * q);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(P + ((size_t)b * HD + d) * C + 4 * q);
+      unsigned a0, a1, a2, b0, b1, b2;
+      pidm_split3_pk(v[0], v[1], a0, a1, a2);
+      pidm_split3_pk(v[2], v[3], b0, b1, b2);
+      char* da = WA + (size_t)d * RA + 8 * q;
+      *reinterpret_cast<u32x2_t*>(da) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(da + 2 * C) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(da + 4 * C) = u32x2_t{a2, b2};
+      unsigned t0 = __float_as_uint(w[0]), t1 = __float_as_uint(w[1]), t2 = __float_as_uint(w[2]), t3 = __float_as_uint(w[3]);
+      {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(t0, t2, false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(t1, t3, false, false);
+        const auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        t0 = s01[0]; t1 = s01[1]; t2 = s23[0]; t3 = s23[1];
+      }
+      // now: channel c' = 4 q + la, rows d = (2 sl + pb) 4 + 0..3
+      pidm_split3_pk(__uint_as_float(t0), __uint_as_float(t1), a0, a1, a2);
+      pidm_split3_pk(__uint_as_float(t2), __uint_as_float(t3), b0, b1, b2);
+      char* dt = PT + (size_t)(4 * q + la) * RT + (size_t)((sl * 2 + pb) * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(dt) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)C * RT) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)2 * C * RT) = u32x2_t{a2, b2};
+    }
+  }
+  __syncthreads();
+#define PIDM_LAP_SIX(acc_, a_, b_)                                                                                 \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[2], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[2], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[1], b_[0], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[1], acc_);                                                              \
+  acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[0], acc_);
+  const int t_end = (wg + 1) * tiles_per_wg < N / 32 ? (wg + 1) * tiles_per_wg : N / 32;
+  for (int t = wg * tiles_per_wg + wave; t < t_end; t += 8) {
+    const size_t pix = (size_t)b * N + (size_t)t * 32 + l31;
+    // B operand of every head's q tile: xn[px][16 s + 8 half .. + 7], lane = px, split once
+    u32x4 xb[C / 16][3];
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xn + pix * C + 16 * s + 8 * half);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(xn + pix * C + 16 * s + 8 * half + 4);
+      unsigned p0[4], p1[4], p2[4];
+      pidm_split3_pk(x0[0], x0[1], p0[0], p1[0], p2[0]);
+      pidm_split3_pk(x0[2], x0[3], p0[1], p1[1], p2[1]);
+      pidm_split3_pk(x1[0], x1[1], p0[2], p1[2], p2[2]);
+      pidm_split3_pk(x1[2], x1[3], p0[3], p1[3], p2[3]);
+      xb[s][0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+      xb[s][1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+      xb[s][2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    }
+    f32x16 yacc;
+    for (int r = 0; r < 16; ++r) yacc[r] = 0.f;
+    for (int h = 0; h < heads; ++h) {
+      f32x16 qt;
+      for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+      const char* wrow = WA + (size_t)(h * kLapDH + l31) * RA + 16 * half;
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        u32x4 wa[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wa[pc] = *reinterpret_cast<const u32x4*>(wrow + pc * 2 * C + 32 * s);
+        PIDM_LAP_SIX(qt, wa, xb[s])
+      }
+      // qt[d][px]: lane = pixel, registers = 16 of the 32 head channels; softmax over d = in-lane + the other half
+      float mx = qt[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qt[r] = lap_exp(qt[r] - mx);
+        sm += qt[r];
+      }
+      sm += __shfl_xor(sm, 32);
+      const float inv = 1.f / sm;
+      if (half == 0) *reinterpret_cast<float2*>(qstat + (pix * heads + h) * 2) = make_float2(mx, inv);
+      const float sc = inv * scale;
+      // y^T[c'][px] += P_h^T[c'][d] qs^T[d][px]: B = the softmax tile (rows 8 s .. 8 s + 7 = d 16 s + 4 half + {0..3, 8..11})
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 qb[3], pa[3];
+        {
+          unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pidm_split3_pk(qt[8 * s + 2 * j] * sc, qt[8 * s + 2 * j + 1] * sc, p0[j], p1[j], p2[j]);
+          qb[0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+          qb[1] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+          qb[2] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+        }
+        const char* prow = PT + (size_t)l31 * RT + (size_t)(h * kLapDH + 16 * s + 4 * half) * 2;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(prow + (size_t)pc * C * RT);
+          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(prow + (size_t)pc * C * RT + 16);
+          pa[pc] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        PIDM_LAP_SIX(yacc, pa, qb)
+      }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int c0 = 8 * q4 + 4 * half;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + pix * C + c0);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = yacc[4 * q4 + i] + bv[i] + rv[i];
+      *reinterpret_cast<f32x4*>(y + pix * C + c0) = o;
+    }
+  }
+#undef PIDM_LAP_SIX
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // backward 1: G_h[d][c'] = sum_n qs_h[n][d] dY[n][c'] per (image, pixel range, head); part layout [32][C] per (b, ns, h)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1047,8 +1186,22 @@ static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, 
   int tpw = 4;
   while ((long)B * ((N / 32 + tpw - 1) / tpw) > 2048 && tpw < 64) tpw *= 2;
   const int wgs = B * ((N / 32 + tpw - 1) / tpw);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_out_kernel<CB>), dim3(wgs), dim3(256), lds3, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tpw,
-                     0.17677669529663687f);
+  if (split1 && CB == 1 && HD % 8 == 0) {
+    // 8 waves per workgroup (the pieces of Wq and P^T take 104 KB: one workgroup per CU)
+    int tp8 = 8;
+    while ((long)B * ((N / 32 + tp8 - 1) / tp8) > 1024 && tp8 < 64) tp8 *= 2;
+    const int wg8 = B * ((N / 32 + tp8 - 1) / tp8);
+    const size_t ldso = (size_t)HD * (6 * C + 16) + (size_t)3 * C * (HD * 2 + 16);
+    static bool attr_o = false;
+    if (!attr_o) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_out_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr_o = true;
+    }
+    hipLaunchKernelGGL(lap_out_split_kernel, dim3(wg8), dim3(512), ldso, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tp8, 0.17677669529663687f);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_out_kernel<CB>), dim3(wgs), dim3(256), lds3, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tpw,
+                       0.17677669529663687f);
+  }
   PIDM_CHECK_LAUNCH("lap_out_kernel");
   return 0;
 }

@@ -285,6 +285,7 @@ def main():
     if not args.no_alt:
         os.environ["PIDM_CONV_SPLIT"] = "0"
         os.environ["PIDM_WGRAD_SPLIT"] = "0"
+        os.environ["PIDM_LAP_SPLIT"] = "0"
         n_alt = min(args.steps, 20)
         for _ in range(3):
             step()
@@ -299,8 +300,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         alt = {"value": round(B * world * n_alt / el, 2), "ms_per_step": round(el / n_alt * 1e3, 3), "steps": n_alt,
-               "what": "PIDM_CONV_SPLIT=0 PIDM_WGRAD_SPLIT=0: every contraction on the fp32 MFMA"}
-        del os.environ["PIDM_CONV_SPLIT"], os.environ["PIDM_WGRAD_SPLIT"]
+               "what": "PIDM_CONV_SPLIT=0 PIDM_WGRAD_SPLIT=0 PIDM_LAP_SPLIT=0: every contraction on the fp32 MFMA"}
+        del os.environ["PIDM_CONV_SPLIT"], os.environ["PIDM_WGRAD_SPLIT"], os.environ["PIDM_LAP_SPLIT"]
 
     roofline = None
     if not args.no_roofline:
@@ -359,7 +360,8 @@ def main():
             workload = ("sample.py DDPM sampling, Darcy 64x64, 1000-step schedule, Unet3D dim=32; a step = one p_sample step of the "
                         "whole batch (a full chain = 1000 steps; sample.py:145-150)")
         cfg = {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-               "arithmetic": "fp32 tensors and accumulation; 3x3 convolution contractions (fwd, dgrad, wgrad) as 6 bf16 MFMA terms on "
+               "arithmetic": "fp32 tensors and accumulation; 3x3 convolution contractions (fwd, dgrad, wgrad) and the pixel sums / projections "
+                             "of the projected attention forward and of G = qs^T dY as 6 bf16 MFMA terms on "
                              "round-to-nearest 3-piece splits of both operands (24 mantissa bits; error <= the fp32 MFMA's own, "
                              "profiles/r02_bf16_split_probe.txt), everything else fp32 MFMA / VALU"}
         if train:

@@ -817,23 +817,32 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
 
-template <int NW>
+// MODE 0: 3x3 / stride 1 / pad 1.  MODE 1: the 4x4 / stride-2 convolution (and the input gradient of the transposed one) as 4
+// K-phases of 2x2 taps over the parity sub-images of the input (ConvGeom::nph = 4: stage = (tile, phase, 16-channel chunk), the
+// halo tile is gathered with a stride of 2 pixels).  MODE 2: the transposed 4x4 / stride-2 convolution (and the input gradient of
+// the strided one) as 4 output-parity problems of 2x2 taps (ConvGeom::nz = 4: work item = (parity, n-tile, m-tile), the epilogue
+// scatters with an output stride of 2).  Both keep the 3x3 halo-tile layout (one halo row / column on either side; the tap
+// offsets depend on the phase / parity) and run 4 taps = 24 MFMAs per wave and stage.
+template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                             const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, float* __restrict__ out, int n_items,
                                                             int items_per_wg, int trace) {
-  constexpr int RB = kSplitRow, T = 9, NT = 64 * NW;        // NW waves: 8 (256-pixel tile, two waves per SIMD) or 4 (128 pixels)
-  constexpr int NB = 32 / NW;                               // 1 KB pieces of the weight slab per wave (31.5 KB: the last one is half)
+  constexpr int RB = kSplitRow, T = (MODE == 0) ? 9 : 4, NT = 64 * NW;   // NW waves: 8 (256-pixel tile, two waves per SIMD) or 4 (128 pixels)
+  constexpr int NB = ((MODE == 0) ? 32 : 16) / NW;          // 1 KB pieces of the weight slab per wave (31.5 KB / 14 KB: the tail spills)
+  constexpr int NBT = (MODE == 0) ? 4 : 2;                  // taps the slab copies are spread over
+  constexpr int SLAB = T * 32 * kSplitRow, BPAD = (MODE == 0) ? 512 : 2048;
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int z = 0;
   const int npixA = g.NI * g.IHt * g.IWt;
-  const int bufsz = (npixA + T * 32) * RB + 512;       // bytes per buffer: halo tile | 9 x 32 weight rows | spill of the last 1 KB piece
+  const int bufsz = (npixA + T * 32) * RB + BPAD;      // bytes per buffer: halo tile | T x 32 weight rows | spill of the last 1 KB pieces
   const int tpi = g.Hv / g.TH;
-  const int NCH = g.Cin >> 4;
+  const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;     // 16-channel chunks per tile (MODE 1: 4 phases x Cin)
+  const int CCH = g.Cin >> 4;
+  const int ntn = g.Cout >> 5;
   const int item0 = blockIdx.x * items_per_wg;
   const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
   const int nst = my_items * NCH;
@@ -859,7 +868,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
     const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
     a_lds[k] = ((img * g.IHt + hy) * g.IWt + x + 1) * RB + 48 * hh;
-    a_vo[k] = (unsigned)(x * g.ld0 + 8 * hh) * 4u;
+    a_vo[k] = (unsigned)((MODE == 1 ? 2 * x : x) * g.ld0 + 8 * hh) * 4u;
     a_im[k] = img;
     a_hy[k] = hy;
   }
@@ -880,25 +889,28 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   float akeep[2] = {0.f, 0.f};
   const char* l_sp = reinterpret_cast<const char*>(src0);
   const char* l_wn = reinterpret_cast<const char*>(ws);
-  int l_b0 = 0, l_iy0 = 0;
+  int l_b0 = 0, l_iy0 = 0, l_py = 0;
 #define PIDM_SP_STAGE(s_)                                                                                          \
   {                                                                                                                \
     int ss__ = (s_);                                                                                               \
     if (ss__ >= nst) ss__ = nst - 1;                                                                               \
     const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
-    const int tn__ = it__ / g.tiles_m, tm__ = it__ - tn__ * g.tiles_m;                                             \
-    const int c0__ = ch__ * 16;                                                                                    \
+    const int tq__ = it__ / g.tiles_m, tm__ = it__ - tq__ * g.tiles_m;       /* tq = n-tile (MODE 2: parity * ntn + n-tile) */ \
+    const int ph__ = (MODE == 1) ? ch__ / CCH : 0;                                                                 \
+    const int c0__ = (ch__ - ph__ * CCH) * 16;                                                                     \
     l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
-    l_iy0 = (tm__ % tpi) * g.TH - g.pad_y[z];                                                                      \
-    l_sp = reinterpret_cast<const char*>((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0));                      \
-    l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tn__ * NCH + ch__) * kSplitSlab;                           \
+    l_iy0 = (tm__ % tpi) * g.TH - 1;                                          /* input (sub-image) row of LDS row 0 */ \
+    l_py = (MODE == 1) ? g.ph_oy[ph__] : 0;                                                                        \
+    l_sp = reinterpret_cast<const char*>(((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                    \
+                                         ((MODE == 1) ? g.ph_ox[ph__] * g.ld0 : 0));                               \
+    l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tq__ * NCH + ch__) * SLAB;                                 \
   }
   // unconditional loads (rows outside the image read row 0 and are zeroed on their way to LDS)
 #define PIDM_SP_LOAD_A(k_)                                                                                         \
   {                                                                                                                \
     const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
-    const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < g.Hi);                                                   \
-    const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + iy__) * g.Wi : 0;                                            \
+    const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < (MODE == 1 ? g.Hv : g.Hi));                              \
+    const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + (MODE == 1 ? 2 * iy__ + l_py : iy__)) * g.Wi : 0;            \
     const f32x4* p__ = reinterpret_cast<const f32x4*>(l_sp + row__ * (size_t)g.ld0 * 4 + a_vo[k_]);                \
     ra[k_][0] = p__[0];                                                                                            \
     ra[k_][1] = p__[1];                                                                                            \
@@ -949,13 +961,23 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     const char* wn1 = l_wn;        // weight slab of stage s+1 (copied during this stage)
     PIDM_SP_STAGE(s + 2)           // geometry of the activation loads issued during this stage
     // the epilogue's bias, fetched a stage ahead of its use (unconditional load, any valid address when there is no bias)
-    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[((item0 + s / NCH) / g.tiles_m) * 32 + l31];
-    const char* afp = bufc + a_frag;
+    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[(((item0 + s / NCH) / g.tiles_m) % ntn) * 32 + l31];
+    // tap offsets inside the halo tile: 3x3: (ky, kx); 2x2 taps: (jy - pad_y + 1, jx - pad_x + 1) with the pads of this stage's
+    // phase (MODE 1) or of this item's output parity (MODE 2)
+    int oy0 = 0, ox0 = 0;
+    if (MODE == 1) {
+      const int ph = (s - (s / NCH) * NCH) / CCH;
+      oy0 = 1 - g.ph_pad_y[ph]; ox0 = 1 - g.ph_pad_x[ph];
+    } else if (MODE == 2) {
+      const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
+      oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
+    }
+    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : (oy0 * g.IWt + ox0) * RB);
     const char* bfp = bufc + b_frag;
     u32x4 fa[2][3], fb[2][3];
 #define PIDM_SP_FRAGS(set_, t_)                                                                                    \
   {                                                                                                                \
-    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)(((t_) / 3) * g.IWt + ((t_) % 3)) * RB);      \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * g.IWt + ((t_) % 3) : ((t_) >> 1) * g.IWt + ((t_) & 1)) * RB); \
     const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
       if (!(PIDM_SPLIT_ABLATE & 2) || (t_) == 0) fa[set_][p] = ar__[p]; else fa[set_][p] = fa[(set_) ^ 1][p];      \
@@ -991,9 +1013,9 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
       if (t == 0 && !(PIDM_SPLIT_ABLATE & 4)) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
       if (t == 1 && !(PIDM_SPLIT_ABLATE & 4)) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
-      if (t >= 2 && t < 6 && !(PIDM_SPLIT_ABLATE & 8)) {    // the weight copies of stage s+1, spread over taps 2..5
+      if (t >= 2 && t < 2 + NBT && !(PIDM_SPLIT_ABLATE & 8)) {    // the weight copies of stage s+1, spread over taps 2..
 #pragma unroll
-        for (int k = NB * (t - 2) / 4; k < NB * (t - 1) / 4; ++k) PIDM_SP_COPY_B(k, wn1, bufn)
+        for (int k = NB * (t - 2) / NBT; k < NB * (t - 1) / NBT; ++k) PIDM_SP_COPY_B(k, wn1, bufn)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1005,7 +1027,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     if (ch == NCH - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += accb[r];
-      const int tn = it / g.tiles_m, tm = it - tn * g.tiles_m;
+      const int tq = it / g.tiles_m, tm = it - tq * g.tiles_m;
+      const int zz = (MODE == 2) ? tq / ntn : 0, tn = tq - zz * ntn;
       const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
       const int c = n0 + l31;
       const float bv = bias ? bv_pre : 0.f;
@@ -1041,8 +1064,16 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
           x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
           const int prow = 8 * q4 + 4 * half + (l31 & 3);
           f32x4 o = {x0, x1, x2, x3};
+          if (MODE == 2) {
+            // output parity (ooy, oox): pixel (vy, vx) of the tile goes to (2 vy + ooy, 2 vx + oox)
+            const int pp = p0 + prow, vx = pp & (g.Wv - 1), vy = vy0 + ((pp >> g.wsh) & (g.TH - 1));
+            const size_t opx = (size_t)(2 * vy + g.ooy[zz]) * g.Wo + 2 * vx + g.oox[zz];
+            if (residual) o += *reinterpret_cast<const f32x4*>(residual + ((size_t)b * g.Ho * g.Wo + opx) * g.ldr + n0 + 4 * (l31 >> 2));
+            *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + opx * g.sox + n0 + 4 * (l31 >> 2)) = o;
+          } else {
           if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);
           *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
+          }
         }
       }
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
@@ -1063,10 +1094,16 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 static bool split_shape_ok(const ConvGeom& g) {
   return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && (g.Cin % 32 == 0) && (g.Cout % 32 == 0);
 }
-__device__ __forceinline__ void split_store(unsigned short* ws, int nch, int n, int t, int k, float v) {
+// the 4x4 / stride-2 family as 2x2 taps: 4 K-phases (nph = 4, one matrix with K = 4 Cin) or 4 output parities (nz = 4, four slabs)
+static bool split_shape_ok2(const ConvGeom& g) {
+  return g.KH == 2 && g.KW == 2 && g.stride == 1 && ((g.nph == 4 && g.nz == 1) || (g.nz == 4 && g.nph == 1)) && (g.Cin % 32 == 0) &&
+         (g.Cout % 32 == 0);
+}
+// pieces of packed element (parity slab z, row n, tap t, column k): [z][n / 32][k / 16][T taps][32 rows][2 halves][3 pieces][8 + pad]
+__device__ __forceinline__ void split_store(unsigned short* ws, int nch, int T, int ntn, int z, int n, int t, int k, float v) {
   unsigned p0, p1, p2;
   pidm_split3_pk(v, 0.f, p0, p1, p2);
-  const size_t o = ((((size_t)(n >> 5) * nch + (k >> 4)) * 9 + t) * 32 + (n & 31)) * (kSplitRow / 2) + ((k >> 3) & 1) * 24 + (k & 7);
+  const size_t o = ((((((size_t)z * ntn + (n >> 5)) * nch + (k >> 4)) * T + t) * 32 + (n & 31))) * (kSplitRow / 2) + ((k >> 3) & 1) * 24 + (k & 7);
   ws[o] = (unsigned short)(p0 & 0xffffu);
   ws[o + 8] = (unsigned short)(p1 & 0xffffu);
   ws[o + 16] = (unsigned short)(p2 & 0xffffu);
@@ -1085,7 +1122,7 @@ __device__ __forceinline__ int parity_tap(int par, int j) { return par == 0 ? 3 
 // iterates over the SOURCE-valid elements (n < N, k < K) only; padding is zero-filled once by the caller.
 // (n_off, k_off) place a source tensor inside a larger packed matrix (concatenated time-MLP linears).
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int nz, int N, int K,
-                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off, unsigned short* __restrict__ split, int nch) {
+                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off, unsigned short* __restrict__ split, int nch, int ntn) {
   const size_t total = (size_t)nz * N * T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % K);
@@ -1100,6 +1137,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
       v = (kind == 5) ? src[(((size_t)n * K + k) * 4 + ky) * 4 + kx]     // strided conv  W[n][k][ky][kx]
                       : src[(((size_t)n * K + k) * 4 + ky) * 4 + kx];    // dgrad of convT Wt[n][k][ky][kx]
       dst[(((size_t)(n_off + n)) * T + t) * Kp + k_off + z * K + k] = v;
+      if (split) split_store(split, nch, T, ntn, 0, n_off + n, t, k_off + z * K + k, v);
       continue;
     }
     if (kind == 0) {
@@ -1114,7 +1152,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
       v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
     }
     dst[(((size_t)z * Np + n_off + n) * T + t) * Kp + k_off + k] = v;
-    if (split) split_store(split, nch, n_off + n, t, k_off + k, v);
+    if (split) split_store(split, nch, T, ntn, z, n_off + n, t, k_off + k, v);
   }
 }
 
@@ -1142,6 +1180,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
       const int ky = py == 0 ? 1 + 2 * jy : 2 * jy, kx = px == 0 ? 1 + 2 * jx : 2 * jx;
       v = d.src[(((size_t)n * d.K + k) * 4 + ky) * 4 + kx];
       d.dst[(((size_t)(d.n_off + n)) * d.T + t) * d.Kp + d.k_off + z * d.K + k] = v;
+      if (d.split) split_store(d.split, d.nch, d.T, d.ntn, 0, d.n_off + n, t, d.k_off + z * d.K + k, v);
       continue;
     }
     if (d.kind == 0 || d.kind == 4) {
@@ -1154,7 +1193,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
       v = d.src[(((size_t)k * d.N + n) * 4 + ky) * 4 + kx];
     }
     d.dst[(((size_t)z * d.Np + d.n_off + n) * d.T + t) * d.Kp + d.k_off + k] = v;
-    if (d.split) split_store(d.split, d.nch, d.n_off + n, t, d.k_off + k, v);
+    if (d.split) split_store(d.split, d.nch, d.T, d.ntn, z, d.n_off + n, t, d.k_off + k, v);
   }
 }
 
@@ -2351,10 +2390,12 @@ static size_t packed_fp32_floats(const ConvGeom& g) {
 }
 // fp32 packing, followed by the bf16 pieces (3 x 2 bytes per weight) where conv3x3_split_kernel can take the tensor
 size_t packed_floats(const ConvGeom& g) {
-  return packed_fp32_floats(g) + (split_shape_ok(g) ? (size_t)(g.Cout / 32) * (g.Cin / 16) * (kSplitSlab / 4) + 128 : 0);
+  if (split_shape_ok(g)) return packed_fp32_floats(g) + (size_t)(g.Cout / 32) * (g.Cin / 16) * (kSplitSlab / 4) + 128;
+  if (split_shape_ok2(g)) return packed_fp32_floats(g) + (size_t)g.nz * (g.Cout / 32) * (g.Kw / 16) * (4 * 32 * kSplitRow / 4) + 512;
+  return packed_fp32_floats(g);
 }
 static unsigned short* split_part(const ConvGeom& g, float* w_packed) {
-  return split_shape_ok(g) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
+  return (split_shape_ok(g) || split_shape_ok2(g)) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
 }
 
 // w_ref -> packed.  The packed matrix is sized by g (g.Cout rows, g.Cin columns); the source tensor covers rows
@@ -2369,9 +2410,9 @@ int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed
   const size_t total = (size_t)g.nz * N * T * K * g.nph;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  unsigned short* split = (kind == 0 || kind == 2) ? split_part(g, w_packed) : nullptr;
+  unsigned short* split = (n_off == 0 && k_off == 0 && n_src <= 0 && k_src <= 0) ? split_part(g, w_packed) : nullptr;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nph > 1 ? 4 : g.nz, N, K, Np, Kp, srcKH,
-                     srcKW, T, n_off, k_off, split, g.Cin / 16);
+                     srcKW, T, n_off, k_off, split, Kp / 16, g.Cout / 32);
   PIDM_CHECK_LAUNCH("pack_kernel");
   return 0;
 }
@@ -2384,8 +2425,9 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->N = n_src > 0 ? n_src : g.Cout; d->K = k_src > 0 ? k_src : g.Cin;
   d->Np = packed_np(g.Cout); d->Kp = cdiv(g.Kw, KC) * KC; d->KH = srcKH; d->KW = srcKW; d->T = g.KH * g.KW;
   d->n_off = n_off; d->k_off = k_off;
-  d->split = (kind == 0 || kind == 2) ? split_part(g, w_packed) : nullptr;
-  d->nch = g.Cin / 16;
+  d->split = (n_off == 0 && k_off == 0 && n_src <= 0 && k_src <= 0) ? split_part(g, w_packed) : nullptr;
+  d->nch = d->Kp / 16;
+  d->ntn = g.Cout / 32;
   if (g.nph > 1) { d->kind = (kind == 4) ? 6 : 5; d->nz = 4; }   // nz doubles as the phase count for kinds 5/6
   const size_t total = (size_t)d->nz * d->N * d->T * d->K;
   d->nblk = (unsigned)((total + 2047) / 2048);
@@ -2585,6 +2627,68 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
   {
+    // the 4x4 / stride-2 family (2x2 taps as 4 K-phases or 4 output parities) in the split form
+    const char* se = getenv("PIDM_CONV_SPLIT");
+    const bool on = !(se && !atoi(se));
+    const int mode = (g.nph == 4) ? 1 : 2;
+    if (on && split_shape_ok2(g) && g.soc == 1 && (g.C0 % 16 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.C1 == 0 || g.ld1 == g.ld0) &&
+        g.Wv >= 8 && (mode == 1 ? (g.in_step == 2 && 2 * g.Wv == g.Wi && 2 * g.Hv == g.Hi) : (g.os == 2 && g.Wv == g.Wi && g.Hv == g.Hi)) &&
+        !sigmoid_last && !g.gn_part && !g.bn_part && (g.sox & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+        (reinterpret_cast<size_t>(src0) & 15) == 0 && (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0))) {
+      const char* ce = getenv("PIDM_STREAM_WGS");
+      int n_cu = ce ? atoi(ce) : 256;
+      if (n_cu < 1) n_cu = 256;
+      const char* fe = getenv("PIDM_SPLIT_NW");
+      const int force = fe ? atoi(fe) : 0;
+      const int mult = (mode == 2 ? 4 : 1) * (g.Cout / 32);
+      for (int nw = 8; nw >= 4; nw >>= 1) {
+        if (force && force != nw) continue;
+        ConvGeom gs = g;
+        // tile of 32 nw pixels with the 3x3 halo layout (one halo row / column on either side)
+        const int bm = 32 * nw;
+        if (gs.Wv > bm) continue;
+        const int TH = bm / gs.Wv < gs.Hv ? bm / gs.Wv : gs.Hv;
+        int tsh = 0;
+        while ((1 << tsh) < TH) ++tsh;
+        if (gs.Hv % TH || (1 << tsh) != TH) continue;
+        const int NI = bm / (gs.Wv * TH);
+        if (NI * gs.Wv * TH != bm) continue;
+        gs.TH = TH; gs.tsh = tsh; gs.NI = NI; gs.IHt = TH + 2; gs.IWt = gs.Wv + 2;
+        gs.mIHt = (unsigned)((0x100000000ULL + gs.IHt - 1) / gs.IHt);
+        gs.mIWt = (unsigned)((0x100000000ULL + gs.IWt - 1) / gs.IWt);
+        gs.tiles_m = (NI > 1) ? cdiv(gs.B, NI) : gs.B * (gs.Hv / TH);
+        const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
+        const size_t lds = (size_t)2 * ((npixA + 4 * 32) * kSplitRow + 2048);
+        if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
+        const int n_items = gs.tiles_m * mult;
+        if (nw == 8 && !force && n_items < n_cu) continue;        // more, smaller items fill the chip better (the 4-wave tile follows)
+        static bool attr_q = false;
+        if (!attr_q) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          attr_q = true;
+        }
+        const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
+        const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
+        const float* s1 = src1 ? src1 : src0;
+        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", nw, mode, n_items, wgs, lds);
+        const bool prof = prof_enabled();
+        if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
+        const dim3 bd(64 * nw);
+        if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+        else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+        else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 2>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 2>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+        if (prof) prof_end_launch(st);
+        PIDM_CHECK_LAUNCH("conv3x3_split_kernel(2x2)");
+        return 0;
+      }
+    }
+  }
+  {
     // bf16 matrix pipe, fp32-faithful split operands (PIDM_CONV_SPLIT=0: off -> the fp32-MFMA kernels below; read per launch)
     const char* se = getenv("PIDM_CONV_SPLIT");
     const bool on = !(se && !atoi(se));
@@ -2614,8 +2718,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const bool prof = prof_enabled();
         static bool attr_p = false;
         if (!attr_p) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
           attr_p = true;
         }
         gs.w_off[0] = 0;
@@ -2625,10 +2729,10 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
         if (nw == 8)
-          hipLaunchKernelGGL(conv3x3_split_kernel<8>, dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);
         else
-          hipLaunchKernelGGL(conv3x3_split_kernel<4>, dim3(wgs), dim3(256), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 0>), dim3(wgs), dim3(256), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);
         if (prof) prof_end_launch(st);
         PIDM_CHECK_LAUNCH("conv3x3_split_kernel");

@@ -160,8 +160,9 @@ struct PackDesc {
   float* dst;
   int kind, nz, N, K, Np, Kp, KH, KW, T, n_off, k_off;
   unsigned blk0, nblk;
-  unsigned short* split;   // 3x3 / stride-1 tensors also leave their bf16 pieces for conv3x3_split_kernel (null: none)
-  int nch;                 // 16-channel chunks of a row (Cin / 16)
+  unsigned short* split;   // 3x3 / stride-1 and 4x4 / stride-2 tensors also leave their bf16 pieces for conv3x3_split_kernel (null: none)
+  int nch;                 // 16-channel chunks of a packed row (Kp / 16)
+  int ntn;                 // 32-row tiles of one parity slab (Cout / 32)
 };
 
 // one deferred fixed-order reduction (k_conv.hip: reduce_multi_kernel), queued during backward and run in ONE launch:

@@ -240,6 +240,29 @@ def test_conv_epilogue_groupnorm_partials(backend, B, H, C0, C1, Cout, groups):
     assert (pc[..., 0] - ck).abs().max().item() < 1e-4 * ck.abs().max().item()
 
 
+SPLIT2_CASES = [   # the 4x4 / stride-2 family in the split form: strided conv = 4 K-phases, transposed conv = 4 output parities
+    (2, 32, 32, 0, 32, 4, 2, 1, 0),      # downsample 32x32 -> 16x16; its dgrad is the parity form
+    (3, 16, 64, 0, 32, 4, 2, 1, 0),      # 16x16 -> 8x8, ragged batch (several images per tile), 4 chunks per phase
+    (2, 16, 32, 32, 64, 4, 2, 1, 0),     # concat source, two n-tiles
+    (2, 16, 32, 0, 32, 4, 2, 1, 1),      # upsample 16x16 -> 32x32 (parity form); its dgrad is the phased form
+    (3, 8, 64, 0, 64, 4, 2, 1, 1),       # 8x8 -> 16x16, ragged batch, two n-tiles
+]
+
+
+@pytest.mark.parametrize("nw,wgs", [("8", "3"), ("4", "256")])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", SPLIT2_CASES)
+def test_conv_4x4s2_split_forms(backend, monkeypatch, nw, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_SPLIT_NW", nw)
+    monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", SPLIT2_CASES[:1] + SPLIT2_CASES[3:4])
+def test_conv_4x4s2_fp32_forms(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
     """The 3-piece / 6-term bf16 form against a float64 convolution, next to the fp32-MFMA kernels on the same data (K = 576):
     forward, input-gradient and weight-gradient errors of the split form stay within 1.25x of the fp32-MFMA kernels' and below

@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const int nA1 = (2 * SEG - NT) >> 6;
   const int hh = tid & 1;
   int a_lds[2], a_im[2], a_hy[2];
-  unsigned a_vo[2];
+  unsigned a_vo[2], a_ro[2];      // byte offsets inside the source: of the unit inside its row / plus its row's offset from the tile's first
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     int sp = (tid + NT * k) >> 1;
@@ -871,6 +871,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     a_vo[k] = (unsigned)((MODE == 1 ? 2 * x : x) * g.ld0 + 8 * hh) * 4u;
     a_im[k] = img;
     a_hy[k] = hy;
+    // 32-bit: the launcher takes this kernel only for sources below 4 GB
+    a_ro[k] = a_vo[k] + (unsigned)(img * g.Hi + (MODE == 1 ? 2 * hy : hy)) * (unsigned)(g.Wi * g.ld0 * 4);
   }
   // Weight staging: the stage's slab (pre-split, rows already padded to 112 bytes: an image of the LDS rows) is copied by
   // global_load_lds_dwordx4 - 1 KB per wave and instruction straight into the buffer being filled, no registers, no ds_write;
@@ -890,6 +892,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const char* l_sp = reinterpret_cast<const char*>(src0);
   const char* l_wn = reinterpret_cast<const char*>(ws);
   int l_b0 = 0, l_iy0 = 0, l_py = 0;
+  long long l_rb = 0;             // byte offset of the tile's first staged row (row -1 of the first image: may be negative)
 #define PIDM_SP_STAGE(s_)                                                                                          \
   {                                                                                                                \
     int ss__ = (s_);                                                                                               \
@@ -901,6 +904,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
     l_iy0 = (tm__ % tpi) * g.TH - 1;                                          /* input (sub-image) row of LDS row 0 */ \
     l_py = (MODE == 1) ? g.ph_oy[ph__] : 0;                                                                        \
+    l_rb = (long long)(l_b0 * g.Hi + (MODE == 1 ? 2 * l_iy0 + l_py : l_iy0)) * (long long)(g.Wi * g.ld0 * 4);      \
     l_sp = reinterpret_cast<const char*>(((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                    \
                                          ((MODE == 1) ? g.ph_ox[ph__] * g.ld0 : 0));                               \
     l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tq__ * NCH + ch__) * SLAB;                                 \
@@ -908,10 +912,10 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   // unconditional loads (rows outside the image read row 0 and are zeroed on their way to LDS)
 #define PIDM_SP_LOAD_A(k_)                                                                                         \
   {                                                                                                                \
+    /* address = scalar (source + tile's first row) + a per-thread constant; rows outside the image read the unit of row 0 */ \
     const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
     const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < (MODE == 1 ? g.Hv : g.Hi));                              \
-    const size_t row__ = ok__ ? (size_t)(b__ * g.Hi + (MODE == 1 ? 2 * iy__ + l_py : iy__)) * g.Wi : 0;            \
-    const f32x4* p__ = reinterpret_cast<const f32x4*>(l_sp + row__ * (size_t)g.ld0 * 4 + a_vo[k_]);                \
+    const f32x4* p__ = reinterpret_cast<const f32x4*>(ok__ ? l_sp + l_rb + a_ro[k_] : l_sp + a_vo[k_]);            \
     ra[k_][0] = p__[0];                                                                                            \
     ra[k_][1] = p__[1];                                                                                            \
     akeep[k_] = ok__ ? 1.f : 0.f;                                                                                  \
@@ -2635,7 +2639,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         g.Wv >= 8 && (mode == 1 ? (g.in_step == 2 && 2 * g.Wv == g.Wi && 2 * g.Hv == g.Hi) : (g.os == 2 && g.Wv == g.Wi && g.Hv == g.Hi)) &&
         !sigmoid_last && !g.gn_part && !g.bn_part && (g.sox & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
         (reinterpret_cast<size_t>(src0) & 15) == 0 && (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
-        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0))) {
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
+        (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0 < 4.0e9) {
       const char* ce = getenv("PIDM_STREAM_WGS");
       int n_cu = ce ? atoi(ce) : 256;
       if (n_cu < 1) n_cu = 256;
@@ -2697,7 +2702,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         g.Wv >= 8 && g.Wv == g.Wi && g.pad_y[0] == 1 && g.pad_x[0] == 1 && !sigmoid_last && (g.sox & 3) == 0 &&
         (reinterpret_cast<size_t>(out) & 15) == 0 && (reinterpret_cast<size_t>(src0) & 15) == 0 &&
         (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
-        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0))) {
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
+        (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0 < 4.0e9) {
       // 8 waves on a 256-pixel tile, or - when that leaves CUs without a work item - 4 waves on 128 pixels (PIDM_SPLIT_NW forces one)
       const char* fe = getenv("PIDM_SPLIT_NW");
       const int force = fe ? atoi(fe) : 0;

@@ -18,7 +18,8 @@ sample-steps/s).  Same JSON schema, roofline and cpu_baseline for all three.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     - the dominant kernel class (implicit-GEMM conv fwd/dgrad + wgrad on the matrix cores):
                  algorithmic FLOPs / HIP-event time of those launches, measured live on the launch stream
-  fp32_mfma_only - the same step with the 3x3 contractions on the fp32 MFMA instead of the split-bf16 form (training workloads)
+  fp32_mfma_only - the same step with every contraction on the fp32 MFMA instead of the split-bf16 form
+  eager_scalars  - the same step with the tracked loss terms returned as python floats every step (host sync per step)
   cpu_baseline - the CPU oracle (oracle/pidm_oracle.py, a torch-CPU restatement pinned against the reference)
                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -303,6 +304,27 @@ def main():
                "what": "PIDM_CONV_SPLIT=0 PIDM_WGRAD_SPLIT=0 PIDM_LAP_SPLIT=0: every contraction on the fp32 MFMA"}
         del os.environ["PIDM_CONV_SPLIT"], os.environ["PIDM_WGRAD_SPLIT"], os.environ["PIDM_LAP_SPLIT"]
 
+    # and with the tracked loss terms returned as python floats every step (the reference's types: one host sync per step)
+    eager = None
+    if train and not args.no_alt and not args.eager_scalars:
+        diffusion.deferred_scalars = False
+        n_e = min(args.steps, 20)
+        for _ in range(3):
+            step()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(n_e):
+            step()
+        fence()
+        el = time.perf_counter() - t2
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        eager = {"value": round(B * world * n_e / el, 2), "ms_per_step": round(el / n_e * 1e3, 3), "steps": n_e,
+                 "what": "model_estimation_loss returns python floats every step (DenoisingDiffusion.deferred_scalars = False)"}
+        diffusion.deferred_scalars = True
+
     roofline = None
     if not args.no_roofline:
         # same steps again with HIP events around every launch of the dominant kernel class (recorded on the
@@ -376,7 +398,7 @@ def main():
             "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
-            "fp32_mfma_only": alt,
+            "fp32_mfma_only": alt, "eager_scalars": eager,
         }
     if dist is not None:
         dist.destroy_process_group()

@@ -875,18 +875,23 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ kst, const float* __restrict__ dMmat,
                                                       const float* __restrict__ rowdot, float* __restrict__ dxn,
                                                       float* __restrict__ dw_part, int N, int heads, int nper, int nsub,
-                                                      float scale) {
+                                                      float scale, int split_dw) {
   constexpr int C = 32 * CB, CP = C + 4;
   HIP_DYNAMIC_SHARED(float, smem)
   float* xs = smem;                                   // [nper][CP]
   float* ys = xs + (size_t)nper * CP;                 // [nper][CP]
-  float* tiles = ys + (size_t)nper * CP;              // [8][CB][32][33]: transposition tile / d_xn share of each wave
-  float* cst = tiles + (size_t)8 * CB * 32 * kLapTileLd;   // [8][96]: k max, k 1/Z, rowdot of each wave's head
+  constexpr int TSZ = CB * 32 * kLapTileLd;           // floats of a wave's tile region
+  float* tiles = ys + (size_t)nper * CP;              // [8][TSZ]: transposition tile / d_xn share of each wave
+  float* cst = tiles + (size_t)8 * TSZ;               // [8][96]: k max, k 1/Z, rowdot of each wave's head
   // C = 32: the operand matrices that are read row-wise (lane = c) 48 times per tile and head - Wq, Wk (all heads) and this image's
   // dM - live in LDS, rows padded to CP: fetched through L1 with the register file full, every one of those MFMAs waited for its
   // own load (measured: 52 % of the matrix-core rate for the whole kernel)
   constexpr bool WLDS = (CB == 1);
   float* wl = cst + 8 * 96;                           // [3][8*32][CP] when WLDS
+  // split_dw: the weight-gradient pixel sums dWq += dq xn, dWk += dk xn run on the bf16 pipe (3-piece operands): xn of the range also
+  // as pieces [piece][c][px] (B operand, pixels contiguous), dq / dk through the wave's tile as before (A operand: 8 pixels of a row)
+  const int RT = nper * 2 + (WLDS ? 0 : 16);          // bytes per XT row (C = 32: no room for the conflict-avoiding pad)
+  char* XT = reinterpret_cast<char*>(wl + (WLDS ? 3 * 256 * CP : 0));
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = N / (nper * nsub);                  // workgroups per image: each walks nsub consecutive pixel ranges
@@ -902,7 +907,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   }
   const int h = wave;
   const bool act = h < heads;
-  float* tw = tiles + (size_t)wave * CB * 32 * kLapTileLd;
+  float* tw = tiles + (size_t)wave * TSZ;
   float* cw = cst + wave * 96;
   if (act && half == 0) {
     cw[l31] = kst[(((size_t)b * heads + h) * 32 + l31) * 2];
@@ -931,6 +936,46 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   const float* dmT = WLDS ? wl + (size_t)(512 + h * kLapDH) * CP + l31 : dMmat + ((size_t)b * heads + h) * 32 * C + l31;
 
   const float rscale = 1.f / scale;
+  // dW[d][c] += sum_px g[d][px] xn[px][c] for the tile: g (lane = px, 16 rows d per lane) is turned through the wave's LDS tile
+#define PIDM_LAP_DW(g_, dW_)                                                                                       \
+  if (split_dw) {                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = g_[r];                \
+    PIDM_WAVE_LDS_SYNC();                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                \
+      float g0[4], g1[4];                                                                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+        g0[e] = tw[l31 * kLapTileLd + 16 * s + 8 * half + e];                                                      \
+        g1[e] = tw[l31 * kLapTileLd + 16 * s + 8 * half + 4 + e];                                                  \
+      }                                                                                                            \
+      unsigned p0[4], p1[4], p2[4];                                                                                \
+      pidm_split3_pk(g0[0], g0[1], p0[0], p1[0], p2[0]);                                                           \
+      pidm_split3_pk(g0[2], g0[3], p0[1], p1[1], p2[1]);                                                           \
+      pidm_split3_pk(g1[0], g1[1], p0[2], p1[2], p2[2]);                                                           \
+      pidm_split3_pk(g1[2], g1[3], p0[3], p1[3], p2[3]);                                                           \
+      u32x4 ga[3] = {u32x4{p0[0], p0[1], p0[2], p0[3]}, u32x4{p1[0], p1[1], p1[2], p1[3]}, u32x4{p2[0], p2[1], p2[2], p2[3]}}; \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                          \
+        u32x4 xb4[3];                                                                                              \
+        const char* brow = XT + (size_t)(32 * cb + l31) * RT + (size_t)(t * 32 + 16 * s + 8 * half) * 2;           \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) xb4[pc] = *reinterpret_cast<const u32x4*>(brow + (size_t)pc * C * RT); \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[2], xb4[0], dW_[cb]);                                                 \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[0], xb4[2], dW_[cb]);                                                 \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[1], xb4[1], dW_[cb]);                                                 \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[1], xb4[0], dW_[cb]);                                                 \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[0], xb4[1], dW_[cb]);                                                 \
+        dW_[cb] = pidm_mfma_bf16_32x32x16(ga[0], xb4[0], dW_[cb]);                                                 \
+      }                                                                                                            \
+    }                                                                                                              \
+    PIDM_WAVE_LDS_SYNC();                                                                                          \
+  } else {                                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = g_[r];                \
+    PIDM_WAVE_LDS_SYNC();                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                                               \
+      const float a = tw[l31 * kLapTileLd + 2 * s + half];                                                         \
+      const float* brow = xs + (size_t)(t * 32 + 2 * s + half) * CP + l31;                                         \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) dW_[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dW_[cb], 0, 0, 0); \
+    }                                                                                                              \
+    PIDM_WAVE_LDS_SYNC();                                                                                          \
+  }
   for (int sub = 0; sub < nsub; ++sub) {
   const size_t pix0 = (size_t)b * N + ((size_t)nw * nsub + sub) * nper;
   // (re)stage the range's xn and dY slabs; the loop below ends on a barrier, so nobody still reads the previous range
@@ -938,6 +983,30 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     const int px = e / (C / 4), q = e - px * (C / 4);
     *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
     *reinterpret_cast<f32x4*>(ys + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+  }
+  if (split_dw) {
+    constexpr int QN = C / 4, GP = 16 / QN;
+    const int q = lane & (QN - 1), pb = (lane & 15) / QN, la = lane >> 4;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    for (int sl = wave; sl < nper / (4 * GP); sl += 8) {
+      const int px = (sl * GP + pb) * 4 + la;
+      const f32x4 w = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
+      unsigned t0 = __float_as_uint(w[0]), t1 = __float_as_uint(w[1]), t2 = __float_as_uint(w[2]), t3 = __float_as_uint(w[3]);
+      {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(t0, t2, false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(t1, t3, false, false);
+        const auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        t0 = s01[0]; t1 = s01[1]; t2 = s23[0]; t3 = s23[1];
+      }
+      unsigned a0, a1, a2, b0, b1, b2;
+      pidm_split3_pk(__uint_as_float(t0), __uint_as_float(t1), a0, a1, a2);
+      pidm_split3_pk(__uint_as_float(t2), __uint_as_float(t3), b0, b1, b2);
+      char* dt = XT + (size_t)(4 * q + la) * RT + (size_t)((sl * GP + pb) * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(dt) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)C * RT) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(dt + (size_t)2 * C * RT) = u32x2_t{a2, b2};
+    }
   }
   __syncthreads();
   for (int t = 0; t < nper / 32; ++t) {
@@ -1008,17 +1077,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         }
       }
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dq[r];
-      PIDM_WAVE_LDS_SYNC();
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = tw[l31 * kLapTileLd + 2 * s + half];
-        const float* brow = xs + (size_t)(t * 32 + 2 * s + half) * CP + l31;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) dWq[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWq[cb], 0, 0, 0);
-      }
-      PIDM_WAVE_LDS_SYNC();
+      PIDM_LAP_DW(dq, dWq)
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
       f32x16 kt, dk;
       for (int r = 0; r < 16; ++r) { kt[r] = 0.f; dk[r] = 0.f; }
@@ -1075,17 +1134,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           }
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tw[lap_row(r, half) * kLapTileLd + l31] = dk[r];
-      PIDM_WAVE_LDS_SYNC();
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = tw[l31 * kLapTileLd + 2 * s + half];
-        const float* brow = xs + (size_t)(t * 32 + 2 * s + half) * CP + l31;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) dWk[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[32 * cb], dWk[cb], 0, 0, 0);
-      }
-      PIDM_WAVE_LDS_SYNC();
+      PIDM_LAP_DW(dk, dWk)
       // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
@@ -1098,7 +1147,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       const int px = e / (C / 4), c0 = 4 * (e - px * (C / 4));
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < heads; ++w) {
-        const float* tp = tiles + (size_t)w * CB * 32 * kLapTileLd + (size_t)c0 * kLapTileLd + px;
+        const float* tp = tiles + (size_t)w * TSZ + (size_t)c0 * kLapTileLd + px;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] += tp[i * kLapTileLd];
       }
@@ -1118,6 +1167,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         ok[(size_t)lap_row(r, half) * C + 32 * cb + l31] = dWk[cb][r];
       }
   }
+#undef PIDM_LAP_DW
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1253,9 +1303,12 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
                      heads, C, NS2);
   PIDM_CHECK_LAUNCH("lap_mid_kernel");
   const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;
-  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * 256 * (C + 4) : 0)) * sizeof(float);
+  const int split_dw = !(spe && !atoi(spe)) ? 1 : 0;
+  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * 256 * (C + 4) : 0)) * sizeof(float) +
+                      (size_t)3 * C * (np3 * 2 + (CB == 1 ? 0 : 16));
+  if (lds3 > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
-                     N, heads, np3, nsub, scale);
+                     N, heads, np3, nsub, scale, split_dw);
   PIDM_CHECK_LAUNCH("lap_bwd_kernel");
   return 0;
 }

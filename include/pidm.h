@@ -59,6 +59,13 @@ int pidm_darcy_loss_fwd_bwd(const float* x0, const float* x0_pred, const float* 
                             const float* inv_var, float c_data, float c_residual, float inv_h0, float inv_h1,
                             float* residual, float* grad_x0_pred, float* out_scalars, void* workspace,
                             int B, int P, void* stream);
+/* The same with the per-sample weights looked up inside the kernel: t int64 [B] (the step's time levels), p2w_table =
+ * diff_dict['p2_loss_weight'], var_table = diff_dict['posterior_variance_clipped'] (its reciprocal is taken in the kernel) -
+ * replaces the two extract() gathers + the reciprocal of src/denoising_utils.py:677,689-692 as well. */
+int pidm_darcy_loss_fwd_bwd_t(const float* x0, const float* x0_pred, const float* f_s, const int64_t* t,
+                              const float* p2w_table, const float* var_table, float c_data, float c_residual,
+                              float inv_h0, float inv_h1, float* residual, float* grad_x0_pred, float* out_scalars,
+                              void* workspace, int B, int P, void* stream);
 
 /* CoCoGen residual correction: max over all entries of d residual / d p per sample
  *   replaces the dense vmap(jacfwd) Jacobian of src/residuals_darcy.py:217-231 (400 MB per 64x64 sample) by the
@@ -69,6 +76,10 @@ int pidm_darcy_jacobian_max(const float* x0, float inv_h0, float inv_h1, float* 
  * writes x_t in channels-last [B,P*P,C] (what the UNet consumes) from NCHW x0/eps. */
 int pidm_qsample_nhwc(const float* x0, const float* eps, const float* a_t, const float* am1_t, float* xt_nhwc,
                       int B, int C, int HW, void* stream);
+/* the same with the extract() gathers folded in: t int64 [B], a_table = diff_dict['alphas_bar_sqrt'],
+ * am1_table = diff_dict['one_minus_alphas_bar_sqrt']  (src/denoising_utils.py:302-306,633-638) */
+int pidm_qsample_nhwc_t(const float* x0, const float* eps, const int64_t* t, const float* a_table, const float* am1_table,
+                        float* xt_nhwc, int B, int C, int HW, void* stream);
 /* ancestral update x_{t-1} = c1 x0_pred + c2 x_t + sigma z   replaces src/denoising_utils.py:441-455 */
 int pidm_psample_update(const float* x0_pred, const float* x_t, const float* z, float c1, float c2, float sigma,
                         float* x_prev, size_t n, void* stream);
@@ -273,6 +284,9 @@ int pidm_lap_backward(const float* xn, const float* dy, const float* w_qkv, cons
 
 /* measurement aid (tools/conv_trace.py): cycle stamps of the streaming 3x3 convolution kernel, written when PIDM_STREAM_TRACE is set */
 int pidm_debug_stream_trace(unsigned long long* out256);
+/* test aid: host-to-device uploads of the deferred-reduction descriptor table since the library was loaded (a second identical
+ * backward pass must not upload anything: the table is compared with what the device already holds) */
+long long pidm_debug_reduce_table_uploads(void);
 
 #ifdef __cplusplus
 }

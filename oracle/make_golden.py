@@ -645,6 +645,27 @@ def g20():
     print("g20 state_dict", {k: len(v) for k, v in d.items() if k.endswith("/names")})
 
 
+def g21():
+    """Thin tensor-algebra members of DenoisingDiffusion that main.py / sample.py never call (src/denoising_utils.py:547-614,57-68):
+    normal_kl, predict_start_from_noise, predict_noise_from_start, predict_noise_from_mean, loss_variational (both log bases, a
+    batch that contains t == 0), module-level resize_image."""
+    dd = DenoisingDiffusion(100, "cpu")
+    B, C, P = 4, 2, 8
+    x0, xt, out, noise = seeded((B, C, P, P), 211), seeded((B, C, P, P), 212), seeded((B, C, P, P), 213), seeded((B, C, P, P), 214)
+    t = torch.tensor([0, 1, 50, 99])
+    img = seeded((2, 3, 2, 8, 8), 215)
+    np.savez_compressed(
+        os.path.join(OUT, "g21_diffusion_algebra.npz"), x0=npy(x0), xt=npy(xt), out=npy(out), noise=npy(noise), t=npy(t), img=npy(img),
+        normal_kl=npy(dd.normal_kl(x0, 0.3 * xt, out, 0.2 * noise)),
+        start_from_noise=npy(dd.predict_start_from_noise(xt, t, noise)),
+        noise_from_start=npy(dd.predict_noise_from_start(xt, t, x0)),
+        noise_from_mean=npy(dd.predict_noise_from_mean(xt, t, out)),
+        loss_variational=npy(dd.loss_variational(out, x0, xt, t)),
+        loss_variational_base2=npy(dd.loss_variational(out, x0, xt, t, base_2=True)),
+        resized5=npy(du.resize_image(img, 5)), resized13=npy(du.resize_image(img, 13)))
+    print("g21 done")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g10b", "g20"):
         {"g19": g19, "g10b": g10b, "g20": g20, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
@@ -670,4 +691,5 @@ if __name__ == "__main__":
     g19()
     g10b()
     g20()
+    g21()
     print("golden vectors written to", OUT)

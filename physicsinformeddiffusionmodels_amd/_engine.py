@@ -54,7 +54,6 @@ class UnetEngine:
         self.grad_views = None
         self._bound_key = None
         self.workspace = None
-        self._ws_key = None
         self.backward_calls = 0      # backward passes since the last gradient exchange (parallel.GradientExchange)
         self.tape_generation = 0
         self.tape_busy = False   # a training-mode forward whose backward has not run yet owns the tape
@@ -97,15 +96,14 @@ class UnetEngine:
             self._bound_key = key
 
     def _ensure_workspace(self, B: int, training: bool, device):
-        key = (B, training, str(device), self.cond_enabled)
-        if self._ws_key != key or self.workspace is None:
-            nbytes = self.lib.pidm_unet_workspace_bytes(self.handle, B, int(training))
-            if nbytes == 0:
-                raise PidmError("pidm_unet_workspace_bytes: " + self.lib.lib.pidm_last_error().decode())
-            if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != torch.device(device):
-                self.workspace = None
-                self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
-            self._ws_key = key
+        # asked on every call (a cached lookup in the library): the plan depends on knobs that tests / A-B runs flip on a
+        # live handle (PIDM_NO_LAP, PIDM_LAP_MIN_N), not only on the batch size
+        nbytes = self.lib.pidm_unet_workspace_bytes(self.handle, B, int(training))
+        if nbytes == 0:
+            raise PidmError("pidm_unet_workspace_bytes: " + self.lib.lib.pidm_last_error().decode())
+        if self.workspace is None or self.workspace.numel() < nbytes + 256 or self.workspace.device != torch.device(device):
+            self.workspace = None
+            self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         return self.workspace
 
     # ---- forward / backward ------------------------------------------------------------------------------

@@ -48,14 +48,17 @@ class PidmLib:
         L.pidm_last_error.restype = C.c_char_p
         L.pidm_backend.restype = C.c_char_p
         i, f, sz = C.c_int, C.c_float, C.c_size_t
+        self._sig("pidm_debug_reduce_table_uploads", [], C.c_longlong)
         self._sig("pidm_prof_enable", [i])
         self._sig("pidm_prof_collect", [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)])
         self._sig("pidm_darcy_residual_fwd", [vp, vp, f, f, vp, i, i, vp])
         self._sig("pidm_darcy_residual_bwd", [vp, vp, f, f, vp, i, i, vp])
         self._sig("pidm_darcy_loss_ws", [i, i], sz)
         self._sig("pidm_darcy_loss_fwd_bwd", [vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
+        self._sig("pidm_darcy_loss_fwd_bwd_t", [vp, vp, vp, vp, vp, vp, f, f, f, f, vp, vp, vp, vp, i, i, vp])
         self._sig("pidm_darcy_jacobian_max", [vp, f, f, vp, i, i, vp])
         self._sig("pidm_qsample_nhwc", [vp, vp, vp, vp, vp, i, i, i, vp])
+        self._sig("pidm_qsample_nhwc_t", [vp, vp, vp, vp, vp, vp, i, i, i, vp])
         self._sig("pidm_psample_update", [vp, vp, vp, f, f, f, vp, sz, vp])
         self._sig("pidm_mech_apply", [vp, vp, vp, vp, i, vp, vp, i, vp, vp, i, vp])
         self._sig("pidm_mech_solve_ws_bytes", [i, i], sz)

@@ -4,10 +4,10 @@
 // depthwise convolutions + 60 slice scatters of StencilGradientComputation src/grad_utils.py:64-146 and
 // the loss algebra of DenoisingDiffusion.model_estimation_loss src/denoising_utils.py:666-692.
 //
-// One workgroup per sample.  Both fields of the sample (p, K: 2*P*P floats) are staged once in LDS, every
-// derivative is a 3/4-tap read of LDS with the one-sided boundary rows selected per pixel, and the adjoint
+// One workgroup per (sample, band of rows).  The band's rows of both fields (p, K) plus their stencil halo are staged once
+// in LDS, every derivative is a 3/4-tap read of LDS with the one-sided boundary rows selected per pixel, and the adjoint
 // is a GATHER over the transposed stencil (no atomics, run-to-run deterministic).  HBM traffic is the
-// compulsory 32 KB read + 48 KB residual write + 32 KB gradient write per 64x64 sample.
+// compulsory 32 KB read + 48 KB residual write + 32 KB gradient write per 64x64 sample (halo rows are re-read from L2).
 #include "pidm_common.h"
 
 namespace pidm {
@@ -55,45 +55,93 @@ __device__ __forceinline__ float fd_apply_T(const float (&c)[3][4], F a_at, int 
 
 enum { DARCY_RES_ONLY = 0, DARCY_BWD = 1, DARCY_LOSS = 2 };
 
-// dynamic LDS: MODE 0: 2 fields; MODE 1/2: 7 fields of P*P floats
+// Row bands.  One workgroup per (sample, band of R rows): with one workgroup per sample a batch of 64 occupied 64 of the 256
+// CUs with one wave per SIMD each (112 KB of LDS per workgroup) and the kernel was pure latency (64 us for 7 MB).  A band
+// [r0, r1) of gradient rows gathers (transposed stencils) from the intermediate fields of rows [r0-1, r1] plus row 0 / row P-1
+// when it lies within 3 rows of them (the one-sided 4-tap edge stencils), and those rows need p and K one row further out
+// (rows 0..3 / P-4..P-1 for the edge rows): the halo rows are recomputed by both neighbours, nothing is exchanged.
+// R >= 4 keeps the extra rows of the edge stencils inside the first / last band's own halo.
+struct DarcyBands {
+  int nb, R;
+};
+static DarcyBands darcy_bands(int B, int P) {
+  int nb = (1024 + B - 1) / B;              // >= 4 workgroups per CU where the batch alone does not provide them
+  const int nb_min = (P + 15) / 16;         // <= 16 rows per band: 8 fields x 23 rows x 64 floats = 47 KB of LDS -> 3 workgroups per CU
+  if (nb < nb_min) nb = nb_min;
+  int nb_max = P / 4;
+  if (nb_max < 1) nb_max = 1;
+  if (nb > nb_max) nb = nb_max;
+  DarcyBands d;
+  d.R = (P + nb - 1) / nb;
+  d.nb = (P + d.R - 1) / d.R;
+  return d;
+}
+static int darcy_lds_rows(int P, int R) { return (R + 7 < P) ? R + 7 : P; }
+
+// per-sample loss weights: either gathered by the caller (t == nullptr: p2w[b], inv_var[b]) or looked up here from the
+// schedule tables by the sample's time step (p2w = p2_loss_weight table, inv_var = posterior_variance_clipped table; the
+// reciprocal is the correctly rounded fp32 division torch's `1.0 / var[t]` performs)
+__device__ __forceinline__ float darcy_p2w(const float* __restrict__ p2w, const long long* __restrict__ t, int b) {
+  return t ? p2w[t[b]] : p2w[b];
+}
+__device__ __forceinline__ float darcy_inv_var(const float* __restrict__ v, const long long* __restrict__ t, int b) {
+  return t ? 1.0f / v[t[b]] : v[b];
+}
+
+// dynamic LDS: MODE 0: 2 fields; MODE 1/2: 8 fields of darcy_lds_rows(P, R) x P floats
 template <int MODE>
 __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0,       // target (MODE 2) [B,2,P,P]
                                                     const float* __restrict__ pred,     // x0_pred [B,2,P,P]
                                                     const float* __restrict__ f_s,      // [P*P]
                                                     const float* __restrict__ grad_res, // MODE 1: [B,P*P,3]
                                                     const float* __restrict__ p2w, const float* __restrict__ inv_var,
+                                                    const long long* __restrict__ tsteps,
                                                     float c_data, float c_res, float bc1_sign, FdAxis ax0, FdAxis ax1,
                                                     float* __restrict__ residual, float* __restrict__ grad_pred,
-                                                    double* __restrict__ partial,       // MODE 2: [B][4]
-                                                    int B, int P) {
+                                                    double* __restrict__ partial,       // MODE 2: [B][nb][4]
+                                                    int B, int P, int R, int nb, int lds_rows) {
   HIP_DYNAMIC_SHARED(float, smem)
   const int N = P * P;
-  float* sp = smem;
-  float* sK = smem + N;
-  float* sg = smem + 2 * N;
-  float* sa0 = smem + 3 * N;
-  float* sa1 = smem + 4 * N;
-  float* sb0 = smem + 5 * N;
-  float* sb1 = smem + 6 * N;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / nb, band = blockIdx.x - b * nb;
   const int tid = threadIdx.x;
+  const int r0 = band * R, r1 = (r0 + R < P) ? r0 + R : P;
+  // rows of intermediates / of p and K this band works on (see above)
+  int ilo = r0, ihi = r1;
+  if (MODE != DARCY_RES_ONLY) {
+    ilo = (r0 < 4) ? 0 : r0 - 1;
+    ihi = (r1 > P - 4) ? P : r1 + 1;
+  }
+  int dlo = (ilo > 0) ? ilo - 1 : 0, dhi = (ihi < P) ? ihi + 1 : P;
+  if (ilo == 0 && dhi < 4) dhi = 4;
+  if (ihi == P && dlo > P - 4) dlo = P - 4;
+  const int F = lds_rows * P;
+  // field pointers addressed with ABSOLUTE pixel indices i*P + j, i in [dlo, dhi)
+  float* sp = smem - dlo * P;
+  float* sK = sp + F;
+  float* sg = sp + 2 * F;
+  float* sa0 = sp + 3 * F;
+  float* sa1 = sp + 4 * F;
+  float* sb0 = sp + 5 * F;
+  float* sb1 = sp + 6 * F;
+  float* sd = sp + 7 * F;
   const float* pb = pred + (size_t)b * 2 * N;
 
   double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
-  for (int n = tid; n < N; n += 256) {
+  for (int n = dlo * P + tid; n < dhi * P; n += 256) {
     float vp = pb[n], vK = pb[N + n];
     sp[n] = vp;
     sK[n] = vK;
-    if (MODE == DARCY_LOSS) {
+    if (MODE == DARCY_LOSS && n >= r0 * P && n < r1 * P) {
       float d0 = x0[(size_t)b * 2 * N + n] - vp, d1 = x0[(size_t)b * 2 * N + N + n] - vK;
       acc_data += (double)(d0 * d0) + (double)(d1 * d1);
     }
   }
   __syncthreads();
 
-  const float gscale = (MODE == DARCY_LOSS) ? c_res * inv_var[b] / ((float)B * (float)N * 3.0f) : 0.f;
-  for (int n = tid; n < N; n += 256) {
+  const float gscale = (MODE == DARCY_LOSS) ? c_res * darcy_inv_var(inv_var, tsteps, b) / ((float)B * (float)N * 3.0f) : 0.f;
+  for (int n = ilo * P + tid; n < ihi * P; n += 256) {
     const int i = n / P, j = n - i * P;
+    const bool own = (i >= r0) & (i < r1);   // rows this band reports (residual, loss sums); the others are halo recomputation
     const float* colp = sp + j;       // walk axis 0 with stride P
     const float* rowp = sp + i * P;   // walk axis 1 with stride 1
     const float* colK = sK + j;
@@ -114,7 +162,7 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
     float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
     float s1 = (j == 0) ? bc1_sign : ((j == P - 1) ? -bc1_sign : 0.f);
     float bc0 = s0 * p0, bc1 = s1 * p1;
-    if (MODE != DARCY_BWD) {
+    if (MODE != DARCY_BWD && own) {
       float* r = residual + ((size_t)b * N + n) * 3;
       r[0] = eq;
       r[1] = bc0;
@@ -128,8 +176,10 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
       gb0 = gr[1];
       gb1 = gr[2];
     } else {
-      acc_r2 += (double)(eq * eq) + (double)(bc0 * bc0) + (double)(bc1 * bc1);
-      acc_rabs += (double)fabsf(eq) + (double)fabsf(bc0) + (double)fabsf(bc1);
+      if (own) {
+        acc_r2 += (double)(eq * eq) + (double)(bc0 * bc0) + (double)(bc1 * bc1);
+        acc_rabs += (double)fabsf(eq) + (double)fabsf(bc0) + (double)fabsf(bc1);
+      }
       g = gscale * eq;
       gb0 = gscale * bc0;
       gb1 = gscale * bc1;
@@ -139,14 +189,13 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
     sa1[n] = -K1 * g + s1 * gb1;   // coefficient on p1
     sb0[n] = -p0 * g;              // coefficient on K0
     sb1[n] = -p1 * g;              // coefficient on K1
-    // direct dependence of eq on K at the same pixel: -(p00 + p11) * g ; stash in the output buffer
-    grad_pred[(size_t)b * 2 * N + N + n] = -(p00 + p11) * g;
+    sd[n] = -(p00 + p11) * g;      // direct dependence of eq on K at the same pixel
   }
   if (MODE == DARCY_RES_ONLY) return;
   __syncthreads();
 
-  const float dscale = (MODE == DARCY_LOSS) ? 2.f * c_data * p2w[b] / ((float)B * 2.f * (float)N) : 0.f;
-  for (int n = tid; n < N; n += 256) {
+  const float dscale = (MODE == DARCY_LOSS) ? 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N) : 0.f;
+  for (int n = r0 * P + tid; n < r1 * P; n += 256) {
     const int i = n / P, j = n - i * P;
     // grad wrt p: D00^T(-K g) + D11^T(-K g) + D0^T a0 + D1^T a1
     float gp = fd_apply_T(ax0.c2, [&](int ii) { return -sK[ii * P + j] * sg[ii * P + j]; }, i, P, 4);
@@ -154,7 +203,7 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
     gp += fd_apply_T(ax0.c1, [&](int ii) { return sa0[ii * P + j]; }, i, P, 3);
     gp += fd_apply_T(ax1.c1, [&](int jj) { return sa1[i * P + jj]; }, j, P, 3);
     // grad wrt K: direct + D0^T b0 + D1^T b1
-    float gK = grad_pred[(size_t)b * 2 * N + N + n];
+    float gK = sd[n];
     gK += fd_apply_T(ax0.c1, [&](int ii) { return sb0[ii * P + j]; }, i, P, 3);
     gK += fd_apply_T(ax1.c1, [&](int jj) { return sb1[i * P + jj]; }, j, P, 3);
     if (MODE == DARCY_LOSS) {
@@ -177,28 +226,48 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
     __syncthreads();
     if (tid < 3) {
       double s = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-      partial[(size_t)b * 4 + tid] = s;
+      partial[(size_t)blockIdx.x * 4 + tid] = s;
     }
   }
 }
 
-// out[0] = loss, out[1] = c_data*data_loss, out[2] = mean|r|, out[3] = 0
-__global__ void darcy_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w,
-                                    const float* __restrict__ inv_var, float c_data, float c_res, int B, int N,
-                                    float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double data = 0.0, res = 0.0, rabs = 0.0;
-  for (int b = 0; b < B; ++b) {
-    data += partial[b * 4 + 0] / (2.0 * N) * (double)p2w[b];
-    res += partial[b * 4 + 1] * (double)inv_var[b];
-    rabs += partial[b * 4 + 2];
+// out[0] = loss, out[1] = c_data*data_loss, out[2] = mean|r|, out[3] = 0.  One workgroup; fixed summation order (thread tid owns
+// samples tid, tid + 256, ...; bands in order; then a shuffle tree and four wave sums): run-to-run deterministic.
+__global__ void __launch_bounds__(256) darcy_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w,
+                                                           const float* __restrict__ inv_var, const long long* __restrict__ tsteps,
+                                                           float c_data, float c_res, int B, int N, int nb, float* __restrict__ out) {
+  __shared__ double red[3][4];
+  const int tid = threadIdx.x;
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int b = tid; b < B; b += 256) {
+    double d = 0.0, r = 0.0, a = 0.0;
+    for (int k = 0; k < nb; ++k) {
+      const double* pp = partial + ((size_t)b * nb + k) * 4;
+      d += pp[0];
+      r += pp[1];
+      a += pp[2];
+    }
+    v[0] += d / (2.0 * N) * (double)darcy_p2w(p2w, tsteps, b);
+    v[1] += r * (double)darcy_inv_var(inv_var, tsteps, b);
+    v[2] += a;
   }
-  data = data / B * c_data;
-  res = 0.5 * c_res * res / ((double)B * N * 3.0);
-  out[0] = (float)(data + res);
-  out[1] = (float)data;
-  out[2] = (float)(rabs / ((double)B * N * 3.0));
-  out[3] = 0.f;
+  for (int q = 0; q < 3; ++q) {
+    double x = v[q];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((tid & 63) == 0) red[q][tid >> 6] = x;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double data = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    double res = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double rabs = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    data = data / B * c_data;
+    res = 0.5 * c_res * res / ((double)B * N * 3.0);
+    out[0] = (float)(data + res);
+    out[1] = (float)data;
+    out[2] = (float)(rabs / ((double)B * N * 3.0));
+    out[3] = 0.f;
+  }
 }
 
 static FdAxis make_axis(double inv_h) {
@@ -261,10 +330,12 @@ __global__ void __launch_bounds__(256) darcy_jacmax_kernel(const float* __restri
 
 template <int MODE>
 static int launch_darcy(const float* x0, const float* pred, const float* f_s, const float* grad_res, const float* p2w,
-                        const float* inv_var, float c_data, float c_res, float inv_h0, float inv_h1, float* residual,
-                        float* grad_pred, double* partial, int B, int P, hipStream_t st) {
+                        const float* inv_var, const long long* tsteps, float c_data, float c_res, float inv_h0, float inv_h1,
+                        float* residual, float* grad_pred, double* partial, int B, int P, hipStream_t st) {
   if (B <= 0 || P < 5) return fail("darcy: need B>0 and P>=5 (got B=%d P=%d)", B, P);
-  size_t lds = (size_t)(MODE == DARCY_RES_ONLY ? 2 : 7) * P * P * sizeof(float);
+  const DarcyBands bd = darcy_bands(B, P);
+  const int rows = darcy_lds_rows(P, bd.R);
+  size_t lds = (size_t)(MODE == DARCY_RES_ONLY ? 2 : 8) * rows * P * sizeof(float);
   if (lds > 160 * 1024 - 256) return fail("darcy: P=%d does not fit the 160 KiB LDS", P);
   static bool attr_done = false;
   if (!attr_done) {
@@ -272,9 +343,23 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_done = true;
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_kernel<MODE>), dim3(B), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
-                     inv_var, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual, grad_pred, partial, B, P);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
+                     inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,
+                     grad_pred, partial, B, P, bd.R, bd.nb, rows);
   PIDM_CHECK_LAUNCH("darcy_kernel");
+  return 0;
+}
+
+static int darcy_loss_impl(const float* x0, const float* x0_pred, const float* f_s, const float* p2w, const float* inv_var,
+                           const long long* tsteps, float c_data, float c_residual, float inv_h0, float inv_h1, float* residual,
+                           float* grad_x0_pred, float* out_scalars, void* workspace, int B, int P, hipStream_t st) {
+  double* partial = reinterpret_cast<double*>(workspace);
+  int rc = launch_darcy<DARCY_LOSS>(x0, x0_pred, f_s, nullptr, p2w, inv_var, tsteps, c_data, c_residual, inv_h0, inv_h1, residual,
+                                    grad_x0_pred, partial, B, P, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partial, p2w, inv_var, tsteps, c_data, c_residual, B, P * P,
+                     darcy_bands(B, P).nb, out_scalars);
+  PIDM_CHECK_LAUNCH("darcy_loss_finalize");
   return 0;
 }
 
@@ -284,33 +369,36 @@ using namespace pidm;
 
 extern "C" int pidm_darcy_residual_fwd(const float* x0, const float* f_s, float inv_h0, float inv_h1, float* residual,
                                        int B, int P, void* stream) {
-  return launch_darcy<DARCY_RES_ONLY>(nullptr, x0, f_s, nullptr, nullptr, nullptr, 0.f, 0.f, inv_h0, inv_h1, residual,
+  return launch_darcy<DARCY_RES_ONLY>(nullptr, x0, f_s, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, inv_h0, inv_h1, residual,
                                       nullptr, nullptr, B, P, as_stream(stream));
 }
 
 extern "C" int pidm_darcy_residual_bwd(const float* x0, const float* grad_res, float inv_h0, float inv_h1,
                                        float* grad_x0, int B, int P, void* stream) {
-  return launch_darcy<DARCY_BWD>(nullptr, x0, nullptr, grad_res, nullptr, nullptr, 0.f, 0.f, inv_h0, inv_h1, nullptr,
+  return launch_darcy<DARCY_BWD>(nullptr, x0, nullptr, grad_res, nullptr, nullptr, nullptr, 0.f, 0.f, inv_h0, inv_h1, nullptr,
                                  grad_x0, nullptr, B, P, as_stream(stream));
 }
 
 extern "C" size_t pidm_darcy_loss_ws(int B, int P) {
-  (void)P;
-  return (size_t)B * 4 * sizeof(double);
+  if (B <= 0 || P < 5) return 0;
+  return (size_t)B * darcy_bands(B, P).nb * 4 * sizeof(double);
 }
 
 extern "C" int pidm_darcy_loss_fwd_bwd(const float* x0, const float* x0_pred, const float* f_s, const float* p2w,
                                        const float* inv_var, float c_data, float c_residual, float inv_h0,
                                        float inv_h1, float* residual, float* grad_x0_pred, float* out_scalars,
                                        void* workspace, int B, int P, void* stream) {
-  double* partial = reinterpret_cast<double*>(workspace);
-  int rc = launch_darcy<DARCY_LOSS>(x0, x0_pred, f_s, nullptr, p2w, inv_var, c_data, c_residual, inv_h0, inv_h1,
-                                    residual, grad_x0_pred, partial, B, P, as_stream(stream));
-  if (rc) return rc;
-  hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(64), 0, as_stream(stream), partial, p2w, inv_var, c_data,
-                     c_residual, B, P * P, out_scalars);
-  PIDM_CHECK_LAUNCH("darcy_loss_finalize");
-  return 0;
+  return darcy_loss_impl(x0, x0_pred, f_s, p2w, inv_var, nullptr, c_data, c_residual, inv_h0, inv_h1, residual, grad_x0_pred,
+                         out_scalars, workspace, B, P, as_stream(stream));
+}
+
+extern "C" int pidm_darcy_loss_fwd_bwd_t(const float* x0, const float* x0_pred, const float* f_s, const int64_t* t,
+                                         const float* p2w_table, const float* var_table, float c_data, float c_residual,
+                                         float inv_h0, float inv_h1, float* residual, float* grad_x0_pred, float* out_scalars,
+                                         void* workspace, int B, int P, void* stream) {
+  if (!t || !p2w_table || !var_table) return fail("darcy_loss_fwd_bwd_t: null time steps / tables");
+  return darcy_loss_impl(x0, x0_pred, f_s, p2w_table, var_table, reinterpret_cast<const long long*>(t), c_data, c_residual, inv_h0,
+                         inv_h1, residual, grad_x0_pred, out_scalars, workspace, B, P, as_stream(stream));
 }
 
 extern "C" int pidm_darcy_jacobian_max(const float* x0, float inv_h0, float inv_h1, float* max_dr_dp, int B, int P, void* stream) {

@@ -592,14 +592,18 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
 }
 
 // x_t (channels-last) = a[b] * x0 (NCHW) + am1[b] * eps (NCHW)
+// t == nullptr: a / am1 hold the per-sample coefficients; otherwise they are the schedule tables and t [B] the time steps
+// (the gather extract(table, t, x) of src/denoising_utils.py:302-306 done here instead of by two indexing kernels)
 __global__ void qsample_kernel(const float* __restrict__ x0, const float* __restrict__ eps, const float* __restrict__ a,
-                               const float* __restrict__ am1, float* __restrict__ xt, int B, int C, int HW) {
+                               const float* __restrict__ am1, const long long* __restrict__ t, float* __restrict__ xt, int B, int C,
+                               int HW) {
   const size_t total = (size_t)B * C * HW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
     const size_t s = (b * C + c) * HW + p;
-    xt[i] = x0[s] * a[b] + eps[s] * am1[b];
+    const size_t k = t ? (size_t)t[b] : b;
+    xt[i] = x0[s] * a[k] + eps[s] * am1[k];
   }
 }
 
@@ -781,7 +785,16 @@ using namespace pidm;
 extern "C" int pidm_qsample_nhwc(const float* x0, const float* eps, const float* a_t, const float* am1_t, float* xt_nhwc,
                                  int B, int C, int HW, void* stream) {
   hipLaunchKernelGGL(qsample_kernel, dim3(ew_blocks((size_t)B * C * HW)), dim3(256), 0, as_stream(stream), x0, eps, a_t,
-                     am1_t, xt_nhwc, B, C, HW);
+                     am1_t, static_cast<const long long*>(nullptr), xt_nhwc, B, C, HW);
+  PIDM_CHECK_LAUNCH("qsample_kernel");
+  return 0;
+}
+
+extern "C" int pidm_qsample_nhwc_t(const float* x0, const float* eps, const int64_t* t, const float* a_table, const float* am1_table,
+                                   float* xt_nhwc, int B, int C, int HW, void* stream) {
+  if (!t || !a_table || !am1_table) return fail("qsample_nhwc_t: null time steps / tables");
+  hipLaunchKernelGGL(qsample_kernel, dim3(ew_blocks((size_t)B * C * HW)), dim3(256), 0, as_stream(stream), x0, eps, a_table,
+                     am1_table, reinterpret_cast<const long long*>(t), xt_nhwc, B, C, HW);
   PIDM_CHECK_LAUNCH("qsample_kernel");
   return 0;
 }

@@ -12,7 +12,7 @@ struct ReduceQueue {
   unsigned nblocks = 0;
   void push(const float* src, float* dst, const float* bsrc, float* bdst, size_t sstride, int nsplit, int M, int N, int T,
             int MP, int NP) {
-    ReduceDesc d;
+    ReduceDesc d{};   // value-initialised: flush_reductions memcmp()s whole structs, tail padding included
     d.src = src; d.dst = dst; d.bsrc = bsrc; d.bdst = bdst; d.sstride = sstride;
     d.nsplit = nsplit; d.M = M; d.N = N; d.T = T; d.MP = MP; d.NP = NP;
     const size_t total = (size_t)M * N * T + (bdst ? M : 0);

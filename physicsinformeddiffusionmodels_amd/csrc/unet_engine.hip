@@ -58,6 +58,7 @@ struct AttnBlock {
   const float* x = nullptr;
   float *xn = nullptr, *qkvb = nullptr, *kstat = nullptr, *qstat = nullptr, *ctx = nullptr, *attn = nullptr;
   float* lsaved = nullptr;   // projected form (k_attn_proj.hip): k statistics | M | ctx | P; qstat as above; no qkv tensor
+  bool projected = false;    // form the latest forward took (latched: the backward must match it whatever the knobs say by then)
 };
 
 }  // namespace pidm
@@ -112,6 +113,11 @@ struct pidm_unet {
   std::vector<const float*> up_in;    // input of each upsample
   std::map<int, std::pair<size_t, size_t>> ws_cache[2];  // B -> (tape bytes, tmp bytes) for inference/training
   std::map<int, size_t> defer_cache;                     // B -> bytes of the deferred-reduction arena (training)
+  long knob_sig = 0;                                     // attention-form knobs the cached plans were made under
+  // arena plan of the latest training-mode forward: its backward lays the workspace out the same way even if the knobs (and
+  // with them the cached plans) changed in between
+  int plan_B = 0;
+  size_t plan_tape_b = 0, plan_tmp_b = 0, plan_defer_b = 0;
   std::vector<ReduceDesc> red_table;                     // host copy of the last uploaded reduction table
   const void* red_table_dev = nullptr;
   // data-parallel overlap (pidm_unet_set_grad_events): the deferred gradient reduction runs in up to 3 phases - after the
@@ -126,6 +132,7 @@ namespace pidm {
 
 static const size_t kMaxPackDesc = 1024;
 static const size_t kMaxReduceDesc = 1024;
+static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads(): steady state must not upload (tests)
 
 struct Run {
   pidm_unet* U;
@@ -556,13 +563,24 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
 // Linear attention without the qkv tensor (k_attn_proj.hip) where the level is large enough for the recomputation to beat the
 // 768-channel round trips: the 64x64 and 32x32 levels of the Darcy model.  PIDM_NO_LAP=1 keeps the qkv form everywhere (A/B
 // measurements); PIDM_LAP_MIN_N lowers the gate (the unit tests reach the path with small images).
-static bool attn_projected(const AttnBlock& a, int heads) {
+static void lap_knobs(bool* off, int* min_n) {
   const char* e = getenv("PIDM_NO_LAP");       // read per call (a handful of calls per step): tests and A/B runs flip it
-  const bool off = e && atoi(e);
+  *off = e && atoi(e);
   const char* m = getenv("PIDM_LAP_MIN_N");
-  const int min_n = m ? atoi(m) : 1024;
-  const int N = a.H * a.H;
-  return !off && !a.mid && a.out.b >= 0 && N >= min_n && lap_ok(N, heads, a.C, a.C);
+  *min_n = m ? atoi(m) : 1024;
+}
+// the knobs as one number: workspace plans are cached per batch size and must be dropped when the knobs change on a live handle
+static long lap_knob_signature() {
+  bool off; int min_n;
+  lap_knobs(&off, &min_n);
+  return off ? -1 : (long)min_n;
+}
+static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
+// decided by the FORWARD (and stored in AttnBlock::projected); the backward replays the stored decision
+static bool attn_projected(const AttnBlock& a, int heads) {
+  bool off; int min_n;
+  lap_knobs(&off, &min_n);
+  return !off && a.H * a.H >= min_n && attn_shape_projectable(a, heads);
 }
 
 static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
@@ -574,7 +592,8 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   a.x = x;
   a.xn = act_alloc(r, npix * C);
   RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
-  if (attn_projected(a, heads)) {
+  a.projected = attn_projected(a, heads);
+  if (a.projected) {
     a.qkvb = nullptr;
     a.lsaved = act_alloc(r, lap_saved_floats(B, heads, C));
     a.qstat = act_alloc(r, npix * heads * 2);
@@ -811,7 +830,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   const size_t mk = r.tmp.mark();
   float* g_qkv = nullptr;
   float* g_xn = nullptr;
-  if (attn_projected(a, heads)) {
+  if (r.dry ? attn_projected(a, heads) : a.projected) {
     // no qkv tensor, no dqkv tensor: d_xn and the to_qkv / to_out weight-gradient shares come straight from (xn, dY)
     const size_t nr = (size_t)B * lap_dw_ranges(N, C);
     const size_t n_qk = nr * 2 * HD * C, n_v = (size_t)B * HD * C, n_o = (size_t)B * C * HD;
@@ -907,7 +926,8 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
     conv_ws(a.qkv); conv_ws(a.out);
     upd(layernorm_bwd_ws_bytes(a.C) + colsum_ws_bytes(1024, a.C));
     upd(la_scratch_floats(B, a.H * a.H, U->heads) * sizeof(float));
-    if (attn_projected(a, U->heads)) upd(lap_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
+    // both attention forms, whatever the knobs say right now (the backward replays the forward's latched decision)
+    if (attn_shape_projectable(a, U->heads)) upd(lap_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
     if (!a.mid && la_fused_ok(a.H * a.H, U->heads, a.C, a.C) && la_fused_pays(B, a.H * a.H)) upd(la_fused_scratch_floats(B, a.H * a.H, U->heads, a.C) * sizeof(float));
   }
   for (int i = 0; i < U->n_lv - 1; ++i) { conv_ws(U->down[i]); conv_ws(U->up[i]); }
@@ -945,6 +965,7 @@ static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase
       memcpy(U->red_table.data() + first, r.rq.v.data() + first, (n - first) * sizeof(ReduceDesc));
       if (hipMemcpyAsync(red_dev + first, U->red_table.data() + first, (n - first) * sizeof(ReduceDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
         return fail("backward: reduction table upload failed");
+      ++g_red_table_uploads;
       U->red_table_dev = red_dev;
     }
     const unsigned blk0 = r.rq.v[first].blk0;
@@ -1117,6 +1138,13 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
 }
 
 static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, size_t* tmp_bytes) {
+  const long sig = lap_knob_signature();
+  if (sig != U->knob_sig) {    // PIDM_NO_LAP / PIDM_LAP_MIN_N changed on a live handle: the cached plans describe the other form
+    U->ws_cache[0].clear();
+    U->ws_cache[1].clear();
+    U->defer_cache.clear();
+    U->knob_sig = sig;
+  }
   auto& cache = U->ws_cache[training ? 1 : 0];
   auto it = cache.find(B);
   if (it != cache.end()) {
@@ -1154,9 +1182,15 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   return 0;
 }
 
-static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, size_t workspace_bytes, void* stream) {
-  size_t tape_b, tmp_b;
-  if (plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b)) return -1;
+static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, size_t workspace_bytes, void* stream, bool replay_plan = false) {
+  size_t tape_b, tmp_b, defer_b;
+  if (replay_plan && h->plan_B == B) {
+    tape_b = h->plan_tape_b; tmp_b = h->plan_tmp_b; defer_b = h->plan_defer_b;
+  } else {
+    if (plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b)) return -1;
+    defer_b = train ? h->defer_cache[B] : 0;
+    if (train) { h->plan_B = B; h->plan_tape_b = tape_b; h->plan_tmp_b = tmp_b; h->plan_defer_b = defer_b; }
+  }
   const size_t packed_b = align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096);
   if (workspace_bytes < packed_b + tape_b + tmp_b)
     return fail("unet: workspace too small (%zu < %zu bytes)", workspace_bytes, packed_b + tape_b + tmp_b);
@@ -1165,7 +1199,6 @@ static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, s
   r.U = h; r.B = B; r.train = train; r.dry = false; r.st = as_stream(stream);
   r.wpack = reinterpret_cast<float*>(w);
   r.tape.base = w + packed_b; r.tape.cap = tape_b;
-  const size_t defer_b = train ? h->defer_cache[B] : 0;
   r.tmp.base = w + packed_b + tape_b; r.tmp.cap = tmp_b - defer_b;
   r.defer.base = r.tmp.base + r.tmp.cap; r.defer.cap = defer_b;
   r.scratch_floats = scratch_floats_needed(h, B);
@@ -1207,7 +1240,7 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   if (h->tape_B != B) return fail("unet_backward: no matching forward (tape holds B=%d)", h->tape_B);
   if (!h->have_grads) return fail("unet_backward: gradient buffers not bound");
   Run r;
-  if (setup_run(r, h, B, true, workspace, workspace_bytes, stream)) return -1;
+  if (setup_run(r, h, B, true, workspace, workspace_bytes, stream, /*replay_plan=*/true)) return -1;
   if (!h->side_ok && !h->side) {
     // created once per handle; PIDM_NO_OVERLAP=1 keeps the whole backward on the caller's stream (A/B measurements)
     const char* e = getenv("PIDM_NO_OVERLAP");
@@ -1249,6 +1282,8 @@ extern "C" int pidm_unet_grad_phase_range(const pidm_unet* h, int n_phases, int 
   *end_param = (n_phases == 3) ? h->idx_downs_first : h->idx_ups_first;
   return 0;
 }
+
+extern "C" long long pidm_debug_reduce_table_uploads(void) { return pidm::g_red_table_uploads; }
 
 extern "C" int pidm_unet_num_cond_params(const pidm_unet* h) { return h ? (int)h->names.size() - h->cond_first_param : 0; }
 

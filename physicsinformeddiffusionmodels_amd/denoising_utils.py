@@ -50,6 +50,21 @@ def b_xy_c_to_image(tensor, pixels_x=None, pixels_y=None):
     return tensor.reshape(b, pixels_x, pixels_y, c).permute(0, 3, 1, 2)
 
 
+def resize_image(tensor, target_size):
+    """[B, C..., X, Y] -> [B, C..., target, target], bilinear without antialiasing (src/denoising_utils.py:57-68: torchvision
+    Resize = F.interpolate(align_corners=False)).  Forward-only tensors on an MI355X go through the native resize kernel
+    (csrc/k_mech.hip); anything that needs a gradient, or lives on the host, takes torch's own interpolate."""
+    assert len(tensor.shape) > 3, f"Expected image, got {tensor.shape}"
+    shape = tensor.shape
+    flat = tensor.reshape(shape[0], -1, shape[-2], shape[-1])
+    if tensor.is_cuda and not tensor.requires_grad and tensor.dtype == torch.float32 and shape[-1] == shape[-2]:
+        from .residuals_mechanics_K import resize_image as _native_resize
+        out = _native_resize(flat.contiguous(), target_size)
+    else:
+        out = F.interpolate(flat, size=(target_size, target_size), mode='bilinear', align_corners=False, antialias=False)
+    return out.view(shape[0], *shape[1:-2], target_size, target_size)
+
+
 def right_pad_dims_to(x, t):
     padding_dims = x.ndim - t.ndim
     if padding_dims <= 0:
@@ -136,6 +151,10 @@ class EMA(object):
         return sflat, pflat, eng
 
     def update(self, module):
+        if self.backup:
+            # between ema() and restore() the parameters ARE the shadow tensors (pointer flip): averaging the shadow with itself
+            # would silently drop this step's update
+            raise RuntimeError("EMA.update() while the averaged weights are swapped in: call ema.restore(model) first")
         named = self._named(module)
         rest = named
         lay = self._flat_layout(module)
@@ -175,6 +194,21 @@ class EMA(object):
             assert n in self.backup
             p.data = self.backup[n]
         self.backup = {}
+
+    def ema_copy(self, module):
+        """A second model holding the averaged weights (src/denoising_utils.py:195-199; the reference builds it from
+        `module.config`, which its own Unet3D never sets - here the constructor arguments the model was built with are used when
+        it has no `config`).  The copy owns its weights (`backup=False`: copied, not aliased to the shadow)."""
+        if hasattr(module, 'config'):
+            module_copy = type(module)(module.config).to(module.config.device)
+        else:
+            import copy
+            module_copy = copy.deepcopy(module)
+            module_copy.__dict__.pop('_engines', None)          # engine handles, workspaces and flat buffers are per model
+            module_copy.__dict__.pop('_pidm_flat_params', None)
+        module_copy.load_state_dict(module.state_dict())
+        self.ema(module_copy, backup=False)
+        return module_copy
 
     def state_dict(self):
         return self.shadow
@@ -335,10 +369,11 @@ class DeferredFloat:
 
 class _DarcyPidmLossFn(torch.autograd.Function):
     """loss = c_data*mean_b(w_t*mse) + mean(c_r*0.5*r^2/var_t) in one kernel, together with d loss/d x0_pred
-    (src/denoising_utils.py:666-692).  Returns (loss, scalars[4], residual)."""
+    (src/denoising_utils.py:666-692).  `t`, `p2w_table`, `var_table`: the step's time levels and the two schedule tables - the
+    gathers and the reciprocal happen inside the kernel.  Returns (loss, scalars[4], residual)."""
 
     @staticmethod
-    def forward(ctx, x0_pred, x0, f_s, p2w, inv_var, c_data, c_residual, inv_h0, inv_h1, lib):
+    def forward(ctx, x0_pred, x0, f_s, t, p2w_table, var_table, c_data, c_residual, inv_h0, inv_h1, lib):
         pred = x0_pred.contiguous()
         B, C, P, _ = pred.shape
         dev = pred.device
@@ -346,9 +381,9 @@ class _DarcyPidmLossFn(torch.autograd.Function):
         grad = torch.empty_like(pred)
         out = torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
-        lib.check(lib.pidm_darcy_loss_fwd_bwd(ptr(x0), ptr(pred), ptr(f_s), ptr(p2w), ptr(inv_var), float(c_data),
-                                              float(c_residual), inv_h0, inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
-                                              B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd')
+        lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x0), ptr(pred), ptr(f_s), ptr(t), ptr(p2w_table), ptr(var_table),
+                                                float(c_data), float(c_residual), inv_h0, inv_h1, ptr(res), ptr(grad), ptr(out),
+                                                ptr(ws), B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd_t')
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(out, res)
         return out[0].clone(), out, res
@@ -356,7 +391,7 @@ class _DarcyPidmLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out, _g_res):
         (grad,) = ctx.saved_tensors
-        return grad * g_loss, None, None, None, None, None, None, None, None, None
+        return grad * g_loss, None, None, None, None, None, None, None, None, None, None
 
 
 class DenoisingDiffusion(nn.Module):
@@ -458,8 +493,54 @@ class DenoisingDiffusion(nn.Module):
             noise = torch.randn_like(x_0)
         return extract(alphas_bar_sqrt, t, x_0) * x_0 + extract(one_minus_alphas_bar_sqrt, t, x_0) * noise
 
+    def plot_diffusion(self, dataset, alphas_bar_sqrt, one_minus_alphas_bar_sqrt):
+        """Scatter plots of q(x_t) for t = 0, 10, ..., 90 of a 2-D dataset (src/denoising_utils.py:380-386; toy visualisation,
+        host-side; needs matplotlib)."""
+        import matplotlib.pyplot as plt
+        fig, axs = plt.subplots(1, 10, figsize=(18, 2))
+        for i in range(10):
+            q_i = self.q_sample(dataset, torch.tensor([i * 10]), alphas_bar_sqrt, one_minus_alphas_bar_sqrt)
+            axs[i].scatter(q_i[:, 0], q_i[:, 1], s=10)
+            axs[i].set_axis_off()
+            axs[i].set_title('$q(\\mathbf{x}_{' + str(i * 10) + '})$', fontsize=10)
+        plt.show()
+
+    def normal_kl(self, mean1, logvar1, mean2, logvar2):
+        """KL(N(mean1, e^logvar1) || N(mean2, e^logvar2)), elementwise (src/denoising_utils.py:547-552)."""
+        return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
     def gaussian_log_likelihood(self, x, means, variance):
         return -0.5 * ((x - means) ** 2) / variance
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (extract(self.diff_dict['sqrt_recip_alphas_cumprod'], t, x_t) * x_t -
+                extract(self.diff_dict['sqrt_recipm1_alphas_cumprod'], t, x_t) * noise)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (extract(self.diff_dict['sqrt_recip_alphas_cumprod'], t, x_t) * x_t - x0) / \
+            extract(self.diff_dict['sqrt_recipm1_alphas_cumprod'], t, x_t)
+
+    def loss_variational(self, output, x_0, x_t, t, base_2=False):
+        """Variational-bound term with the model variance fixed to the clipped posterior variance (src/denoising_utils.py:576-614):
+        KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) per sample for t > 0, -log p(x_0|x_1) at t == 0; mean over the batch.  Not used
+        by main.py / sample.py (the PIDM loss is model_estimation_loss); plain tensor algebra on the schedule tables."""
+        batch_size = x_0.shape[0]
+        true_mean = (extract(self.diff_dict['posterior_mean_coef1'], t, x_t) * x_0 +
+                     extract(self.diff_dict['posterior_mean_coef2'], t, x_t) * x_t)
+        true_var = extract(self.diff_dict['posterior_variance_clipped'], t, x_t)
+        model_var, model_mean = true_var, output
+        kl = self.normal_kl(true_mean, torch.log(true_var), model_mean, torch.log(model_var))
+        kl = torch.mean(kl.view(batch_size, -1), dim=1)
+        if base_2:
+            kl = kl / np.log(2.)
+        log_likelihood = self.gaussian_log_likelihood(x_0, means=model_mean, variance=model_var)
+        log_likelihood = torch.mean(log_likelihood.view(batch_size, -1), dim=1)
+        if base_2:
+            log_likelihood = log_likelihood / np.log(2.)
+        assert not log_likelihood.isnan().any(), 'Log likelihood is nan.'
+        assert not log_likelihood.isinf().any(), 'Log likelihood is inf.'
+        loss = torch.where(t == 0, -1. * log_likelihood, kl)
+        return loss.mean(-1)
 
     def predict_noise_from_mean(self, x_t, t, mean_t):
         return (extract(self.diff_dict['sqrt_recip_alphas'], t, mean_t) * x_t - mean_t) / \
@@ -539,16 +620,15 @@ class DenoisingDiffusion(nn.Module):
         dev = x_0.device
         dd = self.diff_dict
         x_0 = x_0.contiguous()
-        a = dd['alphas_bar_sqrt'][t].contiguous()
-        am1 = dd['one_minus_alphas_bar_sqrt'][t].contiguous()
+        t = t.to(dtype=torch.int64).contiguous()
         xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
-        lib.check(lib.pidm_qsample_nhwc(ptr(x_0), ptr(e.contiguous()), ptr(a), ptr(am1), ptr(xt), B, C, P * P,
-                                        stream_ptr(dev)), 'pidm_qsample_nhwc')
-        p2w = dd['p2_loss_weight'][t].contiguous()
-        inv_var = (1.0 / dd['posterior_variance_clipped'][t]).contiguous()
+        # the extract() gathers of the schedule tables by t happen inside the kernels (no indexing / reciprocal launches)
+        lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e.contiguous()), ptr(t), ptr(dd['alphas_bar_sqrt']),
+                                          ptr(dd['one_minus_alphas_bar_sqrt']), ptr(xt), B, C, P * P, stream_ptr(dev)),
+                  'pidm_qsample_nhwc_t')
         if residual_func._f_s_flat.device != dev:
             residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
-        args = (residual_func._f_s_flat, p2w, inv_var)
+        args = (residual_func._f_s_flat, t, dd['p2_loss_weight'], dd['posterior_variance_clipped'])
         geo = (residual_func.inv_h0, residual_func.inv_h1, lib)
         if residual_func.use_ddim_x0:
             # x0_estimation 'sample' (src/residuals_darcy.py:127-128): the data term sees model(x_t, t), the residual term

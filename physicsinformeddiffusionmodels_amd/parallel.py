@@ -104,6 +104,7 @@ class GradientExchange:
         dev = eng.params[0].device
         self.on_gpu = dev.type == "cuda"
         self.events, self.stream = None, None
+        self._closed = True                # until the engine has been told about this object
         handles = None
         if self.on_gpu and self.active and os.environ.get("PIDM_DP_NO_OVERLAP") != "1":
             try:
@@ -115,19 +116,51 @@ class GradientExchange:
             except (AttributeError, RuntimeError) as e:            # no raw event handle on this torch build: exchange after backward
                 print(f"GradientExchange: overlapped exchange disabled ({e})")
                 self.events = self.stream = handles = None
-        eng.lib.check(eng.lib.pidm_unet_set_grad_events(eng.handle, self.buckets, handles), "pidm_unet_set_grad_events")
+        # an inactive exchange (one rank, not forced) keeps the engine's single deferred reduction: phases exist for the overlap only
+        self.n_phases = self.buckets if self.active else 1
+        eng.lib.check(eng.lib.pidm_unet_set_grad_events(eng.handle, self.n_phases, handles), "pidm_unet_set_grad_events")
         eng.backward_calls = 0
+        eng._exchange_owner = id(self)     # a later exchange of the same engine takes over; close() of an older one is then a no-op
+        self.last_overlapped = None        # how the latest allreduce() ran (tests / bench read it)
+        self._closed = False
+
+    def close(self):
+        """Detach from the engine: it holds the RAW hipEvent_t handles of this object's torch events and would record on
+        destroyed events once they are garbage-collected.  Called by __del__; idempotent."""
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            eng = self.eng
+            if self.stream is not None:
+                self.stream.synchronize()
+            if getattr(eng, "_exchange_owner", None) == id(self):
+                eng.lib.check(eng.lib.pidm_unet_set_grad_events(eng.handle, 1, None), "pidm_unet_set_grad_events")
+                eng._exchange_owner = None
+        except Exception:
+            pass
+        self.events = self.stream = None
+        self.active = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def allreduce(self):
         """Average the gradients over all ranks (in place).  Call right after loss.backward()."""
         eng = self.eng
         calls, eng.backward_calls = eng.backward_calls, 0
+        if self._closed:
+            raise RuntimeError("GradientExchange.allreduce: the exchange was closed")
         if not self.active:
             return
         flat = eng.flat_grad
         if flat is None:
             raise RuntimeError("GradientExchange.allreduce: no engine gradient buffer - run loss.backward() first")
         overlapped = self.events is not None and calls == 1
+        self.last_overlapped = overlapped
         if not overlapped:
             # several backward passes wrote / accumulated into the buffer after the phase events: exchange once everything is in
             for rs in self.ranges:

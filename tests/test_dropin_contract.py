@@ -89,3 +89,47 @@ def test_src_package_reexports():
                        (dut, ("Dataset", "Dataset_Paths", "cycle"))):
         for n in names:
             assert hasattr(mod, n), (mod.__name__, n)
+
+
+def test_thin_diffusion_members_match_reference():
+    """normal_kl / predict_* / loss_variational / module-level resize_image (src/denoising_utils.py:57-68,547-614) against the
+    genuine reference's outputs (golden g21).  main.py / sample.py never call them; they are part of the drop-in surface."""
+    from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion, resize_image
+    g = np.load(os.path.join(G, "g21_diffusion_algebra.npz"))
+    dd = DenoisingDiffusion(100, "cpu")
+    x0, xt, out, noise, img = (torch.from_numpy(g[k]) for k in ("x0", "xt", "out", "noise", "img"))
+    t = torch.from_numpy(g["t"])
+    close = lambda a, k: np.testing.assert_allclose(a.numpy(), g[k], rtol=1e-6, atol=1e-6, err_msg=k)   # noqa: E731
+    close(dd.normal_kl(x0, 0.3 * xt, out, 0.2 * noise), "normal_kl")
+    close(dd.predict_start_from_noise(xt, t, noise), "start_from_noise")
+    close(dd.predict_noise_from_start(xt, t, x0), "noise_from_start")
+    close(dd.predict_noise_from_mean(xt, t, out), "noise_from_mean")
+    close(dd.loss_variational(out, x0, xt, t), "loss_variational")
+    close(dd.loss_variational(out, x0, xt, t, base_2=True), "loss_variational_base2")
+    close(resize_image(img, 5), "resized5")
+    close(resize_image(img, 13), "resized13")
+
+
+def test_ema_copy_and_update_guard():
+    """EMA.ema_copy (src/denoising_utils.py:195-199) returns a model that owns the averaged weights; EMA.update refuses to run
+    while the averaged weights are swapped in (the parameters alias the shadow then)."""
+    from physicsinformeddiffusionmodels_amd.denoising_utils import EMA
+    from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+    torch.manual_seed(3)
+    m = Unet3D(dim=8, channels=2)
+    ema = EMA(0.5)
+    ema.register(m)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(1.0)
+    ema.update(m)
+    cp = ema.ema_copy(m)
+    named, named_cp = dict(m.named_parameters()), dict(cp.named_parameters())
+    for k, sh in ema.shadow.items():
+        assert torch.equal(named_cp[k], sh) and named_cp[k].data_ptr() != sh.data_ptr(), k
+        assert torch.allclose(named[k], sh + 0.5), k          # shadow = 0.5 (p + 1) + 0.5 p = p + 0.5 -> model = shadow + 0.5
+    ema.ema(m)
+    with pytest.raises(RuntimeError, match="swapped in"):
+        ema.update(m)
+    ema.restore(m)
+    ema.update(m)

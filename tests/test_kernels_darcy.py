@@ -13,7 +13,9 @@ def rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize("P,B", [(16, 3), (64, 2)])
+# (P, B) also pick the row-band plan of the kernel: 64 -> 16 bands of 4 rows, 16 -> 4 x 4, 10 -> 2 x 5 (edge stencils reach across
+# a band border), 7 -> one band, 21 -> 5 bands the last of which is a single row
+@pytest.mark.parametrize("P,B", [(16, 3), (64, 2), (10, 3), (7, 2), (21, 2)])
 def test_darcy_residual_fwd_bwd(backend, P, B):
     L, dev = backend
     st = stream_ptr(dev)
@@ -36,7 +38,7 @@ def test_darcy_residual_fwd_bwd(backend, P, B):
     assert rel(gx, gref) < 5e-6
 
 
-@pytest.mark.parametrize("P,B", [(16, 4), (64, 2)])
+@pytest.mark.parametrize("P,B", [(16, 4), (64, 2), (10, 3), (21, 4)])
 def test_darcy_fused_loss(backend, P, B):
     L, dev = backend
     st = stream_ptr(dev)
@@ -66,3 +68,28 @@ def test_darcy_fused_loss(backend, P, B):
     assert abs(out[1].item() - data.item()) < 1e-5 * abs(data.item())
     assert abs(out[2].item() - rabs.item()) < 1e-5 * abs(rabs.item())
     assert rel(gpred, pr.grad) < 1e-5
+    # the variant that looks the weights up from the schedule tables by t inside the kernel: bit-identical
+    res2, gpred2, out2 = torch.empty_like(res), torch.empty_like(gpred), torch.zeros(4, device=dev)
+    td = t.to(dev)
+    tab_w, tab_v = tables["p2_loss_weight"].to(dev), tables["posterior_variance_clipped"].to(dev)
+    L.check(L.pidm_darcy_loss_fwd_bwd_t(ptr(x0d), ptr(predd), ptr(fsd), ptr(td), ptr(tab_w), ptr(tab_v), 1.0, 1e-3, inv_h, -inv_h,
+                                        ptr(res2), ptr(gpred2), ptr(out2), ptr(ws), B, P, st))
+    assert torch.equal(res2, res) and torch.equal(gpred2, gpred) and torch.equal(out2.cpu(), out)
+
+
+def test_qsample_table_lookup_matches_gathered_form(backend):
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(8)
+    tables = O.diffusion_tables(100)
+    B, C, P = 5, 2, 8
+    x0, eps = torch.randn(B, C, P, P, generator=g).to(dev), torch.randn(B, C, P, P, generator=g).to(dev)
+    t = torch.tensor([0, 99, 3, 50, 50]).to(dev)
+    a_tab, am1_tab = tables["alphas_bar_sqrt"].to(dev), tables["one_minus_alphas_bar_sqrt"].to(dev)
+    a, am1 = a_tab[t].contiguous(), am1_tab[t].contiguous()
+    y1, y2 = torch.empty(B, P * P, C, device=dev), torch.empty(B, P * P, C, device=dev)
+    L.check(L.pidm_qsample_nhwc(ptr(x0), ptr(eps), ptr(a), ptr(am1), ptr(y1), B, C, P * P, st))
+    L.check(L.pidm_qsample_nhwc_t(ptr(x0), ptr(eps), ptr(t), ptr(a_tab), ptr(am1_tab), ptr(y2), B, C, P * P, st))
+    assert torch.equal(y1, y2)
+    ref = (a.view(B, 1, 1, 1) * x0 + am1.view(B, 1, 1, 1) * eps).permute(0, 2, 3, 1).reshape(B, P * P, C)
+    assert rel(y1, ref) < 1e-6

@@ -20,6 +20,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                  algorithmic FLOPs / HIP-event time of those launches, measured live on the launch stream
   fp32_mfma_only - the same step with every contraction on the fp32 MFMA instead of the split-bf16 form
   eager_scalars  - the same step with the tracked loss terms returned as python floats every step (host sync per step)
+  dropin_main_py - the loop body of the reference's main.py:157-183,316 UNCHANGED: python-float loss terms, torch's
+                   clip_grad_norm_ + torch.optim.Adam, ema.update / ema.ema / ema.restore every iteration (what a user who only
+                   swaps the import path gets; darcy / mechanics, N = 1)
+  north_star_b256 - the same headline step at per-GPU batch 256, the configuration north_star quotes its target on (darcy, N = 1)
+  residual_only  - the fused Darcy residual + loss kernel alone (SURVEY 8(d) secondary metric) at batch 64 and 4096, GB/s
+  exchange       - N > 1 (or PIDM_BENCH_FORCE_EXCHANGE=1): torch.distributed backend, world size, ms per gradient exchange
   cpu_baseline - the CPU oracle (oracle/pidm_oracle.py, a torch-CPU restatement pinned against the reference)
                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -42,6 +48,7 @@ FLOPS_PER_SAMPLE_FWD = 3.98e9         # Darcy dim=32 forward only (sampling)
 FLOPS_PER_SAMPLE_MECH = 141.39e9      # mechanics dim=128, 10->3 channels, fwd+bwd (FlopCounterMode on the reference)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 LOG_FREQ = 20                         # main.py:153
 
 
@@ -145,16 +152,59 @@ def cpu_baseline(workload, batch, steps, threads):
 
 
 def pmc_traffic(workload, batch):
-    """HBM bytes per launch of the conv class from the committed PMC passes (tools/pmc_traffic.sh -> profiles/): the
-    counters need rocprofv3 around the process, so they cannot be read live; null when no pass exists for this workload."""
+    """(HBM bytes per launch of the conv class, where the figure comes from).  The PMC counters need rocprofv3 around the
+    process, so they cannot be read live: the figure is the committed pass of tools/pmc_traffic.sh under profiles/ for this
+    workload and batch (FETCH_SIZE / WRITE_SIZE in separate --pmc runs, gfx950 corrections applied); (None, reason) when no pass
+    exists."""
     import json as _json
     tag = f"pmc_traffic_b{batch}.json" if workload == "darcy" else f"pmc_traffic_{workload}_b{batch}.json"
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tag)
     try:
         with open(path) as f:
-            return round(float(_json.load(f)["conv"]["hbm_bytes_per_launch"]), 0)
+            d = _json.load(f)
+        return round(float(d["conv"]["hbm_bytes_per_launch"]), 0), f"committed rocprofv3 --pmc pass profiles/{tag} ({d.get('round', 'round 2')} build), not this run"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, f"no committed PMC pass for workload {workload} at batch {batch} (profiles/{tag} absent)"
+
+
+def residual_only_rates(lib, residuals, diffusion, dev):
+    """SURVEY 8(d) secondary metric: the fused Darcy residual + PIDM loss + d loss / d x0_pred kernel alone (csrc/k_darcy.hip), HIP
+    events on the launch stream, algorithmic bytes = 32 KB prediction read + 48 KB residual write + 32 KB gradient write per 64x64
+    sample (the contract figure; the 32 KB target read of the data term is not counted)."""
+    from physicsinformeddiffusionmodels_amd._lib import ptr, stream_ptr
+    out = {}
+    P = 64
+    for B in (64, 4096):
+        g = torch.Generator(device="cpu").manual_seed(5)
+        x0 = torch.randn(B, 2, P, P, generator=g).to(dev)
+        pred = x0 + 0.1
+        t = torch.randint(0, diffusion.n_steps, (B,), generator=g).to(dev)
+        res = torch.empty(B, P * P, 3, device=dev)
+        grad = torch.empty_like(pred)
+        sc = torch.empty(4, device=dev)
+        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        dd = diffusion.diff_dict
+
+        def call():
+            lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x0), ptr(pred), ptr(residuals._f_s_flat), ptr(t), ptr(dd['p2_loss_weight']),
+                                                    ptr(dd['posterior_variance_clipped']), 1.0, 1e-3, residuals.inv_h0, residuals.inv_h1,
+                                                    ptr(res), ptr(grad), ptr(sc), ptr(ws), B, P, stream_ptr(dev)), "darcy loss")
+        for _ in range(3):
+            call()
+        n = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        nbytes = B * (32 + 48 + 32) * 1024
+        out[f"b{B}"] = {"us_per_launch_pair": round(us, 2), "GB/s": round(nbytes / us / 1e3, 1),
+                        "frac_of_hbm_peak": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
+    out["what"] = ("darcy_kernel<loss> + darcy_loss_finalize (residual, loss terms, d loss/d x0_pred), algorithmic 112 KiB per sample, "
+                   "back-to-back launches timed with events on the launch stream")
+    return out
 
 
 def main():
@@ -233,24 +283,28 @@ def main():
     diffusion.deferred_scalars = not args.eager_scalars
     counter = {"it": 0, "last": None}
 
-    def step():
+    def step(batch_=None, opt_=None, torch_opt=None):
+        """One step on `batch_` (default: the headline batch) with optimizer `opt_` (default: the headline one)."""
         if not train:
             # one ancestral step of the whole batch (src/denoising_utils.py:388-455); the chain restarts at t = 999 when it ends
             (nx, _), _ = diffusion.p_sample(chain["x"], None, chain["i"], save_output=False, surpress_noise=True, residual_func=residuals)
             chain["x"] = nx
             chain["i"] = chain["i"] - 1 if chain["i"] > 0 else 999
             return nx
-        loss, *tracked = diffusion.model_estimation_loss(batch, residual_func=residuals, **loss_kw)
+        b_ = batch if batch_ is None else batch_
+        o_ = optimizer if opt_ is None else opt_
+        use_torch = args.torch_optimizer if torch_opt is None else torch_opt
+        loss, *tracked = diffusion.model_estimation_loss(b_, residual_func=residuals, **loss_kw)
         counter["it"] += 1
         if counter["it"] % LOG_FREQ == 0:      # main.py:167-175: the tracked loss terms are read every log_freq = 20 iterations
             counter["last"] = [float(v) for v in tracked]
-        optimizer.zero_grad()
+        o_.zero_grad()
         loss.backward()
         if exchange is not None:
             exchange.allreduce()
-        if args.torch_optimizer:
+        if use_torch:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
-        optimizer.step()
+        o_.step()
         if ema is not None:
             ema.update(model)
         return loss
@@ -259,6 +313,22 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(fn, n, warm=3):
+        """ms per call of n calls of fn between two fences (after `warm` untimed ones), max over ranks"""
+        for _ in range(warm):
+            fn()
+        fence()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        el_ = time.perf_counter() - t_
+        if dist is not None:
+            tt_ = torch.tensor([el_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            el_ = float(tt_.item())
+        return el_ / n * 1e3
 
     if args.calib_copy:
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
@@ -288,19 +358,8 @@ def main():
         os.environ["PIDM_WGRAD_SPLIT"] = "0"
         os.environ["PIDM_LAP_SPLIT"] = "0"
         n_alt = min(args.steps, 20)
-        for _ in range(3):
-            step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(n_alt):
-            step()
-        fence()
-        el = time.perf_counter() - t1
-        if dist is not None:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        alt = {"value": round(B * world * n_alt / el, 2), "ms_per_step": round(el / n_alt * 1e3, 3), "steps": n_alt,
+        ms_alt = timed(step, n_alt)
+        alt = {"value": round(B * world / ms_alt * 1e3, 2), "ms_per_step": round(ms_alt, 3), "steps": n_alt,
                "what": "PIDM_CONV_SPLIT=0 PIDM_WGRAD_SPLIT=0 PIDM_LAP_SPLIT=0: every contraction on the fp32 MFMA"}
         del os.environ["PIDM_CONV_SPLIT"], os.environ["PIDM_WGRAD_SPLIT"], os.environ["PIDM_LAP_SPLIT"]
 
@@ -309,21 +368,23 @@ def main():
     if train and not args.no_alt and not args.eager_scalars:
         diffusion.deferred_scalars = False
         n_e = min(args.steps, 20)
-        for _ in range(3):
-            step()
-        fence()
-        t2 = time.perf_counter()
-        for _ in range(n_e):
-            step()
-        fence()
-        el = time.perf_counter() - t2
-        if dist is not None:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        eager = {"value": round(B * world * n_e / el, 2), "ms_per_step": round(el / n_e * 1e3, 3), "steps": n_e,
+        ms_e = timed(step, n_e)
+        eager = {"value": round(B * world / ms_e * 1e3, 2), "ms_per_step": round(ms_e, 3), "steps": n_e,
                  "what": "model_estimation_loss returns python floats every step (DenoisingDiffusion.deferred_scalars = False)"}
         diffusion.deferred_scalars = True
+
+    # gradient exchange: what ran and how long one exchange takes (events on the stream the collectives run on)
+    exch = None
+    if exchange is not None:
+        exchange.measure = True
+        for _ in range(min(args.steps, 5)):
+            step()
+        ems = exchange.exchange_ms()
+        exchange.measure = False
+        exch = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ms_per_exchange": None if ems is None else round(ems, 3),
+                "overlapped_with_backward": bool(exchange.last_overlapped), "ranges": [len(r) for r in exchange.ranges],
+                "payload_MB": round(sum(hi - lo for rs in exchange.ranges for lo, hi in rs) * 4 / 1e6, 2),
+                "forced_single_rank": bool(force_dp and world == 1)}
 
     roofline = None
     if not args.no_roofline:
@@ -339,27 +400,89 @@ def main():
         cnt = (C.c_longlong * 4)()
         work = (C.c_double * 4)()
         lib.pidm_prof_collect(ms, cnt, work)
-        conv_ms, conv_fl, conv_n = ms[0] + ms[1], work[0] + work[1], cnt[0] + cnt[1]
+        # classes: 0 / 1 = forward+dgrad / wgrad on the fp32 MFMA, 2 / 3 = the same in split form on the bf16 pipe
+        conv_ms, conv_fl, conv_n = sum(ms), sum(work), sum(cnt)
+        fd_ms, fd_fl = ms[0] + ms[2], work[0] + work[2]
+        wg_ms, wg_fl = ms[1] + ms[3], work[1] + work[3]
+        sp_ms, sp_fl, sp_n = ms[2] + ms[3], work[2] + work[3], cnt[2] + cnt[3]
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         step_flops = B * flops_per_unit
+        traffic, traffic_source = pmc_traffic(wl, B)
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(wl, B),
-            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3: conv3x3_split_kernel / conv_wgrad_split_kernel, 6 bf16 MFMAs "
-                      "per fp32 product on 3-piece split operands; 1x1, 4x4 s2, 7x7: fp32 MFMA)",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3 and 4x4/s2: conv3x3_split_kernel / conv_wgrad_split_kernel, 6 bf16 "
+                      "MFMAs per fp32 product on 3-piece split operands; 1x1, 7x7, 4x4/s2 wgrad: fp32 MFMA)",
             "peak_note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = the fp32 MFMA's dense peak, the rate an fp32 "
-                         "contraction is priced at - the 3x3 kernels do 6x these FLOPs on the bf16 pipe (dense peak 2500 TFLOP/s)",
+                         "contraction is priced at; frac_bf16_pipe prices the split-form launches alone against the pipe they run on",
+            # the split-form launches against THEIR pipe: 6 bf16 MFMA terms per fp32 product / their HIP-event time / 2500 TFLOP/s dense
+            "frac_bf16_pipe": round(6.0 * sp_fl / (sp_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if sp_ms > 0 else None,
+            "split_form": {"launches_per_step": sp_n // nprof, "ms_per_step": round(sp_ms / nprof, 3),
+                           "fp32_equiv_tflops": round(sp_fl / max(sp_ms, 1e-9) / 1e9, 2),
+                           "bf16_tflops": round(6.0 * sp_fl / max(sp_ms, 1e-9) / 1e9, 2), "bf16_peak": PEAK_BF16_MFMA_TFLOPS},
+            "fp32_mfma_form": {"launches_per_step": (cnt[0] + cnt[1]) // nprof, "ms_per_step": round((ms[0] + ms[1]) / nprof, 3),
+                               "tflops": round((work[0] + work[1]) / max(ms[0] + ms[1], 1e-9) / 1e9, 2)},
             "timing": "HIP events per launch in extra steps after the timed region; the library keeps the weight-gradient "
                       "side-stream overlap OFF while these hooks are on (a kernel that shares the chip has no duration of its own); "
                       "`value` is measured with the overlap on",
             "launches_per_step": conv_n // nprof, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "kernel_ms_per_step": round(conv_ms / nprof, 3),
-            "fwd_dgrad": {"ms_per_step": round(ms[0] / nprof, 3), "tflops": round(work[0] / max(ms[0], 1e-9) / 1e9, 2)},
-            "wgrad": {"ms_per_step": round(ms[1] / nprof, 3), "tflops": round(work[1] / max(ms[1], 1e-9) / 1e9, 2)},
+            "fwd_dgrad": {"ms_per_step": round(fd_ms / nprof, 3), "tflops": round(fd_fl / max(fd_ms, 1e-9) / 1e9, 2)},
+            "wgrad": {"ms_per_step": round(wg_ms / nprof, 3), "tflops": round(wg_fl / max(wg_ms, 1e-9) / 1e9, 2)},
             "step_flop_fraction": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
         if wl == "darcy":
             roofline["step_hbm_fraction"] = round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+
+    # ---- the reference's loop body, unchanged (main.py:157-183,316): what a user who only swaps the import path gets ----
+    dropin = None
+    if train and world == 1 and not args.no_alt:
+        from physicsinformeddiffusionmodels_amd.denoising_utils import EMA as _EMA
+        d_opt = torch.optim.Adam(model.parameters(), lr=n_lr)                     # main.py:134
+        d_ema = _EMA(0.99)                                                        # main.py:53,131
+        d_ema.register(model)
+        diffusion.deferred_scalars = False                                        # python floats, as the reference returns them
+        it_d = {"i": 0}
+
+        def dropin_step():
+            model.train()
+            loss, data_loss, residual_loss, ineq_loss, opt_loss = diffusion.model_estimation_loss(batch, residual_func=residuals, **loss_kw)
+            d_opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
+            d_opt.step()
+            if it_d["i"] % LOG_FREQ == 0:
+                _ = f"training loss: {loss.item():.3e}"                           # main.py:168
+            d_ema.update(model)                                                   # main.py:178-179 (iteration > ema_start: steady state)
+            model.eval()
+            d_ema.ema(residuals.model)                                            # main.py:183
+            d_ema.restore(residuals.model)                                        # main.py:316
+            it_d["i"] += 1
+        n_d = min(args.steps, 20)
+        ms_d = timed(dropin_step, n_d)
+        dropin = {"value": round(B / ms_d * 1e3, 2), "ms_per_step": round(ms_d, 3), "steps": n_d,
+                  "what": "main.py:157-183,316 loop body unchanged: python-float loss terms (host sync per step), torch clip_grad_norm_ + "
+                          "torch.optim.Adam, ema.update + ema.ema + ema.restore every iteration"}
+        diffusion.deferred_scalars = not args.eager_scalars
+        model.train()
+        del d_opt, d_ema
+
+    # ---- north-star configuration: per-GPU batch 256 (BASELINE.json north_star), same step as `value` ----
+    b256 = None
+    if wl == "darcy" and world == 1 and B != 256 and not args.no_alt:
+        batch256 = synthetic_darcy_batch(256, 64, seed=300 + rank, device=dev)
+        n_b = min(args.steps, 10)
+        ms_b = timed(lambda: step(batch256), n_b)
+        b256 = {"value": round(256 / ms_b * 1e3, 2), "ms_per_step": round(ms_b, 3), "steps": n_b, "per_gpu_batch": 256,
+                "step_flop_fraction": round(256 * FLOPS_PER_SAMPLE_FWD_BWD / (ms_b * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "step_hbm_fraction": round(256 * BYTES_PER_SAMPLE / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "what": "the headline step (loss + backward + fused clip+Adam, deferred loss scalars) at per-GPU batch 256; fractions = "
+                        "SURVEY 8(d) contract FLOPs / bytes per sample over the measured step time against 157.3 TFLOP/s and 8 TB/s"}
+        del batch256
+
+    resonly = None
+    if wl == "darcy" and world == 1 and rank == 0 and not args.no_alt:
+        resonly = residual_only_rates(lib, residuals, diffusion, dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -398,7 +521,8 @@ def main():
             "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
-            "fp32_mfma_only": alt, "eager_scalars": eager,
+            "fp32_mfma_only": alt, "eager_scalars": eager, "dropin_main_py": dropin, "north_star_b256": b256,
+            "residual_only": resonly, "exchange": exch,
         }
     if dist is not None:
         dist.destroy_process_group()

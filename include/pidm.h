@@ -30,7 +30,8 @@ const char* pidm_last_error(void);
 const char* pidm_backend(void);
 
 /* bench-only: per-launch timing of the dominant kernels with HIP events recorded on the launch stream.
- * class 0 = implicit-GEMM conv forward/dgrad (work = algorithmic FLOPs), class 1 = conv wgrad (FLOPs). */
+ * class 0 = conv forward/dgrad on the fp32 MFMA (work = algorithmic FLOPs), class 1 = conv wgrad on the fp32 MFMA,
+ * class 2 / 3 = the same two in split form on the bf16 pipe (each launch is in exactly one class). */
 int pidm_prof_enable(int on);
 int pidm_prof_collect(double* ms4, long long* launches4, double* work4);
 

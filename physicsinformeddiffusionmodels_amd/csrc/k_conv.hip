@@ -2681,7 +2681,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const float* s1 = src1 ? src1 : src0;
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", nw, mode, n_items, wgs, lds);
         const bool prof = prof_enabled();
-        if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
+        if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
         const dim3 bd(64 * nw);
         if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
@@ -2733,7 +2733,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
         const int trace = getenv("PIDM_STREAM_TRACE") ? 1 : 0;
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
-        if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
+        if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
         if (nw == 8)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);
@@ -3000,6 +3000,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
     } else if (launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
+      if (prof) prof_reclass_last(3);   // split form: counted with the weight gradients and, separately, against the bf16 pipe
       // taken by the bf16-pipe kernel (wg now holds its tiling / split)
     } else {
       // row-aligned staging without vector arithmetic where the geometry allows it (PIDM_WGRAD_ROWST=0: off, for A/B runs)

@@ -56,6 +56,7 @@ void prof_begin_launch(int cls, double work, hipStream_t st) {
   g_prof.push_back(r);
 }
 void prof_end_launch(hipStream_t st) { (void)hipEventRecord(g_prof.back().b, st); }
+void prof_reclass_last(int cls) { if (!g_prof.empty()) g_prof.back().cls = cls; }
 }  // namespace pidm
 
 extern "C" int pidm_prof_enable(int on) {

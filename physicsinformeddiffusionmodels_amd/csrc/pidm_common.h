@@ -18,6 +18,7 @@ bool prof_enabled();
 void prof_set_label(const char* label);   // attached to the next prof_begin_launch records (per-shape tables)
 void prof_begin_launch(int cls, double work, hipStream_t st);
 void prof_end_launch(hipStream_t st);
+void prof_reclass_last(int cls);          // the launcher learned which kernel took the launch (2 / 3 = split form of class 0 / 1)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

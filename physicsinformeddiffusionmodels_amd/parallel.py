@@ -122,6 +122,8 @@ class GradientExchange:
         eng.backward_calls = 0
         eng._exchange_owner = id(self)     # a later exchange of the same engine takes over; close() of an older one is then a no-op
         self.last_overlapped = None        # how the latest allreduce() ran (tests / bench read it)
+        self.measure = False               # True: time every allreduce() with events on the stream the collectives run on
+        self._timing = []                  # (start event, end event) per measured call
         self._closed = False
 
     def close(self):
@@ -161,19 +163,41 @@ class GradientExchange:
             raise RuntimeError("GradientExchange.allreduce: no engine gradient buffer - run loss.backward() first")
         overlapped = self.events is not None and calls == 1
         self.last_overlapped = overlapped
+        timing = None
+        if self.measure and self.on_gpu:
+            timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._timing.append(timing)
         if not overlapped:
             # several backward passes wrote / accumulated into the buffer after the phase events: exchange once everything is in
+            if timing:
+                timing[0].record()
             for rs in self.ranges:
                 for lo, hi in rs:
                     _allreduce_avg(flat[lo:hi], self.world, self.group)
+            if timing:
+                timing[1].record()
             return
         cur = torch.cuda.current_stream(flat.device)
         for k, rs in enumerate(self.ranges):
             self.stream.wait_event(self.events[k])
             with torch.cuda.stream(self.stream):
+                if timing and k == 0:
+                    timing[0].record()          # first phase's gradients are final: the exchange starts here
                 for lo, hi in rs:
                     _allreduce_avg(flat[lo:hi], self.world, self.group)
+                if timing and k == len(self.ranges) - 1:
+                    timing[1].record()
         cur.wait_stream(self.stream)
+
+    def exchange_ms(self):
+        """Mean wall time (ms) from the start of the first collective to the end of the last one over the allreduce() calls made
+        while `measure` was on (synchronises; with the overlap on, this span runs concurrently with the rest of backward)."""
+        if not self._timing:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._timing]
+        self._timing = []
+        return sum(ms) / len(ms)
 
 
 def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:

@@ -113,6 +113,45 @@ def test_training_step_determinism_and_shard_average_b64():
     assert (avg - g1).abs().max().item() < 2e-4 * scale
 
 
+def test_training_step_b256_equals_average_of_four_b64_shards():
+    """The north-star configuration (per-GPU batch 256) through the whole step - q-sample, UNet forward, fused residual + loss,
+    UNet backward: the gradient of the batch-256 mean loss equals the average of the gradients of its four batch-64 shards (the
+    quantity the batch-64 parity tests pin against the reference goldens and what a 4-rank data-parallel step computes), the loss
+    terms average the same way, and the step is bit-exact run to run."""
+    m, diff, res, dev = _darcy_setup()
+    g = torch.Generator().manual_seed(15)
+    x0 = torch.randn(256, 2, 64, 64, generator=g).to(dev)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(256, 2, 64, 64, generator=g).to(dev)
+    t = torch.randint(0, 100, (256,), generator=g).to(dev)
+
+    def grads(lo, hi):
+        orig = torch.randint, torch.randn_like
+        torch.randint = lambda *a, **k: t[lo:hi].clone()
+        torch.randn_like = lambda *a, **k: eps[lo:hi].clone()
+        try:
+            loss, data_l, res_l, _, _ = diff.model_estimation_loss(x0[lo:hi].contiguous(), residual_func=res, c_data=1., c_residual=1e-3)
+        finally:
+            torch.randint, torch.randn_like = orig
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        eng = next(iter(m.__dict__["_engines"].values()))
+        return (loss.item(), float(data_l), float(res_l)), eng.flat_grad.clone()
+
+    s_full, g_full = grads(0, 256)
+    s_again, g_again = grads(0, 256)
+    assert s_full == s_again and torch.equal(g_full, g_again)
+    assert torch.isfinite(g_full).all() and g_full.abs().max().item() > 0
+    parts = [grads(64 * k, 64 * (k + 1)) for k in range(4)]
+    avg = sum(p[1] for p in parts) / 4.0
+    for i in range(3):
+        mean_i = sum(p[0][i] for p in parts) / 4.0
+        assert abs(mean_i - s_full[i]) < 1e-5 * abs(s_full[i]), (i, mean_i, s_full[i])
+    scale = g_full.abs().max().item()
+    assert (avg - g_full).abs().max().item() < 2e-4 * scale
+
+
 def test_attention_forms_agree_b64(monkeypatch):
     """Three executions of the same attention blocks at batch 64: without a qkv tensor (k_attn_proj.hip, the default of the 64x64
     and 32x32 levels), with the qkv tensor and the attention fused into the to_out projection, and with separate kernels.

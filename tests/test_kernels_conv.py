@@ -300,3 +300,75 @@ def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
     for e_split, e_fp32, what in zip(errs["split"], errs["fp32"], ("forward", "dgrad", "wgrad")):
         assert e_split < 1.25 * e_fp32 + 1e-8, (what, errs)
         assert e_split < 2e-6, (what, errs)
+
+
+@pytest.mark.parametrize("form", ["split", "fp32"])
+def test_conv_extreme_magnitudes(backend, monkeypatch, form):
+    """Non-finite and extreme inputs through the 3x3 kernels, split form next to the fp32-MFMA form (same expectations for both):
+    * +-inf / NaN in the input make exactly the outputs of their 3x3 footprint non-finite (the split form turns inf into NaN -
+      x - bf16(x) = inf - inf - where the fp32 kernels keep +-inf; a fp32 value above the bf16 maximum 3.3895e38 rounds its
+      first piece to inf and behaves like inf) and leave every other output untouched;
+    * 3e38 (below the bf16 maximum) is carried exactly by the three pieces: relative error at the fp32 level;
+    * values around 1e-38 and fp32 denormals lose their low pieces (bf16 pieces below 2^-133 vanish) - an ABSOLUTE error far
+      below anything representable next to O(1) data, and no NaN.
+    Same for the input gradient (specials in dy) and the weight gradient (specials in x)."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "1" if form == "split" else "0")
+    monkeypatch.setenv("PIDM_WGRAD_SPLIT", "1" if form == "split" else "0")
+    g = torch.Generator().manual_seed(7)
+    B, H, Cin, Cout = 2, 16, 32, 32
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    w = torch.where(w.abs() < 1e-3, torch.full_like(w, 1e-3), w)          # no zero weight: inf * w is never NaN in the reference
+    specials = [((0, 3, 2, 2), float("inf")), ((0, 7, 2, 8), float("-inf")), ((0, 1, 2, 13), float("nan")),
+                ((0, 5, 8, 2), 3e38), ((1, 9, 3, 3), 1e-38), ((1, 2, 3, 4), 1e-40), ((1, 2, 9, 9), -1e-38)]
+
+    def plant(t):
+        t = t.clone()
+        for (b, c, y, x_), v in specials:
+            t[b, c, y, x_] = v
+        t[1, :, 11:16, 0:5] *= 1e-38      # a whole patch at the bottom of the fp32 range
+        return t
+
+    def check(out, ref, what):
+        out, ref = out.detach().cpu(), ref.detach().cpu()
+        bad_ref = ~torch.isfinite(ref)
+        assert torch.equal(~torch.isfinite(out), bad_ref), what         # the same set of non-finite outputs
+        huge = (ref.abs() > 1e30) & ~bad_ref
+        ok = ~bad_ref & ~huge
+        scale = ref[ok].abs().max().item()
+        assert (out[ok] - ref[ok]).abs().max().item() < 5e-6 * scale, what
+        if huge.any():
+            assert ((out[huge] - ref[huge]).abs() <= 5e-6 * ref[huge].abs()).all(), what
+        return int(bad_ref.sum()), int(huge.sum())
+
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=Cout)
+    wd_ = w.to(dev)
+    # forward
+    x = plant(torch.randn(B, Cin, H, H, generator=g))
+    ref = F.conv2d(x, w, None, padding=1)
+    wp = torch.empty(L.pidm_conv_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wp), 0, st))
+    out = torch.empty(B, H, H, Cout, device=dev)
+    xn = nhwc(x).to(dev)                  # (named: the kernels get raw pointers, the tensors must outlive the calls)
+    L.check(L.pidm_conv_forward(d, ptr(xn), None, ptr(wp), None, None, ptr(out), st))
+    nbad, nhuge = check(out.permute(0, 3, 1, 2), ref, "forward")
+    assert nbad == 3 * 9 * Cout and nhuge == 9 * Cout
+    # input gradient
+    dy = plant(torch.randn(B, Cout, H, H, generator=g))
+    dx_ref = torch.nn.grad.conv2d_input((B, Cin, H, H), w, dy, padding=1)
+    wdg = torch.empty(L.pidm_conv_dgrad_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wdg), 1, st))
+    dx = torch.empty(B, H, H, Cin, device=dev)
+    dyn = nhwc(dy).to(dev)
+    L.check(L.pidm_conv_dgrad(d, ptr(dyn), Cout, ptr(wdg), None, ptr(dx), Cin, st))
+    check(dx.permute(0, 3, 1, 2), dx_ref, "dgrad")
+    # weight gradient: a special value in channel c of x reaches every tap of dW[:, c]
+    dy2 = torch.randn(B, Cout, H, H, generator=g)
+    dy2 = torch.where(dy2.abs() < 1e-3, torch.full_like(dy2, 1e-3), dy2)
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy2, padding=1)
+    ws = torch.empty(L.pidm_conv_wgrad_ws(d), dtype=torch.uint8, device=dev)
+    dw = torch.empty_like(wd_)
+    dy2n = nhwc(dy2).to(dev)
+    L.check(L.pidm_conv_wgrad(d, ptr(xn), None, ptr(dy2n), Cout, ptr(dw), None, ptr(ws), st))
+    check(dw, dw_ref, "wgrad")

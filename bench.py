@@ -335,14 +335,31 @@ def main():
         dst = torch.empty_like(src)
         dst.copy_(src)
         del src, dst
+    def launch_counts():
+        a = (C.c_longlong * 4)()
+        lib.pidm_debug_launch_counts(a)
+        return list(a)
+
     for _ in range(args.warmup):
         step()
     fence()
+    lc0 = launch_counts()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0          # the host is done enqueuing; the GPU still works through the queue
     fence()
     elapsed = time.perf_counter() - t0
+    lc1 = launch_counts()
+    launches = {
+        "kernels_enqueued_one_by_one_per_step": round((lc1[0] - lc0[0]) / args.steps, 1),
+        "graph_launches_per_step": round((lc1[1] - lc0[1]) / args.steps, 2),
+        "kernels_inside_graphs_per_step": round((lc1[2] - lc0[2]) / args.steps, 1),
+        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
+        "what": "library-side accounting over the timed region (pidm_debug_launch_counts): the UNet forward and backward are replayed "
+                "hipGraphs (PIDM_GRAPH=0 turns that off); kernels enqueued one by one = q-sample, loss, optimizer kernels (torch's own "
+                "launches - RNG, the loss-scalar copy - are not counted); host_enqueue = wall time until the host has enqueued a step",
+    }
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -522,7 +539,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
             "fp32_mfma_only": alt, "eager_scalars": eager, "dropin_main_py": dropin, "north_star_b256": b256,
-            "residual_only": resonly, "exchange": exch,
+            "residual_only": resonly, "exchange": exch, "launches": launches,
         }
     if dist is not None:
         dist.destroy_process_group()

@@ -288,6 +288,10 @@ int pidm_debug_stream_trace(unsigned long long* out256);
 /* test aid: host-to-device uploads of the deferred-reduction descriptor table since the library was loaded (a second identical
  * backward pass must not upload anything: the table is compared with what the device already holds) */
 long long pidm_debug_reduce_table_uploads(void);
+/* launch accounting since the library was loaded: out4 = {kernels enqueued launch by launch, hipGraphLaunch calls, kernels inside
+ * the launched graphs, stream captures}.  pidm_unet_forward / pidm_unet_backward replay a captured hipGraph from the third call
+ * with the same arguments on (PIDM_GRAPH=0: always launch by launch). */
+int pidm_debug_launch_counts(long long* out4);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,7 @@ class PidmLib:
         L.pidm_backend.restype = C.c_char_p
         i, f, sz = C.c_int, C.c_float, C.c_size_t
         self._sig("pidm_debug_reduce_table_uploads", [], C.c_longlong)
+        self._sig("pidm_debug_launch_counts", [C.POINTER(C.c_longlong)])
         self._sig("pidm_prof_enable", [i])
         self._sig("pidm_prof_collect", [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)])
         self._sig("pidm_darcy_residual_fwd", [vp, vp, f, f, vp, i, i, vp])

@@ -6,6 +6,7 @@
 
 namespace pidm {
 static thread_local char g_err[512] = "";
+long long g_kernel_enqueues = 0;
 
 void set_error(const char* fmt, ...) {
   va_list ap;

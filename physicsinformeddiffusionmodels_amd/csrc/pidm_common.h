@@ -22,8 +22,13 @@ void prof_reclass_last(int cls);          // the launcher learned which kernel t
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// kernels enqueued through the library since it was loaded: directly (eager) + recorded into graphs during a capture; the engine
+// subtracts what a capture recorded (pidm_debug_launch_counts)
+extern long long g_kernel_enqueues;
+
 #define PIDM_CHECK_LAUNCH(what)                                                     \
   do {                                                                              \
+    ++::pidm::g_kernel_enqueues;                                                    \
     hipError_t e__ = hipGetLastError();                                             \
     if (e__ != hipSuccess) return ::pidm::fail("%s: %s", what, hipGetErrorString(e__)); \
   } while (0)

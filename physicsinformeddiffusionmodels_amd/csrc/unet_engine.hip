@@ -15,6 +15,8 @@
 
 #include "pidm_launch.h"
 
+extern char** environ;
+
 namespace pidm {
 
 struct Arena {
@@ -60,6 +62,56 @@ struct AttnBlock {
   float* lsaved = nullptr;   // projected form (k_attn_proj.hip): k statistics | M | ctx | P; qstat as above; no qkv tensor
   bool projected = false;    // form the latest forward took (latched: the backward must match it whatever the knobs say by then)
 };
+
+// ---- hipGraph replay ---------------------------------------------------------------------------------------
+// The launch sequence of a forward or backward pass is a pure function of (batch size, mode, knobs, every pointer the kernels
+// receive): the second time a pass is asked for with the same key it is stream-captured, afterwards it is ONE hipGraphLaunch per
+// segment instead of ~200 launches.  A backward pass under the data-parallel overlap is cut into one segment per gradient phase so
+// that the caller's (external) phase events are recorded for real between them.
+struct GraphSeg {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipEvent_t ev_after = nullptr;   // external event recorded on the launch stream after this segment (phase events)
+  long long kernels = 0;
+};
+// host-side record of a forward pass that its backward walks ("tape" pointers inside the workspace + the arena plan)
+struct TapeState {
+  std::vector<ResBlock> rb;
+  std::vector<AttnBlock> attn;
+  std::vector<const float*> skip, down_in, up_in;
+  int tape_B = 0;
+  const float* x_in = nullptr;
+  float *emb = nullptr, *h1 = nullptr, *h1g = nullptr, *temb = nullptr, *st = nullptr, *ss = nullptr, *h0 = nullptr, *xfinal = nullptr;
+  const float* out_nchw = nullptr;
+  bool tape_cond = false;
+  const float* cond_in = nullptr;
+  float *e1 = nullptr, *e1g = nullptr, *e2 = nullptr, *h0pre = nullptr;
+  int plan_B = 0;
+  size_t plan_tape_b = 0, plan_tmp_b = 0, plan_defer_b = 0;
+};
+struct GraphEntry {
+  std::vector<uint64_t> key;
+  std::vector<GraphSeg> segs;
+  TapeState tape;                  // forward entries (training mode): the host state the pass leaves behind
+  const void* red_dev = nullptr;   // backward entries: where the pass expects its reduction descriptor table on the device
+  uint64_t stamp = 0;
+};
+struct GraphCapture {              // an open capture
+  GraphEntry* entry = nullptr;
+  hipStream_t user_st = nullptr;   // stream the finished segments are launched on
+  bool open = false, failed = false;
+  long long kernels0 = 0;
+};
+static const size_t kMaxGraphs = 6;      // per handle and pass kind (LRU)
+static const size_t kMaxSeenKeys = 16;
+static long long g_graph_launches = 0, g_graph_kernels = 0, g_graph_captures = 0;
+static void graph_entry_free(GraphEntry& e) {
+  for (auto& sg : e.segs) {
+    if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+    if (sg.graph) (void)hipGraphDestroy(sg.graph);
+  }
+  e.segs.clear();
+}
 
 }  // namespace pidm
 
@@ -126,6 +178,14 @@ struct pidm_unet {
   int n_phases = 1;
   hipEvent_t phase_ev[3] = {nullptr, nullptr, nullptr};
   int idx_downs_first = 0, idx_ups_first = 0;            // canonical parameter indices that bound the phases
+  // hipGraph replay
+  hipStream_t cap_stream = nullptr;                      // private capture stream (the caller's may be the null stream, which cannot capture)
+  bool cap_stream_ok = false;
+  std::vector<GraphEntry> graphs[2];                     // [0] forward, [1] backward
+  std::vector<std::vector<uint64_t>> seen[2];            // keys seen once (captured on their second sighting)
+  uint64_t graph_stamp = 0, bind_sig = 0, fwd_key_hash = 0;
+  uint64_t arena_sig = 0;                                // layout of the latest pass that used the workspace arena
+  uint64_t red_table_owner = 0;                          // layout that uploaded the reduction descriptor table
 };
 
 namespace pidm {
@@ -150,6 +210,7 @@ struct Run {
   bool defer_on = false;
   bool overlap = false;        // weight gradients on the side stream (real backward runs only)
   bool side_pending = false;   // side-stream work issued since the last join
+  GraphCapture* cap = nullptr; // non-null while this pass is being stream-captured (r.st is the capture stream then)
   float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
   ReduceQueue* q() { return defer_on ? &rq : nullptr; }
 };
@@ -372,6 +433,9 @@ extern "C" int pidm_unet_create(const pidm_unet_cfg* cfg, pidm_unet** out) {
 
 extern "C" void pidm_unet_destroy(pidm_unet* h) {
   if (!h) return;
+  for (int k = 0; k < 2; ++k)
+    for (auto& e : h->graphs[k]) pidm::graph_entry_free(e);
+  if (h->cap_stream_ok) (void)hipStreamDestroy(h->cap_stream);
   if (h->side_ok) {
     (void)hipStreamDestroy(h->side);
     (void)hipEventDestroy(h->ev_fork);
@@ -395,6 +459,15 @@ extern "C" int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, 
     h->G[i] = grad_ptrs_host ? reinterpret_cast<float*>(grad_ptrs_host[i]) : nullptr;
   }
   h->have_grads = grad_ptrs_host != nullptr;
+  {
+    // graphs are keyed on the bound pointer set (flipping back to an earlier set - EMA swap in / out - finds its graphs again)
+    uint64_t sig = 1469598103934665603ull;
+    for (size_t i = 0; i < h->names.size(); ++i) {
+      sig ^= (uint64_t)reinterpret_cast<uintptr_t>(h->P[i]); sig *= 1099511628211ull;
+      sig ^= (uint64_t)reinterpret_cast<uintptr_t>(h->G[i]); sig *= 1099511628211ull; sig ^= sig >> 29;
+    }
+    h->bind_sig = sig;
+  }
   h->cond_grads_dirty = true;    // new gradient buffers: contents unknown
   h->pack_table_valid = false;   // parameter pointers may have changed
   if (h->have_grads) {
@@ -442,6 +515,10 @@ static int pack_all(Run& r) {
   if (U->packed_zeroed_for == r.wpack && U->pack_table_valid) {
     // same workspace, same parameter pointers: the descriptor table on the device is still valid
     return launch_pack_multi(table_dev, (int)U->pack_table.size(), U->pack_blocks, r.st);
+  }
+  if (r.cap) {        // needs a host -> device upload of the descriptor table: never captured, the pass is re-run eagerly
+    r.cap->failed = true;
+    return 0;
   }
   if (hipMemsetAsync(r.wpack, 0, U->packed_floats_total * sizeof(float), r.st) != hipSuccess) return fail("memset failed");
   U->packed_zeroed_for = r.wpack;
@@ -934,10 +1011,61 @@ static size_t scratch_floats_needed(pidm_unet* U, int B) {
   return mx;
 }
 
+// ---- stream capture of a pass into graph segments ---------------------------------------------------------------------------
+static int cap_begin(Run& r) {
+  GraphCapture* c = r.cap;
+  if (hipStreamBeginCapture(r.st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    c->failed = true;
+    return fail("graph capture: hipStreamBeginCapture failed");
+  }
+  c->open = true;
+  c->kernels0 = g_kernel_enqueues;
+  return 0;
+}
+// closes the open segment, instantiates and LAUNCHES it on the caller's stream (a capture records, it does not execute), records
+// `ev_after` there, and opens the next segment when `reopen`.  After a failure nothing more is launched: the caller discards the
+// entry and runs the whole pass eagerly (every pass is idempotent: it only writes its own outputs and temporaries).
+static int cap_end_segment(Run& r, hipEvent_t ev_after, bool reopen) {
+  GraphCapture* c = r.cap;
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(r.st, &g);
+  c->open = false;
+  if (e != hipSuccess || !g) {
+    (void)hipGetLastError();
+    c->failed = true;
+    if (g) (void)hipGraphDestroy(g);
+    return fail("graph capture: hipStreamEndCapture failed (%s)", hipGetErrorString(e));
+  }
+  GraphSeg seg;
+  seg.graph = g;
+  seg.ev_after = ev_after;
+  seg.kernels = g_kernel_enqueues - c->kernels0;
+  g_kernel_enqueues = c->kernels0;     // recorded, not enqueued: counted per replay instead
+  if (!c->failed && hipGraphInstantiate(&seg.exec, g, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    seg.exec = nullptr;
+    c->failed = true;
+  }
+  c->entry->segs.push_back(seg);
+  if (!c->failed) {
+    if (hipGraphLaunch(seg.exec, c->user_st) != hipSuccess) {
+      (void)hipGetLastError();
+      c->failed = true;
+    } else {
+      ++g_graph_launches;
+      g_graph_kernels += seg.kernels;
+      if (ev_after && hipEventRecord(ev_after, c->user_st) != hipSuccess) return fail("backward: phase event record failed");
+    }
+  }
+  if (reopen) return cap_begin(r);
+  return 0;
+}
+
 // Runs the fixed-order reductions queued since the previous flush (weight / bias / norm-parameter gradients) in one launch.
 // `phase` >= 0: also record that phase's event (data-parallel overlap).  The descriptor table lives at the head of the deferred
 // arena; only the part that differs from what the device already holds is uploaded (steady state: nothing).
-static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase) {
+static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase, bool final_flush = false) {
   pidm_unet* U = r.U;
   if (r.dry) return 0;
   if (join_side(r)) return -1;
@@ -947,7 +1075,9 @@ static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase
     if (U->red_table.capacity() < kMaxReduceDesc) U->red_table.reserve(kMaxReduceDesc);   // never reallocates afterwards: async uploads read it
     const bool same = U->red_table_dev == red_dev && U->red_table.size() >= n &&
                       memcmp(U->red_table.data() + first, r.rq.v.data() + first, (n - first) * sizeof(ReduceDesc)) == 0;
-    if (!same) {
+    if (!same && r.cap) {
+      r.cap->failed = true;      // a table upload is never captured: host and device table stay as they are, the pass is re-run eagerly
+    } else if (!same) {
       if (getenv("PIDM_REDUCE_STATS")) {   // one line per table change: what the deferred reduction reads
         double bytes = 0, outs = 0;
         for (size_t i = first; i < n; ++i) {
@@ -967,14 +1097,20 @@ static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase
         return fail("backward: reduction table upload failed");
       ++g_red_table_uploads;
       U->red_table_dev = red_dev;
+      U->red_table_owner = U->arena_sig;     // the layout whose defer arena holds the table
     }
     const unsigned blk0 = r.rq.v[first].blk0;
     RUN(launch_reduce_multi(red_dev + first, (int)(n - first), r.rq.nblocks - blk0, r.st, blk0));
     *done = n;
   }
-  if (phase >= 0 && phase < 3 && U->phase_ev[phase]) {
-    if (hipEventRecord(U->phase_ev[phase], r.st) != hipSuccess) return fail("backward: phase event record failed");
+  hipEvent_t ev = (phase >= 0 && phase < 3) ? U->phase_ev[phase] : nullptr;
+  if (r.cap) {
+    // an external event cannot be recorded from inside a capture: the segment ends here, is launched, and the event is recorded
+    // on the caller's stream behind it
+    if (ev || final_flush) return cap_end_segment(r, ev, !final_flush);
+    return 0;
   }
+  if (ev && hipEventRecord(ev, r.st) != hipSuccess) return fail("backward: phase event record failed");
   return 0;
 }
 
@@ -1088,13 +1224,6 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (conv_wgrad(r, U->emb1, U->cond_in, nullptr, g_e1)) return -1;
     g_h0 = g_h0p;
     if (!r.dry) U->cond_grads_dirty = true;
-  } else if (!r.dry && U->have_grads && U->cond_grads_dirty) {
-    // the conditioning parameters were not used by this forward: their slots of the (flat) gradient buffer must not keep
-    // an earlier step's values (the wrapper leaves p.grad = None for them, as the reference does).  Freshly bound
-    // buffers count as dirty; after one zero-fill nothing needs to be done until the branch is used again.
-    for (size_t i = (size_t)U->cond_first_param; i < U->names.size(); ++i)
-      if (hipMemsetAsync(U->G[i], 0, U->numels[i] * sizeof(float), r.st) != hipSuccess) return fail("backward: memset failed");
-    U->cond_grads_dirty = false;
   }
   if (conv_wgrad(r, U->init_conv, U->x_in, nullptr, g_h0)) return -1;
   if (grad_x_nhwc) {
@@ -1133,7 +1262,7 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (conv_wgrad(r, U->lin1, U->emb, nullptr, d_h1)) return -1;
   }
   // ---- every remaining queued fixed-order reduction (weight/bias/norm-parameter gradients) in one launch ----
-  if (flush_reductions(r, red_dev, &red_done, n_phases - 1)) return -1;
+  if (flush_reductions(r, red_dev, &red_done, n_phases - 1, /*final_flush=*/true)) return -1;
   return 0;
 }
 
@@ -1182,6 +1311,36 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   return 0;
 }
 
+// Static input / output buffers of a pass, between the packed weights and the tape: the kernels of a pass only ever see these
+// addresses (a captured graph is then valid for ANY caller buffers: the wrappers copy x / t / cond / grad_out in and out /
+// grad_x out with plain device copies around the graph launch).
+struct IoRegion {
+  float *x = nullptr, *cond = nullptr, *out = nullptr, *gout = nullptr, *gx = nullptr;
+  int64_t* t = nullptr;
+  size_t x_bytes = 0, cond_bytes = 0, out_bytes = 0, t_bytes = 0, total = 0;
+};
+static IoRegion io_region(const pidm_unet* h, int B, char* base) {
+  IoRegion io;
+  const size_t HW = (size_t)h->cfg.image_size * h->cfg.image_size;
+  io.x_bytes = (size_t)B * HW * h->init_conv.C0 * sizeof(float);
+  io.cond_bytes = h->cond_enabled ? (size_t)B * HW * h->cfg.channels * sizeof(float) : 0;
+  io.out_bytes = (size_t)B * HW * h->cfg.out_dim * sizeof(float);
+  io.t_bytes = (size_t)B * sizeof(int64_t);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+  io.x = reinterpret_cast<float*>(take(io.x_bytes));
+  io.cond = reinterpret_cast<float*>(take(io.cond_bytes));
+  io.out = reinterpret_cast<float*>(take(io.out_bytes));
+  io.gout = reinterpret_cast<float*>(take(io.out_bytes));
+  io.gx = reinterpret_cast<float*>(take(io.x_bytes));
+  io.t = reinterpret_cast<int64_t*>(take(io.t_bytes));
+  io.total = align_up(off, 4096);
+  return io;
+}
+static size_t packed_region_bytes(const pidm_unet* h) {
+  return align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096);
+}
+
 static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, size_t workspace_bytes, void* stream, bool replay_plan = false) {
   size_t tape_b, tmp_b, defer_b;
   if (replay_plan && h->plan_B == B) {
@@ -1191,7 +1350,7 @@ static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, s
     defer_b = train ? h->defer_cache[B] : 0;
     if (train) { h->plan_B = B; h->plan_tape_b = tape_b; h->plan_tmp_b = tmp_b; h->plan_defer_b = defer_b; }
   }
-  const size_t packed_b = align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096);
+  const size_t packed_b = packed_region_bytes(h) + io_region(h, B, nullptr).total;   // the static I/O buffers follow the packed weights
   if (workspace_bytes < packed_b + tape_b + tmp_b)
     return fail("unet: workspace too small (%zu < %zu bytes)", workspace_bytes, packed_b + tape_b + tmp_b);
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail("unet: workspace must be 256-byte aligned");
@@ -1211,8 +1370,171 @@ static int setup_run(Run& r, pidm_unet* h, int B, bool train, void* workspace, s
 extern "C" size_t pidm_unet_workspace_bytes(const pidm_unet* h, int B, int training) {
   size_t tape_b, tmp_b;
   if (plan_sizes(const_cast<pidm_unet*>(h), B, training, &tape_b, &tmp_b)) return 0;
-  return align_up(h->packed_floats_total * sizeof(float) + kMaxPackDesc * sizeof(PackDesc), 4096) + tape_b + tmp_b + 256;
+  return packed_region_bytes(h) + io_region(h, B, nullptr).total + tape_b + tmp_b + 256;
 }
+
+namespace pidm {
+
+// ---- graph cache ---------------------------------------------------------------------------------------------------------------
+static uint64_t hash_words(const uint64_t* w, size_t n, uint64_t h = 1469598103934665603ull) {
+  for (size_t i = 0; i < n; ++i) {
+    h ^= w[i];
+    h *= 1099511628211ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+// every PIDM_* environment variable (the launchers read their knobs per call; a replayed graph has them frozen in)
+static uint64_t env_signature() {
+  uint64_t h = 1469598103934665603ull;
+  for (char** e = ::environ; e && *e; ++e) {
+    if (strncmp(*e, "PIDM_", 5) != 0) continue;
+    for (const char* c = *e; *c; ++c) {
+      h ^= (unsigned char)*c;
+      h *= 1099511628211ull;
+    }
+    h ^= h >> 31;
+  }
+  return h;
+}
+static bool graphs_enabled() {
+  const char* e = getenv("PIDM_GRAPH");        // 0: every pass is enqueued launch by launch (A/B measurements)
+  return !(e && !atoi(e)) && !prof_enabled();  // per-launch event timing needs individual launches
+}
+static GraphEntry* graph_find(pidm_unet* h, int kind, const std::vector<uint64_t>& key) {
+  for (auto& e : h->graphs[kind])
+    if (e.key == key) {
+      e.stamp = ++h->graph_stamp;
+      return &e;
+    }
+  return nullptr;
+}
+// true when `key` was seen before (and forgets it); remembers it otherwise: a pass is captured on its SECOND sighting, so callers
+// whose buffers move every call (no stable key) simply keep the eager path
+static bool graph_second_sighting(pidm_unet* h, int kind, const std::vector<uint64_t>& key) {
+  auto& seen = h->seen[kind];
+  for (size_t i = 0; i < seen.size(); ++i)
+    if (seen[i] == key) {
+      seen.erase(seen.begin() + i);
+      return true;
+    }
+  if (seen.size() >= kMaxSeenKeys) seen.erase(seen.begin());
+  seen.push_back(key);
+  return false;
+}
+static GraphEntry* graph_new_entry(pidm_unet* h, int kind, const std::vector<uint64_t>& key) {
+  auto& v = h->graphs[kind];
+  if (v.size() >= kMaxGraphs) {
+    size_t lru = 0;
+    for (size_t i = 1; i < v.size(); ++i)
+      if (v[i].stamp < v[lru].stamp) lru = i;
+    graph_entry_free(v[lru]);
+    v.erase(v.begin() + lru);
+  }
+  v.emplace_back();
+  v.back().key = key;
+  v.back().stamp = ++h->graph_stamp;
+  return &v.back();
+}
+static void graph_drop_entry(pidm_unet* h, int kind, GraphEntry* e) {
+  auto& v = h->graphs[kind];
+  graph_entry_free(*e);
+  v.erase(v.begin() + (e - v.data()));
+}
+static int graph_replay(GraphEntry* e, hipStream_t st) {
+  for (auto& sg : e->segs) {
+    if (hipGraphLaunch(sg.exec, st) != hipSuccess) return fail("graph replay: hipGraphLaunch failed (%s)", hipGetErrorString(hipGetLastError()));
+    ++g_graph_launches;
+    g_graph_kernels += sg.kernels;
+    if (sg.ev_after && hipEventRecord(sg.ev_after, st) != hipSuccess) return fail("graph replay: phase event record failed");
+  }
+  return 0;
+}
+static bool ensure_cap_stream(pidm_unet* h) {
+  if (!h->cap_stream_ok && !h->cap_stream) {
+    h->cap_stream_ok = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+    if (!h->cap_stream_ok) {
+      (void)hipGetLastError();
+      h->cap_stream = reinterpret_cast<hipStream_t>(1);   // marks "decided: no capture stream"
+    }
+  }
+  return h->cap_stream_ok;
+}
+static void tape_save(const pidm_unet* U, TapeState* t) {
+  t->rb = U->rb; t->attn = U->attn; t->skip = U->skip; t->down_in = U->down_in; t->up_in = U->up_in;
+  t->tape_B = U->tape_B; t->x_in = U->x_in; t->emb = U->emb; t->h1 = U->h1; t->h1g = U->h1g; t->temb = U->temb; t->st = U->st;
+  t->ss = U->ss; t->h0 = U->h0; t->xfinal = U->xfinal; t->out_nchw = U->out_nchw; t->tape_cond = U->tape_cond; t->cond_in = U->cond_in;
+  t->e1 = U->e1; t->e1g = U->e1g; t->e2 = U->e2; t->h0pre = U->h0pre;
+  t->plan_B = U->plan_B; t->plan_tape_b = U->plan_tape_b; t->plan_tmp_b = U->plan_tmp_b; t->plan_defer_b = U->plan_defer_b;
+}
+static void tape_restore(pidm_unet* U, const TapeState& t) {
+  U->rb = t.rb; U->attn = t.attn; U->skip = t.skip; U->down_in = t.down_in; U->up_in = t.up_in;
+  U->tape_B = t.tape_B; U->x_in = t.x_in; U->emb = t.emb; U->h1 = t.h1; U->h1g = t.h1g; U->temb = t.temb; U->st = t.st;
+  U->ss = t.ss; U->h0 = t.h0; U->xfinal = t.xfinal; U->out_nchw = t.out_nchw; U->tape_cond = t.tape_cond; U->cond_in = t.cond_in;
+  U->e1 = t.e1; U->e1g = t.e1g; U->e2 = t.e2; U->h0pre = t.h0pre;
+  U->plan_B = t.plan_B; U->plan_tape_b = t.plan_tape_b; U->plan_tmp_b = t.plan_tmp_b; U->plan_defer_b = t.plan_defer_b;
+}
+// A pass with another arena layout may overwrite the reduction descriptor table a training layout keeps on the device (an
+// inference forward with a larger batch in the same workspace, ...): if its arena reaches the table, the table has to be uploaded
+// again by the next backward (and no backward graph may run before that)
+static void touch_arena(pidm_unet* h, int B, bool train, const void* workspace, size_t workspace_bytes) {
+  const uint64_t w[4] = {(uint64_t)B, (uint64_t)train, (uint64_t)reinterpret_cast<uintptr_t>(workspace), (uint64_t)workspace_bytes};
+  const uint64_t sig = hash_words(w, 4);
+  if (sig != h->arena_sig && sig != h->red_table_owner && h->red_table_dev) {
+    size_t tape_b = 0, tmp_b = 0;
+    const char* ws = reinterpret_cast<const char*>(workspace);
+    const char* tab = reinterpret_cast<const char*>(h->red_table_dev);
+    const size_t packed_b = packed_region_bytes(h) + io_region(h, B, nullptr).total;
+    const bool planned = plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b) == 0;
+    const bool inside = tab >= ws && tab < ws + workspace_bytes;
+    if (getenv("PIDM_DEBUG_ARENA")) fprintf(stderr, "[pidm] arena touch B=%d train=%d: extent %zu, table at %zu\n", B, (int)train, packed_b + tape_b + tmp_b, (size_t)(tab - ws));
+    if (!planned || !inside || ws + packed_b + tape_b + tmp_b > tab) h->red_table_dev = nullptr;
+  }
+  h->arena_sig = sig;
+}
+
+static int forward_body(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B, bool train, bool repack,
+                        const float* cond, void* workspace, size_t workspace_bytes, hipStream_t st, GraphCapture* cap) {
+  Run r;
+  r.cap = cap;
+  if (setup_run(r, h, B, train, workspace, workspace_bytes, st)) return -1;
+  if (cap && cap_begin(r)) return -1;
+  if (repack || h->packed_zeroed_for != r.wpack || !h->pack_table_valid) {
+    if (pack_all(r)) return -1;
+  }
+  if (forward_impl(r, x_nhwc, t, out_nchw, cond)) return -1;
+  if (r.tape.overflow() || r.tmp.overflow()) return fail("unet_forward: internal arena overflow");
+  if (cap && cap->open && cap_end_segment(r, nullptr, false)) return -1;
+  return 0;
+}
+
+static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x_nhwc, int B, void* workspace, size_t workspace_bytes,
+                         hipStream_t st, GraphCapture* cap) {
+  Run r;
+  r.cap = cap;
+  if (setup_run(r, h, B, true, workspace, workspace_bytes, st, /*replay_plan=*/true)) return -1;
+  // per-kernel HIP-event timing (bench.py's roofline leg) needs kernels that own the chip: concurrent kernels share it and
+  // their individual durations stop being a property of the kernel - the overlap is off while the profiler hooks are on
+  r.overlap = h->side_ok && !prof_enabled();
+  if (cap && cap_begin(r)) return -1;
+  if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
+  if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
+  if (cap && cap->open && cap_end_segment(r, nullptr, false)) return -1;   // (the final flush normally closed the last segment)
+  return 0;
+}
+
+// closes a capture that an error left open, so that the stream can be used again
+static void cap_abort(pidm_unet* h, GraphCapture* cap) {
+  if (cap->open) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(h->cap_stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    cap->open = false;
+  }
+}
+
+}  // namespace pidm
 
 extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_t* t, float* out_nchw, int B,
                                  int save_for_backward, int repack_weights, void* workspace, size_t workspace_bytes,
@@ -1221,16 +1543,53 @@ extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_
   if (B <= 0) return fail("unet_forward: B must be positive");
   for (size_t i = 0; i < h->P.size(); ++i)
     if (!h->P[i]) return fail("unet_forward: parameters not bound (pidm_unet_bind)");
-  Run r;
-  if (setup_run(r, h, B, save_for_backward != 0, workspace, workspace_bytes, stream)) return -1;
-  if (repack_weights || h->packed_zeroed_for != r.wpack || !h->pack_table_valid) {
-    if (pack_all(r)) return -1;
-  }
   const float* cond = h->cond_next;
   h->cond_next = nullptr;
   if (cond && !h->cond_enabled) return fail("unet_forward: conditioning input given but pidm_unet_enable_cond was not called");
-  if (forward_impl(r, x_nhwc, t, out_nchw, cond)) return -1;
-  if (r.tape.overflow() || r.tmp.overflow()) return fail("unet_forward: internal arena overflow");
+  const bool train = save_for_backward != 0;
+  const hipStream_t st = as_stream(stream);
+  touch_arena(h, B, train, workspace, workspace_bytes);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail("unet: workspace must be 256-byte aligned");
+  if (workspace_bytes < packed_region_bytes(h) + io_region(h, B, nullptr).total) return fail("unet: workspace too small");
+  // the pass runs on the static I/O buffers of the workspace (see IoRegion): inputs in, output out, by plain device copies
+  const IoRegion io = io_region(h, B, reinterpret_cast<char*>(workspace) + packed_region_bytes(h));
+  if (x_nhwc != io.x && hipMemcpyAsync(io.x, x_nhwc, io.x_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("unet_forward: input copy failed");
+  if (hipMemcpyAsync(io.t, t, io.t_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("unet_forward: time-step copy failed");
+  if (cond && hipMemcpyAsync(io.cond, cond, io.cond_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("unet_forward: condition copy failed");
+  const float* cond_s = cond ? io.cond : nullptr;
+  const uint64_t kw[11] = {0xF0, (uint64_t)B, (uint64_t)train, (uint64_t)(repack_weights != 0), (uint64_t)(cond != nullptr),
+                           (uint64_t)reinterpret_cast<uintptr_t>(workspace), (uint64_t)workspace_bytes,
+                           h->bind_sig, env_signature(), (uint64_t)h->cond_enabled, (uint64_t)h->have_grads};
+  const std::vector<uint64_t> key(kw, kw + 11);
+  if (train) h->fwd_key_hash = hash_words(kw, 11);
+  int rc = -1;
+  bool done = false;
+  // a graph may run only while the device-side pack descriptor table in this workspace describes the bound parameters
+  const bool tables_ok = h->packed_zeroed_for == workspace && h->pack_table_valid;
+  if (graphs_enabled() && tables_ok) {
+    if (GraphEntry* e = graph_find(h, 0, key)) {
+      rc = graph_replay(e, st);
+      if (rc == 0 && train) tape_restore(h, e->tape);
+      done = true;
+    } else if (graph_second_sighting(h, 0, key) && ensure_cap_stream(h)) {
+      e = graph_new_entry(h, 0, key);
+      GraphCapture cap;
+      cap.entry = e;
+      cap.user_st = st;
+      rc = forward_body(h, io.x, io.t, io.out, B, train, repack_weights != 0, cond_s, workspace, workspace_bytes, h->cap_stream, &cap);
+      cap_abort(h, &cap);
+      if (rc == 0 && !cap.failed) {
+        ++g_graph_captures;
+        if (train) tape_save(h, &e->tape);
+        done = true;
+      } else {
+        graph_drop_entry(h, 0, e);     // not capturable right now: the eager path below redoes the whole pass
+      }
+    }
+  }
+  if (!done) rc = forward_body(h, io.x, io.t, io.out, B, train, repack_weights != 0, cond_s, workspace, workspace_bytes, st, nullptr);
+  if (rc) return rc;
+  if (out_nchw != io.out && hipMemcpyAsync(out_nchw, io.out, io.out_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("unet_forward: output copy failed");
   return 0;
 }
 
@@ -1239,8 +1598,7 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   if (!h || !grad_out_nchw || !workspace) return fail("unet_backward: null argument");
   if (h->tape_B != B) return fail("unet_backward: no matching forward (tape holds B=%d)", h->tape_B);
   if (!h->have_grads) return fail("unet_backward: gradient buffers not bound");
-  Run r;
-  if (setup_run(r, h, B, true, workspace, workspace_bytes, stream, /*replay_plan=*/true)) return -1;
+  const hipStream_t st = as_stream(stream);
   if (!h->side_ok && !h->side) {
     // created once per handle; PIDM_NO_OVERLAP=1 keeps the whole backward on the caller's stream (A/B measurements)
     const char* e = getenv("PIDM_NO_OVERLAP");
@@ -1252,11 +1610,64 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
       h->side = reinterpret_cast<hipStream_t>(1);   // marks "decided: off"
     }
   }
-  // per-kernel HIP-event timing (bench.py's roofline leg) needs kernels that own the chip: concurrent kernels share it and
-  // their individual durations stop being a property of the kernel - the overlap is off while the profiler hooks are on
-  r.overlap = h->side_ok && !prof_enabled();
-  if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
-  if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
+  touch_arena(h, B, true, workspace, workspace_bytes);
+  if (!h->tape_cond && h->cond_grads_dirty) {
+    // the conditioning parameters were not used by this forward: their slots of the (flat) gradient buffer must not keep
+    // an earlier step's values (the wrapper leaves p.grad = None for them, as the reference does).  Freshly bound
+    // buffers count as dirty; after one zero-fill nothing needs to be done until the branch is used again.
+    for (size_t i = (size_t)h->cond_first_param; i < h->names.size(); ++i)
+      if (hipMemsetAsync(h->G[i], 0, h->numels[i] * sizeof(float), st) != hipSuccess) return fail("backward: memset failed");
+    h->cond_grads_dirty = false;
+  }
+  const IoRegion io = io_region(h, B, reinterpret_cast<char*>(workspace) + packed_region_bytes(h));
+  if (grad_out_nchw != io.gout && hipMemcpyAsync(io.gout, grad_out_nchw, io.out_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail("unet_backward: gradient copy failed");
+  float* gx_s = grad_x_nhwc ? io.gx : nullptr;
+  const uint64_t kw[14] = {0xB0, (uint64_t)B, (uint64_t)(grad_x_nhwc != nullptr),
+                           (uint64_t)reinterpret_cast<uintptr_t>(workspace), (uint64_t)workspace_bytes, h->bind_sig, env_signature(),
+                           h->fwd_key_hash, (uint64_t)h->n_phases, (uint64_t)reinterpret_cast<uintptr_t>(h->phase_ev[0]),
+                           (uint64_t)reinterpret_cast<uintptr_t>(h->phase_ev[1]), (uint64_t)reinterpret_cast<uintptr_t>(h->phase_ev[2]),
+                           (uint64_t)h->tape_cond, (uint64_t)h->side_ok};
+  const std::vector<uint64_t> key(kw, kw + 14);
+  int rc = -1;
+  bool done = false;
+  if (graphs_enabled()) {
+    GraphEntry* e = graph_find(h, 1, key);
+    // the reduction descriptor table the graph's reduce launches read must still be the one this layout uploaded
+    if (e && e->red_dev == h->red_table_dev && h->red_table_dev) {
+      rc = graph_replay(e, st);
+      done = true;
+    } else if (!e && h->red_table_dev && graph_second_sighting(h, 1, key) && ensure_cap_stream(h)) {
+      e = graph_new_entry(h, 1, key);
+      GraphCapture cap;
+      cap.entry = e;
+      cap.user_st = st;
+      rc = backward_body(h, io.gout, gx_s, B, workspace, workspace_bytes, h->cap_stream, &cap);
+      cap_abort(h, &cap);
+      if (rc == 0 && !cap.failed) {
+        ++g_graph_captures;
+        e->red_dev = h->red_table_dev;
+        done = true;
+      } else {
+        graph_drop_entry(h, 1, e);   // the eager path below redoes the whole pass
+      }
+    }
+  }
+  if (!done) rc = backward_body(h, io.gout, gx_s, B, workspace, workspace_bytes, st, nullptr);
+  if (rc == 0 && h->tape_cond) h->cond_grads_dirty = true;
+  if (rc == 0 && grad_x_nhwc && grad_x_nhwc != io.gx &&
+      hipMemcpyAsync(grad_x_nhwc, io.gx, io.x_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail("unet_backward: input-gradient copy failed");
+  return rc;
+}
+
+// eager kernel enqueues, graph launches, kernels inside the launched graphs, captures - since the library was loaded
+extern "C" int pidm_debug_launch_counts(long long* out4) {
+  if (!out4) return fail("debug_launch_counts: null argument");
+  out4[0] = pidm::g_kernel_enqueues;
+  out4[1] = pidm::g_graph_launches;
+  out4[2] = pidm::g_graph_kernels;
+  out4[3] = pidm::g_graph_captures;
   return 0;
 }
 

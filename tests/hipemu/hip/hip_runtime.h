@@ -300,8 +300,50 @@ static inline float __ldg(const float* p) { return *p; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
-static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+// ---- stream capture / graphs: while a capture is open every launch, async memset and async copy is RECORDED (not executed),
+// exactly like hipStreamBeginCapture; hipGraphLaunch replays the recorded operations in order.  Streams are not modelled beyond
+// "null or not" (the null stream cannot be captured, as on the GPU); cross-stream fork / join by events is program order here.
+namespace hipemu {
+struct Graph { std::vector<std::function<void()>> ops; };
+Graph*& capturing_graph();     // hipemu.cpp: the open capture, or nullptr
+}
+typedef hipemu::Graph* hipGraph_t;
+typedef hipemu::Graph* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  if (!s || hipemu::capturing_graph()) return hipErrorInvalidValue;
+  hipemu::capturing_graph() = new hipemu::Graph();
+  return hipSuccess;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+  if (!hipemu::capturing_graph()) return hipErrorInvalidValue;
+  *g = hipemu::capturing_graph();
+  hipemu::capturing_graph() = nullptr;
+  return hipSuccess;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) {
+  *e = new hipemu::Graph(*g);
+  return hipSuccess;
+}
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  if (!e || hipemu::capturing_graph()) return hipErrorInvalidValue;
+  for (auto& op : e->ops) op();
+  return hipSuccess;
+}
+static inline hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t*, size_t* n) { *n = g ? g->ops.size() : 0; return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  if (hipemu::capturing_graph()) hipemu::capturing_graph()->ops.push_back([=]() { memset(p, v, n); });
+  else memset(p, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  if (hipemu::capturing_graph()) hipemu::capturing_graph()->ops.push_back([=]() { memcpy(d, s, n); });
+  else memcpy(d, s, n);
+  return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -310,7 +352,10 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 
 template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
-  hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
+  if (hipemu::capturing_graph())
+    hipemu::capturing_graph()->ops.push_back([=]() { hipemu::launch(grid, block, shmem, [=]() { kernel(args...); }); });
+  else
+    hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
 }
 
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -318,7 +363,11 @@ template <typename K> static inline hipError_t hipFuncSetAttribute(K, hipFuncAtt
 
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  static uintptr_t next = 0x1000;       // distinct non-null handles (the null stream is special: it cannot be captured)
+  *s = reinterpret_cast<hipStream_t>(next += 16);
+  return hipSuccess;
+}
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // launches run in program order
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }

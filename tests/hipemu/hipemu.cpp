@@ -179,6 +179,10 @@ struct Pool {
   }
 };
 static Pool* g_pool = nullptr;
+Graph*& capturing_graph() {
+  static Graph* g = nullptr;
+  return g;
+}
 static std::mutex g_launch_mu;
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
       const float xh__ = (xv__[r] - mean__) * rstd__;                                                               \
       const float v__ = (xh__ * gm__ + bt__) * sc__ + sh__;                                                         \
-      const float sg__ = 1.f / (1.f + expf(-v__));                                                                  \
+      const float sg__ = pidm_sigmoid(v__);                                                                         \
       const float dv__ = ((acc_)[r] + (bv_)) * (sg__ * (1.f + v__ * (1.f - sg__)));                                 \
       a1__ += dv__;                                                                                                 \
       a2__ += dv__ * xh__;                                                                                          \

@@ -9,7 +9,7 @@
 
 namespace pidm {
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float sigmoidf_(float v) { return pidm_sigmoid(v); }
 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm statistics: partial (sum, sumsq) per (b, chunk, g) in double, then mean / rstd

@@ -60,6 +60,14 @@ __device__ __forceinline__ float pidm_quad_xor2(float v) {
 }
 #endif
 
+// logistic function on the hardware's exp2 and reciprocal units (v_exp_f32, v_rcp_f32: ~1 ulp each; relative error of the result
+// <= 2e-7 + |v| * 6e-8 * min(1, e^v)) instead of libm expf + a correctly rounded division (~5x the VALU instructions, which made
+// the GroupNorm kernels - one or two SiLUs per element - and the dgrad epilogue sums instruction-bound rather than HBM-bound).
+// The host emulator's shadow header supplies its own.
+#ifndef PIDM_HAVE_FAST_SIGMOID
+__device__ __forceinline__ float pidm_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+#endif
+
 // ---- fp32 contractions on the bf16 matrix pipe ("split" form) ---------------------------------------------------------------
 // x = p0 + p1 + p2 with three round-to-nearest bf16 pieces (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1): 24 mantissa
 // bits, the remainders are exact in fp32), and a*b ~ a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0 (the dropped terms are below

@@ -1,0 +1,27 @@
+"""Host cost of enqueuing one Darcy training step with an EMPTY queue (no back-pressure): per phase, graph replay vs launch by launch."""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch
+from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion
+from physicsinformeddiffusionmodels_amd.residuals_darcy import ResidualsDarcy
+from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model = Unet3D(dim=32, channels=2).to(dev); diff = DenoisingDiffusion(100, dev); diff.deferred_scalars = True
+res = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=64, pixels_at_boundary=True, reverse_d1=True, device=dev, bcs='none', domain_length=1.)
+batch = synthetic_darcy_batch(B, 64, seed=1, device=dev); opt = FusedClipAdam(model, lr=1e-4, max_norm=1., image_size=64)
+T = {"fwd+loss": 0.0, "zero_grad": 0.0, "backward": 0.0, "opt": 0.0, "gpu": 0.0}
+def step(acc):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loss, *_ = diff.model_estimation_loss(batch, residual_func=res, c_data=1., c_residual=1e-3); t1 = time.perf_counter()
+    opt.zero_grad(); t2 = time.perf_counter()
+    loss.backward(); t3 = time.perf_counter()
+    opt.step(); t4 = time.perf_counter()
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    if acc:
+        T["fwd+loss"] += t1 - t0; T["zero_grad"] += t2 - t1; T["backward"] += t3 - t2; T["opt"] += t4 - t3; T["gpu"] += t5 - t0
+for _ in range(6): step(False)
+N = 12
+for _ in range(N): step(True)
+print(f"PIDM_GRAPH={os.environ.get('PIDM_GRAPH','1')} PIDM_NO_OVERLAP={os.environ.get('PIDM_NO_OVERLAP','0')} B={B}: host ms per step: " + ", ".join(f"{k} {1e3*v/N:.3f}" for k, v in T.items()))

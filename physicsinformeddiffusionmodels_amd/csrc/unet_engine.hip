@@ -1514,8 +1514,11 @@ static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x
   r.cap = cap;
   if (setup_run(r, h, B, true, workspace, workspace_bytes, st, /*replay_plan=*/true)) return -1;
   // per-kernel HIP-event timing (bench.py's roofline leg) needs kernels that own the chip: concurrent kernels share it and
-  // their individual durations stop being a property of the kernel - the overlap is off while the profiler hooks are on
-  r.overlap = h->side_ok && !prof_enabled();
+  // their individual durations stop being a property of the kernel - the overlap is off while the profiler hooks are on.
+  // A captured pass is linear as well: a graph with ~40 fork / join pairs replays SLOWER than the launch-by-launch form it
+  // replaces (11.68 vs 11.15 ms per step, profiles/r03_graph_ab.txt; HIP maps the branches onto internal streams and
+  // synchronises them with events), while the linear graph equals the eager step with the overlap (11.21 ms).
+  r.overlap = h->side_ok && !prof_enabled() && !cap;
   if (cap && cap_begin(r)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");

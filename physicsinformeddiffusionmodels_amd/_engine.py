@@ -52,6 +52,11 @@ class UnetEngine:
         self.cond_enabled = False
         self.flat_grad = None
         self.grad_views = None
+        # staging buffer of an EARLY backward (denoising_utils._DarcyStepFn): the pass runs at forward time into this buffer and
+        # `loss.backward()` later scales / copies it into `flat_grad` (which `p.grad` alias) - never visible to the caller
+        self.early_grad = None
+        self.early_views = None
+        self.early_generation = -1   # tape generation whose gradients `early_grad` holds
         self._bound_key = None
         self.workspace = None
         self.backward_calls = 0      # backward passes since the last gradient exchange (parallel.GradientExchange)
@@ -66,7 +71,17 @@ class UnetEngine:
             pass
 
     # ---- memory owned by torch, borrowed by the engine -------------------------------------------------
-    def _ensure_bound(self, need_grad: bool):
+    def _flat_buffer(self, dev):
+        total = sum(self.numels)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p, ne in zip(self.params, self.numels):
+            views.append(flat[off:off + ne].view(p.shape))
+            off += ne
+        return flat, views
+
+    def _ensure_bound(self, need_grad: bool, early: bool = False):
+        """Binds parameter (and gradient) pointers.  early=True: the backward pass writes the private staging buffer."""
         dev = self.params[0].device
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
@@ -74,22 +89,20 @@ class UnetEngine:
         if need_grad and (self.flat_grad is None or self.flat_grad.device != dev):
             # one flat gradient buffer in the engine's canonical order: p.grad become views of it (a single
             # all-reduce payload for data parallel training, contiguous FiLM-linear gradients for the engine)
-            total = sum(self.numels)
-            self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-            self.grad_views, off = [], 0
-            for p, ne in zip(self.params, self.numels):
-                self.grad_views.append(self.flat_grad[off:off + ne].view(p.shape))
-                off += ne
+            self.flat_grad, self.grad_views = self._flat_buffer(dev)
             self._bound_key = None
+        if early and (self.early_grad is None or self.early_grad.device != dev):
+            self.early_grad, self.early_views = self._flat_buffer(dev)
         # once a gradient buffer exists it stays bound: an inference-mode forward between a training forward and its
         # backward (EMA evaluation, sampling inside a step) must not unbind it
         with_grad = need_grad or self.flat_grad is not None
-        key = (tuple(p.data_ptr() for p in self.params), with_grad and self.flat_grad.data_ptr())
+        target = (self.early_views if early else self.grad_views) if with_grad else None
+        key = (tuple(p.data_ptr() for p in self.params), with_grad and target[0].data_ptr())
         if key != self._bound_key:
             n = len(self.params)
             pp = (vp * n)(*[vp(p.data_ptr()) for p in self.params])
             if with_grad:
-                gp = (vp * n)(*[vp(g.data_ptr()) for g in self.grad_views])
+                gp = (vp * n)(*[vp(g.data_ptr()) for g in target])
                 self.lib.check(self.lib.pidm_unet_bind(self.handle, pp, gp), "pidm_unet_bind")
             else:
                 self.lib.check(self.lib.pidm_unet_bind(self.handle, pp, None), "pidm_unet_bind")
@@ -108,10 +121,10 @@ class UnetEngine:
 
     # ---- forward / backward ------------------------------------------------------------------------------
     def forward(self, x_nhwc: torch.Tensor, t: torch.Tensor, training: bool, repack: bool = True,
-                cond: torch.Tensor | None = None) -> torch.Tensor:
+                cond: torch.Tensor | None = None, early: bool = False) -> torch.Tensor:
         B = x_nhwc.shape[0]
         dev = x_nhwc.device
-        self._ensure_bound(training)
+        self._ensure_bound(training, early=early)
         if cond is not None:
             if not self.cond_enabled:          # size the workspace for the conditioning branch from now on
                 self.lib.check(self.lib.pidm_unet_enable_cond(self.handle, 1), "pidm_unet_enable_cond")

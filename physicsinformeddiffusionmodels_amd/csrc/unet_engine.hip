@@ -183,7 +183,7 @@ struct pidm_unet {
   bool cap_stream_ok = false;
   std::vector<GraphEntry> graphs[2];                     // [0] forward, [1] backward
   std::vector<std::vector<uint64_t>> seen[2];            // keys seen once (captured on their second sighting)
-  uint64_t graph_stamp = 0, bind_sig = 0, fwd_key_hash = 0;
+  uint64_t graph_stamp = 0, bind_sig = 0, param_sig = 0, fwd_key_hash = 0;
   uint64_t arena_sig = 0;                                // layout of the latest pass that used the workspace arena
   uint64_t red_table_owner = 0;                          // layout that uploaded the reduction descriptor table
 };
@@ -459,17 +459,23 @@ extern "C" int pidm_unet_bind(pidm_unet* h, const void* const* param_ptrs_host, 
     h->G[i] = grad_ptrs_host ? reinterpret_cast<float*>(grad_ptrs_host[i]) : nullptr;
   }
   h->have_grads = grad_ptrs_host != nullptr;
+  bool keep_pack_table = false;
   {
-    // graphs are keyed on the bound pointer set (flipping back to an earlier set - EMA swap in / out - finds its graphs again)
-    uint64_t sig = 1469598103934665603ull;
+    // graphs are keyed on the bound pointer sets (flipping back to an earlier set - EMA swap in / out, alternating gradient
+    // buffers - finds its graphs again): the forward only on the parameters, the backward on parameters and gradients
+    uint64_t ps = 1469598103934665603ull, gs = 1099511628211ull;
+    bool params_changed = false;
     for (size_t i = 0; i < h->names.size(); ++i) {
-      sig ^= (uint64_t)reinterpret_cast<uintptr_t>(h->P[i]); sig *= 1099511628211ull;
-      sig ^= (uint64_t)reinterpret_cast<uintptr_t>(h->G[i]); sig *= 1099511628211ull; sig ^= sig >> 29;
+      ps ^= (uint64_t)reinterpret_cast<uintptr_t>(h->P[i]); ps *= 1099511628211ull; ps ^= ps >> 29;
+      gs ^= (uint64_t)reinterpret_cast<uintptr_t>(h->G[i]); gs *= 1099511628211ull; gs ^= gs >> 29;
     }
-    h->bind_sig = sig;
+    params_changed = ps != h->param_sig;
+    h->param_sig = ps;
+    h->bind_sig = ps ^ (gs * 0x9E3779B97F4A7C15ull);
+    if (!params_changed && h->pack_table_valid) keep_pack_table = true;   // same parameters: the device-side pack table still describes them
   }
   h->cond_grads_dirty = true;    // new gradient buffers: contents unknown
-  h->pack_table_valid = false;   // parameter pointers may have changed
+  if (!keep_pack_table) h->pack_table_valid = false;   // parameter pointers changed
   if (h->have_grads) {
     // the FiLM linear gradients must be contiguous (see pidm_unet_create)
     const int nf = 4 * h->n_lv + 2;
@@ -1562,7 +1568,7 @@ extern "C" int pidm_unet_forward(pidm_unet* h, const float* x_nhwc, const int64_
   const float* cond_s = cond ? io.cond : nullptr;
   const uint64_t kw[11] = {0xF0, (uint64_t)B, (uint64_t)train, (uint64_t)(repack_weights != 0), (uint64_t)(cond != nullptr),
                            (uint64_t)reinterpret_cast<uintptr_t>(workspace), (uint64_t)workspace_bytes,
-                           h->bind_sig, env_signature(), (uint64_t)h->cond_enabled, (uint64_t)h->have_grads};
+                           h->param_sig, env_signature(), (uint64_t)h->cond_enabled, 0};
   const std::vector<uint64_t> key(kw, kw + 11);
   if (train) h->fwd_key_hash = hash_words(kw, 11);
   int rc = -1;

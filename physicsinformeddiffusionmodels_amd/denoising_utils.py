@@ -394,6 +394,75 @@ class _DarcyPidmLossFn(torch.autograd.Function):
         return grad * g_loss, None, None, None, None, None, None, None, None, None, None
 
 
+class _DarcyStepFn(torch.autograd.Function):
+    """The whole Darcy mean-estimation step as ONE autograd node with an EARLY backward: q-sample, UNet forward, fused residual +
+    loss + d loss/d x0_pred AND the UNet backward pass are enqueued inside `forward`; `loss.backward()` later only scales the
+    staged parameter gradients by its upstream gradient and attaches them as `p.grad`.
+
+    Why: the reference API returns the tracked loss terms as python floats (`.item()`, src/denoising_utils.py:681,688), i.e. one
+    host synchronisation per step right after the loss kernel.  With the backward pass enqueued BEFORE that synchronisation the GPU
+    keeps working through it while the host wakes up, runs `optimizer.zero_grad()` and the autograd dispatch (0.5 ms of idle GPU
+    per step otherwise, bench.py `eager_scalars` / `dropin_main_py`).  The gradients are the same numbers: backward is linear in the
+    upstream gradient, and the staging buffer is private, so nothing the caller can observe changes before `backward()` - `p.grad`
+    of an earlier step stay intact until then (main.py calls `zero_grad()` AFTER `model_estimation_loss`, and accumulation without
+    `zero_grad()` still adds).  Used only when it pays and is safe: python-float scalars, `model.training`, gradients enabled, no
+    data-parallel exchange attached, one UNet call per step (DenoisingDiffusion._darcy_step)."""
+
+    @staticmethod
+    def forward(ctx, anchor, eng, diffusion, x_0, e, t, residual_func, c_data, c_residual):
+        lib = residual_func.lib
+        B, C, P, _ = x_0.shape
+        dev = x_0.device
+        dd = diffusion.diff_dict
+        xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
+        lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e), ptr(t), ptr(dd['alphas_bar_sqrt']), ptr(dd['one_minus_alphas_bar_sqrt']),
+                                          ptr(xt), B, C, P * P, stream_ptr(dev)), 'pidm_qsample_nhwc_t')
+        eng.tape_generation += 1
+        ctx.generation = eng.tape_generation
+        pred = eng.forward(xt, t, training=True, early=True)
+        res = torch.empty(B, P * P, 3, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(pred)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x_0), ptr(pred), ptr(residual_func._f_s_flat), ptr(t), ptr(dd['p2_loss_weight']),
+                                                ptr(dd['posterior_variance_clipped']), float(c_data), float(c_residual),
+                                                residual_func.inv_h0, residual_func.inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
+                                                B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd_t')
+        # the UNet backward for an upstream gradient of 1, into the engine's private staging buffer
+        eng.backward(grad, False, C)
+        eng.early_generation = ctx.generation
+        eng.tape_busy = False
+        ctx.eng = eng
+        ctx.mark_non_differentiable(out, res)
+        return out[0].clone(), out, res
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out, _g_res):
+        eng = ctx.eng
+        if eng.early_generation != ctx.generation:
+            from ._lib import PidmError
+            raise PidmError("the staged gradients of this step were overwritten by a later training-mode forward of the same model "
+                            "(only the latest step can be differentiated)")
+        first = eng.params[0]
+        aliased = first.grad is not None and first.grad.data_ptr() == eng.grad_views[0].data_ptr()
+        g = g_loss.to(eng.early_grad.dtype)
+        if aliased:
+            eng.flat_grad.add_(eng.early_grad * g)        # a second backward without zero_grad: torch semantics are accumulation
+        else:
+            torch.mul(eng.early_grad, g, out=eng.flat_grad)
+        eng.early_generation = -1
+        eng.backward_calls += 1 if not aliased else 2
+        n_plain = len(eng.params) - eng.n_cond
+        for i, (p, gv) in enumerate(zip(eng.params, eng.grad_views)):
+            if not p.requires_grad or i >= n_plain:
+                continue                                   # conditioning branch: not used by this step, grads stay None
+            if p.grad is None:
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                p.grad.add_(eng.early_views[i] * g)
+        return None, None, None, None, None, None, None, None, None
+
+
 class DenoisingDiffusion(nn.Module):
     """Drop-in for reference DenoisingDiffusion (src/denoising_utils.py:308-788)."""
 
@@ -621,6 +690,14 @@ class DenoisingDiffusion(nn.Module):
         dd = self.diff_dict
         x_0 = x_0.contiguous()
         t = t.to(dtype=torch.int64).contiguous()
+        if residual_func._f_s_flat.device != dev:
+            residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
+        eng = self._early_backward_engine(residual_func, x_0)
+        if eng is not None:
+            # python-float loss terms (one host sync per step): the backward pass is enqueued before that sync
+            loss, scalars, _res = _DarcyStepFn.apply(eng.params[0], eng, self, x_0, e.contiguous(), t, residual_func, c_data, c_residual)
+            d, r = self._host_scalars(scalars, [(1,), (2,)])
+            return loss, d, r, 0., 0.
         xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
         # the extract() gathers of the schedule tables by t happen inside the kernels (no indexing / reciprocal launches)
         lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e.contiguous()), ptr(t), ptr(dd['alphas_bar_sqrt']),
@@ -642,6 +719,22 @@ class DenoisingDiffusion(nn.Module):
         loss, scalars, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, *args, c_data, c_residual, *geo)
         d, r = self._host_scalars(scalars, [(1,), (2,)])
         return loss, d, r, 0., 0.
+
+    def _early_backward_engine(self, residual_func, x_0):
+        """The engine to run the step's backward pass at forward time on (see _DarcyStepFn), or None when that is not applicable."""
+        from ._engine import get_engine
+        from .unet_model import Unet3D
+        model = residual_func.model
+        if (self.deferred_scalars or not torch.is_grad_enabled() or os.environ.get('PIDM_EARLY_BACKWARD') == '0'
+                or type(model) is not Unet3D or not model.training or model.self_condition or residual_func.use_ddim_x0
+                or not (x_0.is_cuda or self._lib is not None) or x_0.requires_grad or model._forward_hooks or model._forward_pre_hooks
+                or x_0.shape[1] != model.channels or x_0.shape[-1] != x_0.shape[-2]
+                or getattr(model, '_pidm_tape_slot', None)):
+            return None
+        eng = get_engine(model, x_0.shape[-1], model._pidm_lib)
+        if getattr(eng, '_exchange_owner', None) is not None or eng.tape_busy or not all(p.requires_grad for p in eng.params):
+            return None
+        return eng
 
     def _mech_step(self, x_0, conditioning, bcs, e, t, residual_func, c_data, c_residual, c_ineq, lambda_opt):
         """Mechanics configuration (main.py:102-109,139): the loss algebra of src/denoising_utils.py:666-708 on top of the

@@ -1,0 +1,139 @@
+"""Early backward of the Darcy step (denoising_utils._DarcyStepFn): with python-float loss terms (the reference API: one host sync
+per step) the UNet backward pass is enqueued inside model_estimation_loss, before that sync; `loss.backward()` only scales /
+attaches the staged gradients.  Nothing observable may change: same numbers as the two-node path (PIDM_EARLY_BACKWARD=0), `p.grad`
+of an earlier step intact until zero_grad / backward, accumulation, scaled losses, undifferentiated losses."""
+import pytest
+import torch
+
+from oracle import pidm_oracle as O
+from physicsinformeddiffusionmodels_amd._engine import get_engine
+from physicsinformeddiffusionmodels_amd._lib import PidmError
+from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion
+from physicsinformeddiffusionmodels_amd.residuals_darcy import ResidualsDarcy
+from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+
+
+def _setup(backend):
+    L, dev = backend
+    lib = L if dev.type == "cpu" else None
+    m = Unet3D(dim=8, channels=2)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = lib
+    diff = DenoisingDiffusion(100, dev, lib=lib)
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=16, pixels_at_boundary=True, reverse_d1=True, device=dev, lib=lib)
+    g = torch.Generator().manual_seed(41)
+    data = []
+    for _ in range(4):
+        x0 = torch.randn(3, 2, 16, 16, generator=g)
+        x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+        data.append((x0.to(dev), torch.randn(3, 2, 16, 16, generator=g).to(dev), torch.randint(0, 100, (3,), generator=g).to(dev)))
+    return m, diff, res, data
+
+
+def _loss(diff, res, x0, eps, t):
+    orig = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda *a, **k: eps.clone()
+    try:
+        return diff.model_estimation_loss(x0, residual_func=res, c_data=1., c_residual=1e-3)
+    finally:
+        torch.randint, torch.randn_like = orig
+
+
+def _grads(m):
+    return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def test_early_path_is_taken_and_matches_the_two_node_path(backend, monkeypatch):
+    m, diff, res, data = _setup(backend)
+    eng = get_engine(m, 16, m._pidm_lib)
+    monkeypatch.setenv("PIDM_EARLY_BACKWARD", "0")
+    ref = []
+    for d in data:
+        for p in m.parameters():
+            p.grad = None
+        loss, dl, rl, _, _ = _loss(diff, res, *d)
+        loss.backward()
+        ref.append((loss.item(), dl, rl, _grads(m)))
+    assert eng.early_grad is None
+    monkeypatch.delenv("PIDM_EARLY_BACKWARD")
+    for d, (l_ref, dl_ref, rl_ref, g_ref) in zip(data, ref):
+        loss, dl, rl, _, _ = _loss(diff, res, *d)            # main.py order: loss first ...
+        assert isinstance(dl, float) and isinstance(rl, float)
+        for p in m.parameters():                             # ... then optimizer.zero_grad() ...
+            p.grad = None
+        assert eng.early_generation == eng.tape_generation   # the backward pass has already been enqueued
+        loss.backward()                                      # ... then backward
+        assert (loss.item(), dl, rl) == (l_ref, dl_ref, rl_ref)
+        got = _grads(m)
+        assert got.keys() == g_ref.keys() and len(got) == 259
+        for k in got:
+            assert torch.equal(got[k], g_ref[k]), k          # upstream gradient 1: the staged gradients are copied unchanged
+            assert got[k].data_ptr() != eng.early_grad.data_ptr()
+    assert eng.early_grad is not None
+
+
+def test_previous_gradients_stay_intact_until_backward(backend):
+    m, diff, res, data = _setup(backend)
+    loss, *_ = _loss(diff, res, *data[0])
+    loss.backward()
+    before = _grads(m)
+    loss2, *_ = _loss(diff, res, *data[1])                  # enqueues the next step's backward already
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, before[k]), k         # ... into the private staging buffer: p.grad is untouched
+    loss2.backward()                                         # no zero_grad in between: accumulation
+    for p in m.parameters():
+        p.grad = None
+    loss3, *_ = _loss(diff, res, *data[1])
+    loss3.backward()
+    second = _grads(m)
+    for p in m.parameters():
+        p.grad = None
+    (_loss(diff, res, *data[0])[0]).backward()
+    (_loss(diff, res, *data[1])[0]).backward()
+    acc = _grads(m)
+    for k in acc:
+        ref = before[k] + second[k]
+        assert (acc[k] - ref).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1e-12), k
+
+
+def test_scaled_loss_undifferentiated_loss_and_double_backward(backend):
+    m, diff, res, data = _setup(backend)
+    loss, *_ = _loss(diff, res, *data[0])
+    loss.backward()
+    g1 = _grads(m)
+    for p in m.parameters():
+        p.grad = None
+    loss, *_ = _loss(diff, res, *data[0])
+    (0.25 * loss).backward()                                 # upstream gradient 0.25
+    for k, v in _grads(m).items():
+        assert torch.equal(v, 0.25 * g1[k]), k               # power-of-two scale: exact
+    # a loss that is never differentiated (main.py:187 validation with grad enabled), then a normal step
+    for p in m.parameters():
+        p.grad = None
+    _ = _loss(diff, res, *data[2])
+    loss, *_ = _loss(diff, res, *data[0])
+    loss.backward()
+    for k, v in _grads(m).items():
+        assert torch.equal(v, g1[k]), k
+    with pytest.raises((PidmError, RuntimeError)):
+        loss.backward()                                      # the staged gradients were consumed
+
+
+def test_early_backward_is_off_where_it_does_not_apply(backend):
+    m, diff, res, data = _setup(backend)
+    eng = get_engine(m, 16, m._pidm_lib)
+    diff.deferred_scalars = True                             # no host sync to hide
+    loss, *_ = _loss(diff, res, *data[0])
+    assert eng.early_generation != eng.tape_generation
+    loss.backward()
+    diff.deferred_scalars = False
+    m.eval()                                                 # evaluation mode (main.py validation): nothing is staged
+    loss, *_ = _loss(diff, res, *data[0])
+    assert eng.early_generation != eng.tape_generation
+    m.train()
+    with torch.no_grad():
+        _loss(diff, res, *data[0])
+    assert eng.early_generation != eng.tape_generation

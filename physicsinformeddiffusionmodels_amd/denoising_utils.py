@@ -428,13 +428,18 @@ class _DarcyStepFn(torch.autograd.Function):
                                                 ptr(dd['posterior_variance_clipped']), float(c_data), float(c_residual),
                                                 residual_func.inv_h0, residual_func.inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
                                                 B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd_t')
+        # the loss terms start their way to the host NOW, ahead of the backward pass in stream order: the host will wait for this
+        # copy's event, not for the stream
+        ctx.fetch = diffusion._start_scalar_fetch(out) if out.is_cuda else None
+        loss_t = out[0].clone()           # (before the backward pass in stream order: `loss.item()` then does not wait for it)
         # the UNet backward for an upstream gradient of 1, into the engine's private staging buffer
         eng.backward(grad, False, C)
         eng.early_generation = ctx.generation
         eng.tape_busy = False
         ctx.eng = eng
+        diffusion._early_fetch = ctx.fetch
         ctx.mark_non_differentiable(out, res)
-        return out[0].clone(), out, res
+        return loss_t, out, res
 
     @staticmethod
     def backward(ctx, g_loss, _g_out, _g_res):
@@ -481,6 +486,7 @@ class DenoisingDiffusion(nn.Module):
         # main.py:167-175, then never stalls the host in between) - bench.py and main_dp.py run this way
         self.deferred_scalars = False
         self._scalar_ring, self._scalar_slot = [], 0
+        self._early_fetch = None
 
     def _host_scalars(self, scalars, idx_list):
         """floats (or DeferredFloats) for the entries `idx_list` (index tuples) of the device tensor `scalars`"""
@@ -493,6 +499,12 @@ class DenoisingDiffusion(nn.Module):
                     v = v[i]
                 out.append(v)
             return out
+        fetch = self._start_scalar_fetch(scalars)
+        return [DeferredFloat(fetch, tuple(idx)) for idx in idx_list]
+
+    def _start_scalar_fetch(self, scalars):
+        """Enqueues the copy of a small device tensor into pinned host memory and records an event behind it; `.values()` of the
+        returned object waits for THAT event only (not for work enqueued on the stream afterwards)."""
         if not self._scalar_ring:
             self._scalar_ring = [[torch.empty(16, dtype=torch.float32).pin_memory(), None] for _ in range(64)]
         slot = self._scalar_ring[self._scalar_slot]
@@ -504,7 +516,7 @@ class DenoisingDiffusion(nn.Module):
         ev = torch.cuda.Event()
         ev.record()
         slot[1] = _ScalarFetch(host, ev)
-        return [DeferredFloat(slot[1], tuple(idx)) for idx in idx_list]
+        return slot[1]
 
     @property
     def lib(self):
@@ -696,6 +708,10 @@ class DenoisingDiffusion(nn.Module):
         if eng is not None:
             # python-float loss terms (one host sync per step): the backward pass is enqueued before that sync
             loss, scalars, _res = _DarcyStepFn.apply(eng.params[0], eng, self, x_0, e.contiguous(), t, residual_func, c_data, c_residual)
+            fetch, self._early_fetch = self._early_fetch, None
+            if fetch is not None:
+                v = fetch.values()                    # waits for the loss kernel + the 16-byte copy; the backward pass keeps running
+                return loss, v[1], v[2], 0., 0.
             d, r = self._host_scalars(scalars, [(1,), (2,)])
             return loss, d, r, 0., 0.
         xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)

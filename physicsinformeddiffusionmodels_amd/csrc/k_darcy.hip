@@ -8,6 +8,8 @@
 // in LDS, every derivative is a 3/4-tap read of LDS with the one-sided boundary rows selected per pixel, and the adjoint
 // is a GATHER over the transposed stencil (no atomics, run-to-run deterministic).  HBM traffic is the
 // compulsory 32 KB read + 48 KB residual write + 32 KB gradient write per 64x64 sample (halo rows are re-read from L2).
+#include <stdlib.h>
+
 #include "pidm_common.h"
 
 namespace pidm {
@@ -66,7 +68,13 @@ struct DarcyBands {
 };
 static DarcyBands darcy_bands(int B, int P) {
   int nb = (1024 + B - 1) / B;              // >= 4 workgroups per CU where the batch alone does not provide them
-  const int nb_min = (P + 15) / 16;         // <= 16 rows per band: 8 fields x 23 rows x 64 floats = 47 KB of LDS -> 3 workgroups per CU
+  static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
+  if (!max_rows) {
+    const char* e = getenv("PIDM_DARCY_ROWS");
+    max_rows = e ? atoi(e) : 16;
+    if (max_rows < 4) max_rows = 4;
+  }
+  const int nb_min = (P + max_rows - 1) / max_rows;   // 16 rows per band: 8 fields x 23 rows x 64 floats = 47 KB of LDS -> 3 workgroups per CU
   if (nb < nb_min) nb = nb_min;
   int nb_max = P / 4;
   if (nb_max < 1) nb_max = 1;
@@ -86,6 +94,62 @@ __device__ __forceinline__ float darcy_p2w(const float* __restrict__ p2w, const 
 }
 __device__ __forceinline__ float darcy_inv_var(const float* __restrict__ v, const long long* __restrict__ t, int b) {
   return t ? 1.0f / v[t[b]] : v[b];
+}
+
+// Branch-free stencil taps.  Forward: (D a)[i] = sum_k w[k] a[idx[k]] with 4 (position, weight) pairs chosen by the class of i
+// (low edge: rows 0..3, high edge: rows P-1..P-4 in that order, interior: i-1, i, i+1 and a zero-weight fourth tap) - the same
+// taps in the same order as fd_apply above, without its three code paths.  Transposed: (D^T a)[m] = sum over the (at most 5)
+// stencil rows that touch column m: the interior rows m-1, m, m+1 and the two edge rows 0 and P-1; rows that do not touch m get
+// weight 0.  Indices of zero-weight taps are clamped into [lo, hi] (the band's window of LDS rows).
+struct FdTaps4 {
+  int idx[4];
+  float w1[4], w2[4];    // first / second derivative weights
+};
+__device__ __forceinline__ FdTaps4 fd_taps(const FdAxis& ax, int i, int P, int lo, int hi) {
+  FdTaps4 t;
+  const bool low = i == 0, high = i == P - 1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int ix = high ? P - 1 - k : (low ? k : i - 1 + k);
+    ix = ix < lo ? lo : (ix > hi ? hi : ix);
+    t.idx[k] = ix;
+    const float c1i = (k < 3) ? ax.c1[1][k] : 0.f, c2i = (k < 3) ? ax.c2[1][k] : 0.f;
+    t.w1[k] = high ? ax.c1[2][k] : (low ? ax.c1[0][k] : c1i);
+    t.w2[k] = high ? ax.c2[2][k] : (low ? ax.c2[0][k] : c2i);
+  }
+  return t;
+}
+struct FdTaps5 {
+  int idx[5];
+  float w1[5], w2[5];
+};
+__device__ __forceinline__ FdTaps5 fd_taps_T(const FdAxis& ax, int m, int P, int lo, int hi) {
+  FdTaps5 t;
+  // same order as fd_apply_T: row 0, row P-1, then the interior rows m-1, m, m+1
+  const int rows[5] = {0, P - 1, m - 1, m, m + 1};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = rows[k];
+    float a1 = 0.f, a2 = 0.f;
+    if (k == 0) {
+      const int q = m < 4 ? m : 3;
+      a1 = (m < 3) ? ax.c1[0][q] : 0.f;
+      a2 = (m < 4) ? ax.c2[0][q] : 0.f;
+    } else if (k == 1) {
+      const int d = P - 1 - m, q = d < 4 ? d : 3;
+      a1 = (d < 3) ? ax.c1[2][q] : 0.f;
+      a2 = (d < 4) ? ax.c2[2][q] : 0.f;
+    } else {
+      const bool ok = (i >= 1) & (i <= P - 2);
+      const int q = m - (i - 1);          // 2, 1, 0 for k = 2, 3, 4
+      a1 = ok ? ax.c1[1][q] : 0.f;
+      a2 = ok ? ax.c2[1][q] : 0.f;
+    }
+    t.w1[k] = a1;
+    t.w2[k] = a2;
+    t.idx[k] = i < lo ? lo : (i > hi ? hi : i);
+  }
+  return t;
 }
 
 // dynamic LDS: MODE 0: 2 fields; MODE 1/2: 8 fields of darcy_lds_rows(P, R) x P floats
@@ -118,13 +182,15 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
   // field pointers addressed with ABSOLUTE pixel indices i*P + j, i in [dlo, dhi)
   float* sp = smem - dlo * P;
   float* sK = sp + F;
-  float* sg = sp + 2 * F;
+  float* skg = sp + 2 * F;    // -K g
   float* sa0 = sp + 3 * F;
   float* sa1 = sp + 4 * F;
   float* sb0 = sp + 5 * F;
   float* sb1 = sp + 6 * F;
   float* sd = sp + 7 * F;
   const float* pb = pred + (size_t)b * 2 * N;
+  // a thread's column advances by 256 % P and its row by 256 / P (+ carry) per iteration: no division in the loops
+  const int dj = 256 % P, di = 256 / P;
 
   double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
   for (int n = dlo * P + tid; n < dhi * P; n += 256) {
@@ -139,79 +205,114 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
   __syncthreads();
 
   const float gscale = (MODE == DARCY_LOSS) ? c_res * darcy_inv_var(inv_var, tsteps, b) / ((float)B * (float)N * 3.0f) : 0.f;
-  for (int n = ilo * P + tid; n < ihi * P; n += 256) {
-    const int i = n / P, j = n - i * P;
-    const bool own = (i >= r0) & (i < r1);   // rows this band reports (residual, loss sums); the others are halo recomputation
-    const float* colp = sp + j;       // walk axis 0 with stride P
-    const float* rowp = sp + i * P;   // walk axis 1 with stride 1
-    const float* colK = sK + j;
-    const float* rowK = sK + i * P;
-    float p0 = fd_apply(ax0.c1, colp, i, P, P, 3);
-    float p1 = fd_apply(ax1.c1, rowp, j, P, 1, 3);
-    float p00 = fd_apply(ax0.c2, colp, i, P, P, 4);
-    float p11 = fd_apply(ax1.c2, rowp, j, P, 1, 4);
-    float K0 = fd_apply(ax0.c1, colK, i, P, P, 3);
-    float K1 = fd_apply(ax1.c1, rowK, j, P, 1, 3);
-    float Kv = sK[n];
-    // reference op order: vj00 = -K*p00 - K0*p0 ; vj11 = -K*p11 - K1*p1 ; eq = vj00 + vj11 - f_s
-    float vj00 = -Kv * p00 - K0 * p0;
-    float vj11 = -Kv * p11 - K1 * p1;
-    float eq = vj00 + vj11 - f_s[n];
-    // boundary rows: bc0 = -p0 (row 0), +p0 (row P-1); bc1 = +p1 (col 0), -p1 (col P-1) when reverse_d1
-    // (d1 < 0, bc1_sign = +1), opposite signs otherwise (src/residuals_darcy.py:173-180)
-    float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
-    float s1 = (j == 0) ? bc1_sign : ((j == P - 1) ? -bc1_sign : 0.f);
-    float bc0 = s0 * p0, bc1 = s1 * p1;
-    if (MODE != DARCY_BWD && own) {
-      float* r = residual + ((size_t)b * N + n) * 3;
-      r[0] = eq;
-      r[1] = bc0;
-      r[2] = bc1;
-    }
-    if (MODE == DARCY_RES_ONLY) continue;
-    float g, gb0, gb1;
-    if (MODE == DARCY_BWD) {
-      const float* gr = grad_res + ((size_t)b * N + n) * 3;
-      g = gr[0];
-      gb0 = gr[1];
-      gb1 = gr[2];
-    } else {
-      if (own) {
-        acc_r2 += (double)(eq * eq) + (double)(bc0 * bc0) + (double)(bc1 * bc1);
-        acc_rabs += (double)fabsf(eq) + (double)fabsf(bc0) + (double)fabsf(bc1);
+  {
+    int i = ilo + tid / P, j = tid - (tid / P) * P;
+    FdTaps4 tj = fd_taps(ax1, j, P, 0, P - 1);
+    for (int n = ilo * P + tid; n < ihi * P; n += 256) {
+      const bool own = (i >= r0) & (i < r1);   // rows this band reports (residual, loss sums); the others are halo recomputation
+      const FdTaps4 ti = fd_taps(ax0, i, P, dlo, dhi - 1);
+      float p0 = 0.f, p00 = 0.f, K0 = 0.f, p1 = 0.f, p11 = 0.f, K1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float pa = sp[ti.idx[k] * P + j], pr = sp[i * P + tj.idx[k]];
+        p0 = fmaf(ti.w1[k], pa, p0);
+        p00 = fmaf(ti.w2[k], pa, p00);
+        p1 = fmaf(tj.w1[k], pr, p1);
+        p11 = fmaf(tj.w2[k], pr, p11);
+        if (k < 3) {        // the first-derivative stencils have three taps everywhere
+          K0 = fmaf(ti.w1[k], sK[ti.idx[k] * P + j], K0);
+          K1 = fmaf(tj.w1[k], sK[i * P + tj.idx[k]], K1);
+        }
       }
-      g = gscale * eq;
-      gb0 = gscale * bc0;
-      gb1 = gscale * bc1;
+      const float Kv = sK[n];
+      // reference op order: vj00 = -K*p00 - K0*p0 ; vj11 = -K*p11 - K1*p1 ; eq = vj00 + vj11 - f_s
+      const float vj00 = -Kv * p00 - K0 * p0;
+      const float vj11 = -Kv * p11 - K1 * p1;
+      const float eq = vj00 + vj11 - f_s[n];
+      // boundary rows: bc0 = -p0 (row 0), +p0 (row P-1); bc1 = +p1 (col 0), -p1 (col P-1) when reverse_d1
+      // (d1 < 0, bc1_sign = +1), opposite signs otherwise (src/residuals_darcy.py:173-180)
+      const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
+      const float s1 = (j == 0) ? bc1_sign : ((j == P - 1) ? -bc1_sign : 0.f);
+      const float bc0 = s0 * p0, bc1 = s1 * p1;
+      if (MODE != DARCY_BWD && own) {
+        float* r = residual + ((size_t)b * N + n) * 3;
+        r[0] = eq;
+        r[1] = bc0;
+        r[2] = bc1;
+      }
+      if (MODE != DARCY_RES_ONLY) {
+        float g, gb0, gb1;
+        if (MODE == DARCY_BWD) {
+          const float* gr = grad_res + ((size_t)b * N + n) * 3;
+          g = gr[0];
+          gb0 = gr[1];
+          gb1 = gr[2];
+        } else {
+          if (own) {
+            acc_r2 += (double)(eq * eq) + (double)(bc0 * bc0) + (double)(bc1 * bc1);
+            acc_rabs += (double)fabsf(eq) + (double)fabsf(bc0) + (double)fabsf(bc1);
+          }
+          g = gscale * eq;
+          gb0 = gscale * bc0;
+          gb1 = gscale * bc1;
+        }
+        skg[n] = -Kv * g;              // D00^T / D11^T act on -K g
+        sa0[n] = -K0 * g + s0 * gb0;   // coefficient on p0
+        sa1[n] = -K1 * g + s1 * gb1;   // coefficient on p1
+        sb0[n] = -p0 * g;              // coefficient on K0
+        sb1[n] = -p1 * g;              // coefficient on K1
+        sd[n] = -(p00 + p11) * g;      // direct dependence of eq on K at the same pixel
+      }
+      j += dj;
+      i += di;
+      if (j >= P) {
+        j -= P;
+        ++i;
+        tj = fd_taps(ax1, j, P, 0, P - 1);
+      } else if (dj) {
+        tj = fd_taps(ax1, j, P, 0, P - 1);
+      }
     }
-    sg[n] = g;
-    sa0[n] = -K0 * g + s0 * gb0;   // coefficient on p0
-    sa1[n] = -K1 * g + s1 * gb1;   // coefficient on p1
-    sb0[n] = -p0 * g;              // coefficient on K0
-    sb1[n] = -p1 * g;              // coefficient on K1
-    sd[n] = -(p00 + p11) * g;      // direct dependence of eq on K at the same pixel
   }
   if (MODE == DARCY_RES_ONLY) return;
   __syncthreads();
 
   const float dscale = (MODE == DARCY_LOSS) ? 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N) : 0.f;
-  for (int n = r0 * P + tid; n < r1 * P; n += 256) {
-    const int i = n / P, j = n - i * P;
-    // grad wrt p: D00^T(-K g) + D11^T(-K g) + D0^T a0 + D1^T a1
-    float gp = fd_apply_T(ax0.c2, [&](int ii) { return -sK[ii * P + j] * sg[ii * P + j]; }, i, P, 4);
-    gp += fd_apply_T(ax1.c2, [&](int jj) { return -sK[i * P + jj] * sg[i * P + jj]; }, j, P, 4);
-    gp += fd_apply_T(ax0.c1, [&](int ii) { return sa0[ii * P + j]; }, i, P, 3);
-    gp += fd_apply_T(ax1.c1, [&](int jj) { return sa1[i * P + jj]; }, j, P, 3);
-    // grad wrt K: direct + D0^T b0 + D1^T b1
-    float gK = sd[n];
-    gK += fd_apply_T(ax0.c1, [&](int ii) { return sb0[ii * P + j]; }, i, P, 3);
-    gK += fd_apply_T(ax1.c1, [&](int jj) { return sb1[i * P + jj]; }, j, P, 3);
-    if (MODE == DARCY_LOSS) {
-      gp += dscale * (sp[n] - x0[(size_t)b * 2 * N + n]);
-      gK += dscale * (sK[n] - x0[(size_t)b * 2 * N + N + n]);
+  {
+    int i = r0 + tid / P, j = tid - (tid / P) * P;
+    FdTaps5 tj = fd_taps_T(ax1, j, P, 0, P - 1);
+    for (int n = r0 * P + tid; n < r1 * P; n += 256) {
+      const FdTaps5 ti = fd_taps_T(ax0, i, P, ilo, ihi - 1);
+      // grad wrt p: D00^T(-K g) + D11^T(-K g) + D0^T a0 + D1^T a1;  grad wrt K: direct + D0^T b0 + D1^T b1
+      float g00 = 0.f, g11 = 0.f, ga0 = 0.f, ga1 = 0.f, gb0 = 0.f, gb1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int c0 = ti.idx[k] * P + j, c1 = i * P + tj.idx[k];
+        g00 = fmaf(ti.w2[k], skg[c0], g00);
+        ga0 = fmaf(ti.w1[k], sa0[c0], ga0);
+        gb0 = fmaf(ti.w1[k], sb0[c0], gb0);
+        g11 = fmaf(tj.w2[k], skg[c1], g11);
+        ga1 = fmaf(tj.w1[k], sa1[c1], ga1);
+        gb1 = fmaf(tj.w1[k], sb1[c1], gb1);
+      }
+      float gp = ((g00 + g11) + ga0) + ga1;
+      float gK = (sd[n] + gb0) + gb1;
+      if (MODE == DARCY_LOSS) {
+        gp += dscale * (sp[n] - x0[(size_t)b * 2 * N + n]);
+        gK += dscale * (sK[n] - x0[(size_t)b * 2 * N + N + n]);
+      }
+      grad_pred[(size_t)b * 2 * N + n] = gp;
+      grad_pred[(size_t)b * 2 * N + N + n] = gK;
+      j += dj;
+      i += di;
+      if (j >= P) {
+        j -= P;
+        ++i;
+        tj = fd_taps_T(ax1, j, P, 0, P - 1);
+      } else if (dj) {
+        tj = fd_taps_T(ax1, j, P, 0, P - 1);
+      }
     }
-    grad_pred[(size_t)b * 2 * N + n] = gp;
-    grad_pred[(size_t)b * 2 * N + N + n] = gK;
   }
 
   if (MODE == DARCY_LOSS) {

@@ -1093,6 +1093,118 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 #undef PIDM_SP_WRITE_A
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 7x7 / stride 1 / pad 3 convolution with very few input channels: the UNet's init_conv (reference src/unet_model.py:453,568;
+// Cin = 2, or 4 with self-conditioning).  The implicit-GEMM kernels pad Cin to 8 channels PER TAP (49 taps x 8 = 392 columns for
+// 98 real ones) and ran this layer at 16 TFLOP/s - 100 us for 1.6 GFLOP.  Here (kx, channel) of one kernel row is the
+// contraction index: in a channels-last image the 7 x Cin values a pixel needs from input row y + ky - 3 are CONTIGUOUS, so one
+// kernel row is one (Cin = 2: 14 -> 16 wide) or two (Cin = 4: 28 -> 32) k-steps of the 32x32x16 bf16 MFMA, 3-piece split operands
+// as in conv3x3_split_kernel (same accuracy).  A workgroup = 8 waves = 256 output pixels x 32 output channels; the (TH + 6) input
+// rows of the tile sit in LDS with a zero halo; the weights of the 32 channels live in registers, pre-split once per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const float* __restrict__ src, const float* __restrict__ wp, int Kp,
+                                                           const float* __restrict__ bias, const float* __restrict__ residual,
+                                                           float* __restrict__ out, int n_tiles, int tiles_per_wg) {
+  constexpr int RK = 7 * CIN, KS = (RK + 15) / 16, NK = 7 * KS;
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = g.Wv, H = g.Hv, TH = 256 / W, tpi = H / TH;
+  const int RL = ((W + 6) * CIN + (16 * KS - RK) + 1) & ~1;     // floats per staged input row (reads run past the last real tap)
+  const int n0 = blockIdx.y * 32;
+  // ---- this lane's B fragments: output channel n0 + l31, k = 16 s + 8 half + e of kernel row ky ----
+  u32x4 fb[NK][3];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const int ky = ks / KS, sk = ks - ky * KS;
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * sk + 8 * half + e, kx = k / CIN, c = k - kx * CIN;
+      wv[e] = (k < RK) ? wp[((size_t)(n0 + l31) * 49 + ky * 7 + (k < RK ? kx : 0)) * Kp + c] : 0.f;
+    }
+    unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pidm_split3_pk(wv[2 * e], wv[2 * e + 1], q0[e], q1[e], q2[e]);
+    fb[ks][0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    fb[ks][1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    fb[ks][2] = u32x4{q2[0], q2[1], q2[2], q2[3]};
+  }
+  const float bv = bias ? bias[n0 + l31] : 0.f;
+  const int pm = wave * 32 + l31;                   // this lane's pixel of the tile (A row)
+  const int a_ty = pm / W, a_tx = pm - a_ty * W;
+  const int t_first = blockIdx.x * tiles_per_wg;
+  const int t_last = (t_first + tiles_per_wg < n_tiles) ? t_first + tiles_per_wg : n_tiles;
+  for (int tile = t_first; tile < t_last; ++tile) {
+    const int b = tile / tpi, y0 = (tile - b * tpi) * TH;
+    // ---- stage rows y0 - 3 .. y0 + TH + 2 with a 3-pixel zero halo left and right (and zeros behind the last pixel) ----
+    __syncthreads();                                // the previous tile's reads are done
+    for (int e = tid; e < (TH + 6) * RL; e += 512) {
+      const int r = e / RL, q = e - r * RL;
+      const int y = y0 - 3 + r, xc = q - 3 * CIN;   // float index inside the image row
+      float v = 0.f;
+      if (y >= 0 && y < H && xc >= 0 && xc < W * CIN) v = src[((size_t)b * H + y) * (size_t)(g.Wi * g.ld0) + (size_t)(xc / CIN) * g.ld0 + (xc % CIN)];
+      smem[e] = v;
+    }
+    __syncthreads();
+    f32x16 acc, accb;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int ky = ks / KS, sk = ks - ky * KS;
+      const float* ap = smem + (size_t)(a_ty + ky) * RL + a_tx * CIN + 16 * sk + 8 * half;   // 8-byte aligned
+      float av[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 v2 = *reinterpret_cast<const f32x2*>(ap + 2 * e);
+        av[2 * e] = v2[0];
+        av[2 * e + 1] = v2[1];
+      }
+      unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pidm_split3_pk(av[2 * e], av[2 * e + 1], q0[e], q1[e], q2[e]);
+      const u32x4 fa0 = {q0[0], q0[1], q0[2], q0[3]}, fa1 = {q1[0], q1[1], q1[2], q1[3]}, fa2 = {q2[0], q2[1], q2[2], q2[3]};
+      // small terms first; two accumulators (even / odd k-steps) as in conv3x3_split_kernel
+      if (ks & 1) {
+        accb = pidm_mfma_bf16_32x32x16(fa2, fb[ks][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa0, fb[ks][2], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa1, fb[ks][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa1, fb[ks][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa0, fb[ks][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa0, fb[ks][0], accb);
+      } else {
+        acc = pidm_mfma_bf16_32x32x16(fa2, fb[ks][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa0, fb[ks][2], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa1, fb[ks][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa1, fb[ks][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa0, fb[ks][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa0, fb[ks][0], acc);
+      }
+    }
+    // ---- epilogue: bias, 4x4 register transposes (DPP) so that a lane stores 4 consecutive channels of one pixel ----
+    const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+    const int p0 = wave * 32;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      float x0 = acc[4 * q4] + accb[4 * q4] + bv, x1 = acc[4 * q4 + 1] + accb[4 * q4 + 1] + bv;
+      float x2 = acc[4 * q4 + 2] + accb[4 * q4 + 2] + bv, x3 = acc[4 * q4 + 3] + accb[4 * q4 + 3] + bv;
+      const float r01 = pidm_quad_xor1(odd1 ? x0 : x1), r23 = pidm_quad_xor1(odd1 ? x2 : x3);
+      x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+      x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+      const float r02 = pidm_quad_xor2(odd2 ? x0 : x2), r13 = pidm_quad_xor2(odd2 ? x1 : x3);
+      x0 = odd2 ? r02 : x0; x2 = odd2 ? x2 : r02;
+      x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
+      const int pp = p0 + 8 * q4 + 4 * half + (l31 & 3);
+      const int py = pp / W, px = pp - py * W;
+      f32x4 o = {x0, x1, x2, x3};
+      const size_t pin = (size_t)(y0 + py) * W + px;
+      if (residual) o += *reinterpret_cast<const f32x4*>(residual + ((size_t)b * H * W + pin) * g.ldr + n0 + 4 * (l31 >> 2));
+      *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + pin * g.sox + n0 + 4 * (l31 >> 2)) = o;
+    }
+  }
+}
+
 // pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
 // fp32 packing of the same tensor (packed_floats counts both).  Shape-only condition: the launcher may still take another kernel.
 static bool split_shape_ok(const ConvGeom& g) {
@@ -2630,6 +2742,30 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
+  {
+    // the 7x7 init convolution with (kx, channel) flattened into the contraction index, split form (conv7x7_split_kernel)
+    const char* se = getenv("PIDM_CONV_SPLIT");
+    const bool on = !(se && !atoi(se));
+    if (on && g.KH == 7 && g.KW == 7 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && g.pad_y[0] == 3 && g.pad_x[0] == 3 &&
+        g.C1 == 0 && (g.Cin == 2 || g.Cin == 4) && g.ld0 == g.Cin && (g.Cout % 32) == 0 && g.soc == 1 && (g.sox & 3) == 0 &&
+        g.Wv == g.Wi && g.Hv == g.Hi && g.Wv >= 8 && g.Wv <= 256 && (256 % g.Wv) == 0 && (g.Hv % (256 / g.Wv)) == 0 &&
+        (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) && !sigmoid_last && !g.gn_part && !g.bn_part && (reinterpret_cast<size_t>(out) & 15) == 0) {
+      const int KCp = pick_kc(g.Cin), Kp = cdiv(g.Kw, KCp) * KCp;
+      const int TH = 256 / g.Wv, n_tiles = g.B * (g.Hv / TH);
+      const int KSt = (7 * g.Cin + 15) / 16, RL = ((g.Wv + 6) * g.Cin + (16 * KSt - 7 * g.Cin) + 1) & ~1;
+      const size_t lds = (size_t)(TH + 6) * RL * sizeof(float);
+      const int tpw = cdiv(n_tiles, 1024);                      // a few tiles per workgroup amortise the weight prologue
+      const dim3 grid(cdiv(n_tiles, tpw), g.Cout / 32, 1);
+      const bool prof = prof_enabled();
+      if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv7x7_split_kernel<%d>, %d tiles, %d per workgroup, %zu B LDS\n", g.Cin, n_tiles, tpw, lds);
+      if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 49, st);
+      if (g.Cin == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv7x7_split_kernel<2>), grid, dim3(512), lds, st, g, src0, wp, Kp, bias, residual, out, n_tiles, tpw);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv7x7_split_kernel<4>), grid, dim3(512), lds, st, g, src0, wp, Kp, bias, residual, out, n_tiles, tpw);
+      if (prof) prof_end_launch(st);
+      PIDM_CHECK_LAUNCH("conv7x7_split_kernel");
+      return 0;
+    }
+  }
   {
     // the 4x4 / stride-2 family (2x2 taps as 4 K-phases or 4 output parities) in the split form
     const char* se = getenv("PIDM_CONV_SPLIT");

@@ -114,6 +114,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 // Geometry of one implicit-GEMM convolution launch (see k_conv.hip).  "Virtual" output pixels

@@ -30,6 +30,22 @@ CASES = [
 ]
 
 
+CONV7_CASES = [   # the init convolution in the split form with (kx, channel) flattened into K (conv7x7_split_kernel): forward only,
+    (2, 64, 2, 0, 32, 7, 1, 3, 0),       # the Darcy model's shape: 4 rows of 64 per tile        (dgrad / wgrad stay on the fp32 kernels)
+    (3, 16, 2, 0, 64, 7, 1, 3, 0),       # one 16x16 image per tile, two n-tiles, odd batch
+    (2, 32, 4, 0, 32, 7, 1, 3, 0),       # self-conditioning: Cin = 4 -> two k-steps per kernel row
+    (1, 8, 2, 0, 32, 7, 1, 3, 0),        # 8x8 image: the 7x7 window reaches past both borders everywhere; tile = 256 pixels > image? (falls back)
+    (5, 32, 2, 0, 32, 7, 1, 3, 0),       # 8 rows of 32 per tile
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", CONV7_CASES)
+def test_conv_7x7_split_form(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+    monkeypatch.setenv("PIDM_CONV_SPLIT", "0")           # and the fp32 kernel on the same shapes
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 NT4_CASES = [   # 1x1 convs that take the permuted 128-channel tile (forward resp. dgrad) once the occupancy gate is lowered
     (2, 16, 16, 0, 128, 1, 1, 0, 0),
     (3, 8, 128, 128, 16, 1, 1, 0, 0),

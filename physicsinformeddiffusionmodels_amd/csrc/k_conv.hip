@@ -1113,7 +1113,16 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
   const int W = g.Wv, H = g.Hv, TH = 256 / W, tpi = H / TH;
   const int RL = ((W + 6) * CIN + (16 * KS - RK) + 1) & ~1;     // floats per staged input row (reads run past the last real tap)
   const int n0 = blockIdx.y * 32;
-  // ---- this lane's B fragments: output channel n0 + l31, k = 16 s + 8 half + e of kernel row ky ----
+  // ---- this lane's B fragments: output channel n0 + l31, k = 16 s + 8 half + e of kernel row ky.  The 32 channels' packed
+  //      weights ([49 taps][Kp] floats each) come in through LDS with coalesced loads (56 dependent global loads per lane cost
+  //      more than the whole tile loop), rows padded to an odd length so that the 32 lanes of a read hit 32 banks ----
+  const int WR = (49 * Kp) | 1;
+  float* wl = smem + (size_t)(TH + 6) * RL;
+  for (int e = tid; e < 32 * 49 * Kp; e += 512) {
+    const int n = e / (49 * Kp), r = e - n * (49 * Kp);
+    wl[(size_t)n * WR + r] = wp[(size_t)(n0 + n) * 49 * Kp + r];
+  }
+  __syncthreads();
   u32x4 fb[NK][3];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
@@ -1122,7 +1131,7 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 16 * sk + 8 * half + e, kx = k / CIN, c = k - kx * CIN;
-      wv[e] = (k < RK) ? wp[((size_t)(n0 + l31) * 49 + ky * 7 + (k < RK ? kx : 0)) * Kp + c] : 0.f;
+      wv[e] = (k < RK) ? wl[(size_t)l31 * WR + (ky * 7 + (k < RK ? kx : 0)) * Kp + c] : 0.f;
     }
     unsigned q0[4], q1[4], q2[4];
 #pragma unroll
@@ -1140,12 +1149,13 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
     const int b = tile / tpi, y0 = (tile - b * tpi) * TH;
     // ---- stage rows y0 - 3 .. y0 + TH + 2 with a 3-pixel zero halo left and right (and zeros behind the last pixel) ----
     __syncthreads();                                // the previous tile's reads are done
-    for (int e = tid; e < (TH + 6) * RL; e += 512) {
-      const int r = e / RL, q = e - r * RL;
+    // (thread -> (row, float pair): RL is even and the rows are 8-byte aligned in the source: Cin = 2 or 4, ld0 = Cin)
+    for (int e = tid; e < (TH + 6) * (RL >> 1); e += 512) {
+      const int r = e / (RL >> 1), q = 2 * (e - r * (RL >> 1));
       const int y = y0 - 3 + r, xc = q - 3 * CIN;   // float index inside the image row
-      float v = 0.f;
-      if (y >= 0 && y < H && xc >= 0 && xc < W * CIN) v = src[((size_t)b * H + y) * (size_t)(g.Wi * g.ld0) + (size_t)(xc / CIN) * g.ld0 + (xc % CIN)];
-      smem[e] = v;
+      f32x2 v = {0.f, 0.f};
+      if (y >= 0 && y < H && xc >= 0 && xc < W * CIN) v = *reinterpret_cast<const f32x2*>(src + ((size_t)b * H + y) * (size_t)(W * CIN) + xc);
+      *reinterpret_cast<f32x2*>(smem + (size_t)r * RL + q) = v;
     }
     __syncthreads();
     f32x16 acc, accb;
@@ -2753,8 +2763,11 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       const int KCp = pick_kc(g.Cin), Kp = cdiv(g.Kw, KCp) * KCp;
       const int TH = 256 / g.Wv, n_tiles = g.B * (g.Hv / TH);
       const int KSt = (7 * g.Cin + 15) / 16, RL = ((g.Wv + 6) * g.Cin + (16 * KSt - 7 * g.Cin) + 1) & ~1;
-      const size_t lds = (size_t)(TH + 6) * RL * sizeof(float);
-      const int tpw = cdiv(n_tiles, 1024);                      // a few tiles per workgroup amortise the weight prologue
+      const size_t lds = ((size_t)(TH + 6) * RL + (size_t)32 * ((49 * Kp) | 1)) * sizeof(float);
+      const char* ce7 = getenv("PIDM_STREAM_WGS");              // (the unit tests lower it: several tiles per workgroup)
+      int n_wg7 = ce7 ? atoi(ce7) : 256;                      // 170 registers x 512 threads: one workgroup per CU
+      if (n_wg7 < 1) n_wg7 = 256;
+      const int tpw = cdiv(n_tiles, n_wg7);                     // persistent workgroups: the weight prologue is paid once per workgroup
       const dim3 grid(cdiv(n_tiles, tpw), g.Cout / 32, 1);
       const bool prof = prof_enabled();
       if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv7x7_split_kernel<%d>, %d tiles, %d per workgroup, %zu B LDS\n", g.Cin, n_tiles, tpw, lds);

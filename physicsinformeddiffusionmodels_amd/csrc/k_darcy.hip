@@ -71,10 +71,10 @@ static DarcyBands darcy_bands(int B, int P) {
   static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
   if (!max_rows) {
     const char* e = getenv("PIDM_DARCY_ROWS");
-    max_rows = e ? atoi(e) : 16;
+    max_rows = e ? atoi(e) : 8;        // 8 rows: 31 KB of LDS, 5 workgroups per CU (B = 4096: 355 us, 16 rows 374, 4 rows 455)
     if (max_rows < 4) max_rows = 4;
   }
-  const int nb_min = (P + max_rows - 1) / max_rows;   // 16 rows per band: 8 fields x 23 rows x 64 floats = 47 KB of LDS -> 3 workgroups per CU
+  const int nb_min = (P + max_rows - 1) / max_rows;
   if (nb < nb_min) nb = nb_min;
   int nb_max = P / 4;
   if (nb_max < 1) nb_max = 1;

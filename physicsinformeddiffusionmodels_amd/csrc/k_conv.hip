@@ -1094,6 +1094,264 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same kernel with the two jobs of a stage given to DIFFERENT waves ("warp-specialised", round 3).  The ablation of
+// conv3x3_split_kernel (profiles/r02_split_conv_notes.txt) shows that a stage without its staging runs at the matrix pipe's pace
+// (3850 of 3780 cycles) and that the staging work - global loads, 3-piece split, LDS writes, weight-slab copies: ~900 VALU cycles
+// per SIMD - is what the two waves of a SIMD fail to hide under each other's MFMAs: both reach it at the same point of the stage
+// (the barrier lines them up) and the matrix pipe idles through it.  Here NW consumer waves (two per SIMD, as before) ONLY read
+// operand fragments and issue MFMAs (+ the tile epilogue), and 4 producer waves (one per SIMD) ONLY stage: during stage s they
+// write the activations of stage s+1 (fetched during stage s-1) into the other LDS buffer, start that stage's weight-slab copies
+// and fetch the activations of stage s+2.  The producers' VALU and LDS-write work runs beside the consumers' MFMAs on every SIMD
+// for the whole stage (~900 of ~3850 cycles).  Same buffers, same barrier per stage, same arithmetic in the same order: results
+// are bit-identical to conv3x3_split_kernel.  768 (NW = 8) or 512 (NW = 4) threads.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int MODE>
+__global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                                        const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+                                                                        const float* __restrict__ residual, float* __restrict__ out,
+                                                                        int n_items, int items_per_wg) {
+  constexpr int RB = kSplitRow, T = (MODE == 0) ? 9 : 4;
+  constexpr int NPW = 4, NPT = 64 * NPW;                    // producer waves / threads
+  constexpr int NB = ((MODE == 0) ? 32 : 16) / NPW;         // 1 KB pieces of the weight slab per producer wave
+  constexpr int KA = NW / 2;                                // staging units (8 channels of one pixel) per producer thread
+  constexpr int SLAB = T * 32 * kSplitRow, BPAD = (MODE == 0) ? 512 : 2048;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= NW;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int npixA = g.NI * g.IHt * g.IWt;
+  const int bufsz = (npixA + T * 32) * RB + BPAD;
+  const int tpi = g.Hv / g.TH;
+  const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;
+  const int CCH = g.Cin >> 4;
+  const int ntn = g.Cout >> 5;
+  const int item0 = blockIdx.x * items_per_wg;
+  const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
+  const int nst = my_items * NCH;
+  const int b_reg = npixA * RB;
+
+  // zero halo columns of both buffers (all waves)
+  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 64 * NW + NPT) {
+    const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * RB + 16 * q) = zero4;
+  }
+  char* bufc = smem;               // buffer the MFMAs read
+  char* bufn = smem + bufsz;       // buffer being filled
+
+  if (producer) {
+    // =============================== producer waves: staging only ===============================
+    const int pt = tid - 64 * NW, pw = wave - NW;           // producer thread / wave index
+    const int SEG = g.NI * g.IHt * g.Wv;                    // staged pixels per tile
+    const int hh = pt & 1;
+    int a_lds[KA], a_im[KA], a_hy[KA];
+    unsigned a_vo[KA], a_ro[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      int sp = (pt + NPT * k) >> 1;
+      if (sp >= SEG) sp = SEG - 1;                          // surplus slots repeat the last unit (same data to the same place)
+      const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
+      const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
+      a_lds[k] = ((img * g.IHt + hy) * g.IWt + x + 1) * RB + 48 * hh;
+      a_vo[k] = (unsigned)((MODE == 1 ? 2 * x : x) * g.ld0 + 8 * hh) * 4u;
+      a_im[k] = img;
+      a_hy[k] = hy;
+      a_ro[k] = a_vo[k] + (unsigned)(img * g.Hi + (MODE == 1 ? 2 * hy : hy)) * (unsigned)(g.Wi * g.ld0 * 4);
+    }
+    const unsigned b_lane = 16u * lane;
+    f32x4 ra[KA][2];
+    float akeep[KA];
+    const char* l_sp = reinterpret_cast<const char*>(src0);
+    const char* l_wn = reinterpret_cast<const char*>(ws);
+    int l_b0 = 0, l_iy0 = 0, l_py = 0;
+    long long l_rb = 0;
+#define PIDM_WS_STAGE(s_)                                                                                          \
+  {                                                                                                                \
+    int ss__ = (s_);                                                                                               \
+    if (ss__ >= nst) ss__ = nst - 1;                                                                               \
+    const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
+    const int tq__ = it__ / g.tiles_m, tm__ = it__ - tq__ * g.tiles_m;                                             \
+    const int ph__ = (MODE == 1) ? ch__ / CCH : 0;                                                                 \
+    const int c0__ = (ch__ - ph__ * CCH) * 16;                                                                     \
+    l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
+    l_iy0 = (tm__ % tpi) * g.TH - 1;                                                                               \
+    l_py = (MODE == 1) ? g.ph_oy[ph__] : 0;                                                                        \
+    l_rb = (long long)(l_b0 * g.Hi + (MODE == 1 ? 2 * l_iy0 + l_py : l_iy0)) * (long long)(g.Wi * g.ld0 * 4);      \
+    l_sp = reinterpret_cast<const char*>(((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                    \
+                                         ((MODE == 1) ? g.ph_ox[ph__] * g.ld0 : 0));                               \
+    l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tq__ * NCH + ch__) * SLAB;                                 \
+  }
+#define PIDM_WS_LOAD_A(k_)                                                                                         \
+  {                                                                                                                \
+    const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
+    const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < (MODE == 1 ? g.Hv : g.Hi));                              \
+    const f32x4* p__ = reinterpret_cast<const f32x4*>(ok__ ? l_sp + l_rb + a_ro[k_] : l_sp + a_vo[k_]);            \
+    ra[k_][0] = p__[0];                                                                                            \
+    ra[k_][1] = p__[1];                                                                                            \
+    akeep[k_] = ok__ ? 1.f : 0.f;                                                                                  \
+  }
+#define PIDM_WS_COPY_B(k_, wn_, buf_) pidm_glds_b128((wn_) + 1024 * (pw + NPW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (pw + NPW * (k_)));
+#define PIDM_WS_WRITE_A(k_, buf_)                                                                                  \
+  {                                                                                                                \
+    const f32x4 v0__ = ra[k_][0] * akeep[k_], v1__ = ra[k_][1] * akeep[k_];                                        \
+    unsigned q0__[4], q1__[4], q2__[4];                                                                            \
+    pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
+    pidm_split3_pk(v0__[2], v0__[3], q0__[1], q1__[1], q2__[1]);                                                   \
+    pidm_split3_pk(v1__[0], v1__[1], q0__[2], q1__[2], q2__[2]);                                                   \
+    pidm_split3_pk(v1__[2], v1__[3], q0__[3], q1__[3], q2__[3]);                                                   \
+    u32x4* d__ = reinterpret_cast<u32x4*>((buf_) + a_lds[k_]);                                                     \
+    d__[0] = u32x4{q0__[0], q0__[1], q0__[2], q0__[3]};                                                            \
+    d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \
+    d__[2] = u32x4{q2__[0], q2__[1], q2__[2], q2__[3]};                                                            \
+  }
+    // prologue: stage 0 into bufc; the activations of stage 1 stay in registers
+    PIDM_WS_STAGE(0)
+#pragma unroll
+    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, l_wn, bufc)
+#pragma unroll
+    for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(k, bufc)
+    PIDM_WS_STAGE(1)
+#pragma unroll
+    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+      const char* wn1 = l_wn;        // weight slab of stage s+1
+      // stage s+1: registers -> the other buffer, weight slab by LDS-direct copies; then the activations of stage s+2
+#pragma unroll
+      for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(k, bufn)
+#pragma unroll
+      for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, wn1, bufn)
+      PIDM_WS_STAGE(s + 2)
+#pragma unroll
+      for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
+      __syncthreads();               // buffer (s+1)&1 complete (this wave's part), buffer s&1 free
+      char* tswap = bufc; bufc = bufn; bufn = tswap;
+    }
+#undef PIDM_WS_STAGE
+#undef PIDM_WS_LOAD_A
+#undef PIDM_WS_COPY_B
+#undef PIDM_WS_WRITE_A
+    return;
+  }
+
+  // =============================== consumer waves: fragments, MFMAs, epilogue ===============================
+  const int pm = wave * 32 + l31;
+  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
+  const int a_frag = abase * RB + 48 * half;
+  const int b_frag = (npixA + l31) * RB + 48 * half;
+  __syncthreads();                   // stage 0 is in bufc
+  f32x16 acc, accb;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+  for (int s = 0; s < nst; ++s) {
+    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[(((item0 + s / NCH) / g.tiles_m) % ntn) * 32 + l31];
+    int oy0 = 0, ox0 = 0;
+    if (MODE == 1) {
+      const int ph = (s - (s / NCH) * NCH) / CCH;
+      oy0 = 1 - g.ph_pad_y[ph]; ox0 = 1 - g.ph_pad_x[ph];
+    } else if (MODE == 2) {
+      const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
+      oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
+    }
+    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : (oy0 * g.IWt + ox0) * RB);
+    const char* bfp = bufc + b_frag;
+    u32x4 fa[2][3], fb[2][3];
+#define PIDM_WS_FRAGS(set_, t_)                                                                                    \
+  {                                                                                                                \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * g.IWt + ((t_) % 3) : ((t_) >> 1) * g.IWt + ((t_) & 1)) * RB); \
+    const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
+      fa[set_][p] = ar__[p];                                                                                       \
+      fb[set_][p] = br__[p];                                                                                       \
+    }                                                                                                              \
+  }
+    PIDM_WS_FRAGS(0, 0)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < T) PIDM_WS_FRAGS(cur ^ 1, t + 1)
+      if (t & 1) {
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], accb);
+        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
+      } else {
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
+        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PIDM_WS_FRAGS
+    const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
+    if (ch == NCH - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += accb[r];
+      const int tq = it / g.tiles_m, tm = it - tq * g.tiles_m;
+      const int zz = (MODE == 2) ? tq / ntn : 0, tn = tq - zz * ntn;
+      const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
+      const int c = n0 + l31;
+      const float bv = bias ? bv_pre : 0.f;
+      const int p0 = wave * 32;
+      const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
+      const int b = b0 + img0;
+      if (b < g.B && img0 < g.NI) {        // wave-uniform
+        const int pin = (vy0 + ty0) * g.Wv + tx0;
+        float v[16];
+        float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = acc[r] + bv;
+          gs1 += v[r];
+          gs2 += v[r] * v[r];
+        }
+        if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
+        if (g.bn_part) {
+          const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
+          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout)
+        }
+        const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+        const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
+        const size_t rpix = ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + n0 + 4 * (l31 >> 2);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float x0 = v[4 * q4], x1 = v[4 * q4 + 1], x2 = v[4 * q4 + 2], x3 = v[4 * q4 + 3];
+          const float r01 = pidm_quad_xor1(odd1 ? x0 : x1), r23 = pidm_quad_xor1(odd1 ? x2 : x3);
+          x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+          x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+          const float r02 = pidm_quad_xor2(odd2 ? x0 : x2), r13 = pidm_quad_xor2(odd2 ? x1 : x3);
+          x0 = odd2 ? r02 : x0; x2 = odd2 ? x2 : r02;
+          x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
+          const int prow = 8 * q4 + 4 * half + (l31 & 3);
+          f32x4 o = {x0, x1, x2, x3};
+          if (MODE == 2) {
+            const int pp = p0 + prow, vx = pp & (g.Wv - 1), vy = vy0 + ((pp >> g.wsh) & (g.TH - 1));
+            const size_t opx = (size_t)(2 * vy + g.ooy[zz]) * g.Wo + 2 * vx + g.oox[zz];
+            if (residual) o += *reinterpret_cast<const f32x4*>(residual + ((size_t)b * g.Ho * g.Wo + opx) * g.ldr + n0 + 4 * (l31 >> 2));
+            *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + opx * g.sox + n0 + 4 * (l31 >> 2)) = o;
+          } else {
+            if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);
+            *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
+          }
+        }
+      }
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+    }
+    __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    char* tswap = bufc; bufc = bufn; bufn = tswap;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 7x7 / stride 1 / pad 3 convolution with very few input channels: the UNet's init_conv (reference src/unet_model.py:453,568;
 // Cin = 2, or 4 with self-conditioning).  The implicit-GEMM kernels pad Cin to 8 channels PER TAP (49 taps x 8 = 392 columns for
 // 98 real ones) and ran this layer at 16 TFLOP/s - 100 us for 1.6 GFLOP.  Here (kx, channel) of one kernel row is the
@@ -1215,6 +1473,11 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
   }
 }
 
+// PIDM_SPLIT_WS (read per launch): 1 = the warp-specialised form of the split convolution kernels (default), 0 = every wave stages and computes
+static bool split_ws_on() {
+  const char* e = getenv("PIDM_SPLIT_WS");
+  return !(e && !atoi(e));
+}
 // pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
 // fp32 packing of the same tensor (packed_floats counts both).  Shape-only condition: the launcher may still take another kernel.
 static bool split_shape_ok(const ConvGeom& g) {
@@ -2832,6 +3095,21 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const bool prof = prof_enabled();
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
         const dim3 bd(64 * nw);
+        if (split_ws_on()) {
+          static bool attr_w = false;
+          if (!attr_w) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            attr_w = true;
+          }
+          const dim3 bw(64 * nw + 256);
+          if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
+          else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
+          else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
+        } else
         if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 2>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
@@ -2883,6 +3161,20 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const int trace = getenv("PIDM_STREAM_TRACE") ? 1 : 0;
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
+        if (split_ws_on() && !trace) {
+          static bool attr_w0 = false;
+          if (!attr_w0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            attr_w0 = true;
+          }
+          if (nw == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 0>), dim3(wgs), dim3(768), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
+                               out, n_items, ipw);
+          else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
+                               out, n_items, ipw);
+        } else
         if (nw == 8)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);

@@ -113,11 +113,14 @@ SPLIT_CASES = STREAM3_CASES[:4] + [
 ]
 
 
+@pytest.mark.parametrize("ws", ["1", "0"])
 @pytest.mark.parametrize("nw,wgs,p,maxns", [("8", "3", "256", "2"), ("4", "256", "128", "1"), ("4", "2", "256", "3")])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", SPLIT_CASES)
-def test_conv_3x3_split_forms(backend, monkeypatch, nw, wgs, p, maxns, B, H, C0, C1, Cout, K, stride, pad, transposed):
+def test_conv_3x3_split_forms(backend, monkeypatch, ws, nw, wgs, p, maxns, B, H, C0, C1, Cout, K, stride, pad, transposed):
     """3x3 forward / dgrad / wgrad on the bf16 matrix pipe with 3-piece operands: both tile sizes of each kernel, several work
-    items per workgroup (forward) and several tiles per split (wgrad); same tolerance as the fp32-MFMA kernels."""
+    items per workgroup (forward) and several tiles per split (wgrad); same tolerance as the fp32-MFMA kernels.  ws = 1: the
+    warp-specialised forward / dgrad kernel (producer waves stage, consumer waves compute), ws = 0: every wave does both."""
+    monkeypatch.setenv("PIDM_SPLIT_WS", ws)
     monkeypatch.setenv("PIDM_SPLIT_NW", nw)
     monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
     monkeypatch.setenv("PIDM_WGRAD_SPLIT_P", p)
@@ -265,9 +268,11 @@ SPLIT2_CASES = [   # the 4x4 / stride-2 family in the split form: strided conv =
 ]
 
 
+@pytest.mark.parametrize("ws", ["1", "0"])
 @pytest.mark.parametrize("nw,wgs", [("8", "3"), ("4", "256")])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", SPLIT2_CASES)
-def test_conv_4x4s2_split_forms(backend, monkeypatch, nw, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+def test_conv_4x4s2_split_forms(backend, monkeypatch, ws, nw, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    monkeypatch.setenv("PIDM_SPLIT_WS", ws)
     monkeypatch.setenv("PIDM_SPLIT_NW", nw)
     monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
@@ -277,6 +282,39 @@ def test_conv_4x4s2_split_forms(backend, monkeypatch, nw, wgs, B, H, C0, C1, Cou
 def test_conv_4x4s2_fp32_forms(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", [SPLIT_CASES[0], SPLIT_CASES[5], SPLIT2_CASES[0], SPLIT2_CASES[3]])
+def test_warp_specialised_kernel_is_bit_identical(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """Producer / consumer waves change who does the work, not the arithmetic or its order: same bits as the one-role kernel."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(321)
+    Cin = C0 + C1
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = (torch.randn(Cin, Cout, K, K, generator=g) if transposed else torch.randn(Cout, Cin, K, K, generator=g)) * 0.05
+    bias = torch.randn(Cout, generator=g).to(dev)
+    x0 = nhwc(x[:, :C0]).to(dev)
+    x1 = nhwc(x[:, C0:]).to(dev) if C1 else None
+    wd_ = w.to(dev)
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=C0, C1=C1, ld0=C0, ld1=C1, Cout=Cout, KH=K, KW=K, stride=stride, pad=pad, transposed=transposed,
+                 out_nchw=0, ldo=Cout)
+    Ho = (H - 1) * stride - 2 * pad + K if transposed else (H + 2 * pad - K) // stride + 1
+    outs = {}
+    for ws in ("1", "0"):
+        monkeypatch.setenv("PIDM_SPLIT_WS", ws)
+        wp = torch.zeros(L.pidm_conv_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wp), 0, st))
+        out = torch.full((B, Ho, Ho, Cout), float("nan"), device=dev)
+        L.check(L.pidm_conv_forward(d, ptr(x0), ptr(x1), ptr(wp), ptr(bias), None, ptr(out), st))
+        wdg = torch.zeros(L.pidm_conv_dgrad_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wdg), 1, st))
+        dyn = torch.randn(B, Ho, Ho, Cout, generator=torch.Generator().manual_seed(5)).to(dev)
+        dx = torch.full((B, H, H, Cin), float("nan"), device=dev)
+        L.check(L.pidm_conv_dgrad(d, ptr(dyn), Cout, ptr(wdg), None, ptr(dx), Cin, st))
+        outs[ws] = (out.clone(), dx.clone())
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    assert torch.isfinite(outs["1"][0]).all() and torch.isfinite(outs["1"][1]).all()
 
 
 def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):

@@ -1161,8 +1161,11 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       a_ro[k] = a_vo[k] + (unsigned)(img * g.Hi + (MODE == 1 ? 2 * hy : hy)) * (unsigned)(g.Wi * g.ld0 * 4);
     }
     const unsigned b_lane = 16u * lane;
-    f32x4 ra[KA][2];
-    float akeep[KA];
+    // two register sets: the activations of stage k travel in set k & 1 - fetched during stage k-2 (a whole stage before they are
+    // needed: with a single set the fetch latency sat between every barrier and the first LDS write of the next stage, and the
+    // producers, not the matrix pipe, set the pace), split and written to LDS during stage k-1
+    f32x4 ra[2][KA][2];
+    float akeep[2][KA];
     const char* l_sp = reinterpret_cast<const char*>(src0);
     const char* l_wn = reinterpret_cast<const char*>(ws);
     int l_b0 = 0, l_iy0 = 0, l_py = 0;
@@ -1183,19 +1186,19 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
                                          ((MODE == 1) ? g.ph_ox[ph__] * g.ld0 : 0));                               \
     l_wn = reinterpret_cast<const char*>(ws) + ((size_t)tq__ * NCH + ch__) * SLAB;                                 \
   }
-#define PIDM_WS_LOAD_A(k_)                                                                                         \
+#define PIDM_WS_LOAD_A(set_, k_)                                                                                   \
   {                                                                                                                \
     const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
     const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < (MODE == 1 ? g.Hv : g.Hi));                              \
     const f32x4* p__ = reinterpret_cast<const f32x4*>(ok__ ? l_sp + l_rb + a_ro[k_] : l_sp + a_vo[k_]);            \
-    ra[k_][0] = p__[0];                                                                                            \
-    ra[k_][1] = p__[1];                                                                                            \
-    akeep[k_] = ok__ ? 1.f : 0.f;                                                                                  \
+    ra[set_][k_][0] = p__[0];                                                                                      \
+    ra[set_][k_][1] = p__[1];                                                                                      \
+    akeep[set_][k_] = ok__ ? 1.f : 0.f;                                                                            \
   }
 #define PIDM_WS_COPY_B(k_, wn_, buf_) pidm_glds_b128((wn_) + 1024 * (pw + NPW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (pw + NPW * (k_)));
-#define PIDM_WS_WRITE_A(k_, buf_)                                                                                  \
+#define PIDM_WS_WRITE_A(set_, k_, buf_)                                                                            \
   {                                                                                                                \
-    const f32x4 v0__ = ra[k_][0] * akeep[k_], v1__ = ra[k_][1] * akeep[k_];                                        \
+    const f32x4 v0__ = ra[set_][k_][0] * akeep[set_][k_], v1__ = ra[set_][k_][1] * akeep[set_][k_];                \
     unsigned q0__[4], q1__[4], q2__[4];                                                                            \
     pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
     pidm_split3_pk(v0__[2], v0__[3], q0__[1], q1__[1], q2__[1]);                                                   \
@@ -1206,31 +1209,37 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \
     d__[2] = u32x4{q2__[0], q2__[1], q2__[2], q2__[3]};                                                            \
   }
-    // prologue: stage 0 into bufc; the activations of stage 1 stay in registers
+    // one producer iteration = consumer stage s_: weight slab of stage s_+1 (LDS-direct), fetch of stage s_+2 into set (s_ & 1)
+    // (free since the previous iteration), then stage s_+1 from set ((s_+1) & 1) into the other buffer
+#define PIDM_WS_ITER(s_, setL_, setW_)                                                                             \
+  {                                                                                                                \
+    const char* wn1__ = l_wn;                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, wn1__, bufn)                                  \
+    PIDM_WS_STAGE((s_) + 2)                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(setL_, k)                                        \
+    _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(setW_, k, bufn)                                 \
+    PIDM_WAIT_VMEM();                /* the LDS-direct copies (and the fetch) have landed */                       \
+    __syncthreads();                 /* buffer (s+1)&1 complete (this wave's part), buffer s&1 free */             \
+    char* tswap__ = bufc; bufc = bufn; bufn = tswap__;                                                             \
+  }
+    // prologue: stage 0 into bufc; the activations of stage 1 stay in registers (set 1)
     PIDM_WS_STAGE(0)
 #pragma unroll
-    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
+    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(0, k)
 #pragma unroll
     for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, l_wn, bufc)
 #pragma unroll
-    for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(k, bufc)
+    for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(0, k, bufc)
     PIDM_WS_STAGE(1)
 #pragma unroll
-    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
+    for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(1, k)
+    PIDM_WAIT_VMEM();
     __syncthreads();
-    for (int s = 0; s < nst; ++s) {
-      const char* wn1 = l_wn;        // weight slab of stage s+1
-      // stage s+1: registers -> the other buffer, weight slab by LDS-direct copies; then the activations of stage s+2
-#pragma unroll
-      for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(k, bufn)
-#pragma unroll
-      for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, wn1, bufn)
-      PIDM_WS_STAGE(s + 2)
-#pragma unroll
-      for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(k)
-      __syncthreads();               // buffer (s+1)&1 complete (this wave's part), buffer s&1 free
-      char* tswap = bufc; bufc = bufn; bufn = tswap;
+    for (int s = 0; s < nst; s += 2) {
+      PIDM_WS_ITER(s, 0, 1)
+      if (s + 1 < nst) PIDM_WS_ITER(s + 1, 1, 0)
     }
+#undef PIDM_WS_ITER
 #undef PIDM_WS_STAGE
 #undef PIDM_WS_LOAD_A
 #undef PIDM_WS_COPY_B

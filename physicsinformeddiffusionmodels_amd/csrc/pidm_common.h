@@ -93,6 +93,11 @@ __device__ __forceinline__ pidm_f32x16 pidm_mfma_bf16_32x32x16(u32x4 a, u32x4 b,
 #endif
 // Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is wave-uniform base +
 // 16 * lane, the global source is per lane; completion is counted by vmcnt (a following __syncthreads() drains it).
+// wait until every vector-memory operation of this wave has completed (s_waitcnt vmcnt(0); gfx9 encoding: vmcnt = 0, expcnt and
+// lgkmcnt at their maxima) - global_load_lds writes LDS behind the compiler's back, a barrier that publishes such data says so
+#ifndef PIDM_WAIT_VMEM
+#define PIDM_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
 #ifndef PIDM_HAVE_GLDS
 __device__ __forceinline__ void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,

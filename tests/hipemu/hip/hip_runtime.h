@@ -289,6 +289,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return reinterpret_c
 static inline float hipemu_fast_expf(float x) { return exp2f(x * 1.4426950408889634f); }   // v_mul_f32 + v_exp_f32
 #define __expf(x) hipemu_fast_expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
+#define PIDM_WAIT_VMEM() ((void)0)
 #define PIDM_HAVE_FAST_SIGMOID 1
 static inline float pidm_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 static inline float __frcp_rn(float a) { return 1.0f / a; }

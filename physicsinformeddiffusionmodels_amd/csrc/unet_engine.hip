@@ -816,33 +816,37 @@ static int join_side(Run& r) {
   return 0;
 }
 
-static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* dy) {
+// ld_dy: channel stride of dy (0 = L.Cout, contiguous): the two halves of a concatenation's gradient are read in place
+static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* dy, int ld_dy = 0) {
   pidm_unet* U = r.U;
   if (!U->have_grads && !r.dry) return 0;
+  if (!ld_dy) ld_dy = L.Cout;
   ConvGeom g;
   const int Ho = out_h(L);
   const hipStream_t wst = r.dry ? r.st : fork_side(r);
   if (L.transposed) {
-    if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, L.Cout, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
+    if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, ld_dy, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
     RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, wst, r.q()));
     if (L.b >= 0) {
       float* cpart = r.part_alloc(colsum_ws_bytes((size_t)r.B * Ho * Ho, L.Cout));
-      RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, L.Cout, U->G[L.b], cpart, wst, r.q()));
+      RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, ld_dy, U->G[L.b], cpart, wst, r.q()));
     }
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
-    RUN(launch_wgrad(g, x0, x1, dy, L.Cout, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q()));
+    RUN(launch_wgrad(g, x0, x1, dy, ld_dy, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q()));
   }
   return 0;
 }
 
-static int conv_dgrad(Run& r, const ConvLayer& L, const float* dy, const float* residual, float* dx) {
+// ld_dy / ld_res: channel strides of dy and of the residual (0 = contiguous)
+static int conv_dgrad(Run& r, const ConvLayer& L, const float* dy, const float* residual, float* dx, int ld_dy = 0, int ld_res = 0) {
   pidm_conv_desc d = desc_of(L, r.B);
   ConvGeom g;
   int kind;
-  if (geom_dgrad(&d, L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
+  if (geom_dgrad(&d, ld_dy ? ld_dy : L.Cout, L.C0 + L.C1, &g, &kind)) return -1;
+  if (ld_res) g.ldr = ld_res;
   RUN(launch_conv(g, dy, nullptr, r.wpack + L.off_d, nullptr, residual, dx, 0, r.st));
   return 0;
 }
@@ -1149,21 +1153,26 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   // final resblock: input cat(x, h0)
   float* g_cat = r.tmp.alloc((size_t)B * HW * 2 * dim);
   if (resblock_bwd(r, U->rb[irb--], g_x, g_cat, dss)) return -1;
-  float* g_r = r.tmp.alloc((size_t)B * HW * dim);
+  const float* g_r = g_cat + dim;      // gradient wrt h0 through the final concat: read in place (stride 2 dim) where it is added to g_h0
   g_x = r.tmp.alloc((size_t)B * HW * dim);
   RUN(launch_copy_add(g_x, dim, g_cat, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
-  RUN(launch_copy_add(g_r, dim, g_cat + dim, 2 * dim, nullptr, 0, (size_t)B * HW, dim, r.st));
-  std::vector<float*> g_skip(n, nullptr);
+  // The gradient of a concatenation cat(x, skip) is one [pixels][2 dout] tensor; its two halves are consumed IN PLACE through a
+  // channel stride of 2 dout wherever the consumer is a convolution (dy of the next up-sampling layer, residual of the
+  // down-sampling layer's input gradient) - only the halves that feed normalisation / attention kernels are copied out
+  std::vector<const float*> g_skip(n, nullptr);
+  std::vector<int> g_skip_ld(n, 0);
+  int ld_gx = 0;                   // channel stride of g_x (0 = contiguous)
   for (int j = n - 1; j >= 0; --j) {
     const int lvl = n - 1 - j;
     const int din = U->dims[lvl], dout = U->dims[lvl + 1], H = P >> lvl;
     const size_t npix = (size_t)B * H * H;
     if (j < n - 1) {
       const ConvLayer& L = U->up[j];
-      if (conv_wgrad(r, L, U->up_in[j], nullptr, g_x)) return -1;
+      if (conv_wgrad(r, L, U->up_in[j], nullptr, g_x, ld_gx)) return -1;
       float* g = r.tmp.alloc(npix * din);
-      if (conv_dgrad(r, L, g_x, nullptr, g)) return -1;
+      if (conv_dgrad(r, L, g_x, nullptr, g, ld_gx)) return -1;
       g_x = g;
+      ld_gx = 0;
     }
     float* g1 = r.tmp.alloc(npix * din);
     if (attn_bwd(r, U->attn[iat--], g_x, g1)) return -1;
@@ -1171,10 +1180,16 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (resblock_bwd(r, U->rb[irb--], g1, g2, dss)) return -1;
     float* gc = r.tmp.alloc(npix * 2 * dout);
     if (resblock_bwd(r, U->rb[irb--], g2, gc, dss)) return -1;
-    g_x = r.tmp.alloc(npix * dout);
-    g_skip[lvl] = r.tmp.alloc(npix * dout);
-    RUN(launch_copy_add(g_x, dout, gc, 2 * dout, nullptr, 0, npix, dout, r.st));
-    RUN(launch_copy_add(g_skip[lvl], dout, gc + dout, 2 * dout, nullptr, 0, npix, dout, r.st));
+    g_skip[lvl] = gc + dout;
+    g_skip_ld[lvl] = 2 * dout;
+    if (j > 0) {
+      g_x = gc;                    // read by the convolutions of up[j-1] with stride 2 dout
+      ld_gx = 2 * dout;
+    } else {
+      g_x = r.tmp.alloc(npix * dout);   // feeds the bottleneck's GroupNorm backward: contiguous
+      RUN(launch_copy_add(g_x, dout, gc, 2 * dout, nullptr, 0, npix, dout, r.st));
+      ld_gx = 0;
+    }
   }
   // decoder half done: every gradient of ups.* / final_conv.* is final after this flush
   if (n_phases >= 2 && flush_reductions(r, red_dev, &red_done, 0)) return -1;
@@ -1196,9 +1211,9 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     if (i < n - 1) {
       const ConvLayer& L = U->down[i];
       if (conv_wgrad(r, L, U->down_in[i], nullptr, g_x)) return -1;
-      if (conv_dgrad(r, L, g_x, g_skip[i], g_la)) return -1;
+      if (conv_dgrad(r, L, g_x, g_skip[i], g_la, 0, g_skip_ld[i])) return -1;
     } else {
-      RUN(launch_copy_add(g_la, dout, g_x, dout, g_skip[i], dout, npix, dout, r.st));
+      RUN(launch_copy_add(g_la, dout, g_x, dout, g_skip[i], g_skip_ld[i], npix, dout, r.st));
     }
     float* g1 = r.tmp.alloc(npix * dout);
     if (attn_bwd(r, U->attn[iat--], g_la, g1)) return -1;
@@ -1212,7 +1227,7 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   if (n_phases >= 3 && flush_reductions(r, red_dev, &red_done, 1)) return -1;
   // h0 feeds both the first resblock and the final concat
   float* g_h0 = r.tmp.alloc((size_t)B * HW * dim);
-  RUN(launch_copy_add(g_h0, dim, g_x, dim, g_r, dim, (size_t)B * HW, dim, r.st));
+  RUN(launch_copy_add(g_h0, dim, g_x, dim, g_r, 2 * dim, (size_t)B * HW, dim, r.st));
   if (U->tape_cond) {
     const size_t nh = (size_t)B * HW * dim;
     if (conv_wgrad(r, U->comb, U->h0pre, U->e2, g_h0)) return -1;

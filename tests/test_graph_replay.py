@@ -72,7 +72,7 @@ def test_replay_survives_interleaved_passes_and_rebinding(backend):
     L, dev = backend
     m = _model(dev, L)
     ref_m = _model(dev, L)
-    data = _inputs(dev, 8)
+    data = _inputs(dev, 7)
     other = _inputs(dev, 2, B=3, seed=12)
     import os
     for i, d in enumerate(data):
@@ -108,7 +108,7 @@ def test_changed_weights_are_seen_by_the_replayed_forward(backend):
     L, dev = backend
     import os
     ma, mb = _model(dev, L), _model(dev, L)
-    data = _inputs(dev, 5)
+    data = _inputs(dev, 4)
     for i, d in enumerate(data):
         os.environ["PIDM_GRAPH"] = "0"
         try:
@@ -164,9 +164,9 @@ def test_conditioning_branch_replay(backend):
     L, dev = backend
     import os
     ma, mb = _model(dev, L), _model(dev, L)
-    data = _inputs(dev, 8)
+    data = _inputs(dev, 6)
     g = torch.Generator().manual_seed(21)
-    conds = [torch.randn(2, 256, 2, generator=g).to(dev) for _ in range(8)]
+    conds = [torch.randn(2, 256, 2, generator=g).to(dev) for _ in range(6)]
     for i, d in enumerate(data):
         c = conds[i] if i % 2 == 0 else None
         os.environ["PIDM_GRAPH"] = "0"

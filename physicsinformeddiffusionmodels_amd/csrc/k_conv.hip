@@ -1482,10 +1482,14 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
   }
 }
 
-// PIDM_SPLIT_WS (read per launch): 1 = the warp-specialised form of the split convolution kernels (default), 0 = every wave stages and computes
-static bool split_ws_on() {
+// Which form of the split convolution kernel takes a launch (PIDM_SPLIT_WS, read per launch): unset = the warp-specialised form
+// for the 4-wave / 128-pixel tile only (one consumer wave per SIMD cannot hide its own staging: 15-19 % faster there, 8x8 level
+// 22.4 -> 18.4 us, 38.3 -> 31.5, 64.1 -> 51.9), the one-role form for the 8-wave tile (two waves per SIMD already overlap each
+// other and the extra producer waves cost 2-3 %: 63.8 -> 65.7 us; profiles/r03_ws_conv.txt); 1 / 0 force one form everywhere.
+static bool split_ws_on(int nw) {
   const char* e = getenv("PIDM_SPLIT_WS");
-  return !(e && !atoi(e));
+  if (!e) return nw == 4;
+  return atoi(e) != 0;
 }
 // pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
 // fp32 packing of the same tensor (packed_floats counts both).  Shape-only condition: the launcher may still take another kernel.
@@ -3104,7 +3108,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const bool prof = prof_enabled();
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
         const dim3 bd(64 * nw);
-        if (split_ws_on()) {
+        if (split_ws_on(nw)) {
           static bool attr_w = false;
           if (!attr_w) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -3170,7 +3174,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const int trace = getenv("PIDM_STREAM_TRACE") ? 1 : 0;
         if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
-        if (split_ws_on() && !trace) {
+        if (split_ws_on(nw) && !trace) {
           static bool attr_w0 = false;
           if (!attr_w0) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

@@ -869,7 +869,13 @@ __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ 
 // backward 2: per (image, pixel range): d_xn of the range (all heads, summed across the 8 waves through LDS) and this range's
 // share of dWq, dWk (one head per wave, accumulated over the range's tiles).  dw part layout: [b*NS+ns][2*HD][C] (q rows, k rows)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CB>
+// SP (C = 32 only, needs split_dw): the four per-pixel PROJECTIONS of a head - qt = Wq xn^T, dqs = P dY^T, kt = Wk xn^T,
+// dks = dM xn^T: 64 of the 112 fp32 MFMAs per head and tile - run on the bf16 pipe with 3-piece operands as well: the head's four
+// 32 x 32 operand matrices are split ONCE per workgroup into registers (96 VGPRs, A operands with lane = d), the xn / dY tile is
+// split once per tile by the whole workgroup into a pixel-major LDS image ([px][k-step][half][piece] - the B operands, lane = px).
+// The fp32 slabs of xn / dY and the padding of the Wq | Wk | dM rows in LDS (only the register fragments read them row-wise now)
+// make room for it.  The d_xn products keep the fp32 MFMA (their B operands chain from the accumulators).
+template <int CB, bool SP>
 __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ dy,
                                                       const float* __restrict__ wqkv, const float* __restrict__ P,
                                                       const float* __restrict__ kst, const float* __restrict__ dMmat,
@@ -877,11 +883,14 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ dw_part, int N, int heads, int nper, int nsub,
                                                       float scale, int split_dw) {
   constexpr int C = 32 * CB, CP = C + 4;
+  static_assert(!SP || CB == 1, "the split projections keep the head's operand matrices in registers: C = 32 only");
+  constexpr int WCP = SP ? C : CP;                    // row stride of Wq | Wk | dM in LDS
+  constexpr int PR = 208;                             // SP: bytes per pixel row of the xn / dY piece images (13 x 16: odd)
   HIP_DYNAMIC_SHARED(float, smem)
-  float* xs = smem;                                   // [nper][CP]
-  float* ys = xs + (size_t)nper * CP;                 // [nper][CP]
+  float* xs = smem;                                   // [nper][CP]   (not SP)
+  float* ys = xs + (SP ? 0 : (size_t)nper * CP);      // [nper][CP]   (not SP)
   constexpr int TSZ = CB * 32 * kLapTileLd;           // floats of a wave's tile region
-  float* tiles = ys + (size_t)nper * CP;              // [8][TSZ]: transposition tile / d_xn share of each wave
+  float* tiles = ys + (SP ? 0 : (size_t)nper * CP);   // [8][TSZ]: transposition tile / d_xn share of each wave
   float* cst = tiles + (size_t)8 * TSZ;               // [8][96]: k max, k 1/Z, rowdot of each wave's head
   // C = 32: the operand matrices that are read row-wise (lane = c) 48 times per tile and head - Wq, Wk (all heads) and this image's
   // dM - live in LDS, rows padded to CP: fetched through L1 with the register file full, every one of those MFMAs waited for its
@@ -891,7 +900,9 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // split_dw: the weight-gradient pixel sums dWq += dq xn, dWk += dk xn run on the bf16 pipe (3-piece operands): xn of the range also
   // as pieces [piece][c][px] (B operand, pixels contiguous), dq / dk through the wave's tile as before (A operand: 8 pixels of a row)
   const int RT = nper * 2 + (WLDS ? 0 : 16);          // bytes per XT row (C = 32: no room for the conflict-avoiding pad)
-  char* XT = reinterpret_cast<char*>(wl + (WLDS ? 3 * 256 * CP : 0));
+  char* XT = reinterpret_cast<char*>(wl + (WLDS ? 3 * 256 * WCP : 0));
+  char* XP = XT + (size_t)3 * C * RT;                 // SP: [nper][PR] xn pieces, then the same for dY
+  char* YP = XP + (size_t)nper * PR;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = N / (nper * nsub);                  // workgroups per image: each walks nsub consecutive pixel ranges
@@ -902,7 +913,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       const int m = e / (HD * (C / 4)), rem = e - m * (HD * (C / 4));
       const int row = rem / (C / 4), q = rem - row * (C / 4);
       const float* src = (m < 2) ? wqkv + ((size_t)m * HD + row) * C : dMmat + ((size_t)b * HD + row) * C;
-      *reinterpret_cast<f32x4*>(wl + ((size_t)m * 256 + row) * CP + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      *reinterpret_cast<f32x4*>(wl + ((size_t)m * 256 + row) * WCP + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
     }
   }
   const int h = wave;
@@ -920,20 +931,43 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   f32x16 dWq[CB], dWk[CB];
   const size_t bh = (size_t)b * heads + (act ? h : 0);
   const int hrow = (act ? h : 0) * kLapDH + l31;
-  const float* wq_p = WLDS ? wl + (size_t)hrow * CP + 4 * half : wqkv + (size_t)hrow * C + 4 * half;
-  const float* wk_p = WLDS ? wl + (size_t)(256 + hrow) * CP + 4 * half : wqkv + ((size_t)HD + hrow) * C + 4 * half;
-  const float* dm_p = WLDS ? wl + (size_t)(512 + hrow) * CP + 4 * half : dMmat + (bh * 32 + l31) * C + 4 * half;
+  const float* wq_p = WLDS ? wl + (size_t)hrow * WCP + 4 * half : wqkv + (size_t)hrow * C + 4 * half;
+  const float* wk_p = WLDS ? wl + (size_t)(256 + hrow) * WCP + 4 * half : wqkv + ((size_t)HD + hrow) * C + 4 * half;
+  const float* dm_p = WLDS ? wl + (size_t)(512 + hrow) * WCP + 4 * half : dMmat + (bh * 32 + l31) * C + 4 * half;
   const float* pp_p = P + (bh * 32 + l31) * C + 4 * half;
+  // SP: the head's operand rows as bf16 pieces in registers: f..[k-step][piece], lane = (d = l31, k = 16 ks + 8 half + 0..7)
+  u32x4 fwq[SP ? C / 16 : 1][3], fwk[SP ? C / 16 : 1][3], fpp[SP ? C / 16 : 1][3], fdm[SP ? C / 16 : 1][3];
+  if constexpr (SP) {
+    __syncthreads();                                  // Wq | Wk | dM are in LDS
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) {
+      const float* srcs[4] = {wl + (size_t)hrow * WCP + 16 * ks + 8 * half, wl + (size_t)(256 + hrow) * WCP + 16 * ks + 8 * half,
+                              P + (bh * 32 + l31) * C + 16 * ks + 8 * half, wl + (size_t)(512 + hrow) * WCP + 16 * ks + 8 * half};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(srcs[m]), v1 = *reinterpret_cast<const f32x4*>(srcs[m] + 4);
+        unsigned q0[4], q1[4], q2[4];
+        pidm_split3_pk(v0[0], v0[1], q0[0], q1[0], q2[0]);
+        pidm_split3_pk(v0[2], v0[3], q0[1], q1[1], q2[1]);
+        pidm_split3_pk(v1[0], v1[1], q0[2], q1[2], q2[2]);
+        pidm_split3_pk(v1[2], v1[3], q0[3], q1[3], q2[3]);
+        u32x4(&f)[3] = (m == 0) ? fwq[ks] : (m == 1) ? fwk[ks] : (m == 2) ? fpp[ks] : fdm[ks];
+        f[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        f[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        f[2] = u32x4{q2[0], q2[1], q2[2], q2[3]};
+      }
+    }
+  }
   if (act) {
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
       for (int r = 0; r < 16; ++r) { dWq[cb][r] = 0.f; dWk[cb][r] = 0.f; }
   }
   // Wq_h[d][c = l31 + 32 cb] etc. for the d_xn products (A operand, lane = c); row stride ldT
-  const int ldT = WLDS ? CP : C;
-  const float* wqT = WLDS ? wl + (size_t)(h * kLapDH) * CP + l31 : wqkv + (size_t)h * kLapDH * C + l31;
-  const float* wkT = WLDS ? wl + (size_t)(256 + h * kLapDH) * CP + l31 : wqkv + ((size_t)HD + h * kLapDH) * C + l31;
-  const float* dmT = WLDS ? wl + (size_t)(512 + h * kLapDH) * CP + l31 : dMmat + ((size_t)b * heads + h) * 32 * C + l31;
+  const int ldT = WLDS ? WCP : C;
+  const float* wqT = WLDS ? wl + (size_t)(h * kLapDH) * WCP + l31 : wqkv + (size_t)h * kLapDH * C + l31;
+  const float* wkT = WLDS ? wl + (size_t)(256 + h * kLapDH) * WCP + l31 : wqkv + ((size_t)HD + h * kLapDH) * C + l31;
+  const float* dmT = WLDS ? wl + (size_t)(512 + h * kLapDH) * WCP + l31 : dMmat + ((size_t)b * heads + h) * 32 * C + l31;
 
   const float rscale = 1.f / scale;
   // dW[d][c] += sum_px g[d][px] xn[px][c] for the tile: g (lane = px, 16 rows d per lane) is turned through the wave's LDS tile
@@ -981,8 +1015,27 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // (re)stage the range's xn and dY slabs; the loop below ends on a barrier, so nobody still reads the previous range
   for (int e = tid; e < nper * (C / 4); e += 512) {
     const int px = e / (C / 4), q = e - px * (C / 4);
-    *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
-    *reinterpret_cast<f32x4*>(ys + (size_t)px * CP + 4 * q) = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+    const f32x4 vx = *reinterpret_cast<const f32x4*>(xn + (pix0 + px) * C + 4 * q);
+    const f32x4 vy = *reinterpret_cast<const f32x4*>(dy + (pix0 + px) * C + 4 * q);
+    if constexpr (SP) {
+      // 4 channels of one pixel -> 3 pieces x 2 dwords at [px][k-step = q / 4][half = (q / 2) & 1][piece][low / high 4 channels]
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const size_t o = (size_t)px * PR + ((q >> 2) * 2 + ((q >> 1) & 1)) * 48 + (q & 1) * 8;
+      unsigned a0, a1, a2, b0, b1, b2;
+      pidm_split3_pk(vx[0], vx[1], a0, a1, a2);
+      pidm_split3_pk(vx[2], vx[3], b0, b1, b2);
+      *reinterpret_cast<u32x2_t*>(XP + o) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(XP + o + 16) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(XP + o + 32) = u32x2_t{a2, b2};
+      pidm_split3_pk(vy[0], vy[1], a0, a1, a2);
+      pidm_split3_pk(vy[2], vy[3], b0, b1, b2);
+      *reinterpret_cast<u32x2_t*>(YP + o) = u32x2_t{a0, b0};
+      *reinterpret_cast<u32x2_t*>(YP + o + 16) = u32x2_t{a1, b1};
+      *reinterpret_cast<u32x2_t*>(YP + o + 32) = u32x2_t{a2, b2};
+    } else {
+      *reinterpret_cast<f32x4*>(xs + (size_t)px * CP + 4 * q) = vx;
+      *reinterpret_cast<f32x4*>(ys + (size_t)px * CP + 4 * q) = vy;
+    }
   }
   if (split_dw) {
     constexpr int QN = C / 4, GP = 16 / QN;
@@ -1024,6 +1077,29 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       // ---- q: qs^T[d][px], dqs^T[d][px] = P_h dY^T, softmax Jacobian per pixel (in-lane + other half) ----
       f32x16 qt, dq;
       for (int r = 0; r < 16; ++r) { qt[r] = 0.f; dq[r] = 0.f; }
+      // SP: B operands of the projections: this lane's pixel, 8 channels per k-step half, three pieces each
+      const char* xpr = XP + (size_t)(t * 32 + l31) * PR + 48 * half;
+      const char* ypr = YP + (size_t)(t * 32 + l31) * PR + 48 * half;
+#define PIDM_LAP_SIX(acc_, fa_, fb_)                                                                               \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[2], fb_[0], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[2], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[1], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[0], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[1], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[0], acc_);
+      if constexpr (SP) {
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+          u32x4 xb[3], yb[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            xb[pc] = *reinterpret_cast<const u32x4*>(xpr + 96 * ks + 16 * pc);
+            yb[pc] = *reinterpret_cast<const u32x4*>(ypr + 96 * ks + 16 * pc);
+          }
+          PIDM_LAP_SIX(qt, fwq[ks], xb)
+          PIDM_LAP_SIX(dq, fpp[ks], yb)
+        }
+      } else {
 #pragma unroll
       for (int g8 = 0; g8 < C / 8; ++g8) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wq_p + z0 + 8 * g8);
@@ -1035,6 +1111,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           qt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], x4[s], qt, 0, 0, 0);
           dq = __builtin_amdgcn_mfma_f32_32x32x2f32(p4[s], y4[s], dq, 0, 0, 0);
         }
+      }
       }
       float mx = qt[0];
 #pragma unroll
@@ -1081,6 +1158,16 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
       f32x16 kt, dk;
       for (int r = 0; r < 16; ++r) { kt[r] = 0.f; dk[r] = 0.f; }
+      if constexpr (SP) {
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+          u32x4 xb[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xb[pc] = *reinterpret_cast<const u32x4*>(xpr + 96 * ks + 16 * pc);
+          PIDM_LAP_SIX(kt, fwk[ks], xb)
+          PIDM_LAP_SIX(dk, fdm[ks], xb)
+        }
+      } else {
 #pragma unroll
       for (int g8 = 0; g8 < C / 8; ++g8) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk_p + z0 + 8 * g8);
@@ -1092,6 +1179,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           dk = __builtin_amdgcn_mfma_f32_32x32x2f32(m4[s], x4[s], dk, 0, 0, 0);
         }
       }
+      }
+#undef PIDM_LAP_SIX
       // per-head column constants in accumulator-row order (row d = lap_row(r, half)): k max, k 1/Z, rowdot from the wave's LDS block
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -1279,7 +1368,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_g_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_bwd_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_bwd_kernel<CB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
@@ -1304,10 +1393,25 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   PIDM_CHECK_LAUNCH("lap_mid_kernel");
   const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;
   const int split_dw = !(spe && !atoi(spe)) ? 1 : 0;
+  const char* ppe = getenv("PIDM_LAP_SPLIT_PROJ");            // 0: the four per-pixel projections of lap_bwd stay on the fp32 MFMA
+  if (CB == 1 && split_dw && !(ppe && !atoi(ppe))) {
+    const size_t lds3p = ((size_t)8 * 32 * kLapTileLd + 8 * 96 + (size_t)3 * 256 * C) * sizeof(float) + (size_t)3 * C * (np3 * 2) +
+                         (size_t)2 * np3 * 208;
+    if (lds3p > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3p);
+    static bool attr_p = false;
+    if (!attr_p) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_bwd_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr_p = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<1, true>), dim3(B * NS3), dim3(512), lds3p, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn,
+                       dwqk_part, N, heads, np3, nsub, scale, 1);
+    PIDM_CHECK_LAUNCH("lap_bwd_kernel");
+    return 0;
+  }
   const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * 256 * (C + 4) : 0)) * sizeof(float) +
                       (size_t)3 * C * (np3 * 2 + (CB == 1 ? 0 : 16));
   if (lds3 > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB, false>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
                      N, heads, np3, nsub, scale, split_dw);
   PIDM_CHECK_LAUNCH("lap_bwd_kernel");
   return 0;

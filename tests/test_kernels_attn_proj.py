@@ -68,11 +68,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("form", ["split", "fp32"])
+@pytest.mark.parametrize("form", ["split", "split_fp32proj", "fp32"])
 @pytest.mark.parametrize("B,H,heads,C", CASES)
 def test_projected_attention_vs_oracle(backend, monkeypatch, form, B, H, heads, C):
-    """form: the k / context pixel sums of the forward on the bf16 matrix pipe with 3-piece operands (default) or on the fp32 MFMA"""
-    monkeypatch.setenv("PIDM_LAP_SPLIT", "1" if form == "split" else "0")
+    """form: the pixel sums of the forward / backward and (C = 32) the four per-pixel projections of the backward on the bf16 matrix pipe
+    with 3-piece operands (default); the same with the projections on the fp32 MFMA; everything on the fp32 MFMA"""
+    monkeypatch.setenv("PIDM_LAP_SPLIT", "0" if form == "fp32" else "1")
+    monkeypatch.setenv("PIDM_LAP_SPLIT_PROJ", "0" if form == "split_fp32proj" else "1")
     L, dev = backend
     HD = heads * 32
     g = torch.Generator().manual_seed(5 + H + C)

@@ -362,7 +362,9 @@ def main():
         "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
         "what": "library-side accounting over the timed region (pidm_debug_launch_counts): the UNet forward and backward are replayed "
                 "hipGraphs (PIDM_GRAPH=0 turns that off); kernels enqueued one by one = q-sample, loss, optimizer kernels (torch's own "
-                "launches - RNG, the loss-scalar copy - are not counted); host_enqueue = wall time until the host has enqueued a step",
+                "launches - RNG, the loss-scalar copy - are not counted); host_enqueue = wall time until the host has enqueued a step INSIDE this "
+                "loop, where the launch queue is full and the host is held to the GPU's pace - the unloaded cost (queue drained: 1.2 ms per step "
+                "with graphs, 2.7-3.4 without) is in profiles/r03_graph_ab.txt",
     }
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

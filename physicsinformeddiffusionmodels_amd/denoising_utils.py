@@ -394,55 +394,44 @@ class _DarcyPidmLossFn(torch.autograd.Function):
         return grad * g_loss, None, None, None, None, None, None, None, None, None, None
 
 
-class _DarcyStepFn(torch.autograd.Function):
-    """The whole Darcy mean-estimation step as ONE autograd node with an EARLY backward: q-sample, UNet forward, fused residual +
-    loss + d loss/d x0_pred AND the UNet backward pass are enqueued inside `forward`; `loss.backward()` later only scales the
+class _EarlyStepFn(torch.autograd.Function):
+    """A whole single-UNet-call training step as ONE autograd node with an EARLY backward: UNet forward, the fused loss kernel
+    (loss + d loss/d x0_pred) AND the UNet backward pass are enqueued inside `forward`; `loss.backward()` later only scales the
     staged parameter gradients by its upstream gradient and attaches them as `p.grad`.
 
-    Why: the reference API returns the tracked loss terms as python floats (`.item()`, src/denoising_utils.py:681,688), i.e. one
-    host synchronisation per step right after the loss kernel.  With the backward pass enqueued BEFORE that synchronisation the GPU
-    keeps working through it while the host wakes up, runs `optimizer.zero_grad()` and the autograd dispatch (0.5 ms of idle GPU
-    per step otherwise, bench.py `eager_scalars` / `dropin_main_py`).  The gradients are the same numbers: backward is linear in the
-    upstream gradient, and the staging buffer is private, so nothing the caller can observe changes before `backward()` - `p.grad`
-    of an earlier step stay intact until then (main.py calls `zero_grad()` AFTER `model_estimation_loss`, and accumulation without
-    `zero_grad()` still adds).  Used only when it pays and is safe: python-float scalars, `model.training`, gradients enabled, no
-    data-parallel exchange attached, one UNet call per step (DenoisingDiffusion._darcy_step)."""
+    Why: the reference API returns the tracked loss terms as python floats (`.item()`, src/denoising_utils.py:681,688,699,707), i.e.
+    one host synchronisation per step right after the loss kernel.  With the backward pass enqueued BEFORE that synchronisation (and
+    the 16-byte scalar copy ahead of it in stream order) the GPU keeps working through it while the host wakes up, runs
+    `optimizer.zero_grad()` and the autograd dispatch (0.5 ms of idle GPU per Darcy step otherwise, bench.py `eager_scalars` /
+    `dropin_main_py`).  The gradients are the same numbers: backward is linear in the upstream gradient, and the staging buffer is
+    private, so nothing the caller can observe changes before `backward()` - `p.grad` of an earlier step stay intact until then
+    (main.py calls `zero_grad()` AFTER `model_estimation_loss`, and accumulation without `zero_grad()` still adds).  Used only when
+    it pays and is safe: python-float scalars, `model.training`, gradients enabled, no data-parallel exchange attached, one UNet
+    call per step (DenoisingDiffusion._early_backward_engine).
+
+    loss_call(pred) runs the fused loss kernel and returns (grad wrt pred, device scalars with the loss in [0])."""
 
     @staticmethod
-    def forward(ctx, anchor, eng, diffusion, x_0, e, t, residual_func, c_data, c_residual):
-        lib = residual_func.lib
-        B, C, P, _ = x_0.shape
-        dev = x_0.device
-        dd = diffusion.diff_dict
-        xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
-        lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e), ptr(t), ptr(dd['alphas_bar_sqrt']), ptr(dd['one_minus_alphas_bar_sqrt']),
-                                          ptr(xt), B, C, P * P, stream_ptr(dev)), 'pidm_qsample_nhwc_t')
+    def forward(ctx, anchor, eng, diffusion, x_bxyc, t, loss_call):
         eng.tape_generation += 1
         ctx.generation = eng.tape_generation
-        pred = eng.forward(xt, t, training=True, early=True)
-        res = torch.empty(B, P * P, 3, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(pred)
-        out = torch.empty(4, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
-        lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x_0), ptr(pred), ptr(residual_func._f_s_flat), ptr(t), ptr(dd['p2_loss_weight']),
-                                                ptr(dd['posterior_variance_clipped']), float(c_data), float(c_residual),
-                                                residual_func.inv_h0, residual_func.inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
-                                                B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd_t')
+        pred = eng.forward(x_bxyc, t, training=True, early=True)
+        grad, out = loss_call(pred)
         # the loss terms start their way to the host NOW, ahead of the backward pass in stream order: the host will wait for this
         # copy's event, not for the stream
         ctx.fetch = diffusion._start_scalar_fetch(out) if out.is_cuda else None
         loss_t = out[0].clone()           # (before the backward pass in stream order: `loss.item()` then does not wait for it)
         # the UNet backward for an upstream gradient of 1, into the engine's private staging buffer
-        eng.backward(grad, False, C)
+        eng.backward(grad, False, x_bxyc.shape[-1])
         eng.early_generation = ctx.generation
         eng.tape_busy = False
         ctx.eng = eng
         diffusion._early_fetch = ctx.fetch
-        ctx.mark_non_differentiable(out, res)
-        return loss_t, out, res
+        ctx.mark_non_differentiable(out)
+        return loss_t, out
 
     @staticmethod
-    def backward(ctx, g_loss, _g_out, _g_res):
+    def backward(ctx, g_loss, _g_out):
         eng = ctx.eng
         if eng.early_generation != ctx.generation:
             from ._lib import PidmError
@@ -465,7 +454,7 @@ class _DarcyStepFn(torch.autograd.Function):
                 p.grad = gv
             elif p.grad.data_ptr() != gv.data_ptr():
                 p.grad.add_(eng.early_views[i] * g)
-        return None, None, None, None, None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class DenoisingDiffusion(nn.Module):
@@ -704,21 +693,33 @@ class DenoisingDiffusion(nn.Module):
         t = t.to(dtype=torch.int64).contiguous()
         if residual_func._f_s_flat.device != dev:
             residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
-        eng = self._early_backward_engine(residual_func, x_0)
+        xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
+        # the extract() gathers of the schedule tables by t happen inside the kernels (no indexing / reciprocal launches)
+        lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e.contiguous()), ptr(t), ptr(dd['alphas_bar_sqrt']),
+                                          ptr(dd['one_minus_alphas_bar_sqrt']), ptr(xt), B, C, P * P, stream_ptr(dev)),
+                  'pidm_qsample_nhwc_t')
+        eng = self._early_backward_engine(residual_func, xt.shape[-1], P) if not residual_func.use_ddim_x0 else None
         if eng is not None:
             # python-float loss terms (one host sync per step): the backward pass is enqueued before that sync
-            loss, scalars, _res = _DarcyStepFn.apply(eng.params[0], eng, self, x_0, e.contiguous(), t, residual_func, c_data, c_residual)
+            f_s = residual_func._f_s_flat
+
+            def loss_call(pred):
+                res = torch.empty(B, P * P, 3, dtype=torch.float32, device=dev)
+                grad = torch.empty_like(pred)
+                out = torch.empty(4, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+                lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x_0), ptr(pred), ptr(f_s), ptr(t), ptr(dd['p2_loss_weight']),
+                                                        ptr(dd['posterior_variance_clipped']), float(c_data), float(c_residual),
+                                                        residual_func.inv_h0, residual_func.inv_h1, ptr(res), ptr(grad), ptr(out), ptr(ws),
+                                                        B, P, stream_ptr(dev)), 'pidm_darcy_loss_fwd_bwd_t')
+                return grad, out
+            loss, scalars = _EarlyStepFn.apply(eng.params[0], eng, self, xt, t, loss_call)
             fetch, self._early_fetch = self._early_fetch, None
             if fetch is not None:
                 v = fetch.values()                    # waits for the loss kernel + the 16-byte copy; the backward pass keeps running
                 return loss, v[1], v[2], 0., 0.
             d, r = self._host_scalars(scalars, [(1,), (2,)])
             return loss, d, r, 0., 0.
-        xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
-        # the extract() gathers of the schedule tables by t happen inside the kernels (no indexing / reciprocal launches)
-        lib.check(lib.pidm_qsample_nhwc_t(ptr(x_0), ptr(e.contiguous()), ptr(t), ptr(dd['alphas_bar_sqrt']),
-                                          ptr(dd['one_minus_alphas_bar_sqrt']), ptr(xt), B, C, P * P, stream_ptr(dev)),
-                  'pidm_qsample_nhwc_t')
         if residual_func._f_s_flat.device != dev:
             residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
         args = (residual_func._f_s_flat, t, dd['p2_loss_weight'], dd['posterior_variance_clipped'])
@@ -736,18 +737,18 @@ class DenoisingDiffusion(nn.Module):
         d, r = self._host_scalars(scalars, [(1,), (2,)])
         return loss, d, r, 0., 0.
 
-    def _early_backward_engine(self, residual_func, x_0):
-        """The engine to run the step's backward pass at forward time on (see _DarcyStepFn), or None when that is not applicable."""
+    def _early_backward_engine(self, residual_func, channels, image_size):
+        """The engine to run the step's backward pass at forward time on (see _EarlyStepFn), or None when that is not applicable."""
         from ._engine import get_engine
         from .unet_model import Unet3D
         model = residual_func.model
+        first = next(model.parameters())
         if (self.deferred_scalars or not torch.is_grad_enabled() or os.environ.get('PIDM_EARLY_BACKWARD') == '0'
-                or type(model) is not Unet3D or not model.training or model.self_condition or residual_func.use_ddim_x0
-                or not (x_0.is_cuda or self._lib is not None) or x_0.requires_grad or model._forward_hooks or model._forward_pre_hooks
-                or x_0.shape[1] != model.channels or x_0.shape[-1] != x_0.shape[-2]
-                or getattr(model, '_pidm_tape_slot', None)):
+                or type(model) is not Unet3D or not model.training or model.self_condition
+                or not (first.is_cuda or self._lib is not None) or model._forward_hooks or model._forward_pre_hooks
+                or channels != model.channels or getattr(model, '_pidm_tape_slot', None)):
             return None
-        eng = get_engine(model, x_0.shape[-1], model._pidm_lib)
+        eng = get_engine(model, image_size, model._pidm_lib)
         if getattr(eng, '_exchange_owner', None) is not None or eng.tape_busy or not all(p.requires_grad for p in eng.params):
             return None
         return eng
@@ -786,6 +787,33 @@ class DenoisingDiffusion(nn.Module):
             l_res, s_res = _MechLossFn.apply(x0_pred, *fixed, 0., c_residual, c_ineq, lambda_opt, residual_func.stiffs, lib)
             d, r, q, o = self._host_scalars(torch.stack((s_data, s_res)), [(0, 1), (1, 2), (1, 3), (1, 4)])
             return l_data + l_res, d, r, q, o
+        eng = self._early_backward_engine(residual_func, net_in.shape[1], P) if not net_in.requires_grad else None
+        if eng is not None:
+            # python-float loss terms (one host sync per step): the backward pass is enqueued before that sync (_EarlyStepFn)
+            stiffs = residual_func.stiffs
+            tgt, bcs_c, vf_c = fixed[0].float(), fixed[1].float(), vf.float()
+            nel = P
+            x_bxyc = net_in.permute(0, 2, 3, 1).reshape(net_in.shape[0], P * P, net_in.shape[1]).contiguous().float()
+            tt = t.to(dtype=torch.int64).contiguous()
+
+            def loss_call(pred):
+                Bm = pred.shape[0]
+                grad = torch.empty_like(pred)
+                out = torch.empty(8, dtype=torch.float32, device=pred.device)
+                ws = torch.empty(lib.pidm_mech_loss_ws(Bm), dtype=torch.uint8, device=pred.device)
+                lib.check(lib.pidm_mech_loss_fwd_bwd(ptr(pred), ptr(tgt), ptr(bcs_c), ptr(vf_c), ptr(p2w), ptr(inv_var), ptr(ivs),
+                                                     float(c_data), float(c_residual), float(c_ineq), float(lambda_opt),
+                                                     ptr(stiffs.kloc_dev), stiffs.kloc_stride, ptr(stiffs.elem_dofs32),
+                                                     ptr(stiffs.dof_elems32), nel, ptr(grad), ptr(out), ptr(ws), Bm,
+                                                     stream_ptr(pred.device)), 'pidm_mech_loss_fwd_bwd')
+                return grad, out
+            loss, scalars = _EarlyStepFn.apply(eng.params[0], eng, self, x_bxyc, tt, loss_call)
+            fetch, self._early_fetch = self._early_fetch, None
+            if fetch is not None:
+                v = fetch.values()
+                return loss, v[1], v[2], v[3], v[4]
+            d, r, q, o = self._host_scalars(scalars, [(1,), (2,), (3,), (4,)])
+            return loss, d, r, q, o
         x0_pred = residual_func.model(net_in, t)
         loss, scalars = _MechLossFn.apply(x0_pred, *fixed, c_data, c_residual, c_ineq, lambda_opt, residual_func.stiffs, lib)
         d, r, q, o = self._host_scalars(scalars, [(1,), (2,), (3,), (4,)])

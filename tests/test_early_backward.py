@@ -137,3 +137,45 @@ def test_early_backward_is_off_where_it_does_not_apply(backend):
     with torch.no_grad():
         _loss(diff, res, *data[0])
     assert eng.early_generation != eng.tape_generation
+
+
+def test_mechanics_step_takes_the_early_path_and_matches(backend, monkeypatch):
+    """Topology-optimisation configuration (c_ineq > 0, lambda > 0): the same single-node early backward, same numbers as the
+    two-node path."""
+    from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
+    from tests.test_data_parallel import _inputs as dp_inputs
+    L, dev = backend
+    lib = L if dev.type == "cpu" else None
+    m = Unet3D(dim=8, channels=10, out_dim=3, sigmoid_last_channel=True)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = lib
+    diff = DenoisingDiffusion(100, dev, lib=lib)
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder="/nonexistent/", device=dev,
+                             topopt_eval=False, lib=lib)
+    inp, eps, t = (z.to(dev) for z in dp_inputs("mechanics"))
+    eng = get_engine(m, 64, lib)
+
+    def run():
+        orig = torch.randint, torch.randn_like
+        torch.randint = lambda *a, **k: t.clone()
+        torch.randn_like = lambda *a, **k: eps.clone()
+        for p in m.parameters():
+            p.grad = None
+        try:
+            out = diff.model_estimation_loss(inp, residual_func=res, c_data=1., c_residual=1e-3, c_ineq=0.5, lambda_opt=0.01)
+        finally:
+            torch.randint, torch.randn_like = orig
+        staged = eng.early_generation == eng.tape_generation
+        out[0].backward()
+        return staged, [out[0].item()] + [float(v) for v in out[1:]], _grads(m)
+
+    monkeypatch.setenv("PIDM_EARLY_BACKWARD", "0")
+    s0, v0, g0 = run()
+    monkeypatch.delenv("PIDM_EARLY_BACKWARD")
+    s1, v1, g1 = run()
+    assert not s0 and s1
+    assert v0 == v1 and all(isinstance(x, float) for x in v1[1:])
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k

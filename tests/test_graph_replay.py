@@ -164,9 +164,9 @@ def test_conditioning_branch_replay(backend):
     L, dev = backend
     import os
     ma, mb = _model(dev, L), _model(dev, L)
-    data = _inputs(dev, 6)
+    data = _inputs(dev, 8)       # a key is replayed from its fourth use on (first: tables not yet on the device, then sighting, capture)
     g = torch.Generator().manual_seed(21)
-    conds = [torch.randn(2, 256, 2, generator=g).to(dev) for _ in range(6)]
+    conds = [torch.randn(2, 256, 2, generator=g).to(dev) for _ in range(8)]
     for i, d in enumerate(data):
         c = conds[i] if i % 2 == 0 else None
         os.environ["PIDM_GRAPH"] = "0"

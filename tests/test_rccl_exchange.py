@@ -83,7 +83,8 @@ def test_forced_single_rank_exchange_is_the_identity(nccl_single_rank, monkeypat
         ex = GradientExchange(m, image_size=32, diffusion=diff, force=True)
         assert ex.active and ex.world == 1 and [len(r) for r in ex.ranges] == want_ranges
         ex.measure = True
-        for _ in range(2):                                      # twice: steady state (events re-recorded, table not re-uploaded)
+        for _ in range(5):                                      # steady state: from the third step on the backward is a replayed hipGraph
+                                                                # cut at the phase events (recorded for real between the segments)
             got = _step(m, diff, res, x0, eps, t, ex)
             assert ex.last_overlapped == want_overlap, env
             assert torch.equal(got, ref), env                   # AVG over one rank: bit-identical gradients

@@ -332,6 +332,272 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same kernel with FOUR pixels of a row per thread (P / 4 a power of two: the 64 x 64 fields of every configuration): 16-byte
+// LDS and global accesses (the residual's 4 x 3 floats leave as three float4 stores instead of twelve scattered dwords), the
+// column-direction taps (rows i-1, i, i+1 or the edge rows) are shared by the four pixels, the row-direction taps come from a
+// six-value window a[j0-1 .. j0+4] (one 16-byte read + two scalars) - only the first and the last quad of a row contain an edge
+// pixel, and those are handled by selects on pixel 0 / pixel 3.  ~4x fewer LDS instructions and ~3x fewer VALU instructions per
+// pixel than darcy_kernel: at batch 4096 the scalar kernel was LDS / VALU bound at 1.3 TB/s of algorithmic traffic.
+// Same bands, same LDS layout, same summation order within each stencil as darcy_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fd_edge3(const float (&c)[4], float a0, float a1, float a2) { return fmaf(c[2], a2, fmaf(c[1], a1, c[0] * a0)); }
+__device__ __forceinline__ float fd_edge4(const float (&c)[4], float a0, float a1, float a2, float a3) {
+  return fmaf(c[3], a3, fmaf(c[2], a2, fmaf(c[1], a1, c[0] * a0)));
+}
+// row-direction derivatives of the quad's four pixels from the window w[0..5] = a[j0-1 .. j0+4]
+__device__ __forceinline__ void quad_d1(const FdAxis& ax, const float (&w)[6], bool lowq, bool highq, float (&d)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) d[m] = fd_edge3(ax.c1[1], w[m], w[m + 1], w[m + 2]);
+  const float lo = fd_edge3(ax.c1[0], w[1], w[2], w[3]), hi = fd_edge3(ax.c1[2], w[4], w[3], w[2]);
+  d[0] = lowq ? lo : d[0];
+  d[3] = highq ? hi : d[3];
+}
+__device__ __forceinline__ void quad_d2(const FdAxis& ax, const float (&w)[6], bool lowq, bool highq, float (&d)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) d[m] = fd_edge3(ax.c2[1], w[m], w[m + 1], w[m + 2]);
+  const float lo = fd_edge4(ax.c2[0], w[1], w[2], w[3], w[4]), hi = fd_edge4(ax.c2[2], w[4], w[3], w[2], w[1]);
+  d[0] = lowq ? lo : d[0];
+  d[3] = highq ? hi : d[3];
+}
+// transposed row-direction stencil: weights of the quad's four columns on a[0], a[P-1] and the window positions c-1, c, c+1
+struct QuadT {
+  float e0[4], eP[4], m1[4], z0[4], p1[4];
+};
+__device__ __forceinline__ QuadT quad_T(const float (&c)[3][4], int j0, int P, int nt) {
+  QuadT t;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int col = j0 + m, d = P - 1 - col;
+    const int qa = col < 4 ? col : 3, qb = d < 4 ? d : 3;
+    t.e0[m] = (col < nt) ? c[0][qa] : 0.f;
+    t.eP[m] = (d < nt) ? c[2][qb] : 0.f;
+    t.m1[m] = (col - 1 >= 1 && col - 1 <= P - 2) ? c[1][2] : 0.f;
+    t.z0[m] = (col >= 1 && col <= P - 2) ? c[1][1] : 0.f;
+    t.p1[m] = (col + 1 >= 1 && col + 1 <= P - 2) ? c[1][0] : 0.f;
+  }
+  return t;
+}
+__device__ __forceinline__ void quad_gather(const QuadT& t, float a0, float aP, const float (&w)[6], float (&g)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float r = t.e0[m] * a0;                  // same order as fd_apply_T: row 0, row P-1, then m-1, m, m+1
+    r = fmaf(t.eP[m], aP, r);
+    r = fmaf(t.m1[m], w[m], r);
+    r = fmaf(t.z0[m], w[m + 1], r);
+    g[m] = fmaf(t.p1[m], w[m + 2], r);
+  }
+}
+// window a[j0-1 .. j0+4] of row `rowp` (pointer to the row's column 0); the two outer values are clamped at the row ends
+// (their weights are zero there)
+__device__ __forceinline__ void quad_window(const float* rowp, int j0, int P, float (&w)[6]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + j0);
+  w[0] = rowp[j0 > 0 ? j0 - 1 : 0];
+  w[1] = v[0]; w[2] = v[1]; w[3] = v[2]; w[4] = v[3];
+  w[5] = rowp[j0 + 4 < P ? j0 + 4 : P - 1];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) darcy_quad_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
+                                                         const float* __restrict__ f_s, const float* __restrict__ grad_res,
+                                                         const float* __restrict__ p2w, const float* __restrict__ inv_var,
+                                                         const long long* __restrict__ tsteps, float c_data, float c_res, float bc1_sign,
+                                                         FdAxis ax0, FdAxis ax1, float* __restrict__ residual, float* __restrict__ grad_pred,
+                                                         double* __restrict__ partial, int B, int P, int R, int nb, int lds_rows) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int N = P * P, QP = P >> 2;           // quads per row (a power of two <= 256)
+  const int b = blockIdx.x / nb, band = blockIdx.x - b * nb;
+  const int tid = threadIdx.x;
+  const int r0 = band * R, r1 = (r0 + R < P) ? r0 + R : P;
+  int ilo = r0, ihi = r1;
+  if (MODE != DARCY_RES_ONLY) {
+    ilo = (r0 < 4) ? 0 : r0 - 1;
+    ihi = (r1 > P - 4) ? P : r1 + 1;
+  }
+  int dlo = (ilo > 0) ? ilo - 1 : 0, dhi = (ihi < P) ? ihi + 1 : P;
+  if (ilo == 0 && dhi < 4) dhi = 4;
+  if (ihi == P && dlo > P - 4) dlo = P - 4;
+  const int F = lds_rows * P;
+  float* sp = smem - dlo * P;
+  float* sK = sp + F;
+  float* skg = sp + 2 * F;
+  float* sa0 = sp + 3 * F;
+  float* sa1 = sp + 4 * F;
+  float* sb0 = sp + 5 * F;
+  float* sb1 = sp + 6 * F;
+  float* sd = sp + 7 * F;
+  const float* pb = pred + (size_t)b * 2 * N;
+  const float* tb = x0 + (size_t)b * 2 * N;
+  const int q = tid & (QP - 1), j0 = 4 * q, rstep = 256 / QP, rt = tid / QP;   // this thread's quad column; rows rt, rt + rstep, ...
+  const bool lowq = q == 0, highq = q == QP - 1;
+
+  double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
+  for (int i = dlo + rt; i < dhi; i += rstep) {
+    const int n = i * P + j0;
+    const f32x4 vp = *reinterpret_cast<const f32x4*>(pb + n), vK = *reinterpret_cast<const f32x4*>(pb + N + n);
+    *reinterpret_cast<f32x4*>(sp + n) = vp;
+    *reinterpret_cast<f32x4*>(sK + n) = vK;
+    if (MODE == DARCY_LOSS && i >= r0 && i < r1) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb + n), t1 = *reinterpret_cast<const f32x4*>(tb + N + n);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float d0 = t0[m] - vp[m], d1 = t1[m] - vK[m];
+        acc_data += (double)(d0 * d0) + (double)(d1 * d1);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float gscale = (MODE == DARCY_LOSS) ? c_res * darcy_inv_var(inv_var, tsteps, b) / ((float)B * (float)N * 3.0f) : 0.f;
+  for (int i = ilo + rt; i < ihi; i += rstep) {
+    const int n = i * P + j0;
+    const bool own = (i >= r0) & (i < r1);
+    const FdTaps4 ti = fd_taps(ax0, i, P, dlo, dhi - 1);
+    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p00[4] = {0.f, 0.f, 0.f, 0.f}, K0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + ti.idx[k] * P + j0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        p0[m] = fmaf(ti.w1[k], pa[m], p0[m]);
+        p00[m] = fmaf(ti.w2[k], pa[m], p00[m]);
+      }
+      if (k < 3) {
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + ti.idx[k] * P + j0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) K0[m] = fmaf(ti.w1[k], ka[m], K0[m]);
+      }
+    }
+    float wp[6], wk[6], p1[4], p11[4], K1[4];
+    quad_window(sp + i * P, j0, P, wp);
+    quad_window(sK + i * P, j0, P, wk);
+    quad_d1(ax1, wp, lowq, highq, p1);
+    quad_d2(ax1, wp, lowq, highq, p11);
+    quad_d1(ax1, wk, lowq, highq, K1);
+    const f32x4 fs4 = *reinterpret_cast<const f32x4*>(f_s + n);
+    const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
+    float eq[4], bc0[4], bc1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float Kv = wk[m + 1];
+      // reference op order: vj00 = -K*p00 - K0*p0 ; vj11 = -K*p11 - K1*p1 ; eq = vj00 + vj11 - f_s
+      const float vj00 = -Kv * p00[m] - K0[m] * p0[m];
+      const float vj11 = -Kv * p11[m] - K1[m] * p1[m];
+      eq[m] = vj00 + vj11 - fs4[m];
+      const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+      bc0[m] = s0 * p0[m];
+      bc1[m] = s1 * p1[m];
+    }
+    if (MODE != DARCY_BWD && own) {
+      f32x4* r = reinterpret_cast<f32x4*>(residual + ((size_t)b * N + n) * 3);
+      r[0] = f32x4{eq[0], bc0[0], bc1[0], eq[1]};
+      r[1] = f32x4{bc0[1], bc1[1], eq[2], bc0[2]};
+      r[2] = f32x4{bc1[2], eq[3], bc0[3], bc1[3]};
+    }
+    if (MODE != DARCY_RES_ONLY) {
+      float g[4], gb0[4], gb1[4];
+      if (MODE == DARCY_BWD) {
+        const f32x4* gr = reinterpret_cast<const f32x4*>(grad_res + ((size_t)b * N + n) * 3);
+        const f32x4 a = gr[0], c = gr[1], e = gr[2];
+        g[0] = a[0]; gb0[0] = a[1]; gb1[0] = a[2]; g[1] = a[3];
+        gb0[1] = c[0]; gb1[1] = c[1]; g[2] = c[2]; gb0[2] = c[3];
+        gb1[2] = e[0]; g[3] = e[1]; gb0[3] = e[2]; gb1[3] = e[3];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (own) {
+            acc_r2 += (double)(eq[m] * eq[m]) + (double)(bc0[m] * bc0[m]) + (double)(bc1[m] * bc1[m]);
+            acc_rabs += (double)fabsf(eq[m]) + (double)fabsf(bc0[m]) + (double)fabsf(bc1[m]);
+          }
+          g[m] = gscale * eq[m];
+          gb0[m] = gscale * bc0[m];
+          gb1[m] = gscale * bc1[m];
+        }
+      }
+      f32x4 o_kg, o_a0, o_a1, o_b0, o_b1, o_d;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+        o_kg[m] = -wk[m + 1] * g[m];
+        o_a0[m] = -K0[m] * g[m] + s0 * gb0[m];
+        o_a1[m] = -K1[m] * g[m] + s1 * gb1[m];
+        o_b0[m] = -p0[m] * g[m];
+        o_b1[m] = -p1[m] * g[m];
+        o_d[m] = -(p00[m] + p11[m]) * g[m];
+      }
+      *reinterpret_cast<f32x4*>(skg + n) = o_kg;
+      *reinterpret_cast<f32x4*>(sa0 + n) = o_a0;
+      *reinterpret_cast<f32x4*>(sa1 + n) = o_a1;
+      *reinterpret_cast<f32x4*>(sb0 + n) = o_b0;
+      *reinterpret_cast<f32x4*>(sb1 + n) = o_b1;
+      *reinterpret_cast<f32x4*>(sd + n) = o_d;
+    }
+  }
+  if (MODE == DARCY_RES_ONLY) return;
+  __syncthreads();
+
+  const float dscale = (MODE == DARCY_LOSS) ? 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N) : 0.f;
+  const QuadT t1 = quad_T(ax1.c1, j0, P, 3), t2 = quad_T(ax1.c2, j0, P, 4);
+  for (int i = r0 + rt; i < r1; i += rstep) {
+    const int n = i * P + j0;
+    const FdTaps5 ti = fd_taps_T(ax0, i, P, ilo, ihi - 1);
+    float g00[4] = {0.f, 0.f, 0.f, 0.f}, ga0[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int c0 = ti.idx[k] * P + j0;
+      const f32x4 vkg = *reinterpret_cast<const f32x4*>(skg + c0), va = *reinterpret_cast<const f32x4*>(sa0 + c0),
+                  vb = *reinterpret_cast<const f32x4*>(sb0 + c0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        g00[m] = fmaf(ti.w2[k], vkg[m], g00[m]);
+        ga0[m] = fmaf(ti.w1[k], va[m], ga0[m]);
+        gb0[m] = fmaf(ti.w1[k], vb[m], gb0[m]);
+      }
+    }
+    float w[6], g11[4], ga1[4], gb1[4];
+    const int row = i * P;
+    quad_window(skg + row, j0, P, w);
+    quad_gather(t2, skg[row], skg[row + P - 1], w, g11);
+    quad_window(sa1 + row, j0, P, w);
+    quad_gather(t1, sa1[row], sa1[row + P - 1], w, ga1);
+    quad_window(sb1 + row, j0, P, w);
+    quad_gather(t1, sb1[row], sb1[row + P - 1], w, gb1);
+    const f32x4 vd = *reinterpret_cast<const f32x4*>(sd + n);
+    f32x4 gp, gK;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      gp[m] = ((g00[m] + g11[m]) + ga0[m]) + ga1[m];
+      gK[m] = (vd[m] + gb0[m]) + gb1[m];
+    }
+    if (MODE == DARCY_LOSS) {
+      const f32x4 vp = *reinterpret_cast<const f32x4*>(sp + n), vK = *reinterpret_cast<const f32x4*>(sK + n);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb + n), t1v = *reinterpret_cast<const f32x4*>(tb + N + n);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gp[m] += dscale * (vp[m] - t0[m]);
+        gK[m] += dscale * (vK[m] - t1v[m]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + n) = gp;
+    *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + N + n) = gK;
+  }
+
+  if (MODE == DARCY_LOSS) {
+    __shared__ double red[3][4];
+    double v[3] = {acc_data, acc_r2, acc_rabs};
+    for (int qq = 0; qq < 3; ++qq) {
+      double x = v[qq];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+      if ((tid & 63) == 0) red[qq][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      double sv = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+      partial[(size_t)blockIdx.x * 4 + tid] = sv;
+    }
+  }
+}
+
 // out[0] = loss, out[1] = c_data*data_loss, out[2] = mean|r|, out[3] = 0.  One workgroup; fixed summation order (thread tid owns
 // samples tid, tid + 256, ...; bands in order; then a shuffle tree and four wave sums): run-to-run deterministic.
 __global__ void __launch_bounds__(256) darcy_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w,
@@ -443,6 +709,23 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_kernel<MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_done = true;
+  }
+  const int QP = P >> 2;
+  const char* qe = getenv("PIDM_DARCY_QUAD");     // 0: the one-pixel-per-thread kernel everywhere (A/B measurements, tests)
+  const bool quad = (P & 3) == 0 && P >= 8 && QP <= 256 && (QP & (QP - 1)) == 0 && !(qe && !atoi(qe)) &&
+                    ((reinterpret_cast<size_t>(pred) | reinterpret_cast<size_t>(x0) | reinterpret_cast<size_t>(f_s) |
+                      reinterpret_cast<size_t>(residual) | reinterpret_cast<size_t>(grad_pred) | reinterpret_cast<size_t>(grad_res)) & 15) == 0;
+  if (quad) {
+    static bool attr_q = false;
+    if (!attr_q) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_quad_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr_q = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_quad_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
+                       inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,
+                       grad_pred, partial, B, P, bd.R, bd.nb, rows);
+    PIDM_CHECK_LAUNCH("darcy_quad_kernel");
+    return 0;
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
                      inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,

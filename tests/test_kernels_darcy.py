@@ -15,7 +15,8 @@ def rel(a, b):
 
 # (P, B) also pick the row-band plan of the kernel: 64 -> 16 bands of 4 rows, 16 -> 4 x 4, 10 -> 2 x 5 (edge stencils reach across
 # a band border), 7 -> one band, 21 -> 5 bands the last of which is a single row
-@pytest.mark.parametrize("P,B", [(16, 3), (64, 2), (10, 3), (7, 2), (21, 2)])
+# P / 4 a power of two takes the four-pixels-per-thread kernel (8: every quad holds an edge pixel), the others the one-pixel kernel
+@pytest.mark.parametrize("P,B", [(16, 3), (64, 2), (10, 3), (7, 2), (21, 2), (8, 2), (32, 1), (12, 2)])
 def test_darcy_residual_fwd_bwd(backend, P, B):
     L, dev = backend
     st = stream_ptr(dev)
@@ -38,7 +39,7 @@ def test_darcy_residual_fwd_bwd(backend, P, B):
     assert rel(gx, gref) < 5e-6
 
 
-@pytest.mark.parametrize("P,B", [(16, 4), (64, 2), (10, 3), (21, 4)])
+@pytest.mark.parametrize("P,B", [(16, 4), (64, 2), (10, 3), (21, 4), (8, 3)])
 def test_darcy_fused_loss(backend, P, B):
     L, dev = backend
     st = stream_ptr(dev)
@@ -93,3 +94,10 @@ def test_qsample_table_lookup_matches_gathered_form(backend):
     assert torch.equal(y1, y2)
     ref = (a.view(B, 1, 1, 1) * x0 + am1.view(B, 1, 1, 1) * eps).permute(0, 2, 3, 1).reshape(B, P * P, C)
     assert rel(y1, ref) < 1e-6
+
+
+def test_darcy_one_pixel_kernel_at_64(backend, monkeypatch):
+    """PIDM_DARCY_QUAD=0 keeps the one-pixel-per-thread kernel reachable at the sizes the quad kernel normally takes."""
+    monkeypatch.setenv("PIDM_DARCY_QUAD", "0")
+    test_darcy_residual_fwd_bwd(backend, 64, 2)
+    test_darcy_fused_loss(backend, 16, 4)

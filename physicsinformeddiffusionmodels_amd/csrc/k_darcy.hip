@@ -398,7 +398,7 @@ __device__ __forceinline__ void quad_window(const float* rowp, int j0, int P, fl
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) darcy_quad_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
+__global__ void __launch_bounds__(512) darcy_quad_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
                                                          const float* __restrict__ f_s, const float* __restrict__ grad_res,
                                                          const float* __restrict__ p2w, const float* __restrict__ inv_var,
                                                          const long long* __restrict__ tsteps, float c_data, float c_res, float bc1_sign,
@@ -428,7 +428,8 @@ __global__ void __launch_bounds__(256) darcy_quad_kernel(const float* __restrict
   float* sd = sp + 7 * F;
   const float* pb = pred + (size_t)b * 2 * N;
   const float* tb = x0 + (size_t)b * 2 * N;
-  const int q = tid & (QP - 1), j0 = 4 * q, rstep = 256 / QP, rt = tid / QP;   // this thread's quad column; rows rt, rt + rstep, ...
+  // block size = quads per row x (rows of the band + halo), so that every pass is ONE sweep (no second, nearly empty iteration)
+  const int q = tid & (QP - 1), j0 = 4 * q, rstep = (int)blockDim.x / QP, rt = tid / QP;   // this thread's quad column; rows rt, rt + rstep, ...
   const bool lowq = q == 0, highq = q == QP - 1;
 
   double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(256) darcy_quad_kernel(const float* __restrict
   }
 
   if (MODE == DARCY_LOSS) {
-    __shared__ double red[3][4];
+    __shared__ double red[3][8];
     double v[3] = {acc_data, acc_r2, acc_rabs};
     for (int qq = 0; qq < 3; ++qq) {
       double x = v[qq];
@@ -592,7 +593,8 @@ __global__ void __launch_bounds__(256) darcy_quad_kernel(const float* __restrict
     }
     __syncthreads();
     if (tid < 3) {
-      double sv = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+      double sv = 0.0;
+      for (int w = 0; w < (int)blockDim.x >> 6; ++w) sv += red[tid][w];     // fixed order
       partial[(size_t)blockIdx.x * 4 + tid] = sv;
     }
   }
@@ -721,7 +723,13 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_quad_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_q = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_quad_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
+    // threads = quads per row x rows of the widest pass (band + 2 halo rows each side), a multiple of 64, at most 512
+    int nt = QP * ((bd.R + 4 < P) ? bd.R + 4 : P);
+    nt = (nt + 63) / 64 * 64;
+    if (nt > 512) nt = 512;
+    if (nt < QP) nt = QP;
+    if (nt < 64) nt = 64;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_quad_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(nt), lds, st, x0, pred, f_s, grad_res, p2w,
                        inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,
                        grad_pred, partial, B, P, bd.R, bd.nb, rows);
     PIDM_CHECK_LAUNCH("darcy_quad_kernel");

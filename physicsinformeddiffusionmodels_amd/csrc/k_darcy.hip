@@ -71,7 +71,7 @@ static DarcyBands darcy_bands(int B, int P) {
   static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
   if (!max_rows) {
     const char* e = getenv("PIDM_DARCY_ROWS");
-    max_rows = e ? atoi(e) : 8;        // 8 rows: 31 KB of LDS, 5 workgroups per CU (B = 4096: 355 us, 16 rows 374, 4 rows 455)
+    max_rows = e ? atoi(e) : 16;       // four-pixel kernel at batch 4096: 16 rows 258 us, 8 rows 343 (one-pixel kernel: 374 / 355)
     if (max_rows < 4) max_rows = 4;
   }
   const int nb_min = (P + max_rows - 1) / max_rows;
@@ -723,10 +723,12 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_quad_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_q = true;
     }
-    // threads = quads per row x rows of the widest pass (band + 2 halo rows each side), a multiple of 64, at most 512
+    // threads = quads per row x rows of the widest pass (band + 2 halo rows each side) where that is at most 256 (small bands:
+    // batch 64 runs 4-row bands with 128 threads, 17.0 -> 13.1 us), else 256: 320-thread blocks for 16-row bands measured 421 us
+    // at batch 4096 against 258 with 256 threads (two instead of three workgroups per CU)
     int nt = QP * ((bd.R + 4 < P) ? bd.R + 4 : P);
     nt = (nt + 63) / 64 * 64;
-    if (nt > 512) nt = 512;
+    if (nt > 256) nt = 256;
     if (nt < QP) nt = QP;
     if (nt < 64) nt = 64;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_quad_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(nt), lds, st, x0, pred, f_s, grad_res, p2w,

@@ -2032,7 +2032,6 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
   const int RW = g.Wv + 8;
   const int XROW = wgs_xrow_bytes(g), YROW = P * 2 + 16;
   char* Xs = smem;
-  char* Ys = smem + 96 * XROW;
   const int tpi = g.Hv / g.TH;
   const int SEG8 = (g.NI * g.IHt * g.Wv) >> 3;       // 8-pixel groups of the X halo tile (whole rows), then P / 8 groups of dY
 

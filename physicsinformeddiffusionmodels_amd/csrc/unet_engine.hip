@@ -871,7 +871,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   // partials of conv2 live in r.scratch, where the sums go.
   int pcb = 0;
   {
-    static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr;
+    static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr || getenv("PIDM_NO_BN_EPILOGUE") != nullptr;
     pidm_conv_desc d = desc_of(m.c2, r.B);
     ConvGeom g;
     int kind;

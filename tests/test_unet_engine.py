@@ -74,7 +74,7 @@ ATTN_FORMS = {"proj": {}, "fused": {"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS":
               "separate": {"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1000000"}}
 
 
-@pytest.mark.parametrize("form", ["proj", "fused"])
+@pytest.mark.parametrize("form", ["proj"])     # (all three forms run on the real GPU below; the fused form at small sizes in test_kernels_attn.py)
 def test_unet_dim32_p64_emulated(monkeypatch, form):
     """The full Darcy model (dim=32, 64x64: golden g6 from the genuine reference) through the host emulator, ~15 s
     (the same golden runs on the real GPU in test_unet_dim32_p64_gpu)."""

@@ -811,6 +811,9 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 // The pipeline is the one of conv3x3_stream_kernel: stage s computes from buffer s&1 while the activation registers loaded
 // during stage s-1 go to buffer (s+1)&1 and are re-loaded for stage s+2; one barrier per stage; branch-free loads.
 // ---------------------------------------------------------------------------------------------------
+#ifndef PIDM_SPLIT_CHAINS
+#define PIDM_SPLIT_CHAINS 0   // measured (round 3): alternating the six terms of a tap between the two accumulators changes nothing (10.823 vs 10.821 ms per step)
+#endif
 #ifndef PIDM_SPLIT_ABLATE
 #define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging, 32 = no split arithmetic
 #endif
@@ -999,6 +1002,16 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       const int cur = t & 1;
       if (t + 1 < T) PIDM_SP_FRAGS(cur ^ 1, t + 1)
       // small terms first
+      // PIDM_SPLIT_CHAINS = 1: the six terms of a tap alternate between the two accumulators (consecutive MFMAs never depend on
+      // each other), 0: even taps -> acc, odd taps -> accb
+#if PIDM_SPLIT_CHAINS
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
+#else
       if (t & 1) {
         accb = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], accb);
         accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
@@ -1014,6 +1027,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
         acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
         acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
       }
+#endif
       // staging pieces: a slot's registers go to LDS (the data of stage s+1) and are re-loaded at once with stage s+2's
       if (t == 0 && !(PIDM_SPLIT_ABLATE & 4)) { PIDM_SP_WRITE_A(0, bufn) PIDM_SP_LOAD_A(0) }
       if (t == 1 && !(PIDM_SPLIT_ABLATE & 4)) { if (wave < nA1) PIDM_SP_WRITE_A(1, bufn) PIDM_SP_LOAD_A(1) }
@@ -1283,6 +1297,16 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     for (int t = 0; t < T; ++t) {
       const int cur = t & 1;
       if (t + 1 < T) PIDM_WS_FRAGS(cur ^ 1, t + 1)
+      // PIDM_SPLIT_CHAINS = 1: the six terms of a tap alternate between the two accumulators (consecutive MFMAs never depend on
+      // each other), 0: even taps -> acc, odd taps -> accb
+#if PIDM_SPLIT_CHAINS
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
+      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
+      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
+#else
       if (t & 1) {
         accb = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], accb);
         accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
@@ -1298,6 +1322,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
         acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
         acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_WS_FRAGS

@@ -1,0 +1,81 @@
+"""Constructor arguments and batch shapes the golden vectors do not cover: the native engine (host-emulated build of the unmodified
+.hip sources; the same cases on the real library with -m gpu) against the oracle's functional UNet (oracle/pidm_oracle.py:
+unet_forward, pinned to the reference by g5 / g5b / g6 / g19) - forward and every parameter gradient.  Shapes the kernels do not
+take must raise, never fall back (reference: src/unet_model.py:407-426, 542-623)."""
+import pytest
+import torch
+
+from oracle import pidm_oracle as O
+from physicsinformeddiffusionmodels_amd._engine import unet_apply
+from physicsinformeddiffusionmodels_amd._lib import PidmError
+from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+
+CASES = {
+    "batch_1": (16, 1, dict(dim=8)),
+    "batch_3": (16, 3, dict(dim=8)),
+    "channels_3": (16, 2, dict(dim=8, channels=3)),
+    "channels_1_out_dim_4": (16, 2, dict(dim=8, channels=1, out_dim=4)),
+    "two_levels": (16, 2, dict(dim=8, dim_mults=(1, 2))),
+    "three_levels": (16, 2, dict(dim=8, dim_mults=(1, 2, 4))),
+    "repeated_width": (16, 2, dict(dim=8, dim_mults=(1, 1, 2))),
+    "wide_first_level": (16, 2, dict(dim=16, dim_mults=(2, 4))),
+    "heads_4": (16, 2, dict(dim=8, attn_heads=4)),
+    "groups_4": (16, 2, dict(dim=8, resnet_groups=4)),
+    "init_kernel_5": (16, 2, dict(dim=8, init_kernel_size=5)),
+    "init_kernel_3": (16, 2, dict(dim=8, init_kernel_size=3)),
+    "sigmoid_last_channel": (16, 2, dict(dim=8, sigmoid_last_channel=True)),
+    "image_8": (8, 2, dict(dim=8, dim_mults=(1, 2))),
+}
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_unusual_configuration_matches_the_oracle(backend, name):
+    L, dev = backend
+    P, B, kw = CASES[name]
+    torch.manual_seed(7)
+    m = Unet3D(**kw)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    ch = kw.get("channels", 2)
+    x = torch.randn(B, P * P, ch)
+    t = torch.randint(0, 100, (B,))
+    cfg = O.UnetCfg(kw["dim"], channels=ch, out_dim=kw.get("out_dim"), dim_mults=kw.get("dim_mults", (1, 2, 4, 8)),
+                    heads=kw.get("attn_heads", 8), groups=kw.get("resnet_groups", 8),
+                    sigmoid_last_channel=kw.get("sigmoid_last_channel", False))
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    ref = O.unet_forward(p, x, t, cfg)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    m = m.to(dev)
+    out = unet_apply(m, x.to(dev), t.to(dev), lib=L if dev.type == "cpu" else None)
+    assert tuple(out.shape) == tuple(ref.shape)
+    (out * w.to(dev)).sum().backward()
+    assert rel(out.detach().cpu(), ref.detach()) < 3e-5
+    gmax = max(float(v.grad.norm()) for v in p.values() if v.grad is not None)
+    for k, prm in m.named_parameters():
+        rg = p[k].grad
+        if prm.grad is None:
+            assert rg is None or float(rg.abs().max()) == 0.0, k      # exactly the parameters the forward uses
+            continue
+        rg = torch.zeros_like(p[k]) if rg is None else rg
+        err = float((prm.grad.double().cpu() - rg.double()).norm())
+        assert err <= 1e-3 * float(rg.double().norm()) + 2e-6 * gmax, (k, err)
+
+
+@pytest.mark.parametrize("P,kw,what", [
+    (24, dict(dim=8, dim_mults=(1, 2, 4)), "power of two"),
+    (16, dict(dim=12, resnet_groups=4), "multiple of 8"),
+    (16, dict(dim=24), "groupnorm"),
+])
+def test_shapes_the_kernels_do_not_take_raise(backend, P, kw, what):
+    L, dev = backend
+    m = Unet3D(**kw)
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    x = torch.randn(2, P * P, 2, device=dev)
+    t = torch.randint(0, 100, (2,), device=dev)
+    with pytest.raises(PidmError, match=what):
+        unet_apply(m, x, t, lib=L if dev.type == "cpu" else None)

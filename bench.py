@@ -167,6 +167,18 @@ def pmc_traffic(workload, batch):
         return None, f"no committed PMC pass for workload {workload} at batch {batch} (profiles/{tag} absent)"
 
 
+def pmc_step_traffic(workload, batch):
+    """HBM bytes of the WHOLE step (every kernel class) from the same committed PMC pass, or None."""
+    import json as _json
+    tag = f"pmc_traffic_b{batch}.json" if workload == "darcy" else f"pmc_traffic_{workload}_b{batch}.json"
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tag)) as f:
+            d = _json.load(f)
+        return float(sum(v["hbm_bytes_per_step"] for v in d.values() if isinstance(v, dict) and "hbm_bytes_per_step" in v))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def residual_only_rates(lib, residuals, diffusion, dev):
     """SURVEY 8(d) secondary metric: the fused Darcy residual + PIDM loss + d loss / d x0_pred kernel alone (csrc/k_darcy.hip), HIP
     events on the launch stream, algorithmic bytes = 32 KB prediction read + 48 KB residual write + 32 KB gradient write per 64x64
@@ -456,6 +468,13 @@ def main():
         }
         if wl == "darcy":
             roofline["step_hbm_fraction"] = round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+        st_bytes = pmc_step_traffic(wl, B)
+        if st_bytes is not None:
+            # every kernel class of the step from the same PMC pass; for darcy next to the SURVEY 8(d) contract bytes
+            roofline["step_traffic_bytes"] = round(st_bytes, 0)
+            roofline["step_traffic_tbs"] = round(st_bytes / (ms_per_step * 1e-3) / 1e12, 3)
+            if wl == "darcy":
+                roofline["step_traffic_over_contract"] = round(st_bytes / (B * BYTES_PER_SAMPLE), 3)
 
     # ---- the reference's loop body, unchanged (main.py:157-183,316): what a user who only swaps the import path gets ----
     dropin = None
@@ -501,6 +520,11 @@ def main():
                 "step_hbm_fraction": round(256 * BYTES_PER_SAMPLE / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                 "what": "the headline step (loss + backward + fused clip+Adam, deferred loss scalars) at per-GPU batch 256; fractions = "
                         "SURVEY 8(d) contract FLOPs / bytes per sample over the measured step time against 157.3 TFLOP/s and 8 TB/s"}
+        st256 = pmc_step_traffic("darcy", 256)
+        if st256 is not None:
+            b256["step_traffic_bytes"] = round(st256, 0)
+            b256["step_traffic_over_contract"] = round(st256 / (256 * BYTES_PER_SAMPLE), 3)
+            b256["step_traffic_tbs"] = round(st256 / (ms_b * 1e-3) / 1e12, 3)
         del batch256
 
     resonly = None

@@ -21,6 +21,7 @@ def _counts(L):
 
 
 def _model(dev, L, **kw):
+    kw.setdefault("dim_mults", (1, 2))          # two levels: the replay mechanics do not depend on the depth
     m = Unet3D(dim=8, channels=2, **kw)
     m.load_state_dict(O.fill_state_dict(m.state_dict()))
     m = m.to(dev)
@@ -63,7 +64,7 @@ def test_replayed_steps_equal_eager_steps(backend, monkeypatch):
     _train_step(m1, *data[0])
     c3 = _counts(L)
     assert c3["eager"] == c2["eager"] and c3["graph_launches"] - c2["graph_launches"] == 2
-    assert c3["graph_kernels"] - c2["graph_kernels"] > 300
+    assert c3["graph_kernels"] - c2["graph_kernels"] > 100
 
 
 def test_replay_survives_interleaved_passes_and_rebinding(backend):

@@ -6,10 +6,11 @@ printed next to the result so the correction can be judged on this very run."""
 import collections, csv, glob, json, sys
 
 d, batch = sys.argv[1], int(sys.argv[2])
+workload = sys.argv[3] if len(sys.argv) > 3 else "darcy"
 CLASSES = [("conv7x7", "conv"), ("conv_igemm", "conv"), ("conv3x3_stream", "conv"), ("conv3x3_split", "conv"), ("conv_wgrad", "conv"), ("lap_", "attn"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
            ("pack_", "conv_aux"), ("clip_adam", "optimizer"), ("sqsum", "optimizer"),
            ("colsum", "conv_aux"), ("gn_", "norm"), ("layernorm", "norm"), ("la_", "attn"), ("mid_attn", "attn"),
-           ("darcy", "darcy"), ("qsample", "darcy")]
+           ("darcy", "darcy"), ("qsample", "darcy"), ("mech_", "mechanics"), ("bilinear", "mechanics"), ("psample", "sampler")]
 
 
 def cls(name):
@@ -33,7 +34,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cnt[c][counter] += 1
             if c == "torch_elementwise_and_copies":
                 big[counter][r["Dispatch_Id"]] = max(big[counter].get(r["Dispatch_Id"], 0.0), v)
-res = {"batch": batch, "round": "round 3", "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; 2 steps (1 warm-up + 1 timed)"}
+res = {"batch": batch, "workload": workload, "round": "round 3", "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; 2 steps (1 warm-up + 1 timed)"}
 for c in tot:
     n = max(cnt[c]["FETCH_SIZE"], cnt[c]["WRITE_SIZE"], 1)
     fk, wk = tot[c]["FETCH_SIZE"], tot[c]["WRITE_SIZE"]

@@ -71,7 +71,7 @@ static DarcyBands darcy_bands(int B, int P) {
   static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
   if (!max_rows) {
     const char* e = getenv("PIDM_DARCY_ROWS");
-    max_rows = e ? atoi(e) : 16;       // four-pixel kernel at batch 4096: 16 rows 258 us, 8 rows 343 (one-pixel kernel: 374 / 355)
+    max_rows = e ? atoi(e) : 32;       // four-pixel kernel at batch 4096: 8 rows 343 us, 16 257, 24 275, 32 241, 64 265 (batch 1024: 60.7 / 61.9 / 54.8 / 61.1 for 16 / 24 / 32 / 64)
     if (max_rows < 4) max_rows = 4;
   }
   const int nb_min = (P + max_rows - 1) / max_rows;

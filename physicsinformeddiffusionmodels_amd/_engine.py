@@ -7,6 +7,7 @@ There is no CPU or eager fallback: tensors must live on an MI355X and `libpidm_h
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -62,6 +63,7 @@ class UnetEngine:
         self.backward_calls = 0      # backward passes since the last gradient exchange (parallel.GradientExchange)
         self.tape_generation = 0
         self.tape_busy = False   # a training-mode forward whose backward has not run yet owns the tape
+        self._packed_for = None  # (frozen-scope token, bound key, workspace) of the last inference forward that re-packed the weights
 
     def __del__(self):
         try:
@@ -121,7 +123,10 @@ class UnetEngine:
 
     # ---- forward / backward ------------------------------------------------------------------------------
     def forward(self, x_nhwc: torch.Tensor, t: torch.Tensor, training: bool, repack: bool = True,
-                cond: torch.Tensor | None = None, early: bool = False) -> torch.Tensor:
+                cond: torch.Tensor | None = None, early: bool = False, frozen=None) -> torch.Tensor:
+        """`frozen`: the token of an enclosing `frozen_weights(model)` scope (None outside one).  Inside such a scope the
+        caller guarantees constant parameters, so only the scope's first inference forward of this engine re-packs (and
+        re-splits) the weights; everywhere else every forward does (the parameters may have been written by anything)."""
         B = x_nhwc.shape[0]
         dev = x_nhwc.device
         self._ensure_bound(training, early=early)
@@ -135,6 +140,12 @@ class UnetEngine:
         out = torch.empty(B, self.lib_out_dim, P, P, dtype=torch.float32, device=dev)
         base = ws.data_ptr()
         al = (-base) % 256
+        if frozen is not None and not training and repack:
+            key = (frozen, self._bound_key, base)
+            repack = key != self._packed_for     # same scope, same parameter storage, same workspace: the packed weights are current
+            self._packed_for = key
+        else:
+            self._packed_for = None
         self.lib.check(self.lib.pidm_unet_forward(self.handle, ptr(x_nhwc), ptr(t), ptr(out), B, int(training), int(repack),
                                                   vp(base + al), ws.numel() - al, stream_ptr(dev)), "pidm_unet_forward")
         return out
@@ -181,7 +192,7 @@ class _UnetFunction(torch.autograd.Function):
     Parameters that forward never reads keep `grad is None`, exactly like the reference."""
 
     @staticmethod
-    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool, cond=None, primary=None):
+    def forward(ctx, engine: UnetEngine, x_nhwc, t, anchor, training: bool, cond=None, primary=None, frozen=None):
         ctx.engine = engine
         ctx.primary = primary if primary is not None else engine
         ctx.used_cond = cond is not None
@@ -193,7 +204,7 @@ class _UnetFunction(torch.autograd.Function):
             engine.tape_busy = True
         ctx.generation = engine.tape_generation
         ctx.lease = _TapeLease(engine, engine.tape_generation) if training else None
-        out = engine.forward(x_nhwc, t, training=training, cond=cond)
+        out = engine.forward(x_nhwc, t, training=training, cond=cond, frozen=frozen)
         # the engine keeps RAW pointers to its inputs and output until backward: keep the tensors alive
         if cond is not None:
             ctx.save_for_backward(out, x_nhwc, cond)
@@ -247,7 +258,7 @@ class _UnetFunction(torch.autograd.Function):
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(eng.grad_views[i] if eng is not primary else g)
             # else: p.grad already aliases the primary buffer, which now holds the accumulated gradient
-        return None, gx, None, None, None, None, None
+        return None, gx, None, None, None, None, None, None
 
 
 def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0) -> UnetEngine:
@@ -264,6 +275,20 @@ def get_engine(model, image_size: int, lib: PidmLib | None = None, slot: int = 0
 def used_parameter_names(model, image_size: int = 64, with_condition: bool = False):
     eng = get_engine(model, image_size)
     return list(eng.names) if with_condition else list(eng.names[:len(eng.names) - eng.n_cond])
+
+
+@contextlib.contextmanager
+def frozen_weights(model):
+    """Scope in which the caller guarantees that `model`'s parameters do not change (the sampler loop, the no-grad
+    evaluations of one x0 estimate): the engine re-packs / re-splits the weights for the first inference forward only
+    (csrc/k_conv.hip: pack_multi_kernel, 113 us and 71 MB per call at dim 32).  Nesting is allowed; outside a scope every
+    forward re-packs, because raw-pointer writers (fused optimizer, EMA kernels, `p.data` arithmetic) leave no trace."""
+    prev = getattr(model, "_pidm_frozen", None)
+    model._pidm_frozen = prev if prev is not None else object()
+    try:
+        yield
+    finally:
+        model._pidm_frozen = prev
 
 
 def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None, x_self_cond=None):
@@ -326,7 +351,7 @@ def unet_apply(model, x, time, lib: PidmLib | None = None, cond=None, x_self_con
         if cond.shape != (B, P * P, model.channels):
             raise ValueError(f'cond must be [B, P*P, {model.channels}], got {tuple(cond.shape)}')
         cond = cond.detach().contiguous().float()
-    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training, cond, primary)
+    out = _UnetFunction.apply(eng, x_nhwc, t, anchor, training, cond, primary, getattr(model, "_pidm_frozen", None))
     if video:
         out = out.unsqueeze(2)
     return out

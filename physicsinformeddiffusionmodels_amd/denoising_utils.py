@@ -9,6 +9,7 @@ configurations compose the same native pieces through autograd with the referenc
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from pathlib import Path  # noqa: F401  (re-exported: main.py uses `Path` from the star-import)
 
@@ -893,19 +894,23 @@ class DenoisingDiffusion(nn.Module):
         x_seq = [cur_x.detach().cpu()] if keep_history else []
         interm_imgs = [torch.zeros(shape)] if (save_output and keep_history) else []
         output = None
-        for i in reversed(range(self.n_steps)):
-            residual_correction = False
-            if i < N_correction:            # CoCoGen correction inside the last N steps (:520-523)
-                residual_correction = True
-                eval_residuals = True
-            output = self.p_sample(cur_x.detach(), conditioning_input, i, save_output, surpress_noise, use_dynamic_threshold,
-                                   residual_func=residual_func, eval_residuals=eval_residuals,
-                                   return_optimizer=return_optimizer, return_inequality=return_inequality,
-                                   residual_correction=residual_correction, correction_mode=correction_mode)
-            cur_x, interm_img = output[0]
-            if keep_history:
-                x_seq.append(cur_x.detach().cpu())
-                interm_imgs.append(interm_img.detach().cpu())
+        # nothing inside this loop writes the parameters: the engine packs / splits the weights once, not once per step
+        from ._engine import frozen_weights
+        net = getattr(residual_func, "model", None)
+        with (frozen_weights(net) if isinstance(net, torch.nn.Module) else contextlib.nullcontext()):
+            for i in reversed(range(self.n_steps)):
+                residual_correction = False
+                if i < N_correction:            # CoCoGen correction inside the last N steps (:520-523)
+                    residual_correction = True
+                    eval_residuals = True
+                output = self.p_sample(cur_x.detach(), conditioning_input, i, save_output, surpress_noise, use_dynamic_threshold,
+                                       residual_func=residual_func, eval_residuals=eval_residuals,
+                                       return_optimizer=return_optimizer, return_inequality=return_inequality,
+                                       residual_correction=residual_correction, correction_mode=correction_mode)
+                cur_x, interm_img = output[0]
+                if keep_history:
+                    x_seq.append(cur_x.detach().cpu())
+                    interm_imgs.append(interm_img.detach().cpu())
         for i in range(M_correction):       # CoCoGen post-correction (:535-540)
             cur_x, residual = residual_func.residual_correction(generalized_image_to_b_xy_c(cur_x).contiguous())
             cur_x = generalized_b_xy_c_to_image(cur_x).contiguous()
@@ -935,11 +940,13 @@ class DenoisingDiffusion(nn.Module):
             t = torch.ones(batch, device=xt.device, dtype=torch.long) * t
         # two live activation tapes: the call at (x_t, t) records on engine slot 0, the call at (x_t, 0) on slot 1
         # (_engine.unet_apply); named slots, so tapes of losses that are never differentiated (validation) do not pile up
+        from ._engine import frozen_weights
         try:
-            model._pidm_tape_slot = 0
-            model_out = model(xt, t)
-            model._pidm_tape_slot = 1
-            x0_pred = model(xt, torch.zeros_like(t))
+            with frozen_weights(model):         # (matters for the no-grad case: the second evaluation re-uses the packed weights)
+                model._pidm_tape_slot = 0
+                model_out = model(xt, t)
+                model._pidm_tape_slot = 1
+                x0_pred = model(xt, torch.zeros_like(t))
         finally:
             model._pidm_tape_slot = None
         # RNG parity with :775: the same randn_like call on a tensor of the same shape AND strides as the reference's cur_x

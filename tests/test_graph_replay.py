@@ -177,3 +177,40 @@ def test_conditioning_branch_replay(backend):
             del os.environ["PIDM_GRAPH"]
         o, gg = _train_step(mb, *d, cond=c)
         assert torch.equal(o, o_ref) and torch.equal(gg, g_ref), i
+
+
+def test_frozen_weights_scope_packs_once_and_only_inside_the_scope(backend, monkeypatch):
+    """frozen_weights(model): the first inference forward packs / splits the weights, the following ones of the scope do not (one
+    kernel less each, same numbers); outside a scope every forward packs again - a raw write to a parameter between two forwards
+    (what the fused optimizer and the EMA kernels do) is seen at once."""
+    from physicsinformeddiffusionmodels_amd._engine import frozen_weights
+    L, dev = backend
+    monkeypatch.setenv("PIDM_GRAPH", "0")                   # count kernels launch by launch
+    m = _model(dev, L).eval()
+    (x, t, _), (x2, t2, _) = _inputs(dev, 2)
+
+    def fwd(xx, tt):
+        c0 = _counts(L)["eager"]
+        with torch.no_grad():
+            o = m(xx, tt).clone()
+        return o, _counts(L)["eager"] - c0
+
+    ref, n_pack = fwd(x, t)
+    ref2, n2 = fwd(x2, t2)
+    assert n2 == n_pack                                      # no scope: every forward re-packs
+    with frozen_weights(m):
+        a, na = fwd(x, t)
+        b, nb = fwd(x2, t2)
+        with frozen_weights(m):                              # nested: same scope
+            c, nc = fwd(x, t)
+    assert na == n_pack and nb == n_pack - 1 and nc == n_pack - 1
+    assert torch.equal(a, ref) and torch.equal(b, ref2) and torch.equal(c, ref)
+    assert getattr(m, "_pidm_frozen", None) is None
+    # a write through the raw storage, invisible to autograd's version counters
+    with torch.no_grad():
+        dict(m.named_parameters())["final_conv.1.weight"].data.mul_(1.5)
+    d, nd = fwd(x, t)
+    assert nd == n_pack and not torch.equal(d, ref)
+    with frozen_weights(m):                                  # a NEW scope starts with a pack
+        e, ne = fwd(x, t)
+    assert ne == n_pack and torch.equal(e, d)

@@ -378,8 +378,10 @@ def main():
         "graph_launches_per_step": round((lc1[1] - lc0[1]) / args.steps, 2),
         "kernels_inside_graphs_per_step": round((lc1[2] - lc0[2]) / args.steps, 1),
         "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
-        "what": "library-side accounting over the timed region (pidm_debug_launch_counts): the UNet forward and backward are replayed "
-                "hipGraphs (PIDM_GRAPH=0 turns that off); kernels enqueued one by one = q-sample, loss, optimizer kernels (torch's own "
+        "what": "library-side accounting over the timed region (pidm_debug_launch_counts): the UNet forward and - for models below 512 channels "
+                "(Darcy; not the mechanics model, whose backward stays launch by launch with its weight gradients on a side stream: "
+                "PIDM_GRAPH_BWD) - backward are replayed hipGraphs (PIDM_GRAPH=0 turns that off); kernels enqueued one by one = q-sample, loss, "
+                "optimizer kernels and a launch-by-launch backward (torch's own "
                 "launches - RNG, the loss-scalar copy - are not counted); host_enqueue = wall time until the host has enqueued a step INSIDE this "
                 "loop, where the launch queue is full and the host is held to the GPU's pace - the unloaded cost (queue drained: 1.2 ms per step "
                 "with graphs, 2.7-3.4 without) is in profiles/r03_graph_ab.txt",

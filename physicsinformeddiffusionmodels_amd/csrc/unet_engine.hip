@@ -194,6 +194,21 @@ static const size_t kMaxPackDesc = 1024;
 static const size_t kMaxReduceDesc = 1024;
 static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads(): steady state must not upload (tests)
 
+// The backward pass is enqueued launch by launch - the only mode in which weight gradients can go to the side stream - with
+// PIDM_GRAPH=0, with PIDM_GRAPH_BWD=0 (the backward pass alone; =1: always replayed) and, by default, for WIDE models (>= 512
+// channels at the deepest level: the mechanics configuration, dim 128 x 8).  Measured (tools/r03_r.sh, same box): their deep
+// levels have fewer work items than the chip has CUs, a concurrent weight-gradient kernel fills them - mechanics 798.8 -> 815.4
+// samples/s (main.py's loop unchanged: 750.0 -> 762.6); the Darcy model (256 channels, full launches) ties: 6018 / 6021 / 6037
+// for graph / forward-graph + eager backward / all eager at batch 64, 7999 / 8077 / 7988 at batch 256 - it keeps the replay, which
+// costs the host a third of the launch-by-launch work.
+static bool backward_eager(int widest) {
+  const char* e = getenv("PIDM_GRAPH");
+  if (e && !atoi(e)) return true;
+  const char* b = getenv("PIDM_GRAPH_BWD");
+  if (b) return !atoi(b);
+  const char* w = getenv("PIDM_GRAPH_BWD_WIDE");     // the width threshold (tests reach the rule with small models)
+  return widest >= (w && atoi(w) > 0 ? atoi(w) : 512);
+}
 struct Run {
   pidm_unet* U;
   int B;
@@ -209,6 +224,12 @@ struct Run {
   ReduceQueue rq;
   bool defer_on = false;
   bool overlap = false;        // weight gradients on the side stream (real backward runs only)
+  // Backward arena frames are kept to the end of the pass while side-stream weight gradients may still read them; the sizing dry
+  // run assumes that only where a real pass can take the side stream at all (PIDM_GRAPH=0: captured passes are linear, and with
+  // graph replay on - the default - the two eager passes before the capture are linear too), otherwise frames are recycled and
+  // the plan is the smaller one.
+  bool keep_frames() const { return overlap || (dry && side_allowed); }
+  bool side_allowed = false;   // backward_eager(widest level) of this handle (set by setup / the dry run)
   bool side_pending = false;   // side-stream work issued since the last join
   GraphCapture* cap = nullptr; // non-null while this pass is being stream-captured (r.st is the capture stream then)
   float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
@@ -656,7 +677,10 @@ static void lap_knobs(bool* off, int* min_n) {
 static long lap_knob_signature() {
   bool off; int min_n;
   lap_knobs(&off, &min_n);
-  return off ? -1 : (long)min_n;
+  const char* g = getenv("PIDM_GRAPH");
+  const char* gb = getenv("PIDM_GRAPH_BWD");        // (the backward plan depends on the side stream too)
+  const char* gw = getenv("PIDM_GRAPH_BWD_WIDE");
+  return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0);
 }
 static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
 // decided by the FORWARD (and stored in AttnBlock::projected); the backward replays the stored decision
@@ -892,7 +916,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
     }
   }
   // g_c is dead on THIS stream after the two uses above, but the side-stream wgrad of c2 may still be reading it
-  float* g_a = r.overlap || r.dry ? r.tmp.alloc(n) : g_c;
+  float* g_a = r.keep_frames() ? r.tmp.alloc(n) : g_c;
   RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
                     g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st, dgb1, r.q(), pcb));
   if (conv_wgrad(r, m.c1, m.x0, m.x1, g_a)) return -1;
@@ -905,7 +929,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   }
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
   // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
-  if (!(r.overlap || r.dry)) r.tmp.release(mk);
+  if (!r.keep_frames()) r.tmp.release(mk);
   return 0;
 }
 
@@ -944,7 +968,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
     }
     float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
     RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
-    if (!(r.overlap || r.dry)) r.tmp.release(mk);
+    if (!r.keep_frames()) r.tmp.release(mk);
     return 0;
   }
   if (!a.mid && (la_fused_ok(N, heads, C, C) && la_fused_pays(B, N))) {
@@ -985,7 +1009,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
   // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
-  if (!(r.overlap || r.dry)) r.tmp.release(mk);
+  if (!r.keep_frames()) r.tmp.release(mk);
   return 0;
 }
 
@@ -1287,6 +1311,12 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   return 0;
 }
 
+static int widest_level(const pidm_unet* U) {
+  int w = 0;
+  for (int d : U->dims) w = d > w ? d : w;
+  return w;
+}
+
 static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, size_t* tmp_bytes) {
   const long sig = lap_knob_signature();
   if (sig != U->knob_sig) {    // PIDM_NO_LAP / PIDM_LAP_MIN_N changed on a live handle: the cached plans describe the other form
@@ -1306,6 +1336,7 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   Run r;
   r.U = U; r.B = B; r.train = training != 0; r.dry = true; r.st = nullptr; r.wpack = nullptr;
   r.tape.dry = r.tmp.dry = r.defer.dry = true;
+  r.side_allowed = backward_eager(widest_level(U));
   // state touched by a dry run is restored afterwards
   pidm_unet saved_ptrs = *U;
   r.scratch_floats = scratch_floats_needed(U, B);
@@ -1539,7 +1570,8 @@ static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x
   // A captured pass is linear as well: a graph with ~40 fork / join pairs replays SLOWER than the launch-by-launch form it
   // replaces (11.68 vs 11.15 ms per step, profiles/r03_graph_ab.txt; HIP maps the branches onto internal streams and
   // synchronises them with events), while the linear graph equals the eager step with the overlap (11.21 ms).
-  r.overlap = h->side_ok && !prof_enabled() && !cap;
+  r.side_allowed = backward_eager(widest_level(h));
+  r.overlap = h->side_ok && !prof_enabled() && !cap && r.side_allowed;
   if (cap && cap_begin(r)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");
@@ -1655,7 +1687,7 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   const std::vector<uint64_t> key(kw, kw + 14);
   int rc = -1;
   bool done = false;
-  if (graphs_enabled()) {
+  if (graphs_enabled() && !backward_eager(widest_level(h))) {
     GraphEntry* e = graph_find(h, 1, key);
     // the reduction descriptor table the graph's reduce launches read must still be the one this layout uploaded
     if (e && e->red_dev == h->red_table_dev && h->red_table_dev) {

@@ -22,7 +22,8 @@ def _counts(L):
 
 def _model(dev, L, **kw):
     kw.setdefault("dim_mults", (1, 2))          # two levels: the replay mechanics do not depend on the depth
-    m = Unet3D(dim=8, channels=2, **kw)
+    kw.setdefault("dim", 8)
+    m = Unet3D(channels=2, **kw)
     m.load_state_dict(O.fill_state_dict(m.state_dict()))
     m = m.to(dev)
     m._pidm_lib = L if dev.type == "cpu" else None
@@ -214,3 +215,40 @@ def test_frozen_weights_scope_packs_once_and_only_inside_the_scope(backend, monk
     with frozen_weights(m):                                  # a NEW scope starts with a pack
         e, ne = fwd(x, t)
     assert ne == n_pack and torch.equal(e, d)
+
+
+def test_wide_models_keep_the_backward_launch_by_launch(backend, monkeypatch):
+    """>= 512 channels at the deepest level (the mechanics configuration): forward replayed, backward enqueued kernel by kernel (its
+    weight gradients may take the side stream); PIDM_GRAPH_BWD=1 / =0 force either form for any model.  Same numbers in all forms."""
+    L, dev = backend
+    monkeypatch.setenv("PIDM_GRAPH_BWD_WIDE", "64")          # the rule's threshold (default 512 channels), lowered to this test's size
+    data = _inputs(dev, 3, B=1, P=8)
+
+    def run(**kw):
+        m = _model(dev, L, **kw)
+        c0 = _counts(L)
+        outs = []
+        for x, t, w in data:
+            for p in m.parameters():
+                p.grad = None
+            out = m(x, t)
+            (out * w).sum().backward()
+            outs.append((out.detach().clone(), get_engine(m, 8, m._pidm_lib).flat_grad.clone()))
+        c1 = _counts(L)
+        return outs, c1["captures"] - c0["captures"]
+
+    wide, caps_wide = run(dim=8, dim_mults=(1, 8))
+    assert caps_wide == 1                                    # the forward graph only
+    monkeypatch.setenv("PIDM_GRAPH_BWD", "1")
+    forced, caps_forced = run(dim=8, dim_mults=(1, 8))
+    assert caps_forced == 2
+    monkeypatch.setenv("PIDM_GRAPH_BWD", "0")
+    narrow, caps_narrow = run()
+    assert caps_narrow == 1
+    monkeypatch.delenv("PIDM_GRAPH_BWD")
+    narrow_default, caps_default = run()
+    assert caps_default == 2
+    for (o1, g1), (o2, g2) in zip(wide, forced):
+        assert torch.equal(o1, o2) and torch.equal(g1, g2)
+    for (o1, g1), (o2, g2) in zip(narrow, narrow_default):
+        assert torch.equal(o1, o2) and torch.equal(g1, g2)

@@ -818,6 +818,11 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 #define PIDM_SPLIT_ABLATE 0   // measurement builds only (tools/split_ablate.py): 1 / 2 = B / A fragments read for tap 0 only, 4 / 8 = no A / B staging, 32 = no split arithmetic
 #endif
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
+// extra bytes per halo-tile row (ConvGeom::rpad): see conv3x3_split_kernel; PIDM_SPLIT_ROWPAD=0: off (A/B measurements)
+static int split_row_pad(int Wv) {
+  static const int on = [] { const char* e = getenv("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
+  return (on && Wv <= 16) ? 32 : 0;
+}
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
 
 // MODE 0: 3x3 / stride 1 / pad 1.  MODE 1: the 4x4 / stride-2 convolution (and the input gradient of the transposed one) as 4
@@ -840,8 +845,12 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int npixA = g.NI * g.IHt * g.IWt;
-  const int bufsz = (npixA + T * 32) * RB + BPAD;      // bytes per buffer: halo tile | T x 32 weight rows | spill of the last 1 KB pieces
+  // bytes per halo-tile row: IWt pixels + ConvGeom::rpad (32 bytes at the 8- and 16-wide levels, where the 32 pixels of a wave span
+  // 4 / 2 tile rows: with it consecutive rows start 8 / 0 bank groups apart (mod 16) and the 16 lanes one ds_read_b128 cycle serves hit
+  // 16 different groups; without it 33-48 % of the LDS cycles of those levels were bank conflicts)
+  const int rowB = g.IWt * RB + g.rpad, nrowsA = g.NI * g.IHt;
+  const int b_reg = nrowsA * rowB;                       // byte offset of the weight rows inside a buffer
+  const int bufsz = b_reg + T * 32 * RB + BPAD;        // bytes per buffer: halo tile | T x 32 weight rows | spill of the last 1 KB pieces
   const int tpi = g.Hv / g.TH;
   const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;     // 16-channel chunks per tile (MODE 1: 4 phases x Cin)
   const int CCH = g.Cin >> 4;
@@ -853,9 +862,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   // operand fragments of this lane: A row = pixel wave*32 + l31 of the tile, B row = output channel l31 of the tap
   const int pm = wave * 32 + l31;
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
-  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
-  const int a_frag = abase * RB + 48 * half;
-  const int b_frag = (npixA + l31) * RB + 48 * half;
+  const int a_frag = ((a_img < g.NI) ? (a_img * g.IHt + a_ty) * rowB + a_tx * RB : 0) + 48 * half;
+  const int b_frag = b_reg + l31 * RB + 48 * half;
 
   // Activation staging: a unit = 8 channels of one pixel (32 bytes in, 3 x 16 bytes out); whole image rows, the halo columns
   // are zero for every tile and written once.  Units tid and tid + NT; the second exists for the first nA1 waves.
@@ -870,7 +878,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     if (sp >= SEG) sp = SEG - 1;
     const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
     const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
-    a_lds[k] = ((img * g.IHt + hy) * g.IWt + x + 1) * RB + 48 * hh;
+    a_lds[k] = (img * g.IHt + hy) * rowB + (x + 1) * RB + 48 * hh;
     a_vo[k] = (unsigned)((MODE == 1 ? 2 * x : x) * g.ld0 + 8 * hh) * 4u;
     a_im[k] = img;
     a_hy[k] = hy;
@@ -880,14 +888,13 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   // Weight staging: the stage's slab (pre-split, rows already padded to 112 bytes: an image of the LDS rows) is copied by
   // global_load_lds_dwordx4 - 1 KB per wave and instruction straight into the buffer being filled, no registers, no ds_write;
   // the __syncthreads() at the end of the stage drains it (vmcnt) together with everything else
-  const int b_reg = npixA * RB;                          // byte offset of the weight rows inside a buffer
   const unsigned b_lane = 16u * lane;
 
   // zero halo columns of both buffers
   for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += NT) {
     const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * RB + 16 * q) = zero4;
+    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)row * rowB + (size_t)(side ? g.IWt - 1 : 0) * RB + 16 * q) = zero4;
   }
 
   f32x4 ra[2][2];
@@ -979,12 +986,12 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
       oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
     }
-    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : (oy0 * g.IWt + ox0) * RB);
+    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
     const char* bfp = bufc + b_frag;
     u32x4 fa[2][3], fb[2][3];
 #define PIDM_SP_FRAGS(set_, t_)                                                                                    \
   {                                                                                                                \
-    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * g.IWt + ((t_) % 3) : ((t_) >> 1) * g.IWt + ((t_) & 1)) * RB); \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * rowB + ((t_) % 3) * RB : ((t_) >> 1) * rowB + ((t_) & 1) * RB)); \
     const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
       if (!(PIDM_SPLIT_ABLATE & 2) || (t_) == 0) fa[set_][p] = ar__[p]; else fa[set_][p] = fa[(set_) ^ 1][p];      \
@@ -1135,8 +1142,9 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= NW;
   const int half = lane >> 5, l31 = lane & 31;
-  const int npixA = g.NI * g.IHt * g.IWt;
-  const int bufsz = (npixA + T * 32) * RB + BPAD;
+  const int rowB = g.IWt * RB + g.rpad, nrowsA = g.NI * g.IHt;    // (row pitch: see conv3x3_split_kernel)
+  const int b_reg = nrowsA * rowB;
+  const int bufsz = b_reg + T * 32 * RB + BPAD;
   const int tpi = g.Hv / g.TH;
   const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;
   const int CCH = g.Cin >> 4;
@@ -1144,13 +1152,12 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   const int item0 = blockIdx.x * items_per_wg;
   const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
   const int nst = my_items * NCH;
-  const int b_reg = npixA * RB;
 
   // zero halo columns of both buffers (all waves)
   for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 64 * NW + NPT) {
     const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)(row * g.IWt + (side ? g.IWt - 1 : 0)) * RB + 16 * q) = zero4;
+    *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)row * rowB + (size_t)(side ? g.IWt - 1 : 0) * RB + 16 * q) = zero4;
   }
   char* bufc = smem;               // buffer the MFMAs read
   char* bufn = smem + bufsz;       // buffer being filled
@@ -1168,7 +1175,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       if (sp >= SEG) sp = SEG - 1;                          // surplus slots repeat the last unit (same data to the same place)
       const int sr = sp >> g.wsh, x = sp & (g.Wv - 1);
       const int img = fast_div(sr, g.IHt, g.mIHt), hy = sr - img * g.IHt;
-      a_lds[k] = ((img * g.IHt + hy) * g.IWt + x + 1) * RB + 48 * hh;
+      a_lds[k] = (img * g.IHt + hy) * rowB + (x + 1) * RB + 48 * hh;
       a_vo[k] = (unsigned)((MODE == 1 ? 2 * x : x) * g.ld0 + 8 * hh) * 4u;
       a_im[k] = img;
       a_hy[k] = hy;
@@ -1264,9 +1271,8 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   // =============================== consumer waves: fragments, MFMAs, epilogue ===============================
   const int pm = wave * 32 + l31;
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
-  const int abase = (a_img < g.NI) ? (a_img * g.IHt + a_ty) * g.IWt + a_tx : 0;
-  const int a_frag = abase * RB + 48 * half;
-  const int b_frag = (npixA + l31) * RB + 48 * half;
+  const int a_frag = ((a_img < g.NI) ? (a_img * g.IHt + a_ty) * rowB + a_tx * RB : 0) + 48 * half;
+  const int b_frag = b_reg + l31 * RB + 48 * half;
   __syncthreads();                   // stage 0 is in bufc
   f32x16 acc, accb;
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
@@ -1280,12 +1286,12 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
       oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
     }
-    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : (oy0 * g.IWt + ox0) * RB);
+    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
     const char* bfp = bufc + b_frag;
     u32x4 fa[2][3], fb[2][3];
 #define PIDM_WS_FRAGS(set_, t_)                                                                                    \
   {                                                                                                                \
-    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * g.IWt + ((t_) % 3) : ((t_) >> 1) * g.IWt + ((t_) & 1)) * RB); \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * rowB + ((t_) % 3) * RB : ((t_) >> 1) * rowB + ((t_) & 1) * RB)); \
     const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
       fa[set_][p] = ar__[p];                                                                                       \
@@ -3113,7 +3119,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         gs.mIWt = (unsigned)((0x100000000ULL + gs.IWt - 1) / gs.IWt);
         gs.tiles_m = (NI > 1) ? cdiv(gs.B, NI) : gs.B * (gs.Hv / TH);
         const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
-        const size_t lds = (size_t)2 * ((npixA + 4 * 32) * kSplitRow + 2048);
+        gs.rpad = split_row_pad(gs.Wv);
+        const size_t lds = (size_t)2 * ((npixA + 4 * 32) * kSplitRow + gs.NI * gs.IHt * gs.rpad + 2048);
         if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
         const int n_items = gs.tiles_m * mult;
         if (nw == 8 && !force && n_items < n_cu) continue;        // more, smaller items fill the chip better (the 4-wave tile follows)
@@ -3182,7 +3189,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         gs = g;
         if (!retile_bm(&gs, 32 * nw)) continue;
         const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
-        const size_t lds = (size_t)2 * ((npixA + 9 * 32) * kSplitRow + 512);
+        gs.rpad = split_row_pad(gs.Wv);
+        const size_t lds = (size_t)2 * ((npixA + 9 * 32) * kSplitRow + gs.NI * gs.IHt * gs.rpad + 512);
         if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
         const int n_items = gs.tiles_m * (g.Cout / 32);
         const bool prof = prof_enabled();

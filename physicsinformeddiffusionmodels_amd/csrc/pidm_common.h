@@ -156,6 +156,7 @@ struct ConvGeom {
   unsigned mIWt, mIHt;  // ceil(2^32 / IWt), ceil(2^32 / IHt): n / d == __umulhi(n, m) for n*d < 2^32 (d > 1)
   int tiles_m;       // number of 128-pixel tiles
   int tpw;           // persistent conv kernels: consecutive m-tiles walked by one workgroup (0/1: one tile per workgroup)
+  int rpad;          // split-form 3x3 kernels: extra bytes per halo-tile row in LDS (bank spreading at the 8- / 16-wide levels)
   // GroupNorm statistics of the OUTPUT from the epilogue (k_norm.hip consumes them): per (image, 32-pixel wave chunk, group)
   // sum and sum of squares as doubles at gn_part[((b*gn_nchunk + chunk)*gn_G + g)*2]; gn_part == null: off.
   // Requires Cout % 32 == 0, gn_cpg = Cout/gn_G a power of two in [4, 32], Ho*Wo % 32 == 0, channels-last output, no residual.

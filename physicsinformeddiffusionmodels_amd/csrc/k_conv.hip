@@ -825,6 +825,46 @@ static int split_row_pad(int Wv) {
 }
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
 
+// Position of a stage inside a workgroup's range of work items, kept INCREMENTALLY: stage -> (item, chunk) -> (n-tile, m-tile) ->
+// (image group, row tile) used to be five integer divisions by launch-time values at the top of every stage; the compiler expands
+// each into ~25 vector instructions around v_rcp_iflag_f32 (there is no scalar divide), on the critical path between the stage's
+// barrier and its first loads, in both waves of a SIMD at once.  All fields are wave-uniform (SGPRs).
+struct SplitCursor {
+  int ch, cc, ph;   // 16-channel chunk of the item; MODE 1: chunk inside the K-phase, K-phase
+  int tq, tn, zz;   // n-tile index of the item = zz * ntn + tn (zz = output parity, MODE 2 only)
+  int tm, bi, rt;   // m-tile = bi * tpi + rt: image group, row tile inside the image
+  int left;         // stages after this one
+};
+template <int MODE>
+__device__ __forceinline__ void split_cursor_init(SplitCursor& c, int item0, int nst, int tiles_m, int tpi, int ntn) {
+  c.ch = c.cc = c.ph = 0;
+  c.tq = item0 / tiles_m;
+  c.tm = item0 - c.tq * tiles_m;
+  c.zz = c.tq / ntn;
+  c.tn = c.tq - c.zz * ntn;
+  c.bi = c.tm / tpi;
+  c.rt = c.tm - c.bi * tpi;
+  c.left = nst - 1;
+}
+// next stage; stays on the last one (the pipelines fetch "stage nst" and "nst + 1" as copies of the last)
+template <int MODE>
+__device__ __forceinline__ void split_cursor_next(SplitCursor& c, int NCH, int CCH, int tiles_m, int tpi, int ntn) {
+  if (c.left <= 0) return;
+  --c.left;
+  ++c.ch;
+  if (MODE == 1 && ++c.cc == CCH) { c.cc = 0; ++c.ph; }
+  if (c.ch == NCH) {
+    c.ch = c.cc = c.ph = 0;
+    ++c.tm;
+    if (++c.rt == tpi) { c.rt = 0; ++c.bi; }
+    if (c.tm == tiles_m) {
+      c.tm = c.bi = c.rt = 0;
+      ++c.tq;
+      if (++c.tn == ntn) { c.tn = 0; ++c.zz; }
+    }
+  }
+}
+
 // MODE 0: 3x3 / stride 1 / pad 1.  MODE 1: the 4x4 / stride-2 convolution (and the input gradient of the transposed one) as 4
 // K-phases of 2x2 taps over the parity sub-images of the input (ConvGeom::nph = 4: stage = (tile, phase, 16-channel chunk), the
 // halo tile is gathered with a stride of 2 pixels).  MODE 2: the transposed 4x4 / stride-2 convolution (and the input gradient of
@@ -903,16 +943,17 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const char* l_wn = reinterpret_cast<const char*>(ws);
   int l_b0 = 0, l_iy0 = 0, l_py = 0;
   long long l_rb = 0;             // byte offset of the tile's first staged row (row -1 of the first image: may be negative)
-#define PIDM_SP_STAGE(s_)                                                                                          \
+  SplitCursor lc, cs;             // stage whose activations are being fetched (two ahead) / stage being computed
+  split_cursor_init<MODE>(lc, item0, nst, g.tiles_m, tpi, ntn);
+  cs = lc;
+  // geometry of the fetch cursor's stage
+#define PIDM_SP_STAGE()                                                                                            \
   {                                                                                                                \
-    int ss__ = (s_);                                                                                               \
-    if (ss__ >= nst) ss__ = nst - 1;                                                                               \
-    const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
-    const int tq__ = it__ / g.tiles_m, tm__ = it__ - tq__ * g.tiles_m;       /* tq = n-tile (MODE 2: parity * ntn + n-tile) */ \
-    const int ph__ = (MODE == 1) ? ch__ / CCH : 0;                                                                 \
-    const int c0__ = (ch__ - ph__ * CCH) * 16;                                                                     \
-    l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
-    l_iy0 = (tm__ % tpi) * g.TH - 1;                                          /* input (sub-image) row of LDS row 0 */ \
+    const int ch__ = lc.ch, tq__ = lc.tq;                                      /* tq = n-tile (MODE 2: parity * ntn + n-tile) */ \
+    const int ph__ = (MODE == 1) ? lc.ph : 0;                                                                      \
+    const int c0__ = ((MODE == 1) ? lc.cc : lc.ch) * 16;                                                           \
+    l_b0 = lc.bi * g.NI;                                                                                           \
+    l_iy0 = lc.rt * g.TH - 1;                                                 /* input (sub-image) row of LDS row 0 */ \
     l_py = (MODE == 1) ? g.ph_oy[ph__] : 0;                                                                        \
     l_rb = (long long)(l_b0 * g.Hi + (MODE == 1 ? 2 * l_iy0 + l_py : l_iy0)) * (long long)(g.Wi * g.ld0 * 4);      \
     l_sp = reinterpret_cast<const char*>(((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                    \
@@ -953,13 +994,14 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 
   char* bufc = smem;               // buffer the MFMAs read
   char* bufn = smem + bufsz;       // buffer being filled
-  PIDM_SP_STAGE(0)
+  PIDM_SP_STAGE()
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
 #pragma unroll
   for (int k = 0; k < NB; ++k) PIDM_SP_COPY_B(k, l_wn, bufc)
   PIDM_SP_WRITE_A(0, bufc)
   if (wave < nA1) PIDM_SP_WRITE_A(1, bufc)
-  PIDM_SP_STAGE(1)
+  split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);
+  PIDM_SP_STAGE()
   PIDM_SP_LOAD_A(0) PIDM_SP_LOAD_A(1)
   __syncthreads();
 
@@ -973,18 +1015,17 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   for (int s = 0; s < nst; ++s) {
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 0] = clock64();
     const char* wn1 = l_wn;        // weight slab of stage s+1 (copied during this stage)
-    PIDM_SP_STAGE(s + 2)           // geometry of the activation loads issued during this stage
+    split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);
+    PIDM_SP_STAGE()                // geometry of the activation loads issued during this stage (stage s+2)
     // the epilogue's bias, fetched a stage ahead of its use (unconditional load, any valid address when there is no bias)
-    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[(((item0 + s / NCH) / g.tiles_m) % ntn) * 32 + l31];
+    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[cs.tn * 32 + l31];
     // tap offsets inside the halo tile: 3x3: (ky, kx); 2x2 taps: (jy - pad_y + 1, jx - pad_x + 1) with the pads of this stage's
     // phase (MODE 1) or of this item's output parity (MODE 2)
     int oy0 = 0, ox0 = 0;
     if (MODE == 1) {
-      const int ph = (s - (s / NCH) * NCH) / CCH;
-      oy0 = 1 - g.ph_pad_y[ph]; ox0 = 1 - g.ph_pad_x[ph];
+      oy0 = 1 - g.ph_pad_y[cs.ph]; ox0 = 1 - g.ph_pad_x[cs.ph];
     } else if (MODE == 2) {
-      const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
-      oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
+      oy0 = 1 - g.pad_y[cs.zz]; ox0 = 1 - g.pad_x[cs.zz];
     }
     const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
     const char* bfp = bufc + b_frag;
@@ -1048,13 +1089,11 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 1] = clock64();
     // ---- last chunk of a tile: epilogue as in conv3x3_stream_kernel (bias, GroupNorm partial sums, 4x4 register transposes,
     //      residual, 16-byte stores), accumulator restarts ----
-    const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
-    if (ch == NCH - 1) {
+    if (cs.ch == NCH - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += accb[r];
-      const int tq = it / g.tiles_m, tm = it - tq * g.tiles_m;
-      const int zz = (MODE == 2) ? tq / ntn : 0, tn = tq - zz * ntn;
-      const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
+      const int zz = (MODE == 2) ? cs.zz : 0;
+      const int b0 = cs.bi * g.NI, vy0 = cs.rt * g.TH, n0 = cs.tn * 32;
       const int c = n0 + l31;
       const float bv = bias ? bv_pre : 0.f;
       const int p0 = wave * 32;
@@ -1104,6 +1143,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
     }
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 2] = clock64();
+    split_cursor_next<MODE>(cs, NCH, CCH, g.tiles_m, tpi, ntn);
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
     if (tr_base >= 0 && s < 32) g_stream_trace[tr_base + 4 * s + 3] = clock64();
     char* tswap = bufc; bufc = bufn; bufn = tswap;
@@ -1191,16 +1231,15 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     const char* l_wn = reinterpret_cast<const char*>(ws);
     int l_b0 = 0, l_iy0 = 0, l_py = 0;
     long long l_rb = 0;
-#define PIDM_WS_STAGE(s_)                                                                                          \
+    SplitCursor lc;               // the stage whose activations are being fetched
+    split_cursor_init<MODE>(lc, item0, nst, g.tiles_m, tpi, ntn);
+#define PIDM_WS_STAGE()                                                                                            \
   {                                                                                                                \
-    int ss__ = (s_);                                                                                               \
-    if (ss__ >= nst) ss__ = nst - 1;                                                                               \
-    const int it__ = item0 + ss__ / NCH, ch__ = ss__ - (ss__ / NCH) * NCH;                                         \
-    const int tq__ = it__ / g.tiles_m, tm__ = it__ - tq__ * g.tiles_m;                                             \
-    const int ph__ = (MODE == 1) ? ch__ / CCH : 0;                                                                 \
-    const int c0__ = (ch__ - ph__ * CCH) * 16;                                                                     \
-    l_b0 = (tm__ / tpi) * g.NI;                                                                                    \
-    l_iy0 = (tm__ % tpi) * g.TH - 1;                                                                               \
+    const int ch__ = lc.ch, tq__ = lc.tq;                                                                          \
+    const int ph__ = (MODE == 1) ? lc.ph : 0;                                                                      \
+    const int c0__ = ((MODE == 1) ? lc.cc : lc.ch) * 16;                                                           \
+    l_b0 = lc.bi * g.NI;                                                                                           \
+    l_iy0 = lc.rt * g.TH - 1;                                                                                      \
     l_py = (MODE == 1) ? g.ph_oy[ph__] : 0;                                                                        \
     l_rb = (long long)(l_b0 * g.Hi + (MODE == 1 ? 2 * l_iy0 + l_py : l_iy0)) * (long long)(g.Wi * g.ld0 * 4);      \
     l_sp = reinterpret_cast<const char*>(((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                    \
@@ -1236,7 +1275,8 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   {                                                                                                                \
     const char* wn1__ = l_wn;                                                                                      \
     _Pragma("unroll") for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, wn1__, bufn)                                  \
-    PIDM_WS_STAGE((s_) + 2)                                                                                        \
+    split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);                                                    \
+    PIDM_WS_STAGE()                                                                                                \
     _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(setL_, k)                                        \
     _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(setW_, k, bufn)                                 \
     PIDM_WAIT_VMEM();                /* the LDS-direct copies (and the fetch) have landed */                       \
@@ -1244,14 +1284,15 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     char* tswap__ = bufc; bufc = bufn; bufn = tswap__;                                                             \
   }
     // prologue: stage 0 into bufc; the activations of stage 1 stay in registers (set 1)
-    PIDM_WS_STAGE(0)
+    PIDM_WS_STAGE()
 #pragma unroll
     for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(0, k)
 #pragma unroll
     for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, l_wn, bufc)
 #pragma unroll
     for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(0, k, bufc)
-    PIDM_WS_STAGE(1)
+    split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);
+    PIDM_WS_STAGE()
 #pragma unroll
     for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(1, k)
     PIDM_WAIT_VMEM();
@@ -1273,18 +1314,18 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
   const int a_frag = ((a_img < g.NI) ? (a_img * g.IHt + a_ty) * rowB + a_tx * RB : 0) + 48 * half;
   const int b_frag = b_reg + l31 * RB + 48 * half;
+  SplitCursor cs;                    // the stage being computed
+  split_cursor_init<MODE>(cs, item0, nst, g.tiles_m, tpi, ntn);
   __syncthreads();                   // stage 0 is in bufc
   f32x16 acc, accb;
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
   for (int s = 0; s < nst; ++s) {
-    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[(((item0 + s / NCH) / g.tiles_m) % ntn) * 32 + l31];
+    const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[cs.tn * 32 + l31];
     int oy0 = 0, ox0 = 0;
     if (MODE == 1) {
-      const int ph = (s - (s / NCH) * NCH) / CCH;
-      oy0 = 1 - g.ph_pad_y[ph]; ox0 = 1 - g.ph_pad_x[ph];
+      oy0 = 1 - g.ph_pad_y[cs.ph]; ox0 = 1 - g.ph_pad_x[cs.ph];
     } else if (MODE == 2) {
-      const int zz = ((item0 + s / NCH) / g.tiles_m) / ntn;
-      oy0 = 1 - g.pad_y[zz]; ox0 = 1 - g.pad_x[zz];
+      oy0 = 1 - g.pad_y[cs.zz]; ox0 = 1 - g.pad_x[cs.zz];
     }
     const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
     const char* bfp = bufc + b_frag;
@@ -1332,13 +1373,11 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_WS_FRAGS
-    const int it = item0 + s / NCH, ch = s - (s / NCH) * NCH;
-    if (ch == NCH - 1) {
+    if (cs.ch == NCH - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += accb[r];
-      const int tq = it / g.tiles_m, tm = it - tq * g.tiles_m;
-      const int zz = (MODE == 2) ? tq / ntn : 0, tn = tq - zz * ntn;
-      const int b0 = (tm / tpi) * g.NI, vy0 = (tm % tpi) * g.TH, n0 = tn * 32;
+      const int zz = (MODE == 2) ? cs.zz : 0;
+      const int b0 = cs.bi * g.NI, vy0 = cs.rt * g.TH, n0 = cs.tn * 32;
       const int c = n0 + l31;
       const float bv = bias ? bv_pre : 0.f;
       const int p0 = wave * 32;
@@ -1386,6 +1425,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       }
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
     }
+    split_cursor_next<MODE>(cs, NCH, CCH, g.tiles_m, tpi, ntn);
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
     char* tswap = bufc; bufc = bufn; bufn = tswap;
   }

@@ -2154,9 +2154,11 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
 
   f32x4 rr[NSLOT];
   unsigned keep = 0;           // wave-uniform: bit k = slot k of the loads in flight is inside the batch / image
-#define PIDM_WS_PREFETCH(tile_)                                                                                    \
+  // (image group, row tile) of the tile being fetched, advanced incrementally: no integer division in the tile loop
+  int pf_bi = 0, pf_rt = 0;
+#define PIDM_WS_PREFETCH()                                                                                         \
   {                                                                                                                \
-    const int b0__ = ((tile_) / tpi) * g.NI, vy0__ = ((tile_) % tpi) * g.TH;                                       \
+    const int b0__ = pf_bi * g.NI, vy0__ = pf_rt * g.TH;                                                           \
     _Pragma("unroll") for (int k = 0; k < NSLOT; ++k) {                                                            \
       const int b__ = b0__ + s_img[k];                                                                             \
       const int iy__ = vy0__ + s_row[k] - (s_kind[k] == 1 ? 1 : 0);                                                \
@@ -2177,7 +2179,9 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
 
   const int tile_lo = split * wg.tiles_per_split;
   const int tile_hi = (tile_lo + wg.tiles_per_split < g.tiles_m) ? tile_lo + wg.tiles_per_split : g.tiles_m;
-  if (tile_lo < tile_hi) PIDM_WS_PREFETCH(tile_lo)
+  pf_bi = tile_lo / tpi;
+  pf_rt = tile_lo - pf_bi * tpi;
+  if (tile_lo < tile_hi) PIDM_WS_PREFETCH()
   // PIDM_STREAM_TRACE=1: cycle stamps of workgroup (0,0), wave 0: [0] kernel entry, then per tile 5 stamps (top, past barrier 1,
   // staged, past barrier 2, k-steps done), then the end of the kernel
   const bool tr_on = trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
@@ -2217,7 +2221,10 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
     if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
     __syncthreads();
     if (tr_on && tr_n < 240) g_stream_trace[tr_n++] = clock64();
-    if (tile + 1 < tile_hi) PIDM_WS_PREFETCH(tile + 1)
+    if (tile + 1 < tile_hi) {
+      if (++pf_rt == tpi) { pf_rt = 0; ++pf_bi; }
+      PIDM_WS_PREFETCH()
+    }
     // ---- the wave's k-steps: 3 dY fragments, 3 x (aligned X chunk + dword before + dword after), 18 MFMAs ----
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {

@@ -1629,8 +1629,102 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
   }
 }
 
-// all weight tensors of the model in ONE launch: a device-side descriptor table, each block owns 2048 elements
+// all weight tensors of the model in ONE launch: a device-side descriptor table.
+//
+// TILED tensors (PackDesc::tiled: kinds 0 / 2 / 4 with 1 or 9 taps - the 3x3 and 1x1 convolutions and the linears, > 80 % of the
+// weights): a block owns 32 packed rows x 32 packed columns x all taps.  The source is read as 32 contiguous runs of 32 T floats
+// (rows of the [N][K][T] tensor for the forward packing, of the [K][N][T] tensor for the input-gradient packing, whose taps are
+// flipped on their way into LDS), the packing leaves as whole 128-byte lines and the bf16 pieces as whole 3.5 KB images of 32 LDS
+// rows.  The element-wise form below read 4 bytes per lane at a stride of 36 bytes (forward) or 36 KB (input gradient) and
+// scattered the pieces as 2-byte stores: 0.9 TB/s on the 130 M-parameter mechanics model (2.3 ms per step).
+//
+// Everything else (4x4 / stride-2 tensors in their parity / phase forms, the 7x7 init convolution): element-wise, each block
+// 2048 elements, index arithmetic in 32 bits and hierarchical (three unsigned divisions per element instead of four 64-bit
+// divisions and three remainders), two consecutive k per thread where K is even.
+__device__ __forceinline__ size_t pack_src_index(const PackDesc& d, unsigned z, unsigned n, unsigned t, unsigned k) {
+  if (d.kind == 5 || d.kind == 6) {
+    const unsigned py = z >> 1, px = z & 1, jy = t >> 1, jx = t & 1;
+    const unsigned ky = py == 0 ? 1 + 2 * jy : 2 * jy, kx = px == 0 ? 1 + 2 * jx : 2 * jx;
+    return (((size_t)n * d.K + k) * 4 + ky) * 4 + kx;
+  }
+  if (d.kind == 0 || d.kind == 4) return ((size_t)n * d.K + k) * d.T + t;
+  if (d.kind == 2) {
+    const unsigned ky = d.KH - 1 - t / d.KW, kx = d.KW - 1 - t % d.KW;
+    return (((size_t)k * d.N + n) * d.KH + ky) * d.KW + kx;
+  }
+  const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
+  return (((size_t)k * d.N + n) * 4 + ky) * 4 + kx;
+}
+// source stride between k and k + 1
+__device__ __forceinline__ size_t pack_src_kstride(const PackDesc& d) {
+  if (d.kind == 5 || d.kind == 6) return 16;
+  if (d.kind == 0 || d.kind == 4) return (size_t)d.T;
+  if (d.kind == 2) return (size_t)d.N * d.KH * d.KW;
+  return (size_t)d.N * 16;
+}
+
+static constexpr int kPackTileT = 9;       // most taps a tiled tensor has (LDS: 32 x 33 x 9 floats)
+__device__ __forceinline__ void pack_tile(const PackDesc& d, unsigned tile_id, float* __restrict__ tile) {
+  const unsigned T = (unsigned)d.T, N = (unsigned)d.N, K = (unsigned)d.K;
+  const unsigned ktiles = (K + 31u) >> 5;
+  const unsigned nt = tile_id / ktiles, kt = tile_id - nt * ktiles;
+  const unsigned n0 = nt * 32u, k0 = kt * 32u;
+  const unsigned tid = threadIdx.x, RUN = 32u * T;
+  const unsigned magicT = (T > 1) ? (unsigned)((0x100000000ULL + T - 1) / T) : 0u;     // e / T == __umulhi(e, magicT) for e * T < 2^32
+  const unsigned magicR = (unsigned)((0x100000000ULL + RUN - 1) / RUN);
+  // ---- source tile -> LDS as tile[(nl * 33 + kl) * T + t] (33: the piece pass reads 32 rows nl at one kl) ----
+  if (d.kind == 2) {
+    // [K][N][T] tensor: run kl = the 32 T floats of rows n0 .. n0 + 31 of column k0 + kl; tap t' of the source is tap T - 1 - t'
+    for (unsigned e = tid; e < 32u * RUN; e += 256u) {
+      const unsigned kl = __umulhi(e, magicR), r = e - kl * RUN;
+      const unsigned nl = (T > 1) ? __umulhi(r, magicT) : r, ts = r - nl * T;
+      float v = 0.f;
+      if (k0 + kl < K && n0 + nl < N) v = d.src[((size_t)(k0 + kl) * N + n0) * T + r];
+      tile[(nl * 33u + kl) * T + (T - 1u - ts)] = v;
+    }
+  } else {
+    // [N][K][T] tensor: run nl = the 32 T floats of columns k0 .. k0 + 31 of row n0 + nl, already in the tile's order
+    for (unsigned e = tid; e < 32u * RUN; e += 256u) {
+      const unsigned nl = __umulhi(e, magicR), r = e - nl * RUN;
+      const unsigned kl = (T > 1) ? __umulhi(r, magicT) : r;
+      float v = 0.f;
+      if (n0 + nl < N && k0 + kl < K) v = d.src[((size_t)(n0 + nl) * K + k0) * T + r];
+      tile[nl * 33u * T + r] = v;
+    }
+  }
+  __syncthreads();
+  // ---- fp32 packing: row (n, t) = 32 consecutive columns = one 128-byte line; 8 rows per sweep ----
+  {
+    const unsigned kl = tid & 31u;
+    for (unsigned row = tid >> 5; row < RUN; row += 8u) {          // row = nl * T + t
+      const unsigned nl = (T > 1) ? __umulhi(row, magicT) : row, t = row - nl * T;
+      if (n0 + nl < N && k0 + kl < K)
+        d.dst[((size_t)(d.n_off + n0 + nl) * T + t) * d.Kp + d.k_off + k0 + kl] = tile[(nl * 33u + kl) * T + t];
+    }
+  }
+  // ---- bf16 pieces: unit (t, 16-column chunk c) = the 32 LDS rows of the n-tile, one wave each: lane (row, half) splits its 8 ----
+  if (d.split) {
+    const unsigned lane = tid & 63u, wv = tid >> 6, nrow = lane >> 1, half = lane & 1u;
+    const unsigned ntile = ((unsigned)d.n_off + n0) >> 5, chunk0 = ((unsigned)d.k_off + k0) >> 4;
+    for (unsigned u = wv; u < 2u * T; u += 4u) {
+      const unsigned c = (u >= T) ? 1u : 0u, t = u - c * T;
+      if (chunk0 + c >= (unsigned)d.nch) continue;                 // (wave-uniform: K % 32 == 16 leaves the last tile one chunk)
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[(nrow * 33u + c * 16u + half * 8u + j) * T + t];
+      unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pidm_split3_pk(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
+      unsigned short* o = d.split + ((((size_t)ntile * d.nch + chunk0 + c) * T + t) * 32u + nrow) * (kSplitRow / 2) + half * 24u;
+      *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+      *reinterpret_cast<u32x4*>(o + 8) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+      *reinterpret_cast<u32x4*>(o + 16) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restrict__ table, int ndesc) {
+  __shared__ float tile[32 * 33 * kPackTileT];
   int lo = 0, hi = ndesc - 1;
   const unsigned bid = blockIdx.x;
   while (lo < hi) {  // last descriptor with blk0 <= bid
@@ -1638,35 +1732,64 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
     if (table[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
   }
   const PackDesc d = table[lo];
-  const size_t total = (size_t)d.nz * d.N * d.T * d.K;
-  const size_t base = (size_t)(bid - d.blk0) * 2048;
+  if (d.tiled) {
+    pack_tile(d, bid - d.blk0, tile);
+    return;
+  }
+  const unsigned K = (unsigned)d.K, T = (unsigned)d.T, N = (unsigned)d.N;
+  const unsigned total = (unsigned)d.nz * N * T * K;
+  const unsigned base = (bid - d.blk0) * 2048u;
+  const bool phased = d.kind == 5 || d.kind == 6;
+  const size_t ks = pack_src_kstride(d);
+  if ((K & 1u) == 0) {
+    // pairs (k, k + 1): k is even, and so is every packed column below when its offset is (checked per element: the concatenated
+    // time-MLP linears have arbitrary offsets)
+#pragma unroll 2
+    for (int it = 0; it < 4; ++it) {
+      const unsigned idx = base + it * 512u + 2u * threadIdx.x;
+      if (idx >= total) break;
+      const unsigned q1 = idx / K, k = idx - q1 * K;
+      const unsigned q2 = q1 / T, t = q1 - q2 * T;
+      const unsigned z = q2 / N, n = q2 - z * N;
+      const size_t si = pack_src_index(d, z, n, t, k);
+      const float v0 = d.src[si], v1 = d.src[si + ks];
+      const unsigned zz = phased ? 0u : z;
+      const unsigned col = (unsigned)d.k_off + (phased ? z * K : 0u) + k;
+      float* o = d.dst + (((size_t)zz * d.Np + d.n_off + n) * T + t) * d.Kp + col;
+      if ((col & 1u) == 0) {
+        *reinterpret_cast<f32x2*>(o) = f32x2{v0, v1};
+      } else {
+        o[0] = v0;
+        o[1] = v1;
+      }
+      if (d.split) {
+        const unsigned nn = (unsigned)d.n_off + n;
+        if ((col & 1u) == 0) {
+          unsigned p0, p1, p2;
+          pidm_split3_pk(v0, v1, p0, p1, p2);
+          const size_t so = ((((((size_t)zz * d.ntn + (nn >> 5)) * d.nch + (col >> 4)) * T + t) * 32 + (nn & 31))) * (kSplitRow / 2) + ((col >> 3) & 1) * 24 + (col & 7);
+          *reinterpret_cast<unsigned*>(d.split + so) = p0;
+          *reinterpret_cast<unsigned*>(d.split + so + 8) = p1;
+          *reinterpret_cast<unsigned*>(d.split + so + 16) = p2;
+        } else {           // (never for a tensor with pieces: they exist for whole, un-offset matrices only)
+          split_store(d.split, d.nch, d.T, d.ntn, (int)zz, (int)nn, (int)t, (int)col, v0);
+          split_store(d.split, d.nch, d.T, d.ntn, (int)zz, (int)nn, (int)t, (int)col + 1, v1);
+        }
+      }
+    }
+    return;
+  }
   for (int it = 0; it < 8; ++it) {
-    const size_t idx = base + it * 256 + threadIdx.x;
+    const unsigned idx = base + it * 256u + threadIdx.x;
     if (idx >= total) break;
-    const int k = (int)(idx % d.K);
-    const int t = (int)((idx / d.K) % d.T);
-    const int n = (int)((idx / ((size_t)d.K * d.T)) % d.N);
-    const int z = (int)(idx / ((size_t)d.K * d.T * d.N));
-    float v;
-    if (d.kind == 5 || d.kind == 6) {
-      const int py = z >> 1, px = z & 1, jy = t >> 1, jx = t & 1;
-      const int ky = py == 0 ? 1 + 2 * jy : 2 * jy, kx = px == 0 ? 1 + 2 * jx : 2 * jx;
-      v = d.src[(((size_t)n * d.K + k) * 4 + ky) * 4 + kx];
-      d.dst[(((size_t)(d.n_off + n)) * d.T + t) * d.Kp + d.k_off + z * d.K + k] = v;
-      if (d.split) split_store(d.split, d.nch, d.T, d.ntn, 0, d.n_off + n, t, d.k_off + z * d.K + k, v);
-      continue;
-    }
-    if (d.kind == 0 || d.kind == 4) {
-      v = d.src[((size_t)n * d.K + k) * d.T + t];
-    } else if (d.kind == 2) {
-      const int ky = d.KH - 1 - t / d.KW, kx = d.KW - 1 - t % d.KW;
-      v = d.src[(((size_t)k * d.N + n) * d.KH + ky) * d.KW + kx];
-    } else {
-      const int ky = parity_tap(z >> 1, t >> 1), kx = parity_tap(z & 1, t & 1);
-      v = d.src[(((size_t)k * d.N + n) * 4 + ky) * 4 + kx];
-    }
-    d.dst[(((size_t)z * d.Np + d.n_off + n) * d.T + t) * d.Kp + d.k_off + k] = v;
-    if (d.split) split_store(d.split, d.nch, d.T, d.ntn, z, d.n_off + n, t, d.k_off + k, v);
+    const unsigned q1 = idx / K, k = idx - q1 * K;
+    const unsigned q2 = q1 / T, t = q1 - q2 * T;
+    const unsigned z = q2 / N, n = q2 - z * N;
+    const float v = d.src[pack_src_index(d, z, n, t, k)];
+    const unsigned zz = phased ? 0u : z;
+    const unsigned col = (unsigned)d.k_off + (phased ? z * K : 0u) + k;
+    d.dst[(((size_t)zz * d.Np + d.n_off + n) * T + t) * d.Kp + col] = v;
+    if (d.split) split_store(d.split, d.nch, d.T, d.ntn, (int)zz, d.n_off + (int)n, (int)t, (int)col, v);
   }
 }
 
@@ -2909,7 +3032,17 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->ntn = g.Cout / 32;
   if (g.nph > 1) { d->kind = (kind == 4) ? 6 : 5; d->nz = 4; }   // nz doubles as the phase count for kinds 5/6
   const size_t total = (size_t)d->nz * d->N * d->T * d->K;
-  d->nblk = (unsigned)((total + 2047) / 2048);
+  if (total >= ((size_t)1 << 31)) {          // pack_multi_kernel indexes a tensor in 32 bits
+    fail("weight re-pack: a tensor of %zu elements exceeds the 2^31 limit of the packing kernel", total);
+    d->nblk = 0;
+    return 0;
+  }
+  // tiled form (32 rows x 32 columns x all taps per block, transposed through LDS): the un-phased single-matrix kinds with 1 or 9
+  // taps whose pieces (if any) start on tile borders; PIDM_PACK_TILED=0: element-wise everywhere (A/B measurements)
+  static const bool tiled_on = [] { const char* e = getenv("PIDM_PACK_TILED"); return !(e && !atoi(e)); }();
+  d->tiled = (tiled_on && d->nz == 1 && (d->kind == 0 || d->kind == 2 || d->kind == 4) && (d->T == 1 || d->T == kPackTileT) &&
+              (!d->split || ((d->n_off & 31) == 0 && (d->k_off & 31) == 0))) ? 1 : 0;
+  d->nblk = d->tiled ? (unsigned)(cdiv(d->N, 32) * cdiv(d->K, 32)) : (unsigned)((total + 2047) / 2048);
   return d->nblk;
 }
 // dst[(m*N + n)*T + t] = sum over nsplit slabs partial[split][MP][T][NP] (fixed order); optional bias column sums

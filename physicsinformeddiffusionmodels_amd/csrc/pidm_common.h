@@ -184,6 +184,7 @@ struct PackDesc {
   unsigned short* split;   // 3x3 / stride-1 and 4x4 / stride-2 tensors also leave their bf16 pieces for conv3x3_split_kernel (null: none)
   int nch;                 // 16-channel chunks of a packed row (Kp / 16)
   int ntn;                 // 32-row tiles of one parity slab (Cout / 32)
+  int tiled;               // 1: pack_multi_kernel's LDS-transposed 32 x 32 x taps form (k_conv.hip: pack_tile)
 };
 
 // one deferred fixed-order reduction (k_conv.hip: reduce_multi_kernel), queued during backward and run in ONE launch:

@@ -149,6 +149,7 @@ struct pidm_unet {
   const void* packed_zeroed_for = nullptr;
   std::vector<PackDesc> pack_table;   // host copy of the device-side descriptor table (lives after the packed weights)
   unsigned pack_blocks = 0;
+  bool pack_failed = false;
   bool pack_table_valid = false;
 
   // tape of the latest forward
@@ -516,7 +517,7 @@ namespace pidm {
 static void push_desc(Run& r, const ConvGeom& g, int kind, const float* src, float* dst, int K, int n_off, int k_off, int n_src,
                       int k_src) {
   PackDesc d;
-  make_pack_desc(g, kind, src, dst, K, K, n_off, k_off, n_src, k_src, &d);
+  if (!make_pack_desc(g, kind, src, dst, K, K, n_off, k_off, n_src, k_src, &d)) r.U->pack_failed = true;   // (message set by fail())
   d.blk0 = r.U->pack_blocks;
   r.U->pack_blocks += d.nblk;
   r.U->pack_table.push_back(d);
@@ -551,6 +552,7 @@ static int pack_all(Run& r) {
   U->packed_zeroed_for = r.wpack;
   U->pack_table.clear();
   U->pack_blocks = 0;
+  U->pack_failed = false;
   int rc = 0;
   rc |= pack_layer(r, U->init_conv);
   rc |= pack_layer(r, U->lin1);
@@ -586,6 +588,7 @@ static int pack_all(Run& r) {
   rc |= pack_layer(r, U->emb2);
   rc |= pack_layer(r, U->comb);
   if (rc) return rc;
+  if (U->pack_failed) return -1;
   if (U->pack_table.size() > kMaxPackDesc) return fail("pack: descriptor table overflow");
   if (hipMemcpyAsync(table_dev, U->pack_table.data(), U->pack_table.size() * sizeof(PackDesc), hipMemcpyHostToDevice, r.st) != hipSuccess)
     return fail("pack: descriptor upload failed");

@@ -3038,8 +3038,14 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
     return 0;
   }
   // tiled form (32 rows x 32 columns x all taps per block, transposed through LDS): the un-phased single-matrix kinds with 1 or 9
-  // taps whose pieces (if any) start on tile borders; PIDM_PACK_TILED=0: element-wise everywhere (A/B measurements)
-  static const bool tiled_on = [] { const char* e = getenv("PIDM_PACK_TILED"); return !(e && !atoi(e)); }();
+  // taps whose pieces (if any) start on tile borders; PIDM_PACK_TILED=0 / 1: element-wise everywhere / tiled where eligible
+  // (read per table build, not cached: the host emulator's build defaults to the element-wise form - its fibers make the tile's
+  // barrier expensive - and a test switches the tiled form on for one model)
+#ifndef PIDM_PACK_TILED_DEFAULT
+#define PIDM_PACK_TILED_DEFAULT 1
+#endif
+  const char* te = getenv("PIDM_PACK_TILED");
+  const bool tiled_on = te ? atoi(te) != 0 : PIDM_PACK_TILED_DEFAULT != 0;
   d->tiled = (tiled_on && d->nz == 1 && (d->kind == 0 || d->kind == 2 || d->kind == 4) && (d->T == 1 || d->T == kPackTileT) &&
               (!d->split || ((d->n_off & 31) == 0 && (d->k_off & 31) == 0))) ? 1 : 0;
   d->nblk = d->tiled ? (unsigned)(cdiv(d->N, 32) * cdiv(d->K, 32)) : (unsigned)((total + 2047) / 2048);

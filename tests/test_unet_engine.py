@@ -68,6 +68,16 @@ def test_unet_dim16_p32(backend):
     run_case(backend, "g5b_unet_dim16_p32", 16, True)
 
 
+def test_tiled_weight_repack_on_the_emulator(monkeypatch):
+    """The emulated build packs element by element by default (the tile form's barrier is expensive with fibers; on the GPU the
+    tiled form is the default and every -m gpu test runs it): here the tiled form - 32 x 32 x taps tiles transposed through LDS,
+    csrc/k_conv.hip: pack_tile - against the same golden vectors, forward and input-gradient packings, pieces included."""
+    import torch
+    from tests.emu_util import emu_lib
+    monkeypatch.setenv("PIDM_PACK_TILED", "1")
+    run_case((emu_lib(), torch.device("cpu")), "g5b_unet_dim16_p32", 16, True)
+
+
 # attention forms of the 64x64 / 32x32 levels: "proj" = no qkv tensor (k_attn_proj.hip, the default), "fused" = qkv tensor with the
 # attention fused into the to_out projection, "separate" = qkv tensor, separate projection kernels
 ATTN_FORMS = {"proj": {}, "fused": {"PIDM_NO_LAP": "1", "PIDM_LA_FUSED_MIN_WGS": "1"},

@@ -4,6 +4,13 @@ timeout 900 python -m pytest tests -m gpu -x -q > $o/pytest.log 2>&1; echo "pyte
 bash tools/pmc_traffic.sh 64 > $o/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic/summary.txt $o/ 2>/dev/null; [ -s gpurun_out/pmc_traffic/traffic.json ] && cp gpurun_out/pmc_traffic/traffic.json profiles/pmc_traffic_b64.json; cp profiles/pmc_traffic_b64.json $o/pmc_traffic_b64.json
 rm -rf gpurun_out/pmc_traffic/FETCH_SIZE gpurun_out/pmc_traffic/WRITE_SIZE
+# the other workloads / batch sizes (profiles/pmc_traffic_b256.json, _mechanics_b32, _sampling_b1024)
+mkdir -p $o/pmc
+cp gpurun_out/pmc_traffic/traffic.json $o/pmc/pmc_traffic_b64.json
+rm -rf gpurun_out/pmc_traffic; bash tools/pmc_traffic.sh 256 darcy > $o/pmc_b256.log 2>&1; cp gpurun_out/pmc_traffic/traffic.json $o/pmc/pmc_traffic_b256.json; rm -rf gpurun_out/pmc_traffic
+bash tools/pmc_traffic.sh 32 mechanics > $o/pmc_mech.log 2>&1; cp gpurun_out/pmc_traffic_mechanics/traffic.json $o/pmc/pmc_traffic_mechanics_b32.json; rm -rf gpurun_out/pmc_traffic_mechanics
+bash tools/pmc_traffic.sh 1024 sampling > $o/pmc_samp.log 2>&1; cp gpurun_out/pmc_traffic_sampling/traffic.json $o/pmc/pmc_traffic_sampling_b1024.json; rm -rf gpurun_out/pmc_traffic_sampling
+cp $o/pmc/*.json profiles/
 timeout 600 python bench.py 2>$o/bench.err | tail -1 > $o/bench.json
 timeout 600 python bench.py --workload mechanics --steps 10 --warmup 4 2>>$o/bench.err | tail -1 > $o/bench_mechanics.json
 timeout 600 python bench.py --workload sampling --steps 20 --warmup 5 2>>$o/bench.err | tail -1 > $o/bench_sampling.json
@@ -11,6 +18,7 @@ for w in darcy mechanics sampling; do
   st=20; [ $w = mechanics ] && st=6
   (cd /tmp && PIDM_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_$w -o p -- python $R/bench.py --workload $w --steps $st --warmup 5 --no-cpu-baseline --no-alt > $o/prof_$w.log 2>&1)
 done
+(cd /tmp && PIDM_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_darcy_b256 -o p -- python $R/bench.py --batch 256 --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $o/prof_darcy_b256.log 2>&1)
 find $o -name '*.db' -delete; find $o -name '*agent_info.csv' -delete; find $o -name '*kernel_trace.csv' -delete
 python - $o <<'PY'
 import json,sys

@@ -1432,6 +1432,232 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 1x1 / stride-1 convolution = a GEMM [pixels] x [Cin] x [Cout] in the split form (to_qkv / to_out of the qkv-form attention levels,
+// res_conv, the linears of wide models - and their input gradients, which are 1x1 convolutions with the transposed weight).  The fp32
+// implicit-GEMM kernel ran these at 40-65 TFLOP/s where they are compute bound (16x16 128 -> 768: 49 us).
+// Nothing is shared between neighbouring pixels here, so the reuse has to come from the OUTPUT width: a workgroup owns 128 pixels x
+// NTG * 32 output channels, each of the 4 consumer waves (one per SIMD) 32 pixels x NTG accumulator tiles, and an activation
+// fragment is read from LDS once per NTG * 6 MFMAs.  A stage = 32 input channels (two k-steps): 12 NTG MFMAs per consumer wave;
+// the 4 producer waves stage the 128 x 32 activation block (fetched a stage ahead, split, [k-step][pixel] rows of 112 bytes) and
+// copy the stage's pre-split weight slab ([k-step][sub-tile][32 rows], pack layout of 1x1 tensors) with global_load_lds, as in
+// conv3x3_split_ws_kernel.  Two accumulator chains per tile (even / odd stages), summed in the epilogue.
+// Pixels are addressed flat (input p * ld, output p * sox): contiguous channels-last tensors, pixel count a multiple of 128.
+// ---------------------------------------------------------------------------------------------------
+// NTGP = tiles per group in the PACKED piece layout (4 or 2), NTG <= NTGP the tiles a workgroup takes: launches with fewer than one
+// item per CU at NTG = 4 run with NTG = 2 on the same packing (a stage's weights are then two runs of 7 KB, one per k-step).
+template <int NTG, int NTGP>
+__global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                            const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, float* __restrict__ out, int n_items,
+                                                            int items_per_wg, int tiles_m) {
+  constexpr int RB = kSplitRow, NW = 4, NPT = 256, KS = 2;
+  constexpr int ABYTES = KS * 128 * RB;                 // activation block of a stage
+  constexpr int SLAB = KS * NTG * 32 * RB;              // weights of a stage in LDS: [k-step][tile][32 rows]
+  constexpr int KRUN = NTG * 32 * RB;                   // ... of one k-step: a whole number of KB (14 / 7), contiguous in the packing
+  constexpr int NPIECE = KRUN / 1024;
+  static_assert(NTG == 2 || NTG == 4, "a k-step's run must be a whole number of KB");
+  static_assert(NTGP % NTG == 0, "a workgroup's tiles lie inside one packed group");
+  constexpr int BUFSZ = ABYTES + SLAB;
+  HIP_DYNAMIC_SHARED(float, smemf)
+  char* smem = reinterpret_cast<char*>(smemf);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int NCH = g.Cin >> 5;                           // stages per item
+  const int item0 = blockIdx.x * items_per_wg;
+  const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
+  const int nst = my_items * NCH;
+  char* bufc = smem;
+  char* bufn = smem + BUFSZ;
+  // position of a stage: chunk ch of item (n-group tq, pixel tile tm), advanced incrementally
+  int c_ch = 0, c_tq = item0 / tiles_m, c_tm = item0 - c_tq * tiles_m, c_left = nst - 1;
+#define PIDM_G1_NEXT()                                                                                             \
+  if (c_left > 0) {                                                                                                \
+    --c_left;                                                                                                      \
+    if (++c_ch == NCH) {                                                                                           \
+      c_ch = 0;                                                                                                    \
+      if (++c_tm == tiles_m) { c_tm = 0; ++c_tq; }                                                                 \
+    }                                                                                                              \
+  }
+  if (wave >= NW) {
+    // =============================== producer waves ===============================
+    const int pt = tid - 64 * NW, pw = wave - NW;
+    // unit u = pt + 256 k: 8 channels (group q of the stage's 32) of pixel px
+    int a_lds[2];
+    unsigned a_go[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = pt + NPT * k, px = u >> 2, q = u & 3;
+      a_lds[k] = ((q >> 1) * 128 + px) * RB + 48 * (q & 1);
+      a_go[k] = (unsigned)(px * g.ld0 + 8 * q) * 4u;
+    }
+    const unsigned b_lane = 16u * lane;
+    f32x4 ra[2][2][2];
+    const char* l_sp = reinterpret_cast<const char*>(src0);
+    const char* l_wn = reinterpret_cast<const char*>(ws);
+#define PIDM_G1_STAGE()                                                                                            \
+  {                                                                                                                \
+    const int c0__ = c_ch * 32;                                                                                    \
+    l_sp = reinterpret_cast<const char*>((c0__ < g.C0) ? src0 + c0__ : src1 + (c0__ - g.C0)) +                     \
+           (size_t)c_tm * 128 * (size_t)g.ld0 * 4;                                                                 \
+    /* k-step 0 of the stage: packed group (c_tq NTG) / NTGP, first tile (c_tq NTG) % NTGP; k-step 1 is NTGP * 32 rows further */ \
+    l_wn = reinterpret_cast<const char*>(ws) +                                                                     \
+           ((((size_t)((c_tq * NTG) / NTGP) * (2 * NCH) + 2 * c_ch) * NTGP + (c_tq * NTG) % NTGP) * 32) * RB;       \
+  }
+#define PIDM_G1_LOAD_A(set_)                                                                                       \
+  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                  \
+    const f32x4* p__ = reinterpret_cast<const f32x4*>(l_sp + a_go[k]);                                             \
+    ra[set_][k][0] = p__[0];                                                                                       \
+    ra[set_][k][1] = p__[1];                                                                                       \
+  }
+#define PIDM_G1_COPY_B(wn_, buf_)                                                                                  \
+  _Pragma("unroll") for (int ks__ = 0; ks__ < KS; ++ks__)                                                          \
+    _Pragma("unroll") for (int k = 0; k < (NPIECE + 3) / 4; ++k)                                                   \
+      if (pw + 4 * k < NPIECE)                                                                                     \
+        pidm_glds_b128((wn_) + (size_t)ks__ * NTGP * 32 * RB + 1024 * (pw + 4 * k) + b_lane,                       \
+                       (buf_) + ABYTES + ks__ * KRUN + 1024 * (pw + 4 * k));
+#define PIDM_G1_WRITE_A(set_, buf_)                                                                                \
+  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                  \
+    const f32x4 v0__ = ra[set_][k][0], v1__ = ra[set_][k][1];                                                      \
+    unsigned q0__[4], q1__[4], q2__[4];                                                                            \
+    pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
+    pidm_split3_pk(v0__[2], v0__[3], q0__[1], q1__[1], q2__[1]);                                                   \
+    pidm_split3_pk(v1__[0], v1__[1], q0__[2], q1__[2], q2__[2]);                                                   \
+    pidm_split3_pk(v1__[2], v1__[3], q0__[3], q1__[3], q2__[3]);                                                   \
+    u32x4* d__ = reinterpret_cast<u32x4*>((buf_) + a_lds[k]);                                                      \
+    d__[0] = u32x4{q0__[0], q0__[1], q0__[2], q0__[3]};                                                            \
+    d__[1] = u32x4{q1__[0], q1__[1], q1__[2], q1__[3]};                                                            \
+    d__[2] = u32x4{q2__[0], q2__[1], q2__[2], q2__[3]};                                                            \
+  }
+    // one producer iteration = consumer stage s: weight slab of stage s+1, fetch of stage s+2 into set s & 1, stage s+1 from the other set
+#define PIDM_G1_ITER(setL_, setW_)                                                                                 \
+  {                                                                                                                \
+    const char* wn1__ = l_wn;                                                                                      \
+    PIDM_G1_COPY_B(wn1__, bufn)                                                                                    \
+    PIDM_G1_NEXT()                                                                                                 \
+    PIDM_G1_STAGE()                                                                                                \
+    PIDM_G1_LOAD_A(setL_)                                                                                          \
+    PIDM_G1_WRITE_A(setW_, bufn)                                                                                   \
+    PIDM_WAIT_VMEM();                                                                                              \
+    __syncthreads();                                                                                               \
+    char* tswap__ = bufc; bufc = bufn; bufn = tswap__;                                                             \
+  }
+    PIDM_G1_STAGE()
+    PIDM_G1_LOAD_A(0)
+    PIDM_G1_COPY_B(l_wn, bufc)
+    PIDM_G1_WRITE_A(0, bufc)
+    PIDM_G1_NEXT()
+    PIDM_G1_STAGE()
+    PIDM_G1_LOAD_A(1)
+    PIDM_WAIT_VMEM();
+    __syncthreads();
+    for (int s = 0; s < nst; s += 2) {
+      PIDM_G1_ITER(0, 1)
+      if (s + 1 < nst) PIDM_G1_ITER(1, 0)
+    }
+#undef PIDM_G1_STAGE
+#undef PIDM_G1_LOAD_A
+#undef PIDM_G1_COPY_B
+#undef PIDM_G1_WRITE_A
+#undef PIDM_G1_ITER
+    return;
+  }
+  // =============================== consumer waves ===============================
+  const int a_frag = (wave * 32 + l31) * RB + 48 * half;
+  const int b_frag = ABYTES + l31 * RB + 48 * half;
+  __syncthreads();                   // stage 0 is in bufc
+  f32x16 acc[NTG][2];
+#pragma unroll
+  for (int j = 0; j < NTG; ++j)
+    for (int r = 0; r < 16; ++r) { acc[j][0][r] = 0.f; acc[j][1][r] = 0.f; }
+  for (int s = 0; s < nst; ++s) {
+    // fragments one (k-step, tile) pair ahead of the MFMAs that use them
+    u32x4 fa[2][3], fb[2][3];
+#define PIDM_G1_FRAG_A(set_, ks_)                                                                                  \
+  {                                                                                                                \
+    const u32x4* ar__ = reinterpret_cast<const u32x4*>(bufc + a_frag + (ks_) * 128 * RB);                          \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) fa[set_][p] = ar__[p];                                           \
+  }
+#define PIDM_G1_FRAG_B(set_, i_)                                                                                   \
+  {                                                                                                                \
+    const u32x4* br__ = reinterpret_cast<const u32x4*>(bufc + b_frag + ((i_) * 32) * RB);                          \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) fb[set_][p] = br__[p];                                           \
+  }
+    PIDM_G1_FRAG_A(0, 0)
+    PIDM_G1_FRAG_B(0, 0)
+#pragma unroll
+    for (int i = 0; i < KS * NTG; ++i) {          // i = ks * NTG + j
+      const int ks = i / NTG, j = i - ks * NTG, cb = i & 1, ca = ks & 1;
+      if (i + 1 < KS * NTG) {
+        PIDM_G1_FRAG_B(cb ^ 1, i + 1)
+        if ((i + 1) % NTG == 0) PIDM_G1_FRAG_A(ca ^ 1, ks + 1)
+      }
+      // small terms first (as in conv3x3_split_kernel); chain = stage parity
+      if (s & 1) {
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][2], fb[cb][0], acc[j][1]);
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][2], acc[j][1]);
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][1], fb[cb][1], acc[j][1]);
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][1], fb[cb][0], acc[j][1]);
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][1], acc[j][1]);
+        acc[j][1] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][0], acc[j][1]);
+      } else {
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][2], fb[cb][0], acc[j][0]);
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][2], acc[j][0]);
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][1], fb[cb][1], acc[j][0]);
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][1], fb[cb][0], acc[j][0]);
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][1], acc[j][0]);
+        acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][0], acc[j][0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PIDM_G1_FRAG_A
+#undef PIDM_G1_FRAG_B
+    if (c_ch == NCH - 1) {
+      // ---- item done: bias, 4x4 register transposes, residual, 16-byte stores (as in conv3x3_split_kernel).  All residual rows of
+      //      the wave's NTG tiles are requested first: one memory latency per item instead of one per tile ----
+      const size_t pbase = (size_t)c_tm * 128 + wave * 32;
+      const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+      f32x4 rres[NTG][4];
+      if (residual) {
+#pragma unroll
+        for (int j = 0; j < NTG; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            rres[j][q4] = *reinterpret_cast<const f32x4*>(residual + (pbase + 8 * q4 + 4 * half + (l31 & 3)) * g.ldr +
+                                                          (c_tq * NTG + j) * 32 + 4 * (l31 >> 2));
+      }
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) {
+        const int n0 = (c_tq * NTG + j) * 32;
+        const float bv = bias ? bias[n0 + l31] : 0.f;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = (acc[j][0][r] + acc[j][1][r]) + bv;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float x0 = v[4 * q4], x1 = v[4 * q4 + 1], x2 = v[4 * q4 + 2], x3 = v[4 * q4 + 3];
+          const float r01 = pidm_quad_xor1(odd1 ? x0 : x1), r23 = pidm_quad_xor1(odd1 ? x2 : x3);
+          x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+          x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+          const float r02 = pidm_quad_xor2(odd2 ? x0 : x2), r13 = pidm_quad_xor2(odd2 ? x1 : x3);
+          x0 = odd2 ? r02 : x0; x2 = odd2 ? x2 : r02;
+          x1 = odd2 ? r13 : x1; x3 = odd2 ? x3 : r13;
+          const size_t p = pbase + 8 * q4 + 4 * half + (l31 & 3);
+          f32x4 o = {x0, x1, x2, x3};
+          if (residual) o += rres[j][q4];
+          *reinterpret_cast<f32x4*>(out + p * g.sox + n0 + 4 * (l31 >> 2)) = o;
+        }
+        for (int r = 0; r < 16; ++r) { acc[j][0][r] = 0.f; acc[j][1][r] = 0.f; }
+      }
+    }
+    PIDM_G1_NEXT()
+    __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    char* tswap = bufc; bufc = bufn; bufn = tswap;
+  }
+#undef PIDM_G1_NEXT
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 7x7 / stride 1 / pad 3 convolution with very few input channels: the UNet's init_conv (reference src/unet_model.py:453,568;
 // Cin = 2, or 4 with self-conditioning).  The implicit-GEMM kernels pad Cin to 8 channels PER TAP (49 taps x 8 = 392 columns for
 // 98 real ones) and ran this layer at 16 TFLOP/s - 100 us for 1.6 GFLOP.  Here (kx, channel) of one kernel row is the
@@ -1572,11 +1798,26 @@ static bool split_shape_ok2(const ConvGeom& g) {
   return g.KH == 2 && g.KW == 2 && g.stride == 1 && ((g.nph == 4 && g.nz == 1) || (g.nz == 4 && g.nph == 1)) && (g.Cin % 32 == 0) &&
          (g.Cout % 32 == 0);
 }
-// pieces of packed element (parity slab z, row n, tap t, column k): [z][n / 32][k / 16][T taps][32 rows][2 halves][3 pieces][8 + pad]
-__device__ __forceinline__ void split_store(unsigned short* ws, int nch, int T, int ntn, int z, int n, int t, int k, float v) {
+// 1x1 / stride-1 tensors for conv1x1_split_kernel: whole 32-channel chunks in, groups of 4 / 2 / 1 32-channel tiles out
+static int split_ntg(const ConvGeom& g) {
+  // (not the linears - 1x1 "images": the concatenated FiLM linear is packed in sub-blocks that carry no pieces, and a batch is too
+  // few pixels for this tile anyway)
+  if (!(g.KH == 1 && g.KW == 1 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && (g.Cin % 32 == 0) && (g.Cout % 64 == 0) &&
+        g.Cin >= 64 && g.Hv * g.Wv > 1))
+    return 0;
+  static const bool on = [] { const char* e = getenv("PIDM_CONV1X1_SPLIT"); return !(e && !atoi(e)); }();
+  if (!on) return 0;
+  return (g.Cout % 128 == 0) ? 4 : 2;
+}
+// pieces of packed element (parity slab z, row n, tap t, column k): [z][n / 32][k / 16][T taps][32 rows][2 halves][3 pieces][8 + pad];
+// ntg > 1 (1x1 tensors, T = 1): the 32-row tiles of a group of ntg are adjacent - [n / (32 ntg)][k / 16][tile in group][32 rows]...
+__device__ __forceinline__ size_t split_row_index(int nch, int T, int ntn, int ntg, int z, int ntile, int chunk, int t) {
+  return ((((size_t)z * (ntn / ntg) + ntile / ntg) * nch + chunk) * T + t) * ntg + (ntile % ntg);
+}
+__device__ __forceinline__ void split_store(unsigned short* ws, int nch, int T, int ntn, int ntg, int z, int n, int t, int k, float v) {
   unsigned p0, p1, p2;
   pidm_split3_pk(v, 0.f, p0, p1, p2);
-  const size_t o = ((((((size_t)z * ntn + (n >> 5)) * nch + (k >> 4)) * T + t) * 32 + (n & 31))) * (kSplitRow / 2) + ((k >> 3) & 1) * 24 + (k & 7);
+  const size_t o = (split_row_index(nch, T, ntn, ntg, z, n >> 5, k >> 4, t) * 32 + (n & 31)) * (kSplitRow / 2) + ((k >> 3) & 1) * 24 + (k & 7);
   ws[o] = (unsigned short)(p0 & 0xffffu);
   ws[o + 8] = (unsigned short)(p1 & 0xffffu);
   ws[o + 16] = (unsigned short)(p2 & 0xffffu);
@@ -1595,7 +1836,8 @@ __device__ __forceinline__ int parity_tap(int par, int j) { return par == 0 ? 3 
 // iterates over the SOURCE-valid elements (n < N, k < K) only; padding is zero-filled once by the caller.
 // (n_off, k_off) place a source tensor inside a larger packed matrix (concatenated time-MLP linears).
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int nz, int N, int K,
-                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off, unsigned short* __restrict__ split, int nch, int ntn) {
+                            int Np, int Kp, int KH, int KW, int T, int n_off, int k_off, unsigned short* __restrict__ split, int nch, int ntn,
+                            int ntg) {
   const size_t total = (size_t)nz * N * T * K;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % K);
@@ -1610,7 +1852,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
       v = (kind == 5) ? src[(((size_t)n * K + k) * 4 + ky) * 4 + kx]     // strided conv  W[n][k][ky][kx]
                       : src[(((size_t)n * K + k) * 4 + ky) * 4 + kx];    // dgrad of convT Wt[n][k][ky][kx]
       dst[(((size_t)(n_off + n)) * T + t) * Kp + k_off + z * K + k] = v;
-      if (split) split_store(split, nch, T, ntn, 0, n_off + n, t, k_off + z * K + k, v);
+      if (split) split_store(split, nch, T, ntn, ntg, 0, n_off + n, t, k_off + z * K + k, v);
       continue;
     }
     if (kind == 0) {
@@ -1625,7 +1867,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
       v = src[(((size_t)k * N + n) * 4 + ky) * 4 + kx];
     }
     dst[(((size_t)z * Np + n_off + n) * T + t) * Kp + k_off + k] = v;
-    if (split) split_store(split, nch, T, ntn, z, n_off + n, t, k_off + k, v);
+    if (split) split_store(split, nch, T, ntn, ntg, z, n_off + n, t, k_off + k, v);
   }
 }
 
@@ -1715,7 +1957,7 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, unsigned tile_id, f
       unsigned q0[4], q1[4], q2[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) pidm_split3_pk(v[2 * j], v[2 * j + 1], q0[j], q1[j], q2[j]);
-      unsigned short* o = d.split + ((((size_t)ntile * d.nch + chunk0 + c) * T + t) * 32u + nrow) * (kSplitRow / 2) + half * 24u;
+      unsigned short* o = d.split + (split_row_index(d.nch, (int)T, d.ntn, d.ntg, 0, (int)ntile, (int)(chunk0 + c), (int)t) * 32u + nrow) * (kSplitRow / 2) + half * 24u;
       *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
       *reinterpret_cast<u32x4*>(o + 8) = u32x4{q1[0], q1[1], q1[2], q1[3]};
       *reinterpret_cast<u32x4*>(o + 16) = u32x4{q2[0], q2[1], q2[2], q2[3]};
@@ -1767,13 +2009,13 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
         if ((col & 1u) == 0) {
           unsigned p0, p1, p2;
           pidm_split3_pk(v0, v1, p0, p1, p2);
-          const size_t so = ((((((size_t)zz * d.ntn + (nn >> 5)) * d.nch + (col >> 4)) * T + t) * 32 + (nn & 31))) * (kSplitRow / 2) + ((col >> 3) & 1) * 24 + (col & 7);
+          const size_t so = (split_row_index(d.nch, (int)T, d.ntn, d.ntg, (int)zz, (int)(nn >> 5), (int)(col >> 4), (int)t) * 32 + (nn & 31)) * (kSplitRow / 2) + ((col >> 3) & 1) * 24 + (col & 7);
           *reinterpret_cast<unsigned*>(d.split + so) = p0;
           *reinterpret_cast<unsigned*>(d.split + so + 8) = p1;
           *reinterpret_cast<unsigned*>(d.split + so + 16) = p2;
         } else {           // (never for a tensor with pieces: they exist for whole, un-offset matrices only)
-          split_store(d.split, d.nch, d.T, d.ntn, (int)zz, (int)nn, (int)t, (int)col, v0);
-          split_store(d.split, d.nch, d.T, d.ntn, (int)zz, (int)nn, (int)t, (int)col + 1, v1);
+          split_store(d.split, d.nch, d.T, d.ntn, d.ntg, (int)zz, (int)nn, (int)t, (int)col, v0);
+          split_store(d.split, d.nch, d.T, d.ntn, d.ntg, (int)zz, (int)nn, (int)t, (int)col + 1, v1);
         }
       }
     }
@@ -1789,7 +2031,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
     const unsigned zz = phased ? 0u : z;
     const unsigned col = (unsigned)d.k_off + (phased ? z * K : 0u) + k;
     d.dst[(((size_t)zz * d.Np + d.n_off + n) * T + t) * d.Kp + col] = v;
-    if (d.split) split_store(d.split, d.nch, d.T, d.ntn, (int)zz, d.n_off + (int)n, (int)t, (int)col, v);
+    if (d.split) split_store(d.split, d.nch, d.T, d.ntn, d.ntg, (int)zz, d.n_off + (int)n, (int)t, (int)col, v);
   }
 }
 
@@ -2994,10 +3236,11 @@ static size_t packed_fp32_floats(const ConvGeom& g) {
 size_t packed_floats(const ConvGeom& g) {
   if (split_shape_ok(g)) return packed_fp32_floats(g) + (size_t)(g.Cout / 32) * (g.Cin / 16) * (kSplitSlab / 4) + 128;
   if (split_shape_ok2(g)) return packed_fp32_floats(g) + (size_t)g.nz * (g.Cout / 32) * (g.Kw / 16) * (4 * 32 * kSplitRow / 4) + 512;
+  if (split_ntg(g)) return packed_fp32_floats(g) + (size_t)(g.Cout / 32) * (g.Cin / 16) * (32 * kSplitRow / 4) + 128;
   return packed_fp32_floats(g);
 }
 static unsigned short* split_part(const ConvGeom& g, float* w_packed) {
-  return (split_shape_ok(g) || split_shape_ok2(g)) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
+  return (split_shape_ok(g) || split_shape_ok2(g) || split_ntg(g)) ? reinterpret_cast<unsigned short*>(w_packed + packed_fp32_floats(g)) : nullptr;
 }
 
 // w_ref -> packed.  The packed matrix is sized by g (g.Cout rows, g.Cin columns); the source tensor covers rows
@@ -3014,7 +3257,7 @@ int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed
   if (blocks > 4096) blocks = 4096;
   unsigned short* split = (n_off == 0 && k_off == 0 && n_src <= 0 && k_src <= 0) ? split_part(g, w_packed) : nullptr;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, w_ref, w_packed, kind, g.nph > 1 ? 4 : g.nz, N, K, Np, Kp, srcKH,
-                     srcKW, T, n_off, k_off, split, Kp / 16, g.Cout / 32);
+                     srcKW, T, n_off, k_off, split, Kp / 16, g.Cout / 32, split_ntg(g) ? split_ntg(g) : 1);
   PIDM_CHECK_LAUNCH("pack_kernel");
   return 0;
 }
@@ -3030,6 +3273,7 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
   d->split = (n_off == 0 && k_off == 0 && n_src <= 0 && k_src <= 0) ? split_part(g, w_packed) : nullptr;
   d->nch = d->Kp / 16;
   d->ntn = g.Cout / 32;
+  d->ntg = split_ntg(g) ? split_ntg(g) : 1;
   if (g.nph > 1) { d->kind = (kind == 4) ? 6 : 5; d->nz = 4; }   // nz doubles as the phase count for kinds 5/6
   const size_t total = (size_t)d->nz * d->N * d->T * d->K;
   if (total >= ((size_t)1 << 31)) {          // pack_multi_kernel indexes a tensor in 32 bits
@@ -3244,6 +3488,50 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
     fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
             g.KW, g.nph, KC, nt4 ? 4 : NT);
+  {
+    // 1x1 / stride-1 convolutions as a split-form GEMM (conv1x1_split_kernel): contiguous channels-last input and output, pixel
+    // count a multiple of 128, whole 32-channel chunks from either source
+    const char* se = getenv("PIDM_CONV_SPLIT");
+    const int ntg = (se && !atoi(se)) ? 0 : split_ntg(g);
+    const long npix = (long)g.B * g.Hv * g.Wv;
+    // Measured (tools/bench_conv1x1.py, batch 64): with two stages per item (Cin = 64) the un-overlapped epilogue dominates - the
+    // memory-bound 64x64 layers and 64 -> 768 are slower than on the fp32 kernel, 64 -> 256 at 16x16 is twice as fast
+    const bool shape_pays = g.Cin >= 128 || (g.Cout <= 256 && npix <= 65536);
+    if (ntg && shape_pays && g.Hv == g.Hi && g.Wv == g.Wi && g.Ho == g.Hv && g.Wo == g.Wv && g.pad_y[0] == 0 && g.pad_x[0] == 0 && (npix % 128) == 0 &&
+        g.soc == 1 && g.soy == (long)g.Wo * g.sox && g.sob == (long)g.Ho * g.Wo * g.sox && (g.sox & 3) == 0 && (g.ld0 & 3) == 0 &&
+        (g.C0 % 32) == 0 && (g.C1 == 0 || (g.ld1 == g.ld0 && src1)) && (size_t)npix * g.ld0 * 4 < ((size_t)1 << 32) && !sigmoid_last &&
+        !g.gn_part && !g.bn_part && (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
+        (reinterpret_cast<size_t>(src0) & 15) == 0 && (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
+        (reinterpret_cast<size_t>(out) & 15) == 0) {
+      const int tiles_m = (int)(npix / 128);
+      const char* ce1 = getenv("PIDM_STREAM_WGS");           // (the unit tests lower it: several items per workgroup)
+      int n_cu1 = ce1 ? atoi(ce1) : 256;
+      if (n_cu1 < 1) n_cu1 = 256;
+      // tiles per workgroup: the packing's 4 unless that leaves CUs without an item
+      const int ntr = (ntg == 4 && tiles_m * (g.Cout / 128) < n_cu1) ? 2 : ntg;
+      const int n_items = tiles_m * (g.Cout / (32 * ntr));
+      const int ipw = cdiv(n_items, n_cu1), wgs = cdiv(n_items, ipw);
+      const size_t lds = (size_t)2 * (2 * 128 * kSplitRow + 2 * ntr * 32 * kSplitRow);
+      const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
+      static bool attr_1 = false;
+      if (!attr_1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_1 = true;
+      }
+      if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv1x1_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", ntr, ntg, n_items, wgs, lds);
+      const bool prof = prof_enabled();
+      if (prof) prof_begin_launch(2, 2.0 * (double)npix * (double)g.Cout * g.Cin, st);
+      const float* s1 = src1 ? src1 : src0;
+      if (ntr == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<4, 4>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      else if (ntg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 4>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 2>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      if (prof) prof_end_launch(st);
+      PIDM_CHECK_LAUNCH("conv1x1_split_kernel");
+      return 0;
+    }
+  }
   {
     // the 7x7 init convolution with (kx, channel) flattened into the contraction index, split form (conv7x7_split_kernel)
     const char* se = getenv("PIDM_CONV_SPLIT");

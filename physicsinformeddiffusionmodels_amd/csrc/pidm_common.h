@@ -185,6 +185,7 @@ struct PackDesc {
   int nch;                 // 16-channel chunks of a packed row (Kp / 16)
   int ntn;                 // 32-row tiles of one parity slab (Cout / 32)
   int tiled;               // 1: pack_multi_kernel's LDS-transposed 32 x 32 x taps form (k_conv.hip: pack_tile)
+  int ntg;                 // 32-row tiles per group in the piece layout (1; 4 / 2 for the 1x1 tensors conv1x1_split_kernel takes)
 };
 
 // one deferred fixed-order reduction (k_conv.hip: reduce_multi_kernel), queued during backward and run in ONE launch:

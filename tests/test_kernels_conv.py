@@ -59,6 +59,29 @@ def test_conv_1x1_permuted_tile(backend, monkeypatch, B, H, C0, C1, Cout, K, str
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+G1_CASES = [   # 1x1 convolutions as a split-form GEMM (conv1x1_split_kernel): forward takes it for Cout % 64 == 0, the input gradient for Cin % 64 == 0
+    (2, 16, 64, 0, 128, 1, 1, 0, 0),     # 512 pixels = 4 tiles, one group of four 32-channel tiles, two stages; dgrad: groups of two
+    (1, 16, 128, 0, 768, 1, 1, 0, 0),    # to_qkv of the 16x16 level: six groups of four; dgrad 768 -> 128: 24 stages
+    (2, 8, 64, 64, 64, 1, 1, 0, 0),      # concatenated sources (res_conv of the up path), groups of two both ways
+    (8, 4, 96, 0, 192, 1, 1, 0, 0),      # three stages, Cout = 6 tiles in groups of two (192 % 128 != 0); dgrad 192 -> 96: fp32 kernel
+    (1, 16, 256, 0, 512, 1, 1, 0, 0),    # 2 pixel tiles x 4 groups: fewer items than the (lowered) workgroup count -> half groups on the packing of four
+    (256, 1, 64, 0, 128, 1, 1, 0, 0),    # a linear (1x1 images): never this kernel (the FiLM linears are packed in sub-blocks without pieces)
+]
+
+
+@pytest.mark.parametrize("wgs", [None, "3", "64"])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", G1_CASES)
+def test_conv_1x1_split_gemm(backend, monkeypatch, wgs, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """wgs = 3: three persistent workgroups walk all items (several pixel tiles and n-groups per workgroup, accumulator restarts);
+    and the fp32 kernel on the same shapes."""
+    if wgs:
+        monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+    if not wgs:
+        monkeypatch.setenv("PIDM_CONV_SPLIT", "0")
+        test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
 STREAM_CASES = [   # 1x1 weight gradients on the LDS-free streaming kernels: ragged pixel counts and channel groups
     (75, 1, 32, 0, 200, 1, 1, 0, 0),     # 128-wide dY operand, last group ragged (72 of 128), 75 pixels (1x1 images)
     (49, 1, 32, 100, 24, 1, 1, 0, 0),    # 128-wide X operand across a concat boundary (32 + 100 channels), Cout < 32, 49 pixels

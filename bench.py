@@ -560,8 +560,9 @@ def main():
             workload = ("sample.py DDPM sampling, Darcy 64x64, 1000-step schedule, Unet3D dim=32; a step = one p_sample step of the "
                         "whole batch (a full chain = 1000 steps; sample.py:145-150)")
         cfg = {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-               "arithmetic": "fp32 tensors and accumulation; 3x3 convolution contractions (fwd, dgrad, wgrad) and the pixel sums / projections "
-                             "of the projected attention forward and of G = qs^T dY as 6 bf16 MFMA terms on "
+               "arithmetic": "fp32 tensors and accumulation; 3x3 / 4x4-stride-2 / 7x7 convolution contractions (fwd, dgrad, 3x3 wgrad), the "
+                             "compute-bound 1x1 convolutions (fwd, dgrad) and the pixel sums / projections of the projected attention "
+                             "as 6 bf16 MFMA terms on "
                              "round-to-nearest 3-piece splits of both operands (24 mantissa bits; error <= the fp32 MFMA's own, "
                              "profiles/r02_bf16_split_probe.txt), everything else fp32 MFMA / VALU"}
         if train:

@@ -379,6 +379,41 @@ def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
         assert e_split < 2e-6, (what, errs)
 
 
+def test_1x1_split_gemm_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
+    """conv1x1_split_kernel against a float64 product, next to the fp32-MFMA kernel on the same data, at the longest contraction of
+    the Darcy model (K = 768: the input gradient of to_qkv; 48 k-steps x 6 terms in two accumulator chains): forward and
+    input-gradient errors within 1.25x of the fp32 kernel's and below 2e-6 of the result's scale."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(98)
+    B, H, Cin, Cout = 2, 16, 768, 128
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None)
+    ref.backward(dy.double())
+    x0, dyn, wd_ = nhwc(x).to(dev), nhwc(dy).to(dev), w.to(dev)
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=1, KW=1, stride=1, pad=0, transposed=0, out_nchw=0, ldo=Cout)
+    errs = {}
+    for form in ("split", "fp32"):
+        monkeypatch.setenv("PIDM_CONV_SPLIT", "1" if form == "split" else "0")
+        wp = torch.empty(L.pidm_conv_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wp), 0, st))
+        out = torch.empty(B, H, H, Cout, device=dev)
+        L.check(L.pidm_conv_forward(d, ptr(x0), None, ptr(wp), None, None, ptr(out), st))
+        wdg = torch.empty(L.pidm_conv_dgrad_packed_weight_floats(d), device=dev)
+        L.check(L.pidm_conv_pack_weights(d, ptr(wd_), ptr(wdg), 1, st))
+        dx = torch.empty(B, H, H, Cin, device=dev)
+        L.check(L.pidm_conv_dgrad(d, ptr(dyn), Cout, ptr(wdg), None, ptr(dx), Cin, st))
+        errs[form] = [float((a.double().cpu() - b).abs().max() / b.abs().max()) for a, b in
+                      ((out, nhwc(ref.detach())), (dx, nhwc(xr.grad)))]
+    print("max error / max |reference| (forward K=768, dgrad K=128):", errs)
+    for e_split, e_fp32, what in zip(errs["split"], errs["fp32"], ("forward", "dgrad")):
+        assert e_split < 1.25 * e_fp32 + 1e-8, (what, errs)
+        assert e_split < 2e-6, (what, errs)
+
+
 @pytest.mark.parametrize("form", ["split", "fp32"])
 def test_conv_extreme_magnitudes(backend, monkeypatch, form):
     """Non-finite and extreme inputs through the 3x3 kernels, split form next to the fp32-MFMA form (same expectations for both):

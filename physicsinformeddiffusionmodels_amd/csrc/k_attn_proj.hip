@@ -151,6 +151,19 @@ static int lap_nper_split(int N, int C) {
   while (n > 32 && N % n) n >>= 1;
   return n;
 }
+// Tile groups of lap_bwd: the pixel-sum kernels run one wave per head, so with heads <= 4 (attn_heads below the model's default of 8)
+// half of the workgroup's 8 wave slots would idle after staging while the others run their dependent MFMA chains alone on their SIMD.
+// With G groups wave w takes head w % heads and every G-th tile of the slab (group w / heads); the groups' weight-gradient shares are
+// summed through LDS at the end.  Measured at 4 heads, batch 64: lap_bwd 224 -> 181 us (64x64, C = 32), 220 -> 178 us (32x32, C = 64).
+// lap_kctx_split / lap_g_split stay at one wave per head: groups there mean G partials per range, and what the pixel-sum kernels
+// gain (2 - 4 us) their merge kernels lose twice over (+8 us lap_kctx_final, +19 us lap_mid).
+static int lap_groups(int heads, int ntiles) {
+  const char* e = getenv("PIDM_LAP_GROUPS");      // 1: one wave per head, the other slots idle (A/B measurements)
+  int g = 8 / heads;
+  if (e && atoi(e) > 0 && atoi(e) < g) g = atoi(e);
+  while (g > 1 && ntiles % g) --g;
+  return g < 1 ? 1 : g;
+}
 template <int CB>
 __global__ void __launch_bounds__(512) lap_kctx_split_kernel(const float* __restrict__ xn, const float* __restrict__ wqkv,
                                                              float* __restrict__ part, int N, int heads, int nper) {
@@ -881,7 +894,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ kst, const float* __restrict__ dMmat,
                                                       const float* __restrict__ rowdot, float* __restrict__ dxn,
                                                       float* __restrict__ dw_part, int N, int heads, int nper, int nsub,
-                                                      float scale, int split_dw) {
+                                                      float scale, int split_dw, int G) {
   constexpr int C = 32 * CB, CP = C + 4;
   static_assert(!SP || CB == 1, "the split projections keep the head's operand matrices in registers: C = 32 only");
   constexpr int WCP = SP ? C : CP;                    // row stride of Wq | Wk | dM in LDS
@@ -896,28 +909,29 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // dM - live in LDS, rows padded to CP: fetched through L1 with the register file full, every one of those MFMAs waited for its
   // own load (measured: 52 % of the matrix-core rate for the whole kernel)
   constexpr bool WLDS = (CB == 1);
-  float* wl = cst + 8 * 96;                           // [3][8*32][CP] when WLDS
+  float* wl = cst + 8 * 96;                           // [3][heads*32][WCP] when WLDS
   // split_dw: the weight-gradient pixel sums dWq += dq xn, dWk += dk xn run on the bf16 pipe (3-piece operands): xn of the range also
   // as pieces [piece][c][px] (B operand, pixels contiguous), dq / dk through the wave's tile as before (A operand: 8 pixels of a row)
   const int RT = nper * 2 + (WLDS ? 0 : 16);          // bytes per XT row (C = 32: no room for the conflict-avoiding pad)
-  char* XT = reinterpret_cast<char*>(wl + (WLDS ? 3 * 256 * WCP : 0));
+  const int HD = heads * kLapDH;
+  char* XT = reinterpret_cast<char*>(wl + (WLDS ? 3 * HD * WCP : 0));
   char* XP = XT + (size_t)3 * C * RT;                 // SP: [nper][PR] xn pieces, then the same for dY
   char* YP = XP + (size_t)nper * PR;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = N / (nper * nsub);                  // workgroups per image: each walks nsub consecutive pixel ranges
   const int b = blockIdx.x / NW, nw = blockIdx.x % NW;
-  const int HD = heads * kLapDH;
   if (WLDS) {
     for (int e = tid; e < 3 * HD * (C / 4); e += 512) {
       const int m = e / (HD * (C / 4)), rem = e - m * (HD * (C / 4));
       const int row = rem / (C / 4), q = rem - row * (C / 4);
       const float* src = (m < 2) ? wqkv + ((size_t)m * HD + row) * C : dMmat + ((size_t)b * HD + row) * C;
-      *reinterpret_cast<f32x4*>(wl + ((size_t)m * 256 + row) * WCP + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      *reinterpret_cast<f32x4*>(wl + ((size_t)m * HD + row) * WCP + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
     }
   }
-  const int h = wave;
-  const bool act = h < heads;
+  // wave -> (tile group, head): group tg takes tiles tg, tg + G, .. of every slab (lap_groups above)
+  const int tg = wave / heads, h = wave - tg * heads;
+  const bool act = tg < G;
   float* tw = tiles + (size_t)wave * TSZ;
   float* cw = cst + wave * 96;
   if (act && half == 0) {
@@ -932,8 +946,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   const size_t bh = (size_t)b * heads + (act ? h : 0);
   const int hrow = (act ? h : 0) * kLapDH + l31;
   const float* wq_p = WLDS ? wl + (size_t)hrow * WCP + 4 * half : wqkv + (size_t)hrow * C + 4 * half;
-  const float* wk_p = WLDS ? wl + (size_t)(256 + hrow) * WCP + 4 * half : wqkv + ((size_t)HD + hrow) * C + 4 * half;
-  const float* dm_p = WLDS ? wl + (size_t)(512 + hrow) * WCP + 4 * half : dMmat + (bh * 32 + l31) * C + 4 * half;
+  const float* wk_p = WLDS ? wl + (size_t)(HD + hrow) * WCP + 4 * half : wqkv + ((size_t)HD + hrow) * C + 4 * half;
+  const float* dm_p = WLDS ? wl + (size_t)(2 * HD + hrow) * WCP + 4 * half : dMmat + (bh * 32 + l31) * C + 4 * half;
   const float* pp_p = P + (bh * 32 + l31) * C + 4 * half;
   // SP: the head's operand rows as bf16 pieces in registers: f..[k-step][piece], lane = (d = l31, k = 16 ks + 8 half + 0..7)
   u32x4 fwq[SP ? C / 16 : 1][3], fwk[SP ? C / 16 : 1][3], fpp[SP ? C / 16 : 1][3], fdm[SP ? C / 16 : 1][3];
@@ -941,8 +955,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     __syncthreads();                                  // Wq | Wk | dM are in LDS
 #pragma unroll
     for (int ks = 0; ks < C / 16; ++ks) {
-      const float* srcs[4] = {wl + (size_t)hrow * WCP + 16 * ks + 8 * half, wl + (size_t)(256 + hrow) * WCP + 16 * ks + 8 * half,
-                              P + (bh * 32 + l31) * C + 16 * ks + 8 * half, wl + (size_t)(512 + hrow) * WCP + 16 * ks + 8 * half};
+      const float* srcs[4] = {wl + (size_t)hrow * WCP + 16 * ks + 8 * half, wl + (size_t)(HD + hrow) * WCP + 16 * ks + 8 * half,
+                              P + (bh * 32 + l31) * C + 16 * ks + 8 * half, wl + (size_t)(2 * HD + hrow) * WCP + 16 * ks + 8 * half};
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(srcs[m]), v1 = *reinterpret_cast<const f32x4*>(srcs[m] + 4);
@@ -965,9 +979,10 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   }
   // Wq_h[d][c = l31 + 32 cb] etc. for the d_xn products (A operand, lane = c); row stride ldT
   const int ldT = WLDS ? WCP : C;
-  const float* wqT = WLDS ? wl + (size_t)(h * kLapDH) * WCP + l31 : wqkv + (size_t)h * kLapDH * C + l31;
-  const float* wkT = WLDS ? wl + (size_t)(256 + h * kLapDH) * WCP + l31 : wqkv + ((size_t)HD + h * kLapDH) * C + l31;
-  const float* dmT = WLDS ? wl + (size_t)(512 + h * kLapDH) * WCP + l31 : dMmat + ((size_t)b * heads + h) * 32 * C + l31;
+  const int hT = act ? h : 0;
+  const float* wqT = WLDS ? wl + (size_t)(hT * kLapDH) * WCP + l31 : wqkv + (size_t)hT * kLapDH * C + l31;
+  const float* wkT = WLDS ? wl + (size_t)(HD + hT * kLapDH) * WCP + l31 : wqkv + ((size_t)HD + hT * kLapDH) * C + l31;
+  const float* dmT = WLDS ? wl + (size_t)(2 * HD + hT * kLapDH) * WCP + l31 : dMmat + ((size_t)b * heads + hT) * 32 * C + l31;
 
   const float rscale = 1.f / scale;
   // dW[d][c] += sum_px g[d][px] xn[px][c] for the tile: g (lane = px, 16 rows d per lane) is turned through the wave's LDS tile
@@ -1010,6 +1025,18 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     }                                                                                                              \
     PIDM_WAVE_LDS_SYNC();                                                                                          \
   }
+#define PIDM_LAP_SIX(acc_, fa_, fb_)                                                                               \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[2], fb_[0], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[2], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[1], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[0], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[1], acc_);                                                            \
+  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[0], acc_);
+  // the two waves of a SIMD (w and w + 4) walk the two halves of a tile's work in opposite order: the per-tile barriers keep all
+  // waves in step, and in the same order their matrix-pipe phases and their vector phases coincide instead of overlapping
+  const bool order_flip = (split_dw & 2) != 0;
+  split_dw &= 1;
+  const bool k_first = (wave & 4) != 0 && order_flip;
   for (int sub = 0; sub < nsub; ++sub) {
   const size_t pix0 = (size_t)b * N + ((size_t)nw * nsub + sub) * nper;
   // (re)stage the range's xn and dY slabs; the loop below ends on a barrier, so nobody still reads the previous range
@@ -1062,7 +1089,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (int t = 0; t < nper / 32; ++t) {
+  for (int t0 = 0; t0 < nper / 32; t0 += G) {
+    const int t = t0 + tg;                 // this wave's tile of the round (act waves only)
     f32x16 dx[CB];
     if (act) {
       int z0 = 0;
@@ -1074,19 +1102,13 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       // across the whole tile costs C/2 registers each)
       const float* xrow = xs + (size_t)(t * 32 + l31) * CP + 4 * half;
       const float* yrow = ys + (size_t)(t * 32 + l31) * CP + 4 * half;
-      // ---- q: qs^T[d][px], dqs^T[d][px] = P_h dY^T, softmax Jacobian per pixel (in-lane + other half) ----
-      f32x16 qt, dq;
-      for (int r = 0; r < 16; ++r) { qt[r] = 0.f; dq[r] = 0.f; }
       // SP: B operands of the projections: this lane's pixel, 8 channels per k-step half, three pieces each
       const char* xpr = XP + (size_t)(t * 32 + l31) * PR + 48 * half;
       const char* ypr = YP + (size_t)(t * 32 + l31) * PR + 48 * half;
-#define PIDM_LAP_SIX(acc_, fa_, fb_)                                                                               \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[2], fb_[0], acc_);                                                            \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[2], acc_);                                                            \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[1], acc_);                                                            \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[1], fb_[0], acc_);                                                            \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[1], acc_);                                                            \
-  acc_ = pidm_mfma_bf16_32x32x16(fa_[0], fb_[0], acc_);
+      // ---- q: qs^T[d][px], dqs^T[d][px] = P_h dY^T, softmax Jacobian per pixel (in-lane + other half) ----
+      auto q_part = [&]() __attribute__((always_inline)) {
+      f32x16 qt, dq;
+      for (int r = 0; r < 16; ++r) { qt[r] = 0.f; dq[r] = 0.f; }
       if constexpr (SP) {
 #pragma unroll
         for (int ks = 0; ks < C / 16; ++ks) {
@@ -1155,7 +1177,9 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       }
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
       PIDM_LAP_DW(dq, dWq)
+      };
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
+      auto k_part = [&]() __attribute__((always_inline)) {
       f32x16 kt, dk;
       for (int r = 0; r < 16; ++r) { kt[r] = 0.f; dk[r] = 0.f; }
       if constexpr (SP) {
@@ -1180,7 +1204,6 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         }
       }
       }
-#undef PIDM_LAP_SIX
       // per-head column constants in accumulator-row order (row d = lap_row(r, half)): k max, k 1/Z, rowdot from the wave's LDS block
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -1224,6 +1247,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         }
       }
       PIDM_LAP_DW(dk, dWk)
+      };
+      if (k_first) { k_part(); q_part(); } else { q_part(); k_part(); }
       // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
@@ -1231,21 +1256,45 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) tw[(cb * 32 + lap_row(r, half)) * kLapTileLd + l31] = dx[cb][r];
     }
     __syncthreads();
-    // sum over the heads (waves) and store d_xn rows: thread -> (pixel, 4 consecutive channels)
-    for (int e = tid; e < 32 * (C / 4); e += 512) {
-      const int px = e / (C / 4), c0 = 4 * (e - px * (C / 4));
+    // sum over the heads (waves of a group) and store d_xn rows of the round's G tiles: thread -> (pixel, 4 consecutive channels)
+    for (int e = tid; e < G * 32 * (C / 4); e += 512) {
+      const int px = e / (C / 4), c0 = 4 * (e - px * (C / 4));      // px: 0 .. 32 G - 1 (group = px / 32)
+      const int gq = px >> 5, p31 = px & 31;
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < heads; ++w) {
-        const float* tp = tiles + (size_t)w * TSZ + (size_t)c0 * kLapTileLd + px;
+      for (int w = gq * heads; w < (gq + 1) * heads; ++w) {
+        const float* tp = tiles + (size_t)w * TSZ + (size_t)c0 * kLapTileLd + p31;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] += tp[i * kLapTileLd];
       }
-      *reinterpret_cast<f32x4*>(dxn + (pix0 + (size_t)t * 32 + px) * C + c0) = o;
+      *reinterpret_cast<f32x4*>(dxn + (pix0 + (size_t)t0 * 32 + px) * C + c0) = o;
     }
     __syncthreads();
   }
   }
-  if (act) {
+  // the groups' dWq / dWk shares of a head are summed in group order through the waves' tiles (free after the last barrier above)
+  for (int m = 0; m < 2 && G > 1; ++m) {
+    if (act && tg > 0) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tw[(cb * 32 + lap_row(r, half)) * kLapTileLd + l31] = m ? dWk[cb][r] : dWq[cb][r];
+    }
+    __syncthreads();
+    if (act && tg == 0) {
+      for (int g = 1; g < G; ++g) {
+        const float* og = tiles + (size_t)(g * heads + h) * TSZ;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = og[(cb * 32 + lap_row(r, half)) * kLapTileLd + l31];
+            if (m) dWk[cb][r] += v; else dWq[cb][r] += v;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (act && tg == 0) {
     float* oq = dw_part + ((size_t)blockIdx.x * 2 * HD + h * kLapDH) * C;
     float* ok = oq + (size_t)HD * C;
 #pragma unroll
@@ -1257,6 +1306,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       }
   }
 #undef PIDM_LAP_DW
+#undef PIDM_LAP_SIX
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1392,11 +1442,18 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
                      heads, C, NS2);
   PIDM_CHECK_LAUNCH("lap_mid_kernel");
   const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;
+  // two tile groups when the heads leave wave slots free: the staged slab then holds two tiles (C = 32: two ranges per staging)
+  int G3 = lap_groups(heads, 2), nslab = np3, nsl = nsub;
+  if (G3 > 1 && (np3 / 32) % G3) {
+    if (nsub % G3 == 0) { nslab = np3 * G3; nsl = nsub / G3; } else G3 = 1;
+  }
+  const char* ofe = getenv("PIDM_LAP_ORDER_FLIP");            // 0: every wave runs a tile's q half before its k half
+  const int oflip = (ofe && !atoi(ofe)) ? 0 : 2;
   const int split_dw = !(spe && !atoi(spe)) ? 1 : 0;
   const char* ppe = getenv("PIDM_LAP_SPLIT_PROJ");            // 0: the four per-pixel projections of lap_bwd stay on the fp32 MFMA
   if (CB == 1 && split_dw && !(ppe && !atoi(ppe))) {
-    const size_t lds3p = ((size_t)8 * 32 * kLapTileLd + 8 * 96 + (size_t)3 * 256 * C) * sizeof(float) + (size_t)3 * C * (np3 * 2) +
-                         (size_t)2 * np3 * 208;
+    const size_t lds3p = ((size_t)8 * 32 * kLapTileLd + 8 * 96 + (size_t)3 * heads * kLapDH * C) * sizeof(float) + (size_t)3 * C * (nslab * 2) +
+                         (size_t)2 * nslab * 208;
     if (lds3p > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3p);
     static bool attr_p = false;
     if (!attr_p) {
@@ -1404,15 +1461,15 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
       attr_p = true;
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<1, true>), dim3(B * NS3), dim3(512), lds3p, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn,
-                       dwqk_part, N, heads, np3, nsub, scale, 1);
+                       dwqk_part, N, heads, nslab, nsl, scale, 1 | oflip, G3);
     PIDM_CHECK_LAUNCH("lap_bwd_kernel");
     return 0;
   }
-  const size_t lds3 = ((size_t)2 * np3 * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * 256 * (C + 4) : 0)) * sizeof(float) +
-                      (size_t)3 * C * (np3 * 2 + (CB == 1 ? 0 : 16));
+  const size_t lds3 = ((size_t)2 * nslab * (C + 4) + (size_t)8 * CB * 32 * kLapTileLd + 8 * 96 + (CB == 1 ? 3 * heads * kLapDH * (C + 4) : 0)) * sizeof(float) +
+                      (size_t)3 * C * (nslab * 2 + (CB == 1 ? 0 : 16));
   if (lds3 > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB, false>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
-                     N, heads, np3, nsub, scale, split_dw);
+                     N, heads, nslab, nsl, scale, split_dw | oflip, G3);
   PIDM_CHECK_LAUNCH("lap_bwd_kernel");
   return 0;
 }

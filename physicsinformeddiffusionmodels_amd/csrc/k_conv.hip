@@ -3851,8 +3851,12 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
         (g.ld0 & 3) == 0 && (ld_dy & 3) == 0 && (reinterpret_cast<size_t>(src0) & 15) == 0 &&
         (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) && (reinterpret_cast<size_t>(dy) & 15) == 0))
     return false;
-  const char* pe = getenv("PIDM_WGRAD_SPLIT_P");      // tests: force the 128-pixel tile
-  for (int P = (pe && atoi(pe) == 128) ? 128 : 256; P >= 128; P >>= 1) {
+  // the 128-pixel tile first where it measures faster than the 256-pixel one (shorter stage / k-step phases, same work per split):
+  // 64-wide images 4-7 % (64->32: 86 -> 80 us), 32- and 16-wide 0-3 %; the 8-wide levels are 1-2 % better on 256 (four whole images per
+  // tile instead of two).  PIDM_WGRAD_SPLIT_P = 128 | 256 forces the first try.
+  const char* pe = getenv("PIDM_WGRAD_SPLIT_P");
+  const int p0 = (pe && atoi(pe) == 128) ? 128 : (pe && atoi(pe) == 256) ? 256 : (g.Wv >= 16 ? 128 : 256);
+  for (int P = p0; P >= 128; P >>= 1) {
     WgradGeom wg = plan;
     if (!retile_bm(&wg.g, P)) continue;
     const ConvGeom& gp = wg.g;

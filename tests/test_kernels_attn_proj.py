@@ -64,7 +64,11 @@ CASES = [
     (2, 16, 8, 32),     # N = 256, one pixel range
     (1, 32, 8, 64),     # 32x32 level of the Darcy model (C = 64): two 64-channel blocks per tile
     (1, 64, 8, 32),     # 64x64 level: eight forward ranges, 16 / 32 backward ranges, online rescaling across tiles
-    (2, 8, 3, 32),      # N = 64, heads < 8: idle waves
+    (2, 8, 3, 32),      # N = 64, heads < 8: idle waves (a single range per workgroup: no tile groups in lap_bwd)
+    (1, 64, 4, 32),     # attn_heads = 4 at the 64x64 level: lap_bwd runs two tile groups and stages two ranges at once
+    (1, 32, 4, 64),     # ... at the 32x32 level: two tile groups over the two tiles of a C = 64 slab
+    (2, 32, 2, 32),     # 2 heads, 1 head: still two groups (a slab holds two tiles), the other wave slots idle
+    (1, 32, 1, 32),
 ]
 
 
@@ -96,3 +100,8 @@ def test_projected_attention_vs_oracle(backend, monkeypatch, form, B, H, heads, 
         sl = slice(c * HD, (c + 1) * HD)
         assert rel(dwq[sl], gwq[sl]) < 3e-5, name
     assert rel(dwo, gwo) < 3e-5
+    if heads <= 4 and form == "split":
+        # PIDM_LAP_GROUPS=1: lap_bwd with one wave per head and the other wave slots idle (the A/B knob) - same sums, another order
+        monkeypatch.setenv("PIDM_LAP_GROUPS", "1")
+        y1, dx1, dwq1, dwo1 = run_lap(L, dev, xn, w_qkv, w_out, b_out, resid, gy, heads)
+        assert rel(y1, y) < 2e-6 and rel(dx1, dx) < 2e-6 and rel(dwq1, dwq) < 5e-6 and rel(dwo1, dwo) < 5e-6

@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           PIDM_LAP_SIX(dq, fpp[ks], yb)
         }
       } else {
-#pragma unroll
+#pragma unroll 2
       for (int g8 = 0; g8 < C / 8; ++g8) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wq_p + z0 + 8 * g8);
         const f32x4 p4 = *reinterpret_cast<const f32x4*>(pp_p + z0 + 8 * g8);
@@ -1192,7 +1192,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           PIDM_LAP_SIX(dk, fdm[ks], xb)
         }
       } else {
-#pragma unroll
+#pragma unroll 2
       for (int g8 = 0; g8 < C / 8; ++g8) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk_p + z0 + 8 * g8);
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(dm_p + z0 + 8 * g8);

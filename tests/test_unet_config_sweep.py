@@ -20,6 +20,8 @@ CASES = {
     "repeated_width": (16, 2, dict(dim=8, dim_mults=(1, 1, 2))),
     "wide_first_level": (16, 2, dict(dim=16, dim_mults=(2, 4))),
     "heads_4": (16, 2, dict(dim=8, attn_heads=4)),
+    # 32 / 64 channels at 32x32 / 16x16: the projected linear attention, whose backward runs two tile groups when attn_heads <= 4
+    "heads_4_projected_attention": (32, 1, dict(dim=32, dim_mults=(1, 2, 4), attn_heads=4)),
     "groups_4": (16, 2, dict(dim=8, resnet_groups=4)),
     "init_kernel_5": (16, 2, dict(dim=8, init_kernel_size=5)),
     "init_kernel_3": (16, 2, dict(dim=8, init_kernel_size=3)),

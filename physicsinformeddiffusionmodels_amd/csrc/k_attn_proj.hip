@@ -32,6 +32,9 @@
 namespace pidm {
 
 static const int kLapDH = 32;
+// threads of the two per-(image, head) merge kernels (lap_kctx_final, lap_mid): B * heads workgroups walk five or six dependent
+// phases of 32-term dot products; with 1024 threads every output element has its own thread and a phase is one chain long
+constexpr int kLapSmallNT = 1024;
 static const int kLapTileLd = 33;    // row stride of a wave's 32x32 transposition tile (conflict-free in both directions)
 
 __device__ __forceinline__ float lap_exp(float x) { return __expf(x); }
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(512) lap_kctx_split_kernel(const float* __rest
 }
 
 // forward 1b, per (image, head): merge the pixel ranges; M = Mt / Z, kst = (m, 1/Z), ctx = M Wv^T / N, P = ctx Wout_h^T
-__global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __restrict__ part, const float* __restrict__ wqkv,
+__global__ void __launch_bounds__(kLapSmallNT) lap_kctx_final_kernel(const float* __restrict__ part, const float* __restrict__ wqkv,
                                                              const float* __restrict__ wout, float* __restrict__ kst,
                                                              float* __restrict__ Mmat, float* __restrict__ ctx,
                                                              float* __restrict__ P, int N, int heads, int C, int NS) {
@@ -334,19 +337,24 @@ __global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __rest
   float* sW = sM + 32 * C;          // [32][C+1] Wv_h rows, later Wout[:, h*32 .. +32] as [C][33]
   float* sC = sW + 32 * (C + 1) + C;   // [32][33] ctx
   float* sw = sC + 32 * 33;         // [NS][32] merge weights
+  float* sst = sw + NS * 32;        // [NS][64] the ranges' (m, Z) rows
   __shared__ float sm_[32], siz[32];
+  constexpr int NT = kLapSmallNT;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
   const int HD = heads * kLapDH;
   const size_t pstride = (size_t)(32 * C + 64);
   const float* p0 = part + ((size_t)b * NS * heads + h) * pstride;
+  // all threads fetch the ranges' statistics rows (2 x 32 floats each) at once; the 32 merging threads then walk them in LDS
+  for (int e = tid; e < NS * 64; e += NT) sst[e] = p0[(size_t)(e >> 6) * heads * pstride + 32 * C + (e & 63)];
+  __syncthreads();
   if (tid < 32) {
     float m = -3.0e38f;
-    for (int k = 0; k < NS; ++k) m = fmaxf(m, p0[(size_t)k * heads * pstride + 32 * C + tid]);
+    for (int k = 0; k < NS; ++k) m = fmaxf(m, sst[k * 64 + tid]);
     float z = 0.f;
     for (int k = 0; k < NS; ++k) {
-      const float w = lap_exp(p0[(size_t)k * heads * pstride + 32 * C + tid] - m);
+      const float w = lap_exp(sst[k * 64 + tid] - m);
       sw[k * 32 + tid] = w;
-      z += p0[(size_t)k * heads * pstride + 32 * C + 32 + tid] * w;
+      z += sst[k * 64 + 32 + tid] * w;
     }
     sm_[tid] = m;
     siz[tid] = 1.f / z;
@@ -354,7 +362,7 @@ __global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __rest
     kst[((size_t)blockIdx.x * 32 + tid) * 2 + 1] = 1.f / z;
   }
   __syncthreads();
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int d = e / C;
     float v = 0.f;
     for (int k = 0; k < NS; ++k) v += p0[(size_t)k * heads * pstride + e] * sw[k * 32 + d];
@@ -366,7 +374,7 @@ __global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __rest
   }
   __syncthreads();
   const float invN = 1.f / (float)N;
-  for (int e = tid; e < 1024; e += 256) {
+  for (int e = tid; e < 1024; e += NT) {
     const int d = e >> 5, ee = e & 31;
     float v = 0.f;
     for (int c = 0; c < C; ++c) v = fmaf(sM[d * C + c], sW[ee * (C + 1) + c], v);
@@ -375,12 +383,12 @@ __global__ void __launch_bounds__(256) lap_kctx_final_kernel(const float* __rest
     ctx[(size_t)blockIdx.x * 1024 + e] = v;
   }
   __syncthreads();
-  for (int e = tid; e < 32 * C; e += 256) {     // sW <- Wout[c'][h*32 + e] as [c'][33]
+  for (int e = tid; e < 32 * C; e += NT) {     // sW <- Wout[c'][h*32 + e] as [c'][33]
     const int cc = e >> 5, ee = e & 31;
     sW[cc * 33 + ee] = wout[(size_t)cc * HD + h * kLapDH + ee];
   }
   __syncthreads();
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int d = e / C, cc = e - d * C;
     float v = 0.f;
 #pragma unroll
@@ -807,7 +815,7 @@ __global__ void __launch_bounds__(512) lap_g_split_kernel(const float* __restric
 
 // backward 1b, per (image, head): G = sum of the ranges; dctx = G Wout_h; dWout share of this image; dM = dctx Wv / N;
 // dWv share of this image; rowdot[d] = sum_c dM[d][c] M[d][c]
-__global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ gpart, const float* __restrict__ wqkv,
+__global__ void __launch_bounds__(kLapSmallNT) lap_mid_kernel(const float* __restrict__ gpart, const float* __restrict__ wqkv,
                                                       const float* __restrict__ wout, const float* __restrict__ ctx,
                                                       const float* __restrict__ Mmat, float* __restrict__ dMmat,
                                                       float* __restrict__ rowdot, float* __restrict__ dwout_part,
@@ -817,10 +825,11 @@ __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ 
   float* sW = sG + 32 * (C + 1);          // [C][33] Wout[c'][h*32+e], later Wv_h [32][C+1]
   float* sD = sW + (C > 33 ? C : 33) * 33 + 32 * (C + 1);   // [32][33] dctx
   float* sM = sD + 32 * 33;               // [32][C+1] M, later dM
+  constexpr int NT = kLapSmallNT;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
   const int HD = heads * kLapDH;
   const float* g0 = gpart + ((size_t)b * NS * heads + h) * (size_t)(32 * C);
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int d = e / C, c = e - d * C;
     float v = 0.f;
     for (int k = 0; k < NS; ++k) v += g0[(size_t)k * heads * 32 * C + e];
@@ -830,14 +839,14 @@ __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ 
     sW[cc * 33 + ee] = wout[(size_t)cc * HD + h * kLapDH + ee];
   }
   __syncthreads();
-  for (int e = tid; e < 1024; e += 256) {           // dctx[d][e] = sum_c' G[d][c'] Wout[c'][h*32+e]
+  for (int e = tid; e < 1024; e += NT) {           // dctx[d][e] = sum_c' G[d][c'] Wout[c'][h*32+e]
     const int d = e >> 5, ee = e & 31;
     float v = 0.f;
     for (int c = 0; c < C; ++c) v = fmaf(sG[d * (C + 1) + c], sW[c * 33 + ee], v);
     sD[d * 33 + ee] = v;
   }
   // dWout[c'][h*32+e] share of this image = sum_d G[d][c'] ctx[d][e]
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int cc = e >> 5, ee = e & 31;
     float v = 0.f;
 #pragma unroll 8
@@ -845,14 +854,14 @@ __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ 
     dwout_part[((size_t)b * C + cc) * HD + h * kLapDH + ee] = v;
   }
   __syncthreads();
-  for (int e = tid; e < 32 * C; e += 256) {         // sW <- Wv_h[e][c] as [32][C+1]
+  for (int e = tid; e < 32 * C; e += NT) {         // sW <- Wv_h[e][c] as [32][C+1]
     const int ee = e / C, c = e - ee * C;
     sW[ee * (C + 1) + c] = wqkv[((size_t)2 * HD + h * kLapDH + ee) * C + c];
   }
   __syncthreads();
   const float invN = 1.f / (float)N;
   // dWv[h*32+e][c] share of this image = sum_d dctx[d][e] M[d][c] / N
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int ee = e / C, c = e - ee * C;
     float v = 0.f;
 #pragma unroll 8
@@ -861,7 +870,7 @@ __global__ void __launch_bounds__(256) lap_mid_kernel(const float* __restrict__ 
   }
   __syncthreads();
   // dM[d][c] = sum_e dctx[d][e] Wv[e][c] / N; rowdot[d] = sum_c dM[d][c] M[d][c]
-  for (int e = tid; e < 32 * C; e += 256) {
+  for (int e = tid; e < 32 * C; e += NT) {
     const int d = e / C, c = e - d * C;
     float v = 0.f;
 #pragma unroll 8
@@ -1366,8 +1375,8 @@ static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_kernel<CB>), dim3(B * NS), dim3(512), lds1, st, xn, wqkv, scratch, N, heads, nper);
   }
   PIDM_CHECK_LAUNCH("lap_kctx_kernel");
-  const size_t lds2 = ((size_t)32 * C + 32 * (C + 1) + C + 32 * 33 + (size_t)NS * 32 + 64) * sizeof(float);
-  hipLaunchKernelGGL(lap_kctx_final_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, kst, Mmat, ctx, P, N, heads, C, NS);
+  const size_t lds2 = ((size_t)32 * C + 32 * (C + 1) + C + 32 * 33 + (size_t)NS * 96 + 64) * sizeof(float);
+  hipLaunchKernelGGL(lap_kctx_final_kernel, dim3(B * heads), dim3(kLapSmallNT), lds2, st, scratch, wqkv, wout, kst, Mmat, ctx, P, N, heads, C, NS);
   PIDM_CHECK_LAUNCH("lap_kctx_final_kernel");
   const int HD = heads * kLapDH;
   const size_t lds3 = ((size_t)HD * (C + 4) + (size_t)HD * C) * sizeof(float);
@@ -1438,7 +1447,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   }
   PIDM_CHECK_LAUNCH("lap_g_kernel");
   const size_t lds2 = ((size_t)32 * (C + 1) + (size_t)(C > 33 ? C : 33) * 33 + 32 * (C + 1) + 32 * 33 + 32 * (C + 1) + 64) * sizeof(float);
-  hipLaunchKernelGGL(lap_mid_kernel, dim3(B * heads), dim3(256), lds2, st, scratch, wqkv, wout, ctx, Mmat, dMmat, rowdot, dwout_part, dwv_part, N,
+  hipLaunchKernelGGL(lap_mid_kernel, dim3(B * heads), dim3(kLapSmallNT), lds2, st, scratch, wqkv, wout, ctx, Mmat, dMmat, rowdot, dwout_part, dwv_part, N,
                      heads, C, NS2);
   PIDM_CHECK_LAUNCH("lap_mid_kernel");
   const int np3 = lap_nper(N, C, 3), nsub = lap_nsub(N, C), NS3 = N / np3 / nsub;

@@ -412,6 +412,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ res,   // BWD: added to dx (residual path)
                                                         float* __restrict__ out,         // FWD: y ; BWD: dx
                                                         float* __restrict__ dgamma_partial,  // BWD: [gridDim.x][C]
+                                                        float* __restrict__ rsum_partial,    // BWD, may be null: [gridDim.x][C] column
+                                                                                             // sums of `res` (the bias gradient of the
+                                                                                             // projection in front of the residual add)
                                                         size_t npix, int C, float eps) {
   __shared__ float dgs[256][16];
   const int C4 = C / 4;
@@ -419,9 +422,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   const int NQ = C4 / TPP;  // quads per lane (1..4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane / TPP, ql = lane % TPP, ppw = 64 / TPP;
-  float dg[16];
+  float dg[16], rs[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) dg[k] = 0.f;
+  for (int k = 0; k < 16; ++k) { dg[k] = 0.f; rs[k] = 0.f; }
   const size_t wave_global = (size_t)blockIdx.x * 4 + wave, nwaves = (size_t)gridDim.x * 4;
   for (size_t pbase = wave_global * ppw; pbase < npix; pbase += nwaves * ppw) {
     const size_t p = pbase + sub;
@@ -497,7 +500,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
           if (res) {
             const float4 r = *reinterpret_cast<const float4*>(res + p * C + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] += r[k];
+            for (int k = 0; k < 4; ++k) {
+              o[k] += r[k];
+              rs[j * 4 + k] += r[k];
+            }
           }
           *reinterpret_cast<float4*>(out + p * C + c) = o;
         }
@@ -514,6 +520,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       for (int w = 0; w < 4; ++w)
         for (int sb = 0; sb < ppw; ++sb) a += dgs[w * 64 + sb * TPP + qlane][j * 4 + k];
       dgamma_partial[(size_t)blockIdx.x * C + c] = a;
+    }
+    if (rsum_partial) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dgs[tid][k] = rs[k];
+      __syncthreads();
+      for (int c = tid; c < C; c += 256) {
+        const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
+        float a = 0.f;
+        for (int w = 0; w < 4; ++w)
+          for (int sb = 0; sb < ppw; ++sb) a += dgs[w * 64 + sb * TPP + qlane][j * 4 + k];
+        rsum_partial[(size_t)blockIdx.x * C + c] = a;
+      }
     }
   }
 }
@@ -725,29 +744,35 @@ static bool ln_ok(int C) {
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
-                     nullptr, y, nullptr, npix, C, 1e-5f);
+                     nullptr, y, nullptr, nullptr, npix, C, 1e-5f);
   PIDM_CHECK_LAUNCH("layernorm_fwd");
   return 0;
 }
 
-size_t layernorm_bwd_ws_bytes(int C) { return (size_t)1024 * C * sizeof(float); }
+// two rows of per-block partials (dgamma, column sums of `res`), at most 1024 blocks
+size_t layernorm_bwd_ws_bytes(int C) { return (size_t)2 * 1024 * C * sizeof(float); }
 
-// dx = LN_bwd(dy) + res ; dgamma = sum_pix dy * xhat
+// dx = LN_bwd(dy) + res ; dgamma = sum_pix dy * xhat ; res_colsum (may be null) = sum_pix res - the kernel reads `res` anyway, and
+// in the attention blocks that sum is the bias gradient of the to_out projection (a separate column-sum pass over dY otherwise)
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer) {
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer, float* res_colsum) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
+  if (res_colsum && !res) return fail("layernorm_bwd: column sums of a null residual");
   const int nb = ln_blocks(npix, C);
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, npix, C,
+  float* partial2 = res_colsum ? partial + (size_t)nb * C : nullptr;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
                      1e-5f);
   PIDM_CHECK_LAUNCH("layernorm_bwd");
   if (defer) {   // `ws` (the per-block partial rows) stays alive until the caller's reduce_multi launch
     defer->push(partial, dgamma, nullptr, nullptr, (size_t)C, nb, 1, C, 1, 1, C);
+    if (res_colsum) defer->push(partial2, res_colsum, nullptr, nullptr, (size_t)C, nb, 1, C, 1, 1, C);
     return 0;
   }
   // fixed-order sum of the per-block partials
-  char* ws2 = reinterpret_cast<char*>(ws) + (size_t)nb * C * sizeof(float);
-  return launch_colsum(partial, (size_t)nb, C, C, dgamma, ws2, st);
+  char* ws2 = reinterpret_cast<char*>(ws) + (size_t)2 * nb * C * sizeof(float);
+  if (launch_colsum(partial, (size_t)nb, C, C, dgamma, ws2, st)) return -1;
+  return res_colsum ? launch_colsum(partial2, (size_t)nb, C, C, res_colsum, ws2, st) : 0;
 }
 
 int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st) {

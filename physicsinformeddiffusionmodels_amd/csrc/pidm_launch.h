@@ -60,7 +60,7 @@ int launch_gn_bwd(const float* x, const float* dy, const float* stats, const flo
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st);
 size_t layernorm_bwd_ws_bytes(int C);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer = nullptr);
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer = nullptr, float* res_colsum = nullptr);
 int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);
 int launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
 int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st);

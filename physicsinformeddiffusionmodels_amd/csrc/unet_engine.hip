@@ -944,6 +944,7 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   const size_t mk = r.tmp.mark();
   float* g_qkv = nullptr;
   float* g_xn = nullptr;
+  bool out_bias_with_ln = false;
   if (r.dry ? attn_projected(a, heads) : a.projected) {
     // no qkv tensor, no dqkv tensor: d_xn and the to_qkv / to_out weight-gradient shares come straight from (xn, dY)
     const size_t nr = (size_t)B * lap_dw_ranges(N, C);
@@ -951,7 +952,6 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
     float* dwqk = r.defer_on ? r.defer.alloc(n_qk) : r.tmp.alloc(n_qk);
     float* dwv = r.defer_on ? r.defer.alloc(n_v) : r.tmp.alloc(n_v);
     float* dwo = r.defer_on ? r.defer.alloc(n_o) : r.tmp.alloc(n_o);
-    float* cpart = r.part_alloc(colsum_ws_bytes(npix, C));
     float* ltmp = r.tmp.alloc(lap_bwd_tmp_floats(B, heads, C));
     g_xn = r.tmp.alloc(npix * C);
     RUN(launch_lap_backward(a.xn, g_out, U->P[a.qkv.w], U->P[a.out.w], a.lsaved, a.qstat, g_xn, dwqk, dwv, dwo, ltmp, C, B, N, heads, r.scratch,
@@ -967,10 +967,11 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
         RUN(launch_split_reduce(dwv, gw + (size_t)2 * HD * C, nullptr, nullptr, B, HD, C, 1, HD, C, r.st));
         RUN(launch_split_reduce(dwo, U->G[a.out.w], nullptr, nullptr, B, C, HD, 1, C, HD, r.st));
       }
-      RUN(launch_colsum(g_out, npix, C, C, U->G[a.out.b], cpart, r.st, r.q()));
     }
+    // the to_out bias gradient (column sums of g_out) rides with the LayerNorm backward, which reads g_out as its residual share
     float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
-    RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
+    RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q(),
+                             (U->have_grads && !r.dry) ? U->G[a.out.b] : nullptr));
     if (!r.keep_frames()) r.tmp.release(mk);
     return 0;
   }
@@ -982,13 +983,12 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
     float* rowdot = r.tmp.alloc((size_t)B * heads * 32);
     const size_t dwn = (size_t)B * C * HD;
     float* dwpart = r.defer_on ? r.defer.alloc(dwn) : r.tmp.alloc(dwn);
-    float* cpart = (a.out.b >= 0) ? r.part_alloc(colsum_ws_bytes(npix, C)) : nullptr;
     RUN(launch_la_backward_fused(a.qkvb, a.kstat, a.qstat, a.ctx, g_out, C, U->P[a.out.w], C, dctx, rowdot, g_qkv, dwpart, B, N,
                                  heads, r.scratch, r.st));
     if (U->have_grads && !r.dry) {
       if (r.q()) r.q()->push(dwpart, U->G[a.out.w], nullptr, nullptr, (size_t)C * HD, B, C, HD, 1, C, HD);
       else RUN(launch_split_reduce(dwpart, U->G[a.out.w], nullptr, nullptr, B, C, HD, 1, C, HD, r.st));
-      if (a.out.b >= 0) RUN(launch_colsum(g_out, npix, C, C, U->G[a.out.b], cpart, r.st, r.q()));
+      if (a.out.b >= 0) out_bias_with_ln = true;      // column sums of g_out: with the LayerNorm backward below
     }
     g_xn = r.tmp.alloc(npix * C);
   } else {
@@ -1009,7 +1009,8 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   if (conv_wgrad(r, a.qkv, a.xn, nullptr, g_qkv)) return -1;
   if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
   float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
-  RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q()));
+  RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q(),
+                           out_bias_with_ln ? U->G[a.out.b] : nullptr));
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
   // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
   if (!r.keep_frames()) r.tmp.release(mk);

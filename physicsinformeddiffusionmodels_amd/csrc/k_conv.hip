@@ -2724,7 +2724,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_smallc_kernel(WgradGeom wg, co
 #pragma unroll
       for (int k = 0; k < 16; ++k) bacc += Ys[(part * 16 + k) * 32 + o];
     }
-#pragma unroll 2
+#pragma unroll 8
     for (int ks = 0; ks < 64; ++ks) {
       const int p = 2 * ks + half;
       const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);

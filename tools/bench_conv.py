@@ -32,6 +32,8 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3  # us
 
 
+if os.environ.get("BENCH_CONV_SHAPES"):      # e.g. "64,128,0,768,1,1,0,0;16,256,0,128,1,1,0,0"
+    SHAPES = [tuple(int(v) for v in sh.split(",")) for sh in os.environ["BENCH_CONV_SHAPES"].split(";")]
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 totf = 0.0
 for (H, C0, C1, Cout, K, s, p, tr) in SHAPES:

@@ -2622,18 +2622,26 @@ __global__ void __launch_bounds__(768) conv_wgrad_split_kernel(WgradGeom wg, con
 #undef PIDM_WS_PREFETCH
   // ---- sum of the 4 pixel quarters through LDS, then the split's partial slab ----
   __syncthreads();
-  float* red = smemf;      // [12 waves][3 kx][1024]
+  // The channel permutation of the staging (row / column r = channel 4 (r & 7) + (r >> 3)) is undone on the way INTO LDS, so the
+  // sums are read as 16-byte vectors of four consecutive channels and leave as 16-byte stores (3 instead of 12 rounds per thread)
+  float* red = smemf;      // [12 waves][3 kx][32 dY channels][32 X channels]
+  const int colp = 4 * (l31 & 7) + (l31 >> 3);
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 3 + kx) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[kx][r];
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[(wave * 3 + kx) * 1024 + (4 * (row & 7) + (row >> 3)) * 32 + colp] = acc[kx][r];
+    }
   __syncthreads();
-  for (int e = tid; e < 9 * 1024; e += 768) {
-    const int tap = e >> 10, el = e & 1023, kyo = tap / 3, kxo = tap - 3 * kyo;
-    const float* rp = red + ((kyo * 4) * 3 + kxo) * 1024 + el;
-    const float sv = (rp[0] + rp[3 * 1024]) + (rp[6 * 1024] + rp[9 * 1024]);
-    const int rr_ = el >> 5, cc_ = el & 31;
-    partial[(((size_t)split * wg.MP + (m0 + 4 * (rr_ & 7) + (rr_ >> 3))) * 9 + tap) * wg.NP + n0 + 4 * (cc_ & 7) + (cc_ >> 3)] = sv;
+  for (int e = tid; e < 9 * 256; e += 768) {
+    const int tap = e >> 8, q4 = e & 255, kyo = tap / 3, kxo = tap - 3 * kyo;
+    const int mrow = q4 >> 3, c4 = (q4 & 7) * 4;
+    const float* rp = red + ((kyo * 4) * 3 + kxo) * 1024 + mrow * 32 + c4;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp), a1 = *reinterpret_cast<const f32x4*>(rp + 3 * 1024);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(rp + 6 * 1024), a3 = *reinterpret_cast<const f32x4*>(rp + 9 * 1024);
+    const f32x4 sv = (a0 + a1) + (a2 + a3);
+    *reinterpret_cast<f32x4*>(partial + (((size_t)split * wg.MP + (m0 + mrow)) * 9 + tap) * wg.NP + n0 + c4) = sv;
   }
   if (do_bias) {
     __syncthreads();

@@ -2040,13 +2040,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackDesc* __restr
 // one workgroup = 32 x 32 output block for up to `tgs` taps, over `tiles_per_split` pixel tiles;
 // the 4 waves split each 128-pixel tile 4-ways along K and are reduced through LDS at the end.
 // ---------------------------------------------------------------------------------------------------
-struct WgradGeom {
-  ConvGeom g;        // pixel tiling / halo geometry of the forward problem (Cout = channels of dY)
-  int ld_dy;         // channel stride of dY
-  int tgs, ntg;      // taps per group, number of groups
-  int nsplit, tiles_per_split;
-  int MP, NP;        // padded (to 32) rows / cols of the partial buffer
-};
+// (struct WgradGeom: pidm_common.h - shared with k_wgrad_rs.hip)
 
 template <int MAXT>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradGeom wg, const float* __restrict__ src0,
@@ -3971,7 +3965,8 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
-    } else if (launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
+    } else if (launch_wgrad_rs(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg) ||
+               launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
       if (prof) prof_reclass_last(3);   // split form: counted with the weight gradients and, separately, against the bf16 pipe
       // taken by the bf16-pipe kernel (wg now holds its tiling / split)
     } else {

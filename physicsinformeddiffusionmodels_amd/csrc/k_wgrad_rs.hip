@@ -1,0 +1,292 @@
+// 3x3 / stride-1 weight gradient on the bf16 matrix pipe, "row-streaming" form (round 4): no LDS and no barrier in the main loop.
+//
+// Replaces the backward of every 3x3 convolution's weight (`Block.proj`, /root/reference/src/unet_model.py:227 through
+// loss.backward(), main.py:164):  dW[m][ky][kx][n] = sum_p dY[p][m] X[p + (ky-1, kx-1)][n].
+//
+// The contraction index of a weight gradient is the PIXEL, so the 32x32x16 bf16 MFMA wants, per lane, 8 consecutive k values =
+// 8 pixels of ONE channel - while the tensors are channels-last.  conv_wgrad_split_kernel (k_conv.hip) transposes through
+// registers + LDS and then takes turns between staging and k-steps (matrix pipe 0.10-0.29 busy, profiles/r03_pmc_split_kernels.txt).
+// Here the transpose is the LOAD: lane l of a wave reads channel l & 31 of pixel x0 + j for j = 0..7 with eight dword loads -
+// each is two whole 128-byte lines (lanes 0-31: one pixel of strip A, lanes 32-63: one pixel of strip B) - and then owns exactly
+// the MFMA operand: 8 consecutive pixels of a row for its channel.  The values are split into their three bf16 pieces in
+// registers (pidm_common.h) and go straight into the MFMA.
+//
+//   work item  = a pair of "strips": 8 pixels wide, R rows high (R a power of two, chosen by the launcher so that every wave of
+//                the chip has an item), one strip per wave half; the wave walks DOWN the rows: a k-step = one row of both
+//                strips = 16 pixels, and the 3x3 window needs the X rows y-1, y, y+1 - of which y-1 and y are the previous
+//                k-steps' rows.  They stay in registers as pieces (rolling window of three rows), so each k-step loads and
+//                splits ONE new X row and ONE dY row: ~110 vector instructions next to 54 MFMAs (9 taps x 6 split terms).
+//   kx = 0 / 2 = the centre row's registers moved by one bf16 (v_alignbit with the piece of the pixel before / after, which is
+//                loaded and split with the row: 10 loads per X row).
+//   padding    = raw buffer loads: a row above / below the image, the pixel left of x = 0 / right of x = W-1 and the missing
+//                second strip of an odd tail are read with an out-of-range offset, which returns 0 without a memory access -
+//                no branches, no selects on the data.
+//   wave       = all 9 taps of a 32 (dY channels) x 32 (X channels) block: 144 accumulator registers, 108 registers of row
+//                pieces; one wave per SIMD (4 waves per workgroup and CU, 512-register budget), loads two k-steps ahead.
+//   workgroup  = (split, block): its 4 waves take consecutive items of the split's range; at the end the four accumulator sets
+//                are summed through LDS (fixed order) and leave as the split's partial slab, exactly the layout
+//                conv_wgrad_split_kernel writes - the deferred fixed-order reduction (reduce_multi_kernel) is unchanged, results
+//                stay bit-identical run to run.
+// Arithmetic per product: identical to conv_wgrad_split_kernel (same pieces, same six terms smallest first); only the order in
+// which pixels meet an accumulator differs.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "pidm_launch.h"
+
+namespace pidm {
+
+namespace {
+
+struct RsRow {        // the bf16 pieces of one X row segment: centre, moved right by one pixel (kx = 0), moved left (kx = 2)
+  u32x4 c[3], l[3], r[3];
+};
+
+__device__ __forceinline__ void rs_split_row(const float (&v)[10], RsRow& o) {
+  // v[0] = pixel before, v[1..8] = the 8 pixels, v[9] = pixel after
+  unsigned e[3];
+  pidm_split3_pk(v[9], v[0], e[0], e[1], e[2]);      // low half: after, high half: before
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned p0, p1, p2;
+    pidm_split3_pk(v[1 + 2 * k], v[2 + 2 * k], p0, p1, p2);
+    o.c[0][k] = p0; o.c[1][k] = p1; o.c[2][k] = p2;
+  }
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+    const unsigned m01 = __builtin_amdgcn_alignbit(o.c[pc][1], o.c[pc][0], 16), m12 = __builtin_amdgcn_alignbit(o.c[pc][2], o.c[pc][1], 16),
+                   m23 = __builtin_amdgcn_alignbit(o.c[pc][3], o.c[pc][2], 16);
+    o.l[pc] = u32x4{__builtin_amdgcn_alignbit(o.c[pc][0], e[pc], 16), m01, m12, m23};
+    o.r[pc] = u32x4{m01, m12, m23, __builtin_amdgcn_alignbit(e[pc], o.c[pc][3], 16)};
+  }
+}
+
+__device__ __forceinline__ float rs_split_dy(const float (&v)[8], u32x4 (&ya)[3]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned p0, p1, p2;
+    pidm_split3_pk(v[2 * k], v[2 * k + 1], p0, p1, p2);
+    ya[0][k] = p0; ya[1][k] = p1; ya[2][k] = p2;
+  }
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+// six bf16 terms of one fp32 product block, smallest first (pidm_common.h)
+#define PIDM_RS_SIX(acc_, ya_, xb_)                                    \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[2], xb_[0], acc_);               \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[0], xb_[2], acc_);               \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[1], xb_[1], acc_);               \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[1], xb_[0], acc_);               \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[0], xb_[1], acc_);               \
+  acc_ = pidm_mfma_bf16_32x32x16(ya_[0], xb_[0], acc_);
+
+constexpr unsigned kRsInv = 0x80000000u;   // a byte offset no tensor reaches (the launcher checks): reads as 0
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) conv_wgrad_rs_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                            const float* __restrict__ dy, float* __restrict__ partial,
+                                                            float* __restrict__ bias_partial) {
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][9 taps][32 dY channels][32 X channels]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = wg.NP / 32;
+  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int split = blockIdx.x;
+  const int H = g.Hi, W = g.Wi, R = wg.rs_R;
+  const int wsh = g.wsh;                                   // log2 W
+  const unsigned ldxb = (unsigned)g.ld0 * 4u, ldyb = (unsigned)wg.ld_dy * 4u;   // bytes between pixels
+  const unsigned rowxb = ldxb << wsh, rowyb = ldyb << wsh;                      // bytes between rows
+  const unsigned tot_x = (unsigned)g.B * (unsigned)H * rowxb, tot_y = (unsigned)g.B * (unsigned)H * rowyb;
+  // the n-tile lies in one source of a concatenation (C0 % 32 == 0, equal channel strides: checked by the launcher)
+  const float* xsrc = (n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0);
+  const pidm_rsrc rx = pidm_make_rsrc(xsrc, tot_x), ry = pidm_make_rsrc(dy + m0, tot_y);
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bacc = 0.f;
+
+  const int wv = split * 4 + wave;                         // this wave among the 4 * nsplit waves of the block
+  const int npairs = (wg.rs_S + 1) >> 1;
+  int pair_lo = wv * wg.rs_ppw, pair_hi = pair_lo + wg.rs_ppw;
+  if (pair_hi > npairs) pair_hi = npairs;
+
+  for (int pair = pair_lo; pair < pair_hi; ++pair) {
+    // ---- this lane's strip: s = ((b * (H / R) + chunk) * (W / 8) + xs) ----
+    const int s = 2 * pair + half;
+    const bool s_ok = s < wg.rs_S;
+    const int xs = s & ((1 << wg.rs_xsh) - 1), t1 = s >> wg.rs_xsh;
+    const int chunk = t1 & ((1 << wg.rs_csh) - 1), b = t1 >> wg.rs_csh;
+    const int x0 = xs << 3, r0 = chunk * R;
+    const bool left_ok = x0 > 0, right_ok = x0 + 8 < W;
+    // byte offset of (image b, row r0 - 1, pixel x0, this lane's channel) - may be "negative" for the row above the tensor,
+    // which is never dereferenced (its loads get kRsInv)
+    unsigned offx = ((unsigned)(b * H + r0 - 1) << wsh) * ldxb + (unsigned)x0 * ldxb + (unsigned)l31 * 4u;
+    unsigned offy = ((unsigned)(b * H + r0) << wsh) * ldyb + (unsigned)x0 * ldyb + (unsigned)l31 * 4u;
+    int yx = r0 - 1;          // image row the next X load reads
+    int ny = 0;               // dY rows of the chunk loaded so far
+
+    float rawx[2][10], rawy[2][8];
+#define PIDM_RS_LOAD_X(dst_)                                                                                        \
+  {                                                                                                                 \
+    const bool ok__ = s_ok & (yx >= 0) & (yx < H) & (yx <= r0 + R);                                                 \
+    const unsigned vc__ = ok__ ? offx : kRsInv, vp__ = (ok__ & left_ok) ? offx - ldxb : kRsInv,                     \
+                   vn__ = (ok__ & right_ok) ? offx : kRsInv;                                                        \
+    dst_[0] = pidm_buf_load_f32(rx, vp__, 0u);                                                                      \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) dst_[1 + j__] = pidm_buf_load_f32(rx, vc__, (unsigned)j__ * ldxb); \
+    dst_[9] = pidm_buf_load_f32(rx, vn__, 8u * ldxb);                                                               \
+    offx += rowxb;                                                                                                  \
+    ++yx;                                                                                                           \
+  }
+#define PIDM_RS_LOAD_Y(dst_)                                                                                        \
+  {                                                                                                                 \
+    const unsigned vy__ = (s_ok & (ny < R)) ? offy : kRsInv;                                                        \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) dst_[j__] = pidm_buf_load_f32(ry, vy__, (unsigned)j__ * ldyb); \
+    offy += rowyb;                                                                                                  \
+    ++ny;                                                                                                           \
+  }
+    RsRow rows[3];
+    u32x4 ya[2][3];
+    {
+      // prologue: rows r0 - 1 and r0 of X, row r0 of dY as pieces; X rows r0 + 1, r0 + 2 and dY rows r0 + 1, r0 + 2 in flight
+      float ta[10], tb[10], ty[8];
+      PIDM_RS_LOAD_X(ta)
+      PIDM_RS_LOAD_X(tb)
+      PIDM_RS_LOAD_Y(ty)
+      PIDM_RS_LOAD_X(rawx[0])
+      PIDM_RS_LOAD_Y(rawy[1])
+      PIDM_RS_LOAD_X(rawx[1])
+      PIDM_RS_LOAD_Y(rawy[0])
+      rs_split_row(ta, rows[0]);
+      rs_split_row(tb, rows[1]);
+      const float sb = rs_split_dy(ty, ya[0]);
+      if (do_bias) bacc += sb;
+    }
+    // ---- the rows of the chunk: iteration i uses X rows i - 1, i, i + 1 (pieces in rows[(i + 0 / 1 / 2) % 3]) and dY row i ----
+    int i = 0;
+    while (i < R) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (i >= R) break;         // wave-uniform
+        RsRow& ra = rows[u % 3];
+        RsRow& rb = rows[(u + 1) % 3];
+        RsRow& rc = rows[(u + 2) % 3];
+        u32x4(&yc)[3] = ya[u & 1];
+        u32x4(&yn)[3] = ya[(u + 1) & 1];
+        rs_split_row(rawx[u & 1], rc);               // X row i + 1
+        PIDM_RS_LOAD_X(rawx[u & 1])                  // X row i + 3
+        PIDM_RS_SIX(acc[0], yc, ra.l)
+        PIDM_RS_SIX(acc[1], yc, ra.c)
+        PIDM_RS_SIX(acc[2], yc, ra.r)
+        PIDM_RS_SIX(acc[3], yc, rb.l)
+        PIDM_RS_SIX(acc[4], yc, rb.c)
+        PIDM_RS_SIX(acc[5], yc, rb.r)
+        const float sb = rs_split_dy(rawy[(u + 1) & 1], yn);   // dY row i + 1 (zeros past the chunk)
+        PIDM_RS_LOAD_Y(rawy[(u + 1) & 1])            // dY row i + 3
+        if (do_bias) bacc += sb;
+        PIDM_RS_SIX(acc[6], yc, rc.l)
+        PIDM_RS_SIX(acc[7], yc, rc.c)
+        PIDM_RS_SIX(acc[8], yc, rc.r)
+        ++i;
+      }
+    }
+#undef PIDM_RS_LOAD_X
+#undef PIDM_RS_LOAD_Y
+  }
+
+  // ---- sum of the 4 waves through LDS (fixed order), then the split's partial slab [split][m][tap][n] ----
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[((wave * 9 + tap) * 32 + row) * 32 + l31] = acc[tap][r];
+    }
+  __syncthreads();
+  {
+    const int mrow = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* rp = red + (tap * 32 + mrow) * 32 + c4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp), a1 = *reinterpret_cast<const f32x4*>(rp + 9 * 1024);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(rp + 18 * 1024), a3 = *reinterpret_cast<const f32x4*>(rp + 27 * 1024);
+      const f32x4 sv = (a0 + a1) + (a2 + a3);
+      *reinterpret_cast<f32x4*>(partial + (((size_t)split * wg.MP + (m0 + mrow)) * 9 + tap) * wg.NP + n0 + c4) = sv;
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[k * 32 + tid];      // (wave, half) in fixed order
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
+// Plan: rows per strip chunk R (power of two <= H) such that the waves of a block (4 per split) get whole items and the longest
+// wave - items x (R rows + the three rows of prologue) - is shortest.
+static void rs_plan(WgradGeom* wg, int nsplit) {
+  const ConvGeom& g = wg->g;
+  const int waves = 4 * nsplit;
+  int xsh = 0;
+  while ((8 << xsh) < g.Wi) ++xsh;
+  long best_cost = -1;
+  for (int R = g.Hi; R >= 1; R >>= 1) {
+    const int cpi = g.Hi / R;
+    const long S = (long)g.B * cpi * (g.Wi / 8), pairs = (S + 1) / 2, ppw = (pairs + waves - 1) / waves;
+    const long cost = ppw * (R + 3);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      int csh = 0;
+      while ((1 << csh) < cpi) ++csh;
+      wg->rs_R = R; wg->rs_csh = csh; wg->rs_xsh = xsh; wg->rs_S = (int)S; wg->rs_ppw = (int)ppw;
+    }
+  }
+  wg->nsplit = nsplit;
+}
+
+// true: launched (and *used holds the split actually written); false: geometry not eligible (the caller goes on to the LDS-staged
+// kernel).  PIDM_WGRAD_RS=0: off (A/B measurements, tests of the older kernel).
+bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
+                     float* bias_partial, hipStream_t st, WgradGeom* used) {
+  const ConvGeom& g = plan.g;
+  const char* off = getenv("PIDM_WGRAD_RS");
+  if (off && !atoi(off)) return false;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!(g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi &&
+        g.Hv == g.Hi && g.Wi >= 8 && pow2(g.Wi) && pow2(g.Hi) && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) &&
+        (g.C1 == 0 || g.ld1 == g.ld0) && (reinterpret_cast<size_t>(src0) & 3) == 0 && (reinterpret_cast<size_t>(dy) & 3) == 0))
+    return false;
+  const size_t pix = (size_t)g.B * g.Hi * g.Wi;
+  if (pix * (size_t)g.ld0 * 4 >= 0x7ff00000ull || pix * (size_t)ld_dy * 4 >= 0x7ff00000ull) return false;   // 32-bit byte offsets
+  WgradGeom wg = plan;
+  wg.ld_dy = ld_dy;
+  int ns = plan.nsplit;                     // never more splits than the workspace was sized for
+  const char* me = getenv("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several items per wave on small problems
+  if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+  rs_plan(&wg, ns);
+  const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
+  const size_t lds = 4 * 9 * 1024 * sizeof(float);
+  static bool attr_ = false;
+  if (!attr_) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_ = true;
+  }
+  if (getenv("PIDM_TRACE_CONV"))
+    fprintf(stderr, "[pidm]   -> conv_wgrad_rs_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per wave\n", wg.nsplit, grid.y,
+            wg.rs_S, wg.rs_R, wg.rs_ppw);
+  hipLaunchKernelGGL(conv_wgrad_rs_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  *used = wg;
+  return true;
+}
+
+}  // namespace pidm

@@ -104,6 +104,18 @@ __device__ __forceinline__ void pidm_glds_b128(const void* gsrc_lane, void* lds_
                                    (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
 }
 #endif
+// Raw buffer loads (buffer_load_dword through a 128-bit resource descriptor): per-lane 32-bit byte offset + a wave-uniform
+// (SGPR) byte offset, hardware range check - an offset at or beyond `bytes` returns 0 without touching memory, which is how the
+// row-streaming weight gradient reads its zero padding (k_wgrad_rs.hip).  The host emulator's shadow header supplies its own.
+#ifndef PIDM_HAVE_BUFLOAD
+typedef __amdgpu_buffer_rsrc_t pidm_rsrc;
+__device__ __forceinline__ pidm_rsrc pidm_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float pidm_buf_load_f32(pidm_rsrc r, unsigned voff, unsigned soff) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+#endif
 // the three pieces of two floats, as bf16 pairs (element 0 in the low half)
 __device__ __forceinline__ void pidm_split3_pk(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
   p0 = pidm_cvt_pk_bf16(x0, x1);
@@ -173,6 +185,19 @@ struct ConvGeom {
   const float* bn_ssb;    // their bias [2*Cout]
   double* bn_part;
   int bn_ldss, bn_cpg, bn_G, bn_nchunk;
+};
+
+// Geometry of one weight-gradient launch (k_conv.hip, k_wgrad_rs.hip): dW[m][t][n] = sum_p dY[p][m] * X[p (+tap)][n]
+// (M = rows of dY's channels, N = X's channels), deterministic split-K over pixel ranges into per-split partial slabs.
+struct WgradGeom {
+  ConvGeom g;        // pixel tiling / halo geometry of the forward problem (Cout = channels of dY)
+  int ld_dy;         // channel stride of dY
+  int tgs, ntg;      // taps per group, number of groups
+  int nsplit, tiles_per_split;
+  int MP, NP;        // padded (to 32) rows / cols of the partial buffer
+  // row-streaming kernel (k_wgrad_rs.hip): rows per strip chunk (power of two), log2 of chunks per image and of 8-pixel
+  // column strips per row, strips in total, strip pairs per wave
+  int rs_R, rs_csh, rs_xsh, rs_S, rs_ppw;
 };
 
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)

@@ -204,9 +204,9 @@ class EMA(object):
             module_copy = type(module)(module.config).to(module.config.device)
         else:
             import copy
-            module_copy = copy.deepcopy(module)
-            module_copy.__dict__.pop('_engines', None)          # engine handles, workspaces and flat buffers are per model
-            module_copy.__dict__.pop('_pidm_flat_params', None)
+            module_copy = copy.deepcopy(module)                 # Unet3D.__deepcopy__ leaves the engine state behind
+            for k in ('_engines', '_pidm_flat_params', '_pidm_frozen', '_pidm_tape_slot'):   # (other module types)
+                module_copy.__dict__.pop(k, None)
         module_copy.load_state_dict(module.state_dict())
         self.ema(module_copy, backup=False)
         return module_copy
@@ -689,9 +689,9 @@ class DenoisingDiffusion(nn.Module):
         lib = residual_func.lib
         B, C, P, _ = x_0.shape
         dev = x_0.device
-        dd = self.diff_dict
+        dd = self._kernel_tables(dev)
         x_0 = x_0.contiguous()
-        t = t.to(dtype=torch.int64).contiguous()
+        t = t.to(device=dev, dtype=torch.int64).contiguous()      # drawn by model_estimation_loss in [0, n_steps)
         if residual_func._f_s_flat.device != dev:
             residual_func._f_s_flat = residual_func._f_s_flat.to(dev)
         xt = torch.empty(B, P * P, C, dtype=torch.float32, device=dev)
@@ -737,6 +737,24 @@ class DenoisingDiffusion(nn.Module):
         loss, scalars, _res = _DarcyPidmLossFn.apply(x0_pred, x_0, *args, c_data, c_residual, *geo)
         d, r = self._host_scalars(scalars, [(1,), (2,)])
         return loss, d, r, 0., 0.
+
+    def _kernel_tables(self, dev):
+        """The schedule tables the kernels index by `t` through raw pointers (q-sample, fused Darcy loss): float32, contiguous
+        and on the batch's device - torch indexing used to raise on a device mismatch, a raw pointer would read foreign memory.
+        Tables built on another device are moved once (cached per device), as `_f_s_flat` is."""
+        cache = self.__dict__.setdefault('_pidm_tables', {})
+        got = cache.get(dev)
+        if got is None or got[0] is not self.diff_dict:
+            tabs = {}
+            for k in ('alphas_bar_sqrt', 'one_minus_alphas_bar_sqrt', 'p2_loss_weight', 'posterior_variance_clipped'):
+                v = self.diff_dict[k]
+                if v.device != dev or v.dtype != torch.float32 or not v.is_contiguous():
+                    v = v.to(device=dev, dtype=torch.float32).contiguous()
+                if v.dim() != 1 or v.numel() != self.n_steps:
+                    raise ValueError(f'schedule table {k!r} has shape {tuple(v.shape)}, expected ({self.n_steps},)')
+                tabs[k] = v
+            cache[dev] = got = (self.diff_dict, tabs)
+        return got[1]
 
     def _early_backward_engine(self, residual_func, channels, image_size):
         """The engine to run the step's backward pass at forward time on (see _EarlyStepFn), or None when that is not applicable."""

@@ -105,25 +105,26 @@ class FusedClipAdam:
             raise PidmError("FusedClipAdam: the model's parameters do not live in the flat buffer (re-allocated after "
                             "flatten_parameters(), or the EMA weights are swapped in: call ema.restore(model) first)")
         g = self._flat_grad()
-        self.step_count += 1
         dev = self.flat.device
         max_norm = -1.0 if self.max_norm is None else self.max_norm
         lay = None
-        if self.ema is not None and self.step_count - 1 > self.ema_start:
+        if self.ema is not None and self.step_count > self.ema_start:
             lay = self.ema._flat_layout(self.model)
         if lay is not None:
-            if self.ema._fused_updates != 0:
+            if self.ema._fused_updates != 0:      # checked before step_count moves: a caller that fixes its loop retries the SAME step
                 # the previous fused update was never acknowledged: the loop's `ema.update(model)` condition and this
                 # optimizer's ema_start disagree (or the call is missing) - applying another one would double-count silently
                 raise PidmError("FusedClipAdam.step(): the EMA update folded into the previous step was not acknowledged by "
                                 "ema.update(model) - call it after every optimizer step with index > ema_start "
                                 f"(ema_start={self.ema_start}), as main.py:178-179 does")
+            self.step_count += 1
             self.lib.check(self.lib.pidm_clip_adam_ema_step(
                 ptr(self.flat), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(lay[0]), self.flat.numel(), self.lr,
                 self.betas[0], self.betas[1], self.eps, self.step_count, max_norm, float(self.ema.mu), ptr(self._norm), ptr(self._ws),
                 stream_ptr(dev)), "pidm_clip_adam_ema_step")
             self.ema._fused_updates += 1
         else:
+            self.step_count += 1
             self.lib.check(self.lib.pidm_clip_adam_step(
                 ptr(self.flat), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
                 self.betas[1], self.eps, self.step_count, max_norm, ptr(self._norm), ptr(self._ws), stream_ptr(dev)),

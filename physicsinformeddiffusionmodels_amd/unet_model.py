@@ -265,6 +265,22 @@ class Unet3D(nn.Module):
         self._pidm_lib = None  # tests may bind the host-emulated build of csrc here; None = libpidm_hip.so
 
     # ---- engine plumbing ------------------------------------------------------------------------
+    # per-model engine state: native handles (ctypes pointers cannot be pickled / deep-copied), workspaces, flat buffers
+    _PIDM_PRIVATE = ('_engines', '_pidm_flat_params', '_pidm_frozen', '_pidm_tape_slot')
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) - what EMA.ema_copy and user code do - copies the nn.Module state only: the copy builds its
+        own engine (handle, workspace, gradient buffer) on its first forward; `_pidm_lib` (which library to bind) is shared."""
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in self._PIDM_PRIVATE:
+                continue
+            new.__dict__[k] = v if k == '_pidm_lib' else copy.deepcopy(v, memo)
+        return new
+
     def used_parameter_names(self):
         """Names (state_dict order) of the tensors `forward` reads - 259 for the default config
         (SURVEY Appendix A); all others keep `.grad is None`, as in the reference."""

@@ -248,6 +248,17 @@ static inline hipemu_f32x16 pidm_mfma_bf16_32x32x16(hipemu_u32x4 a, hipemu_u32x4
   hipemu::wave_sync();
   return c;
 }
+// raw buffer loads (pidm_common.h): base + per-lane offset + uniform offset, zero when the offset leaves the range
+#define PIDM_HAVE_BUFLOAD 1
+struct pidm_rsrc { const char* base; unsigned bytes; };
+static inline pidm_rsrc pidm_make_rsrc(const void* base, unsigned bytes) { return pidm_rsrc{static_cast<const char*>(base), bytes}; }
+static inline float pidm_buf_load_f32(pidm_rsrc r, unsigned voff, unsigned soff) {
+  const uint64_t o = (uint64_t)voff + soff;
+  if (o + 4 > r.bytes) return 0.f;
+  float f;
+  memcpy(&f, r.base + o, 4);
+  return f;
+}
 // global_load_lds_dwordx4 (pidm_common.h): synchronous here
 #define PIDM_HAVE_GLDS 1
 static inline void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {

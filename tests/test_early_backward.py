@@ -179,3 +179,36 @@ def test_mechanics_step_takes_the_early_path_and_matches(backend, monkeypatch):
     assert g0.keys() == g1.keys()
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_ema_copy_and_deepcopy_after_a_training_step(backend):
+    """EMA.ema_copy (src/denoising_utils.py:195-199) and a plain copy.deepcopy must work on a model that has already run
+    (its engine holds ctypes pointers and a workspace, which cannot be deep-copied): the copy carries the nn.Module state only
+    and builds its own engine on first use."""
+    import copy
+    from physicsinformeddiffusionmodels_amd.denoising_utils import EMA
+    m, diff, res, data = _setup(backend)
+    ema = EMA(0.5)
+    ema.register(m)
+    loss, *_ = _loss(diff, res, *data[0])
+    loss.backward()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.25)
+    ema.update(m)
+    cp = ema.ema_copy(m)
+    assert '_engines' in m.__dict__ and '_engines' not in cp.__dict__
+    named_cp = dict(cp.named_parameters())
+    for k, sh in ema.shadow.items():
+        assert torch.equal(named_cp[k], sh) and named_cp[k].data_ptr() != sh.data_ptr(), k
+    cp2 = copy.deepcopy(m)
+    assert cp2._pidm_lib is m._pidm_lib and '_engines' not in cp2.__dict__
+    # the copy is a working model: same output as the original after loading the original's weights
+    cp2.load_state_dict(m.state_dict())
+    x = data[1][0].permute(0, 2, 3, 1).reshape(3, 256, 2).contiguous()
+    t = data[1][2]
+    with torch.no_grad():
+        assert torch.equal(cp2(x, t), m(x, t))
+    # and the original still trains
+    loss, *_ = _loss(diff, res, *data[2])
+    loss.backward()

@@ -26,6 +26,11 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   north_star_b256 - the same headline step at per-GPU batch 256, the configuration north_star quotes its target on (darcy, N = 1)
   residual_only  - the fused Darcy residual + loss kernel alone (SURVEY 8(d) secondary metric) at batch 64 and 4096, GB/s
   exchange       - N > 1 (or PIDM_BENCH_FORCE_EXCHANGE=1): torch.distributed backend, world size, ms per gradient exchange
+  mechanics_b32 / sampling_b1024 - BASELINE configs[3] (per-GPU share) and configs[4] measured by the same script in child processes
+                   (`--workload mechanics|sampling`): value, ms_per_step, step_flop_fraction (darcy headline run, N = 1)
+
+`--gpus N` with N > 1 and no torch.distributed environment (WORLD_SIZE unset) re-launches itself under torch.distributed.run with
+one rank per GPU (127.0.0.1 rendezvous); when WORLD_SIZE is set it must equal --gpus.
   cpu_baseline - the CPU oracle (oracle/pidm_oracle.py, a torch-CPU restatement pinned against the reference)
                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -69,6 +74,10 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra run with the 3x3 convolutions on the fp32 MFMA")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused flat clip+Adam kernel (same math)")
+    ap.add_argument("--selftest-emu", action="store_true",
+                    help="TEST HOOK (tests/test_bench_multirank.py), not a measurement: run this script's control flow - rank set-up, "
+                         "sharding, gradient exchange, max-over-ranks timing, JSON - on CPU tensors with the host-emulated kernel build "
+                         "(tests/hipemu) over gloo at a tiny size; the JSON line says so (`selftest`)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="also run one 1 GiB device copy (known byte count for the PMC traffic passes, tools/pmc_traffic.sh)")
     return ap.parse_args()
@@ -219,20 +228,69 @@ def residual_only_rates(lib, residuals, diffusion, dev):
     return out
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed environment: launch the N ranks ourselves, exactly as the
+    driver would (one process per GPU, 127.0.0.1 rendezvous on a free port), and pass their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd))
+
+
+def child_leg(workload, steps, warmup):
+    """Another BASELINE.json single-GPU configuration measured by this same script in a child process (its own model, workspace and
+    hipGraphs; the parent idles meanwhile): {value, unit, ms_per_step, step_flop_fraction, ...} or {error}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-alt", "--no-roofline"]
+    env = dict(os.environ, PIDM_BENCH_CHILD="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as e:  # noqa: BLE001 - the headline line must not die with a leg
+        return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+            "per_gpu_batch": d["config"]["per_gpu_batch"], "step_flop_fraction": d.get("step_flop_fraction"),
+            "workload": d["config"]["workload"], "how": "child process of this run: " + " ".join(cmd[1:])}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}: "
+                         f"launch with --nproc-per-node {args.gpus} (or let bench.py spawn the ranks: unset WORLD_SIZE)")
+    selftest = args.selftest_emu
+    if selftest:
+        # TEST HOOK: CPU tensors + the host-emulated kernel build (tests/hipemu, test infrastructure) over gloo.  Never a measurement.
+        from tests.emu_util import emu_lib
+        lib = emu_lib()
+        dev = torch.device("cpu")
+        args.no_cpu_baseline = args.no_alt = args.no_roofline = True
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     # PIDM_BENCH_SHARE_GPU=1 (debug only): all ranks share cuda:0 and talk over gloo - exercises the N>1 code path on
     # a single-GPU box; real runs use one GPU per rank over RCCL (backend "nccl").
     share = os.environ.get("PIDM_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not selftest:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node has {torch.cuda.device_count()} GPU(s)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     force_dp = os.environ.get("PIDM_BENCH_FORCE_EXCHANGE") == "1"    # debug: one rank, but the RCCL exchange path runs
     if world > 1 or force_dp:
@@ -243,10 +301,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if share:
+        if share or selftest:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+
+    def dev_sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     from physicsinformeddiffusionmodels_amd._lib import get_lib
     from physicsinformeddiffusionmodels_amd.data_utils import synthetic_darcy_batch, synthetic_mechanics_batch
@@ -256,13 +318,18 @@ def main():
     from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
     from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
 
-    lib = get_lib()
+    if not selftest:
+        lib = get_lib()
+    klib = lib if selftest else None     # what the host classes bind (None = the product library)
     if os.environ.get("PIDM_BENCH_STREAM") == "1":      # experiment: everything on a non-default stream (the null stream has
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # implicit-synchronisation semantics of its own)
     if os.environ.get("PIDM_BENCH_EAGER") == "1":
         args.eager_scalars = True
     wl = args.workload
     B = args.batch or {"darcy": 64, "mechanics": 32, "sampling": 1024}[wl]
+    P_img, dim_darcy = (16, 8) if selftest else (64, 32)      # selftest: a 16x16 / dim 8 model the emulator steps in seconds
+    if selftest:
+        B = args.batch or 2
     torch.manual_seed(0)                      # identical initial weights on every rank
     train = wl != "sampling"
     if wl == "mechanics":
@@ -274,11 +341,12 @@ def main():
         loss_kw = dict(c_data=1., c_residual=1e-3, c_ineq=0.1, lambda_opt=0.01)
         flops_per_unit, n_lr = FLOPS_PER_SAMPLE_MECH, 1.e-4
     else:
-        model = Unet3D(dim=32, channels=2).to(dev)
-        diffusion = DenoisingDiffusion(100 if train else 1000, dev)
-        residuals = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=64, pixels_at_boundary=True, reverse_d1=True,
-                                   device=dev, bcs='none', domain_length=1.)
-        batch = synthetic_darcy_batch(B, 64, seed=100 + rank, device=dev)   # resident in HBM; each rank its own shard
+        model = Unet3D(dim=dim_darcy, channels=2).to(dev)
+        model._pidm_lib = klib
+        diffusion = DenoisingDiffusion(100 if train else 1000, dev, lib=klib)
+        residuals = ResidualsDarcy(model=model, fd_acc=2, pixels_per_dim=P_img, pixels_at_boundary=True, reverse_d1=True,
+                                   device=dev, bcs='none', domain_length=1., lib=klib)
+        batch = synthetic_darcy_batch(B, P_img, seed=100 + rank, device=dev)   # resident in HBM; each rank its own shard
         loss_kw = dict(c_data=1., c_residual=1e-3, c_ineq=0., lambda_opt=0.)
         flops_per_unit, n_lr = (FLOPS_PER_SAMPLE_FWD_BWD if train else FLOPS_PER_SAMPLE_FWD), 1.e-4
     ema = None
@@ -291,8 +359,9 @@ def main():
             optimizer = torch.optim.Adam(model.parameters(), lr=n_lr)
         else:
             from physicsinformeddiffusionmodels_amd.optim import FusedClipAdam
-            optimizer = FusedClipAdam(model, lr=n_lr, max_norm=1., image_size=64, ema=ema, ema_start=-1)   # clip_grad_norm_(1.) + Adam
-        exchange = GradientExchange(model, world, diffusion=diffusion, force=force_dp) if (world > 1 or force_dp) else None
+            optimizer = FusedClipAdam(model, lr=n_lr, max_norm=1., image_size=P_img, ema=ema, ema_start=-1, lib=klib)   # clip_grad_norm_(1.) + Adam
+        exchange = (GradientExchange(model, world, image_size=P_img, diffusion=diffusion, force=force_dp, lib=klib)
+                    if (world > 1 or force_dp) else None)
     torch.manual_seed(1234 + rank)
     chain = {"x": torch.randn(B, 2, 64, 64, device=dev), "i": 999} if not train else None
     if not train:
@@ -334,7 +403,7 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def timed(fn, n, warm=3):
         """ms per call of n calls of fn between two fences (after `warm` untimed ones), max over ranks"""
@@ -454,6 +523,11 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            # the same achieved rate against BOTH matrix peaks: fp32 FLOPs / 157.3 (= frac) and the bf16 terms they are executed as
+            # (6 per fp32 product for the split-form launches, 1 for the rest) / 2500
+            "frac_fp32_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac_bf16_peak": round((6.0 * sp_fl / (conv_ms * 1e-3) / 1e12) / PEAK_BF16_MFMA_TFLOPS, 4) if conv_ms > 0 else None,
+            "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
             "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3 and 4x4/s2: conv3x3_split_kernel / conv_wgrad_split_kernel, 6 bf16 "
                       "MFMAs per fp32 product on 3-piece split operands; 1x1, 7x7, 4x4/s2 wgrad: fp32 MFMA)",
             "peak_note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = the fp32 MFMA's dense peak, the rate an fp32 "
@@ -539,6 +613,12 @@ def main():
     if wl == "darcy" and world == 1 and rank == 0 and not args.no_alt:
         resonly = residual_only_rates(lib, residuals, diffusion, dev)
 
+    # ---- BASELINE configs[3] (per-GPU share) and configs[4] in front of the driver: the same script, child processes ----
+    legs = {}
+    if wl == "darcy" and world == 1 and rank == 0 and not args.no_alt and os.environ.get("PIDM_BENCH_CHILD") != "1":
+        legs["mechanics_b32"] = child_leg("mechanics", min(args.steps, 10), 3)
+        legs["sampling_b1024"] = child_leg("sampling", min(args.steps, 10), 3)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = max(1, min(32, os.cpu_count() or 1))
@@ -579,7 +659,15 @@ def main():
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
             "fp32_mfma_only": alt, "eager_scalars": eager, "dropin_main_py": dropin, "north_star_b256": b256,
             "residual_only": resonly, "exchange": exch, "launches": launches,
+            # contract FLOPs of the step (SURVEY 8(d) / FlopCounterMode on the reference) over the measured step time against the
+            # fp32 MFMA peak - also present when the roofline legs are skipped
+            "step_flop_fraction": round(B * flops_per_unit / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
+        out.update(legs)
+        if selftest:
+            out["selftest"] = ("NOT A MEASUREMENT: --selftest-emu ran this script's control flow on CPU tensors with the host-emulated "
+                               "kernels (tests/hipemu) over gloo, 16x16 fields, Unet3D dim=8")
+            out["data"] = "synthetic (selftest)"
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -140,7 +140,11 @@ def get_lib() -> PidmLib:
     """The product library (gfx950).  Raises if it has not been built - no fallback."""
     global _default
     if _default is None:
-        _default = PidmLib(DEFAULT_LIB)
+        # PIDM_LIBRARY: another BUILD of the same gfx950 library (A/B measurements of compiler flags on one box, tools/r04_*.sh);
+        # it must still be a HIP build - the backend check below keeps the host emulator and any CPU stand-in out
+        _default = PidmLib(os.environ.get("PIDM_LIBRARY") or DEFAULT_LIB)
+        if os.environ.get("PIDM_LIBRARY") and _default.backend != "hip":
+            raise PidmError(f"PIDM_LIBRARY={os.environ['PIDM_LIBRARY']} is a '{_default.backend}' build, not the gfx950 library")
     return _default
 
 

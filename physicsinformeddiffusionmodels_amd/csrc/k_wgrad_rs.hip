@@ -27,6 +27,12 @@
 //                are summed through LDS (fixed order) and leave as the split's partial slab, exactly the layout
 //                conv_wgrad_split_kernel writes - the deferred fixed-order reduction (reduce_multi_kernel) is unchanged, results
 //                stay bit-identical run to run.
+// Measured and not kept (profiles/r04_b_wgrad_rs_variants.txt, r04_c_*): a fourth row buffer so that every MFMA of an iteration
+// reads pieces finished an iteration earlier, the iteration laid out by hand as 18 fenced groups of 3 MFMAs with a slice of the
+// vector work each (the ISA then shows 1-7 vector instructions between consecutive MFMAs instead of one batch of ~140), the same
+// with sched_group_barrier, and -fno-slp-vectorize (no v_pk_add_f32 beside MFMAs): all within +-2 % of this form at batch 64
+// and 256 - like the forward kernels the launch runs at the rate the chip sustains for a bf16 MFMA stream on real data
+// (~1.05 PFLOP/s of bf16 terms = 175 TFLOP/s fp32-equivalent at batch 256), not at an issue limit of its own.
 // Arithmetic per product: identical to conv_wgrad_split_kernel (same pieces, same six terms smallest first); only the order in
 // which pixels meet an accumulator differs.
 #include <stdio.h>

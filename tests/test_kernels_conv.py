@@ -148,6 +148,9 @@ def test_conv_3x3_split_forms(backend, monkeypatch, ws, nw, wgs, p, maxns, B, H,
     monkeypatch.setenv("PIDM_STREAM_WGS", wgs)
     monkeypatch.setenv("PIDM_WGRAD_SPLIT_P", p)
     monkeypatch.setenv("PIDM_WGRAD_SPLIT_MAXNS", maxns)
+    # weight gradient: ws = 1 the row-streaming kernel (k_wgrad_rs.hip: no LDS, rolling rows in registers; strips of 2 ... 64 rows,
+    # odd strip counts, several strip pairs per wave with maxns), ws = 0 the LDS-staged conv_wgrad_split_kernel it replaced
+    monkeypatch.setenv("PIDM_WGRAD_RS", ws)
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 

@@ -666,9 +666,153 @@ def g21():
     print("g21 done")
 
 
+def g23(tag="g23_unet_input_forms", dim=8, P=16, B=2):
+    """Unet3D.forward's three input forms (src/unet_model.py:554-562,616-618): [B, P*P, C], [B, C, P, P] and [B, C, 1, P, P] - outputs
+    (the 5-D form keeps its frame axis) and the gradient of (out * w).sum() with respect to the input for each."""
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    x = seeded((B, 2, P, P), 231)
+    t = torch.tensor([4, 93], dtype=torch.long)
+    w = seeded((B, 2, P, P), 232)
+    d = {"x": npy(x), "t": npy(t), "w": npy(w)}
+    forms = {"bxyc": x.permute(0, 2, 3, 1).reshape(B, P * P, 2), "bcpp": x.clone(), "bc1pp": x.unsqueeze(2).clone()}
+    for name, xin in forms.items():
+        xin = xin.clone().requires_grad_(True)
+        out = m(xin, t)
+        ww = w.unsqueeze(2) if out.dim() == 5 else w
+        (out * ww).sum().backward()
+        d["out_" + name] = npy(out)
+        d["gx_" + name] = npy(xin.grad)
+        print(tag, name, "in", tuple(xin.shape), "out", tuple(out.shape))
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+
+
+def toy_funcs():
+    """The three callables main_toy.py:49-82 defines inline (unit-circle residual, L1-density inequality, x-coordinate objective)."""
+    residual = lambda x: torch.sum(x ** 2, dim=1) - 1.0                                        # noqa: E731
+    def ineq(x):
+        density = torch.sum(torch.abs(x), dim=1)
+        return torch.relu(density - 1.0), density
+    opt = lambda x: x[:, 0]                                                                    # noqa: E731
+    return residual, ineq, opt
+
+
+def g24(tag="g24_toy_config"):
+    """BASELINE configs[0] (main_toy.py:113-130 -> src/denoising_toy_utils.py): default initialisation of ConditionalModel under a
+    seed, model_estimation_loss in its three parameterisations with both x0 estimates (injected RNG), a 6-step p_sample_loop with
+    save_output, and the schedule dictionary."""
+    import src.denoising_toy_utils as toy
+    assert toy.__file__.startswith("/root/reference/"), toy.__file__
+    d = {}
+    torch.manual_seed(5)
+    m0 = toy.ConditionalModel(2, 100)
+    sd0 = m0.state_dict()
+    d["init/names"] = np.array(list(sd0.keys()))
+    d["init/sum"] = np.array([v.double().sum().item() for v in sd0.values()])
+    d["init/abs_sum"] = np.array([v.double().abs().sum().item() for v in sd0.values()])
+    d["init/next_rand"] = npy(torch.rand(3))
+    dd = toy.create_diff_dict(100, "cpu")
+    d["sched/names"] = np.array(sorted(dd.keys()))
+    for k in dd:
+        d["sched/" + k] = npy(dd[k])
+    residual, ineq, opt = toy_funcs()
+    n_steps, B = 100, 9
+    m = toy.ConditionalModel(2, n_steps)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    x0 = seeded((B, 2), 241)
+    x0 = x0 / x0.norm(dim=1, keepdim=True)
+    t_half = torch.tensor([3, 0, 57, 99, 41])             # B // 2 + 1 draws (antithetic completion inside the loss)
+    eps = seeded((B, 2), 242)
+    d["x0"], d["t_half"], d["eps"] = npy(x0), npy(t_half), npy(eps)
+    for mode in ("x0", "eps", "mu"):
+        for ddim in (False, True):
+            extra = [seeded((B, 2), 243 + i) for i in range(4)]
+            it = iter([eps] + extra)
+            orig = torch.randint, torch.randn_like
+            torch.randint = lambda *a, **k: t_half.clone()
+            torch.randn_like = lambda *a, **k: next(it).clone()
+            for p_ in m.parameters():
+                p_.grad = None
+            try:
+                out = toy.model_estimation_loss(m, x0, n_steps, dd, model_pred_mode=mode, residual_func=residual, ineq_func=ineq,
+                                                opt_func=opt, c_data=1.0, c_residual=0.005, c_ineq=0.1, lambda_opt=0.01,
+                                                use_ddim_x0=ddim, reduced_ddim_steps=1 if ddim else 0)
+            finally:
+                torch.randint, torch.randn_like = orig
+            out[0].backward()
+            key = f"loss/{mode}/{'sample' if ddim else 'mean'}"
+            d[key] = np.array([out[0].item(), out[1], out[2], out[3], out[4]])
+            d[key + "/grad_norms"] = np.array([p_.grad.double().norm().item() for p_ in m.parameters()])
+            print(tag, key, d[key])
+    # sampler, x0 parameterisation, 6-step schedule
+    dd6 = toy.create_diff_dict(6, "cpu")
+    m6 = toy.ConditionalModel(2, 6)
+    m6.load_state_dict(fill_state_dict(m6.state_dict()))
+    noises = [seeded((7, 2), 250 + i) for i in range(16)]      # more than the loop draws; the count it consumed is stored
+    used = {"n": 0}
+
+    def draw(*a, **k):
+        used["n"] += 1
+        return noises[used["n"] - 1].clone()
+    orig = torch.randn, torch.randn_like
+    torch.randn = draw
+    torch.randn_like = draw
+    try:
+        with torch.no_grad():
+            x_seq, outs, x0s = toy.p_sample_loop(m6, [7, 2], 6, dd6, model_pred_mode="x0", save_output=True, surpress_noise=True,
+                                                 reduced_ddim_steps=0)
+    finally:
+        torch.randn, torch.randn_like = orig
+    d["sampler/noises"] = np.stack([npy(n) for n in noises])
+    d["sampler/draws"] = np.array(used["n"])
+    d["sampler/x_seq"] = np.stack([npy(x) for x in x_seq])
+    d["sampler/model_outputs"] = np.stack([npy(x) for x in outs])
+    d["sampler/x0_estimations"] = np.stack([npy(x) for x in x0s])
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "written")
+
+
+G22_FRAMES = [0, 1, 2, 10, 100, 500, 900, 990, 999, 1000]
+
+
+def g22(tag="g22_sampler_1000steps_dim8_p16", dim=8, P=16, B=2, n_steps=1000):
+    """The full 1000-step DDPM chain of sample.py:145-150 (DenoisingDiffusion(1000).p_sample_loop, src/denoising_utils.py:494-545) at a
+    size the reference runs in seconds, with injected noise.  The 1001 noise fields are NOT stored: draw k is
+    seeded((B, 2, P, P), 22000 + k) (the fixture holds the seed base); of the 1001 frames only G22_FRAMES are kept."""
+    torch.manual_seed(0)
+    m = Unet3D(dim=dim, channels=2)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    diff = DenoisingDiffusion(n_steps, "cpu")
+    res = ResidualsDarcy(model=m, fd_acc=2, pixels_per_dim=P, pixels_at_boundary=True, reverse_d1=True,
+                         device="cpu", bcs="none", domain_length=1.0)
+    seed_base = 22000
+    k = {"n": 0}
+
+    orig_randn, orig_randn_like = torch.randn, torch.randn_like
+
+    def draw(*a, **kw):
+        z = orig_randn(B, 2, P, P, generator=torch.Generator().manual_seed(seed_base + k["n"]))
+        k["n"] += 1
+        return z
+    torch.randn = draw
+    torch.randn_like = draw
+    try:
+        (x_seq, interm), aux = diff.p_sample_loop(None, (B, 2, P, P), save_output=True, surpress_noise=True,
+                                                  residual_func=res, eval_residuals=True)
+    finally:
+        torch.randn, torch.randn_like = orig_randn, orig_randn_like
+    assert len(x_seq) == n_steps + 1 and k["n"] == n_steps + 1, (len(x_seq), k["n"])
+    d = dict(seed_base=np.array(seed_base), n_steps=np.array(n_steps), frames=np.array(G22_FRAMES),
+             x_seq=np.stack([npy(x_seq[f]) for f in G22_FRAMES]), interm=np.stack([npy(interm[f]) for f in G22_FRAMES]),
+             residual=npy(aux["residual"]), x_absmax=np.array([float(x.abs().max()) for x in x_seq]))
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **d)
+    print(tag, "x_final abs mean", float(np.abs(d["x_seq"][-1]).mean()), "max |x| over the chain", float(d["x_absmax"].max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g10b", "g20"):
-        {"g19": g19, "g10b": g10b, "g20": g20, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g10b", "g20", "g22", "g23", "g24"):
+        {"g24": g24, "g23": g23, "g22": g22, "g19": g19, "g10b": g10b, "g20": g20, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16, "g17": g17, "g18": g18}[sys.argv[1]]()
         sys.exit(0)
     g1()
     g2_g3()
@@ -692,4 +836,7 @@ if __name__ == "__main__":
     g10b()
     g20()
     g21()
+    g22()
+    g23()
+    g24()
     print("golden vectors written to", OUT)

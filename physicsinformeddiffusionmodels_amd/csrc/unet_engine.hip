@@ -197,7 +197,7 @@ static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads()
 
 // The backward pass is enqueued launch by launch - the only mode in which weight gradients can go to the side stream - with
 // PIDM_GRAPH=0, with PIDM_GRAPH_BWD=0 (the backward pass alone; =1: always replayed) and, by default, for WIDE models (>= 512
-// channels at the deepest level: the mechanics configuration, dim 128 x 8).  Measured (tools/r03_r.sh, same box): their deep
+// channels at the deepest level: the mechanics configuration, dim 128 x 8).  Measured (tools/archive/r03_r.sh, same box): their deep
 // levels have fewer work items than the chip has CUs, a concurrent weight-gradient kernel fills them - mechanics 798.8 -> 815.4
 // samples/s (main.py's loop unchanged: 750.0 -> 762.6); the Darcy model (256 channels, full launches) ties: 6018 / 6021 / 6037
 // for graph / forward-graph + eager backward / all eager at batch 64, 7999 / 8077 / 7988 at batch 256 - it keeps the replay, which

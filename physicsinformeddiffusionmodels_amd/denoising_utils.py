@@ -531,7 +531,19 @@ class DenoisingDiffusion(nn.Module):
         raise ValueError(schedule)
 
     def create_diff_dict(self):
-        b = self.make_beta_schedule(schedule='cosine', n_timesteps=self.n_steps, start=1e-5, end=1e-2)
+        d = self._host_schedule(self.n_steps)
+        self._host_tables = {k: v.clone() for k, v in d.items()}  # python-float access without device syncs
+        return {k: v.to(self.device) for k, v in d.items()}
+
+    @staticmethod
+    def schedule_tables(n_steps, device):
+        """The schedule tables alone (no DenoisingDiffusion object): what the toy study's create_diff_dict returns
+        (src/denoising_toy_utils.py:43-83 - the same tables as :315-370 of src/denoising_utils.py)."""
+        return {k: v.to(device) for k, v in DenoisingDiffusion._host_schedule(n_steps).items()}
+
+    @staticmethod
+    def _host_schedule(n_steps):
+        b = DenoisingDiffusion.make_beta_schedule(None, schedule='cosine', n_timesteps=n_steps, start=1e-5, end=1e-2)
         d = {'betas': b}
         d['alphas'] = 1. - b
         d['sqrt_recip_alphas'] = torch.sqrt(1. / d['alphas'])
@@ -556,8 +568,7 @@ class DenoisingDiffusion(nn.Module):
         d['posterior_log_variance_clipped'] = torch.log(pvc)
         snr = ap / (1. - ap)
         d['p2_loss_weight'] = torch.minimum(snr, torch.ones_like(snr) * 5.0)
-        self._host_tables = {k: v.clone() for k, v in d.items()}  # python-float access without device syncs
-        return {k: v.to(self.device) for k, v in d.items()}
+        return d
 
     def q_sample(self, x_0, t, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, noise=None):
         if noise is None:

@@ -144,6 +144,34 @@ def test_sampler_loop():
     assert rel_err(r.numpy(), g["residual"]) < 1e-4
 
 
+def test_sampler_loop_full_1000_step_schedule():
+    """The oracle's ancestral chain over the whole 1000-step schedule (sample.py:145-150) against the genuine reference (golden g22;
+    noise draw k = randn under seed 22000 + k)."""
+    g = load("g22_sampler_1000steps_dim8_p16.npz")
+    p = _unet_params(8)
+    cfg = O.UnetCfg(dim=8, channels=2)
+    n_steps = int(g["n_steps"])
+    tables = O.diffusion_tables(n_steps)
+    base = int(g["seed_base"])
+    frames = {int(f): j for j, f in enumerate(g["frames"])}
+
+    def noise(k):
+        return torch.randn(2, 2, 16, 16, generator=torch.Generator().manual_seed(base + k))
+    x = noise(0)
+    scale = float(g["x_absmax"].max())
+    with torch.no_grad():
+        for j, i in enumerate(reversed(range(n_steps))):
+            t = torch.full((2,), i, dtype=torch.long)
+            x0p = O.unet_forward(p, x, t, cfg)
+            x = O.p_sample_update(tables, x0p, x, i, noise(j + 1))
+            if j + 1 in frames:
+                f = frames[j + 1]
+                assert np.abs(x.numpy() - g["x_seq"][f]).max() / scale < 1e-4, j + 1
+                assert np.abs(x0p.numpy() - g["interm"][f]).max() / np.abs(g["interm"]).max() < 1e-4, j + 1
+        r = O.darcy_residual(x0p)
+    assert rel_err(r.numpy(), g["residual"]) < 2e-4
+
+
 def test_q4_stiffness_known_answers():
     k = O.q4_plane_stress_stiffness(1.0, 0.3, 1.0)
     assert abs(k[0, 0] - 0.4945054945054945) < 1e-12

@@ -302,3 +302,39 @@ def test_attention_form_is_latched_per_forward(backend, monkeypatch):
         assert torch.equal(got[k], ref_proj[k]), k
         # the two forms agree to rounding (mathematically-zero gradients, e.g. conv biases under a GroupNorm, are noise in both)
         assert (ref_qkv[k] - ref_proj[k]).abs().max().item() <= 2e-3 * ref_proj[k].abs().max().item() + 1e-5 * gmax, k
+
+
+@pytest.mark.parametrize("form", ["bxyc", "bcpp", "bc1pp"])
+def test_input_forms_vs_reference(backend, form):
+    """Unet3D.forward accepts [B, P*P, C], [B, C, P, P] and [B, C, 1, P, P] (src/unet_model.py:554-562) and returns [B, out, P, P]
+    - with the frame axis kept for the 5-D form (:616-618).  Output and input gradient of each form against the genuine reference
+    (golden g23)."""
+    L, dev = backend
+    g = np.load(os.path.join(G, "g23_unet_input_forms.npz"))
+    m = build_model(8, dev)
+    m._pidm_lib = L if dev.type == "cpu" else None
+    x = torch.from_numpy(g["x"]).to(dev)
+    t = torch.from_numpy(g["t"]).to(dev)
+    w = torch.from_numpy(g["w"]).to(dev)
+    B, C, P, _ = x.shape
+    xin = {"bxyc": x.permute(0, 2, 3, 1).reshape(B, P * P, C), "bcpp": x, "bc1pp": x.unsqueeze(2)}[form].clone().requires_grad_(True)
+    out = m(xin, t)
+    ref = g["out_" + form]
+    assert tuple(out.shape) == ref.shape == ((B, 2, 1, P, P) if form == "bc1pp" else (B, 2, P, P))
+    assert rel(out.detach().cpu().numpy(), ref) < 3e-5
+    (out * (w.unsqueeze(2) if form == "bc1pp" else w)).sum().backward()
+    assert tuple(xin.grad.shape) == g["gx_" + form].shape
+    assert rel(xin.grad.cpu().numpy(), g["gx_" + form]) < 2e-4
+
+
+def test_input_form_errors(backend):
+    L, dev = backend
+    m = build_model(8, dev)
+    m._pidm_lib = L if dev.type == "cpu" else None
+    t = torch.tensor([1, 2], device=dev)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 16, device=dev), t)                     # neither image nor sequence (src/unet_model.py:561-562)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 2, 3, 16, 16, device=dev), t)           # more than one frame: outside the engine's (image) path
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 16, 16, device=dev), t)              # wrong channel count

@@ -12,6 +12,6 @@ for w in darcy mechanics sampling; do
   st=20; [ $w = mechanics ] && st=6
   (cd /tmp && PIDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_$w -o p -- python $R/bench.py --workload $w --steps $st --warmup 5 --no-cpu-baseline --no-alt > $o/prof_$w.log 2>&1)
 done
-bash tools/r02_gaps.sh ${1:-fin}_gaps 1 > $o/gaps.txt 2>&1
+bash tools/archive/r02_gaps.sh ${1:-fin}_gaps 1 > $o/gaps.txt 2>&1
 find $o -name '*.db' -delete; find $o -name '*agent_info.csv' -delete
 cut -c1-300 $o/bench.json; cut -c1-200 $o/bench_b256.json; cut -c1-200 $o/bench_mechanics.json; cut -c1-200 $o/bench_sampling.json; ls $o

@@ -292,6 +292,24 @@ long long pidm_debug_reduce_table_uploads(void);
  * the launched graphs, stream captures}.  pidm_unet_forward / pidm_unet_backward replay a captured hipGraph from the third call
  * with the same arguments on (PIDM_GRAPH=0: always launch by launch). */
 int pidm_debug_launch_counts(long long* out4);
+/* ---- data-parallel gradient exchange ----------------------------------------------------------------------
+ * No reference counterpart: /root/reference/main.py:157-166 is single-device; north_star shards the batch over the GPUs of a node
+ * and averages the gradients with an RCCL all-reduce over xGMI.  One communicator per process (= per GPU).  RCCL is bound with
+ * dlopen at first use.  The reference-side binding: parallel.py (`PIDM_DP_NATIVE=1`) or any host with a way to hand rank 0's 128-byte
+ * id to the other ranks.
+ *   pidm_comm_unique_id  rank 0: 128 opaque bytes to be sent to every rank (ncclGetUniqueId)
+ *   pidm_comm_init       every rank, with the same id; uses the calling thread's current HIP device (ncclCommInitRank)
+ *   pidm_allreduce_f32   in place on `buf[0..count)`, enqueued on `stream`; average != 0: mean over ranks, else sum
+ *   pidm_comm_destroy    */
+int pidm_comm_unique_id(void* out128);
+int pidm_comm_init(int rank, int world, const void* unique_id128, void** comm);
+int pidm_allreduce_f32(void* comm, float* buf, size_t count, int average, void* stream);
+int pidm_comm_destroy(void* comm);
+
+/* The library reads each PIDM_* tuning variable from the environment once per process (the first time a launcher asks for it).
+ * A process that changes one afterwards - the unit tests, A/B legs of bench.py - calls this to drop the snapshot; the next launch
+ * re-reads.  No reference counterpart (the knobs select between kernels that compute the same result). */
+int pidm_reload_knobs(void);
 
 #ifdef __cplusplus
 }

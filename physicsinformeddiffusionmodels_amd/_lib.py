@@ -34,6 +34,9 @@ class PidmError(RuntimeError):
     pass
 
 
+_loaded: list = []      # every library this process has bound (the product build, and the emulated one under pytest)
+
+
 class PidmLib:
     def __init__(self, path: str | None = None):
         path = path or DEFAULT_LIB
@@ -109,6 +112,12 @@ class PidmLib:
         self._sig("pidm_lap_forward", [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
         self._sig("pidm_lap_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
         self._sig("pidm_debug_stream_trace", [vp])
+        self._sig("pidm_reload_knobs", [])
+        self._sig("pidm_comm_unique_id", [vp])
+        self._sig("pidm_comm_init", [i, i, vp, C.POINTER(vp)])
+        self._sig("pidm_allreduce_f32", [vp, vp, sz, i, vp])
+        self._sig("pidm_comm_destroy", [vp])
+        _loaded.append(self)
         if L.pidm_version() != 1:
             raise PidmError(f"{path}: ABI version {L.pidm_version()} != 1")
 
@@ -134,6 +143,13 @@ class PidmLib:
 
 
 _default: PidmLib | None = None
+
+
+def reload_knobs():
+    """The native library snapshots each PIDM_* tuning variable the first time a launcher reads it; code that changes one inside a
+    live process (unit tests, A/B legs of bench.py) calls this so that the next launch re-reads the environment."""
+    for lib in _loaded:
+        lib.lib.pidm_reload_knobs()
 
 
 def get_lib() -> PidmLib:

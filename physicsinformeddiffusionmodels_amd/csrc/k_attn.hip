@@ -1055,7 +1055,7 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
 // backward of attention + to_out projection; dy [B][N][Cout] (leading dimension ld_dy), w_out [Cout][HD] (reference layout);
 // dwpart [B][Cout][HD]: per-image shares of the to_out weight gradient.  Eligibility: la_fused_ok.
 bool la_fused_ok(int N, int heads, int Cout, int ld_dy) {
-  static const bool off = getenv("PIDM_NO_LA_FUSED") != nullptr;
+  static const bool off = knob("PIDM_NO_LA_FUSED") != nullptr;
   return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1 && heads <= 14;
 }
 // forward: k statistics, context, then attention output x projection (+ bias + residual) in one kernel; y [B][N][Cout]
@@ -1095,7 +1095,7 @@ int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* q
 // fills the chip (>= one workgroup per CU); below that (16x16 level at batch 64: 128 workgroups) the separate projection convs
 // with their own tiling win by ~30 %.  PIDM_LA_FUSED_MIN_WGS overrides (tests: 1).
 bool la_fused_pays(int B, int N) {
-  const char* mw = getenv("PIDM_LA_FUSED_MIN_WGS");
+  const char* mw = knob("PIDM_LA_FUSED_MIN_WGS");
   const long min_wgs = mw ? atol(mw) : 256;
   return (long)B * N / 128 >= min_wgs;
 }

@@ -161,7 +161,7 @@ static int lap_nper_split(int N, int C) {
 // lap_kctx_split / lap_g_split stay at one wave per head: groups there mean G partials per range, and what the pixel-sum kernels
 // gain (2 - 4 us) their merge kernels lose twice over (+8 us lap_kctx_final, +19 us lap_mid).
 static int lap_groups(int heads, int ntiles) {
-  const char* e = getenv("PIDM_LAP_GROUPS");      // 1: one wave per head, the other slots idle (A/B measurements)
+  const char* e = knob("PIDM_LAP_GROUPS");      // 1: one wave per head, the other slots idle (A/B measurements)
   int g = 8 / heads;
   if (e && atoi(e) > 0 && atoi(e) < g) g = atoi(e);
   while (g > 1 && ntiles % g) --g;
@@ -1348,7 +1348,7 @@ template <int CB>
 static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, const float* bias, const float* resid, float* y,
                          float* saved, float* qstat, int B, int N, int heads, float* scratch, hipStream_t st) {
   constexpr int C = 32 * CB;
-  const char* spe = getenv("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
+  const char* spe = knob("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
   const bool split1 = !(spe && !atoi(spe));
   const int nper = split1 ? lap_nper_split(N, C) : lap_nper(N, C, 1), NS = N / nper;
   float* kst = saved;
@@ -1433,7 +1433,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   }
   const int np2 = lap_nper(N, C, 2), NS2 = N / np2;
   const size_t lds1 = (size_t)2 * np2 * (C + 4) * sizeof(float);
-  const char* spe = getenv("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
+  const char* spe = knob("PIDM_LAP_SPLIT");                 // 0: the fp32-MFMA pixel-sum kernel
   if (!(spe && !atoi(spe))) {
     const size_t ldss = (size_t)np2 * (6 * C + 16) + (size_t)3 * C * (np2 * 2 + 16);
     static bool attr_s = false;
@@ -1456,10 +1456,10 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   if (G3 > 1 && (np3 / 32) % G3) {
     if (nsub % G3 == 0) { nslab = np3 * G3; nsl = nsub / G3; } else G3 = 1;
   }
-  const char* ofe = getenv("PIDM_LAP_ORDER_FLIP");            // 0: every wave runs a tile's q half before its k half
+  const char* ofe = knob("PIDM_LAP_ORDER_FLIP");            // 0: every wave runs a tile's q half before its k half
   const int oflip = (ofe && !atoi(ofe)) ? 0 : 2;
   const int split_dw = !(spe && !atoi(spe)) ? 1 : 0;
-  const char* ppe = getenv("PIDM_LAP_SPLIT_PROJ");            // 0: the four per-pixel projections of lap_bwd stay on the fp32 MFMA
+  const char* ppe = knob("PIDM_LAP_SPLIT_PROJ");            // 0: the four per-pixel projections of lap_bwd stay on the fp32 MFMA
   if (CB == 1 && split_dw && !(ppe && !atoi(ppe))) {
     const size_t lds3p = ((size_t)8 * 32 * kLapTileLd + 8 * 96 + (size_t)3 * heads * kLapDH * C) * sizeof(float) + (size_t)3 * C * (nslab * 2) +
                          (size_t)2 * nslab * 208;

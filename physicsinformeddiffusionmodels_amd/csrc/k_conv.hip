@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
 // GroupNorm-backward partial sums from a dgrad epilogue (ConvGeom::bn_part).  acc_ = the lane's 16 rows of dy for channel c_
 // (rows (r&3) + 8(r>>2) + 4half of the wave's 32 pixels), xrow_ = &x[first pixel of the wave][c_], xstep_ = floats between
 // consecutive pixels of the wave in x.  Same arithmetic as gn_recompute (k_norm.hip).
-#define PIDM_BN_PARTIAL(acc_, bv_, b_, pix_in_img_, c_, xrow_, xstep_)                                              \
+#define PIDM_BN_PARTIAL(acc_, bv_, b_, pix_in_img_, c_, xrow_, xstep_, rrow_, rstep_)                               \
   {                                                                                                                 \
     const int gI__ = (c_) / g.bn_cpg;                                                                               \
     const float mean__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2], rstd__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2 + 1]; \
@@ -217,15 +217,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvGeom g, int tgs, in
       sc__ = 1.f + (g.bn_ss[(size_t)(b_) * g.bn_ldss + (c_)] + g.bn_ssb[(c_)]);                                     \
       sh__ = g.bn_ss[(size_t)(b_) * g.bn_ldss + g.Cout + (c_)] + g.bn_ssb[g.Cout + (c_)];                           \
     }                                                                                                               \
-    float xv__[16];                                                                                                 \
+    float xv__[16], rv__[16];                                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
         xv__[r] = (xrow_)[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * (xstep_)];                                  \
+    const float* rr__ = (rrow_);      /* wave-uniform: the residual the epilogue adds to the result, or null */     \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
+        rv__[r] = rr__ ? rr__[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * (rstep_)] : 0.f;                        \
     float a1__ = 0.f, a2__ = 0.f;                                                                                   \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
       const float xh__ = (xv__[r] - mean__) * rstd__;                                                               \
       const float v__ = (xh__ * gm__ + bt__) * sc__ + sh__;                                                         \
       const float sg__ = pidm_sigmoid(v__);                                                                         \
-      const float dv__ = ((acc_)[r] + (bv_)) * (sg__ * (1.f + v__ * (1.f - sg__)));                                 \
+      const float dv__ = (((acc_)[r] + (bv_)) + rv__[r]) * (sg__ * (1.f + v__ * (1.f - sg__)));                     \
       a1__ += dv__;                                                                                                 \
       a2__ += dv__ * xh__;                                                                                          \
     }                                                                                                               \
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
         if (g.bn_part) {   // plain stride-1 geometry (os == 1, output grid == x grid): the wave's pixels are consecutive in x
           const float* xrow = g.bn_x + (((size_t)b * g.Ho + oy) * g.Wo + tx0) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout)
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout, (const float*)nullptr, 0)
         }
       }
     }
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
         if (b0 + img0 < g.B && img0 < g.NI) {
           const float* xrow = g.bn_x + (((size_t)(b0 + img0) * g.Ho + (vy0 + ty0)) * g.Wo) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout)
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout, (const float*)nullptr, 0)
         }
       }
     }
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
           f32x16 accs;
 #pragma unroll
           for (int r = 0; r < 16; ++r) accs[r] = acc[r] + acc1[r];
-          PIDM_BN_PARTIAL(accs, bv, b, pin, c, xrow, g.Cout)
+          PIDM_BN_PARTIAL(accs, bv, b, pin, c, xrow, g.Cout, (const float*)nullptr, 0)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
@@ -820,7 +823,7 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 // extra bytes per halo-tile row (ConvGeom::rpad): see conv3x3_split_kernel; PIDM_SPLIT_ROWPAD=0: off (A/B measurements)
 static int split_row_pad(int Wv) {
-  static const int on = [] { const char* e = getenv("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
   return (on && Wv <= 16) ? 32 : 0;
 }
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
@@ -1112,7 +1115,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
         if (g.bn_part) {
           const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout)
+          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
@@ -1396,7 +1399,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
         if (g.bn_part) {
           const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout)
+          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
@@ -1784,7 +1787,7 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
 // 22.4 -> 18.4 us, 38.3 -> 31.5, 64.1 -> 51.9), the one-role form for the 8-wave tile (two waves per SIMD already overlap each
 // other and the extra producer waves cost 2-3 %: 63.8 -> 65.7 us; profiles/r03_ws_conv.txt); 1 / 0 force one form everywhere.
 static bool split_ws_on(int nw) {
-  const char* e = getenv("PIDM_SPLIT_WS");
+  const char* e = knob("PIDM_SPLIT_WS");
   if (!e) return nw == 4;
   return atoi(e) != 0;
 }
@@ -1805,7 +1808,7 @@ static int split_ntg(const ConvGeom& g) {
   if (!(g.KH == 1 && g.KW == 1 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && (g.Cin % 32 == 0) && (g.Cout % 64 == 0) &&
         g.Cin >= 64 && g.Hv * g.Wv > 1))
     return 0;
-  static const bool on = [] { const char* e = getenv("PIDM_CONV1X1_SPLIT"); return !(e && !atoi(e)); }();
+  static const bool on = [] { const char* e = knob("PIDM_CONV1X1_SPLIT"); return !(e && !atoi(e)); }();
   if (!on) return 0;
   return (g.Cout % 128 == 0) ? 4 : 2;
 }
@@ -3210,7 +3213,7 @@ static int pick_kc(int Cin) {
   // PIDM_KC=8 forces the 8-channel chunk (experiments); default: 16 when the channel count allows it
   static int forced = -1;
   if (forced < 0) {
-    const char* e = getenv("PIDM_KC");
+    const char* e = knob("PIDM_KC");
     forced = e ? atoi(e) : 0;
   }
   if (forced == 8) return 8;
@@ -3290,7 +3293,7 @@ unsigned make_pack_desc(const ConvGeom& g, int kind, const float* w_ref, float* 
 #ifndef PIDM_PACK_TILED_DEFAULT
 #define PIDM_PACK_TILED_DEFAULT 1
 #endif
-  const char* te = getenv("PIDM_PACK_TILED");
+  const char* te = knob("PIDM_PACK_TILED");
   const bool tiled_on = te ? atoi(te) != 0 : PIDM_PACK_TILED_DEFAULT != 0;
   d->tiled = (tiled_on && d->nz == 1 && (d->kind == 0 || d->kind == 2 || d->kind == 4) && (d->T == 1 || d->T == kPackTileT) &&
               (!d->split || ((d->n_off & 31) == 0 && (d->k_off & 31) == 0))) ? 1 : 0;
@@ -3390,7 +3393,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
       if (g.KH == 3) {
         // persistent walk when the launch has more tiles than resident workgroup slots: 2 workgroups per CU, each
         // owning tpw consecutive m-tiles of one n-tile
-        const char* pe = getenv("PIDM_PERSIST_SLOTS");   // experiments / tests: 0 = off, else resident workgroup slots
+        const char* pe = knob("PIDM_PERSIST_SLOTS");   // experiments / tests: 0 = off, else resident workgroup slots
         const long slots = pe ? atol(pe) : 512;
         const long nwork = (long)g.tiles_m * tiles_n * g.nz;
         bool persist = false;
@@ -3398,7 +3401,7 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
           // 256-pixel workgroup tile (MT = 2) when the launch still fills the chip: two accumulator chains per wave,
           // half the barriers and weight staging per MFMA (measured on MI355X: +0..5 % over the persistent 128-pixel
           // walk for 32-channel tiles; with 64-channel tiles it needs 272 registers = one workgroup per CU, so NT == 1 only)
-          const char* me = getenv("PIDM_MT2_MIN_WGS");   // experiments / tests: 0 = off, else the occupancy gate
+          const char* me = knob("PIDM_MT2_MIN_WGS");   // experiments / tests: 0 = off, else the occupancy gate
           const long mt2_min = me ? atol(me) : 512;
           ConvGeom g2 = g;
           if (mt2_min > 0 && retile_bm(&g2, 256)) {
@@ -3468,9 +3471,9 @@ static int launch_conv_t(ConvGeom g, const float* src0, const float* src1, const
 // layout (16-byte stores).  These launches are store-bound (qkv projections: 12.6 MB/sample at 64x64).
 static bool conv_nt4_ok(const ConvGeom& g, int KC) {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("PIDM_NO_NT4"); off = (e && atoi(e)) ? 1 : 0; }
+  if (off < 0) { const char* e = knob("PIDM_NO_NT4"); off = (e && atoi(e)) ? 1 : 0; }
   if (off) return false;
-  const char* mw = getenv("PIDM_NT4_MIN_WGS");   // tests lower the occupancy threshold to reach this path with small shapes
+  const char* mw = knob("PIDM_NT4_MIN_WGS");   // tests lower the occupancy threshold to reach this path with small shapes
   const long min_wgs = mw ? atol(mw) : 512;
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % KC == 0) && (g.C0 % KC == 0);
   return KC == 16 && g.KH == 1 && g.KW == 1 && g.nph == 1 && g.nz == 1 && aligned && (g.Cout % 128 == 0) &&
@@ -3487,13 +3490,14 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
              g.nz, g.gn_part ? " +gnstats" : "", g.bn_part ? " +bnsums" : "", residual ? " +res" : "");
     prof_set_label(lab);
   }
-  if (getenv("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
-    fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
-            g.KW, g.nph, KC, nt4 ? 4 : NT);
+  if (knob("PIDM_TRACE_CONV"))   // debugging aid: which tile configuration a launch takes
+    fprintf(stderr, "[pidm] conv B=%d %dx%d Cin=%d Cout=%d k=%dx%d nph=%d%s%s%s -> KC=%d NT=%d\n", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH,
+            g.KW, g.nph, g.gn_part ? " +gnstats" : "", g.bn_part ? (g.bn_res ? " +bnsums(res)" : " +bnsums") : "", residual ? " +res" : "", KC,
+            nt4 ? 4 : NT);
   {
     // 1x1 / stride-1 convolutions as a split-form GEMM (conv1x1_split_kernel): contiguous channels-last input and output, pixel
     // count a multiple of 128, whole 32-channel chunks from either source
-    const char* se = getenv("PIDM_CONV_SPLIT");
+    const char* se = knob("PIDM_CONV_SPLIT");
     const int ntg = (se && !atoi(se)) ? 0 : split_ntg(g);
     const long npix = (long)g.B * g.Hv * g.Wv;
     // Measured (tools/bench_conv1x1.py, batch 64): with two stages per item (Cin = 64) the un-overlapped epilogue dominates - the
@@ -3506,7 +3510,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         (reinterpret_cast<size_t>(src0) & 15) == 0 && (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
         (reinterpret_cast<size_t>(out) & 15) == 0) {
       const int tiles_m = (int)(npix / 128);
-      const char* ce1 = getenv("PIDM_STREAM_WGS");           // (the unit tests lower it: several items per workgroup)
+      const char* ce1 = knob("PIDM_STREAM_WGS");           // (the unit tests lower it: several items per workgroup)
       int n_cu1 = ce1 ? atoi(ce1) : 256;
       if (n_cu1 < 1) n_cu1 = 256;
       // tiles per workgroup: the packing's 4 unless that leaves CUs without an item
@@ -3522,7 +3526,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         attr_1 = true;
       }
-      if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv1x1_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", ntr, ntg, n_items, wgs, lds);
+      if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv1x1_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", ntr, ntg, n_items, wgs, lds);
       const bool prof = prof_enabled();
       if (prof) prof_begin_launch(2, 2.0 * (double)npix * (double)g.Cout * g.Cin, st);
       const float* s1 = src1 ? src1 : src0;
@@ -3536,7 +3540,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   }
   {
     // the 7x7 init convolution with (kx, channel) flattened into the contraction index, split form (conv7x7_split_kernel)
-    const char* se = getenv("PIDM_CONV_SPLIT");
+    const char* se = knob("PIDM_CONV_SPLIT");
     const bool on = !(se && !atoi(se));
     if (on && g.KH == 7 && g.KW == 7 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && g.pad_y[0] == 3 && g.pad_x[0] == 3 &&
         g.C1 == 0 && (g.Cin == 2 || g.Cin == 4) && g.ld0 == g.Cin && (g.Cout % 32) == 0 && g.soc == 1 && (g.sox & 3) == 0 &&
@@ -3546,13 +3550,13 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       const int TH = 256 / g.Wv, n_tiles = g.B * (g.Hv / TH);
       const int KSt = (7 * g.Cin + 15) / 16, RL = ((g.Wv + 6) * g.Cin + (16 * KSt - 7 * g.Cin) + 1) & ~1;
       const size_t lds = ((size_t)(TH + 6) * RL + (size_t)32 * ((49 * Kp) | 1)) * sizeof(float);
-      const char* ce7 = getenv("PIDM_STREAM_WGS");              // (the unit tests lower it: several tiles per workgroup)
+      const char* ce7 = knob("PIDM_STREAM_WGS");              // (the unit tests lower it: several tiles per workgroup)
       int n_wg7 = ce7 ? atoi(ce7) : 256;                      // 170 registers x 512 threads: one workgroup per CU
       if (n_wg7 < 1) n_wg7 = 256;
       const int tpw = cdiv(n_tiles, n_wg7);                     // persistent workgroups: the weight prologue is paid once per workgroup
       const dim3 grid(cdiv(n_tiles, tpw), g.Cout / 32, 1);
       const bool prof = prof_enabled();
-      if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv7x7_split_kernel<%d>, %d tiles, %d per workgroup, %zu B LDS\n", g.Cin, n_tiles, tpw, lds);
+      if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv7x7_split_kernel<%d>, %d tiles, %d per workgroup, %zu B LDS\n", g.Cin, n_tiles, tpw, lds);
       if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 49, st);
       if (g.Cin == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv7x7_split_kernel<2>), grid, dim3(512), lds, st, g, src0, wp, Kp, bias, residual, out, n_tiles, tpw);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv7x7_split_kernel<4>), grid, dim3(512), lds, st, g, src0, wp, Kp, bias, residual, out, n_tiles, tpw);
@@ -3563,7 +3567,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   }
   {
     // the 4x4 / stride-2 family (2x2 taps as 4 K-phases or 4 output parities) in the split form
-    const char* se = getenv("PIDM_CONV_SPLIT");
+    const char* se = knob("PIDM_CONV_SPLIT");
     const bool on = !(se && !atoi(se));
     const int mode = (g.nph == 4) ? 1 : 2;
     if (on && split_shape_ok2(g) && g.soc == 1 && (g.C0 % 16 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.C1 == 0 || g.ld1 == g.ld0) &&
@@ -3572,10 +3576,10 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         (reinterpret_cast<size_t>(src0) & 15) == 0 && (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
         (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
         (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0 < 4.0e9) {
-      const char* ce = getenv("PIDM_STREAM_WGS");
+      const char* ce = knob("PIDM_STREAM_WGS");
       int n_cu = ce ? atoi(ce) : 256;
       if (n_cu < 1) n_cu = 256;
-      const char* fe = getenv("PIDM_SPLIT_NW");
+      const char* fe = knob("PIDM_SPLIT_NW");
       const int force = fe ? atoi(fe) : 0;
       const int mult = (mode == 2 ? 4 : 1) * (g.Cout / 32);
       for (int nw = 8; nw >= 4; nw >>= 1) {
@@ -3611,7 +3615,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
         const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
         const float* s1 = src1 ? src1 : src0;
-        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", nw, mode, n_items, wgs, lds);
+        if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", nw, mode, n_items, wgs, lds);
         const bool prof = prof_enabled();
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
         const dim3 bd(64 * nw);
@@ -3642,7 +3646,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
   }
   {
     // bf16 matrix pipe, fp32-faithful split operands (PIDM_CONV_SPLIT=0: off -> the fp32-MFMA kernels below; read per launch)
-    const char* se = getenv("PIDM_CONV_SPLIT");
+    const char* se = knob("PIDM_CONV_SPLIT");
     const bool on = !(se && !atoi(se));
     ConvGeom gs = g;
     if (on && split_shape_ok(g) && g.soc == 1 && (g.C0 % 16 == 0) && ((g.ld0 | g.ld1) & 3) == 0 && (g.C1 == 0 || g.ld1 == g.ld0) &&
@@ -3652,10 +3656,10 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
         (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0 < 4.0e9) {
       // 8 waves on a 256-pixel tile, or - when that leaves CUs without a work item - 4 waves on 128 pixels (PIDM_SPLIT_NW forces one)
-      const char* fe = getenv("PIDM_SPLIT_NW");
+      const char* fe = knob("PIDM_SPLIT_NW");
       const int force = fe ? atoi(fe) : 0;
       ConvGeom g8 = g;
-      const char* ce = getenv("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
+      const char* ce = knob("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
       int n_cu = ce ? atoi(ce) : 256;
       if (n_cu < 1) n_cu = 256;
       const bool small = !retile_bm(&g8, 256) || g8.tiles_m * (g.Cout / 32) < n_cu;
@@ -3679,8 +3683,8 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         gs.w_off[0] = 0;
         const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
         const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
-        const int trace = getenv("PIDM_STREAM_TRACE") ? 1 : 0;
-        if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
+        const int trace = knob("PIDM_STREAM_TRACE") ? 1 : 0;
+        if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
         if (split_ws_on(nw) && !trace) {
           static bool attr_w0 = false;
@@ -3708,9 +3712,17 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       }
     }
   }
+  if (g.bn_part && g.bn_res) {
+    // GroupNorm-backward sums of (result + residual): only the split-form 3x3 epilogues above add the residual before summing.
+    // Any other kernel runs the convolution without the sums and says so (1 = sums NOT produced: the caller runs its own pass).
+    ConvGeom g2 = g;
+    g2.bn_part = nullptr;
+    const int rc = launch_conv(g2, src0, src1, wp, bias, residual, out, sigmoid_last, st);
+    return rc < 0 ? rc : 1;
+  }
   {
     // streaming persistent 3x3 kernel (PIDM_CONV_STREAM=0: off, for A/B measurements and to reach the older tilings in tests)
-    const char* se = getenv("PIDM_CONV_STREAM");
+    const char* se = knob("PIDM_CONV_STREAM");
     const bool on = !(se && !atoi(se));
     const int npixA = g.NI * g.IHt * g.IWt;
     const size_t lds = (size_t)2 * (npixA + 9 * 32) * 36 * sizeof(float);
@@ -3728,13 +3740,13 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       ConvGeom gs = g;
       gs.w_off[0] = 0;
       const int n_items = g.tiles_m * (g.Cout / 32);
-      const char* ce = getenv("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
+      const char* ce = knob("PIDM_STREAM_WGS");        // persistent workgroups (default: one per CU of an MI355X); read per launch
       int n_cu = ce ? atoi(ce) : 256;                      // (the unit tests lower it to get several work items per workgroup)
       if (n_cu < 1) n_cu = 256;
       const int ipw = cdiv(n_items, n_cu), wgs = cdiv(n_items, ipw);
       if (prof) prof_begin_launch(0, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
       hipLaunchKernelGGL(conv3x3_stream_kernel, dim3(wgs), dim3(256), lds, st, gs, sigmoid_last, src0, src1 ? src1 : src0, wp, bias, residual, out,
-                         n_items, ipw, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
+                         n_items, ipw, knob("PIDM_STREAM_TRACE") ? 1 : 0);
       if (prof) prof_end_launch(st);
       PIDM_CHECK_LAUNCH("conv3x3_stream_kernel");
       return 0;
@@ -3744,14 +3756,14 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
     // K == 32 (the qkv projections of the 64x64 level, to_out dgrad): one 32-channel chunk = ONE dependent load round per
     // workgroup instead of two (PIDM_KC32=0 disables, for A/B measurements)
     static int kc32 = -1;
-    if (kc32 < 0) { const char* e = getenv("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
+    if (kc32 < 0) { const char* e = knob("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
     if (kc32 && g.Cin == 32 && g.C0 == 32) return launch_conv_t<32, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
     return launch_conv_t<16, 4>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   }
   {
     // 1x1 convolutions with Cin % 32 == 0: 32-channel chunks (half the barriers / dependent load rounds per tile)
     static int kc32 = -1;
-    if (kc32 < 0) { const char* e = getenv("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
+    if (kc32 < 0) { const char* e = knob("PIDM_KC32"); kc32 = (e && !atoi(e)) ? 0 : 1; }
     const bool al32 = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && (g.Cin % 32 == 0) && (g.C0 % 32 == 0);
     if (kc32 && KC == 16 && g.KH == 1 && g.KW == 1 && g.nph == 1 && al32 && g.NI * g.IHt * g.IWt * 8 <= 5 * 256) {
       if (NT == 2) return launch_conv_t<32, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
@@ -3763,7 +3775,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       ((size_t)g.NI * g.IHt * g.IWt + 9 * 32) * 36 * sizeof(float) <= 80 * 1024) {
     // 32-channel chunks for 32-channel-tile 3x3 convolutions: 144 MFMAs per wave between barriers instead of 72 (two
     // workgroups per CU instead of three); +3..14 % on the 8x8 / 64x64 levels, neutral elsewhere (PIDM_KC32_3X3=0: off)
-    const char* e = getenv("PIDM_KC32_3X3");
+    const char* e = knob("PIDM_KC32_3X3");
     if (!(e && !atoi(e))) return launch_conv_t<32, 1>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
   }
   if (KC == 16 && NT == 2) return launch_conv_t<16, 2>(g, src0, src1, wp, bias, residual, out, sigmoid_last, st);
@@ -3782,8 +3794,8 @@ static int wgrad_taps(const ConvGeom& g) { return g.nph > 1 ? 16 : g.KH * g.KW; 
 
 // 0: LDS-staged kernels, 1: LDS-free stream with 32x32 tiles, 2: stream with a 128-wide dY operand, 3: 128-wide X operand
 static int wgrad_stream_mode(const ConvGeom& g, int ld_dy) {
-  static const bool off = getenv("PIDM_NO_WGRAD_STREAM") != nullptr;
-  static const bool off4 = getenv("PIDM_NO_WGRAD_STREAM4") != nullptr;
+  static const bool off = knob("PIDM_NO_WGRAD_STREAM") != nullptr;
+  static const bool off4 = knob("PIDM_NO_WGRAD_STREAM4") != nullptr;
   if (off || g.KH != 1 || g.KW != 1 || g.stride != 1 || g.nph != 1 || g.nz != 1 || wgrad_smallc(g)) return 0;
   if (g.C1 != 0 && g.C0 % 32 != 0) return 0;
   if (off4) return 1;
@@ -3846,7 +3858,7 @@ static int wgs_xrow_bytes_host(const ConvGeom& g) {
 static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
                                float* bias_partial, hipStream_t st, WgradGeom* used) {
   const ConvGeom& g = plan.g;
-  const char* se = getenv("PIDM_WGRAD_SPLIT");
+  const char* se = knob("PIDM_WGRAD_SPLIT");
   if (se && !atoi(se)) return false;
   if (!(g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi &&
         g.Hv == g.Hi && g.Wv >= 8 && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) && (g.C1 == 0 || g.ld1 == g.ld0) &&
@@ -3856,7 +3868,7 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
   // the 128-pixel tile first where it measures faster than the 256-pixel one (shorter stage / k-step phases, same work per split):
   // 64-wide images 4-7 % (64->32: 86 -> 80 us), 32- and 16-wide 0-3 %; the 8-wide levels are 1-2 % better on 256 (four whole images per
   // tile instead of two).  PIDM_WGRAD_SPLIT_P = 128 | 256 forces the first try.
-  const char* pe = getenv("PIDM_WGRAD_SPLIT_P");
+  const char* pe = knob("PIDM_WGRAD_SPLIT_P");
   const int p0 = (pe && atoi(pe) == 128) ? 128 : (pe && atoi(pe) == 256) ? 256 : (g.Wv >= 16 ? 128 : 256);
   for (int P = p0; P >= 128; P >>= 1) {
     WgradGeom wg = plan;
@@ -3867,7 +3879,7 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
     const size_t lds = stage > 12 * 3 * 4096 ? stage : 12 * 3 * 4096;
     if (gp.NI * gp.TH * gp.Wv != P || seg % 8 || seg / 8 + P / 8 > 12 * nslot || lds > 160 * 1024 - 512) continue;
     int ns = plan.nsplit < gp.tiles_m ? plan.nsplit : gp.tiles_m;
-    const char* me = getenv("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several tiles per split on small problems
+    const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several tiles per split on small problems
     if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
     wg.tiles_per_split = cdiv(gp.tiles_m, ns);
     wg.nsplit = cdiv(gp.tiles_m, wg.tiles_per_split);
@@ -3878,11 +3890,11 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
       attr_ = true;
     }
-    if (getenv("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv_wgrad_split_kernel<%d>, %d splits x %d blocks, %d tiles each, %zu B LDS\n", P, wg.nsplit, grid.y, wg.tiles_per_split, lds);
+    if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv_wgrad_split_kernel<%d>, %d splits x %d blocks, %d tiles each, %zu B LDS\n", P, wg.nsplit, grid.y, wg.tiles_per_split, lds);
     if (P == 256)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, knob("PIDM_STREAM_TRACE") ? 1 : 0);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<128>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, getenv("PIDM_STREAM_TRACE") ? 1 : 0);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<128>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial, knob("PIDM_STREAM_TRACE") ? 1 : 0);
     *used = wg;
     return true;
   }
@@ -3971,7 +3983,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       // taken by the bf16-pipe kernel (wg now holds its tiling / split)
     } else {
       // row-aligned staging without vector arithmetic where the geometry allows it (PIDM_WGRAD_ROWST=0: off, for A/B runs)
-      const char* re = getenv("PIDM_WGRAD_ROWST");
+      const char* re = knob("PIDM_WGRAD_ROWST");
       const int seg = g.NI * g.IHt * g.Wv;
       const bool rowst = !(re && !atoi(re)) && g.stride == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi && g.Wv >= 8 &&
                          seg % 32 == 0 && seg <= 256 && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) &&

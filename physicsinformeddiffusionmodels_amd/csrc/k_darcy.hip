@@ -70,7 +70,7 @@ static DarcyBands darcy_bands(int B, int P) {
   int nb = (1024 + B - 1) / B;              // >= 4 workgroups per CU where the batch alone does not provide them
   static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
   if (!max_rows) {
-    const char* e = getenv("PIDM_DARCY_ROWS");
+    const char* e = knob("PIDM_DARCY_ROWS");
     max_rows = e ? atoi(e) : 32;       // four-pixel kernel at batch 4096: 8 rows 343 us, 16 257, 24 275, 32 241, 64 265 (batch 1024: 60.7 / 61.9 / 54.8 / 61.1 for 16 / 24 / 32 / 64)
     if (max_rows < 4) max_rows = 4;
   }
@@ -713,7 +713,7 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
     attr_done = true;
   }
   const int QP = P >> 2;
-  const char* qe = getenv("PIDM_DARCY_QUAD");     // 0: the one-pixel-per-thread kernel everywhere (A/B measurements, tests)
+  const char* qe = knob("PIDM_DARCY_QUAD");     // 0: the one-pixel-per-thread kernel everywhere (A/B measurements, tests)
   const bool quad = (P & 3) == 0 && P >= 8 && QP <= 256 && (QP & (QP - 1)) == 0 && !(qe && !atoi(qe)) &&
                     ((reinterpret_cast<size_t>(pred) | reinterpret_cast<size_t>(x0) | reinterpret_cast<size_t>(f_s) |
                       reinterpret_cast<size_t>(residual) | reinterpret_cast<size_t>(grad_pred) | reinterpret_cast<size_t>(grad_res)) & 15) == 0;

@@ -265,7 +265,7 @@ static void rs_plan(WgradGeom* wg, int nsplit) {
 bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
                      float* bias_partial, hipStream_t st, WgradGeom* used) {
   const ConvGeom& g = plan.g;
-  const char* off = getenv("PIDM_WGRAD_RS");
+  const char* off = knob("PIDM_WGRAD_RS");
   if (off && !atoi(off)) return false;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   if (!(g.KH == 3 && g.KW == 3 && g.stride == 1 && g.nph == 1 && g.nz == 1 && g.pad_y[0] == 1 && g.pad_x[0] == 1 && g.Wv == g.Wi &&
@@ -277,7 +277,7 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
   WgradGeom wg = plan;
   wg.ld_dy = ld_dy;
   int ns = plan.nsplit;                     // never more splits than the workspace was sized for
-  const char* me = getenv("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several items per wave on small problems
+  const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several items per wave on small problems
   if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
   rs_plan(&wg, ns);
   const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
@@ -287,7 +287,7 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_ = true;
   }
-  if (getenv("PIDM_TRACE_CONV"))
+  if (knob("PIDM_TRACE_CONV"))
     fprintf(stderr, "[pidm]   -> conv_wgrad_rs_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per wave\n", wg.nsplit, grid.y,
             wg.rs_S, wg.rs_R, wg.rs_ppw);
   hipLaunchKernelGGL(conv_wgrad_rs_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);

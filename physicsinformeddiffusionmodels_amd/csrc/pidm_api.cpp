@@ -38,9 +38,12 @@ extern "C" const char* pidm_backend(void) {
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline figures)
 // ---------------------------------------------------------------------------------------------------------
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <stdlib.h>
+#include <string.h>
+extern "C" char** environ;
 namespace pidm {
 struct ProfRec { hipEvent_t a, b; int cls; double work; std::string label; };
 static bool g_prof_on = false;
@@ -58,7 +61,50 @@ void prof_begin_launch(int cls, double work, hipStream_t st) {
 }
 void prof_end_launch(hipStream_t st) { (void)hipEventRecord(g_prof.back().b, st); }
 void prof_reclass_last(int cls) { if (!g_prof.empty()) g_prof.back().cls = cls; }
+
+// ---- knobs: one environment read per name and process ------------------------------------------------------------------------
+namespace {
+struct KnobEntry { bool set; std::string val; };
+std::mutex g_knob_mu;
+std::map<std::string, KnobEntry>* g_knobs = nullptr;     // leaked on purpose: launchers may run during static destruction
+uint64_t g_knob_sig = 0;
+bool g_knob_sig_valid = false;
+}  // namespace
+const char* knob(const char* name) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  if (!g_knobs) g_knobs = new std::map<std::string, KnobEntry>();
+  auto it = g_knobs->find(name);
+  if (it == g_knobs->end()) {
+    const char* v = getenv(name);
+    it = g_knobs->emplace(name, KnobEntry{v != nullptr, v ? std::string(v) : std::string()}).first;
+  }
+  return it->second.set ? it->second.val.c_str() : nullptr;
+}
+uint64_t knob_signature() {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  if (!g_knob_sig_valid) {
+    uint64_t h = 1469598103934665603ull;
+    for (char** e = ::environ; e && *e; ++e) {
+      if (strncmp(*e, "PIDM_", 5) != 0) continue;
+      for (const char* c = *e; *c; ++c) {
+        h ^= (unsigned char)*c;
+        h *= 1099511628211ull;
+      }
+      h ^= h >> 31;
+    }
+    g_knob_sig = h;
+    g_knob_sig_valid = true;
+  }
+  return g_knob_sig;
+}
 }  // namespace pidm
+
+extern "C" int pidm_reload_knobs(void) {
+  std::lock_guard<std::mutex> lk(pidm::g_knob_mu);
+  if (pidm::g_knobs) pidm::g_knobs->clear();
+  pidm::g_knob_sig_valid = false;
+  return 0;
+}
 
 extern "C" int pidm_prof_enable(int on) {
   pidm::g_prof_on = on != 0;
@@ -69,7 +115,7 @@ extern "C" int pidm_prof_collect(double* ms, long long* launches, double* work) 
   for (int c = 0; c < 4; ++c) { ms[c] = 0.0; launches[c] = 0; work[c] = 0.0; }
   struct Agg { double ms = 0, work = 0; long n = 0; int cls = 0; };
   std::map<std::string, Agg> by_label;
-  const char* dump = getenv("PIDM_PROF_DUMP");   // per-shape table of the timed launches (tools/, A/B measurements)
+  const char* dump = pidm::knob("PIDM_PROF_DUMP");   // per-shape table of the timed launches (tools/, A/B measurements)
   for (auto& r : pidm::g_prof) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;

@@ -20,6 +20,13 @@ void prof_begin_launch(int cls, double work, hipStream_t st);
 void prof_end_launch(hipStream_t st);
 void prof_reclass_last(int cls);          // the launcher learned which kernel took the launch (2 / 3 = split form of class 0 / 1)
 
+// Tuning / A-B knobs (the PIDM_* environment variables listed in DESIGN.md section 4): read from the environment ONCE per process
+// and name - `knob("PIDM_X")` returns what getenv returned the first time it was asked (or null) - until pidm_reload_knobs()
+// (include/pidm.h; tests and A/B scripts that change a variable inside a live process call it).  knob_signature() identifies
+// the current snapshot of all PIDM_* variables (part of the hipGraph key: a replayed graph has its knobs frozen in).
+const char* knob(const char* name);
+uint64_t knob_signature();
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // kernels enqueued through the library since it was loaded: directly (eager) + recorded into graphs during a capture; the engine
@@ -185,6 +192,7 @@ struct ConvGeom {
   const float* bn_ssb;    // their bias [2*Cout]
   double* bn_part;
   int bn_ldss, bn_cpg, bn_G, bn_nchunk;
+  int bn_res;             // 1: dy = result + residual (the sums are those of the tensor the launch WRITES; split-form 3x3 epilogues only)
 };
 
 // Geometry of one weight-gradient launch (k_conv.hip, k_wgrad_rs.hip): dW[m][t][n] = sum_p dY[p][m] * X[p (+tap)][n]

@@ -203,11 +203,11 @@ static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads()
 // for graph / forward-graph + eager backward / all eager at batch 64, 7999 / 8077 / 7988 at batch 256 - it keeps the replay, which
 // costs the host a third of the launch-by-launch work.
 static bool backward_eager(int widest) {
-  const char* e = getenv("PIDM_GRAPH");
+  const char* e = knob("PIDM_GRAPH");
   if (e && !atoi(e)) return true;
-  const char* b = getenv("PIDM_GRAPH_BWD");
+  const char* b = knob("PIDM_GRAPH_BWD");
   if (b) return !atoi(b);
-  const char* w = getenv("PIDM_GRAPH_BWD_WIDE");     // the width threshold (tests reach the rule with small models)
+  const char* w = knob("PIDM_GRAPH_BWD_WIDE");     // the width threshold (tests reach the rule with small models)
   return widest >= (w && atoi(w) > 0 ? atoi(w) : 512);
 }
 struct Run {
@@ -614,7 +614,7 @@ static int conv_fwd(Run& r, const ConvLayer& L, const float* x0, const float* x1
 // *part_chunks = chunks per image written (0: not produced - shape not eligible or kernel without the epilogue; the caller
 // then runs launch_gn_stats).
 static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float* x1, float* out, int G, int* part_chunks) {
-  static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr;
+  static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr;
   *part_chunks = 0;
   ConvGeom g;
   if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
@@ -671,18 +671,18 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
 // 768-channel round trips: the 64x64 and 32x32 levels of the Darcy model.  PIDM_NO_LAP=1 keeps the qkv form everywhere (A/B
 // measurements); PIDM_LAP_MIN_N lowers the gate (the unit tests reach the path with small images).
 static void lap_knobs(bool* off, int* min_n) {
-  const char* e = getenv("PIDM_NO_LAP");       // read per call (a handful of calls per step): tests and A/B runs flip it
+  const char* e = knob("PIDM_NO_LAP");       // read per call (a handful of calls per step): tests and A/B runs flip it
   *off = e && atoi(e);
-  const char* m = getenv("PIDM_LAP_MIN_N");
+  const char* m = knob("PIDM_LAP_MIN_N");
   *min_n = m ? atoi(m) : 1024;
 }
 // the knobs as one number: workspace plans are cached per batch size and must be dropped when the knobs change on a live handle
 static long lap_knob_signature() {
   bool off; int min_n;
   lap_knobs(&off, &min_n);
-  const char* g = getenv("PIDM_GRAPH");
-  const char* gb = getenv("PIDM_GRAPH_BWD");        // (the backward plan depends on the side stream too)
-  const char* gw = getenv("PIDM_GRAPH_BWD_WIDE");
+  const char* g = knob("PIDM_GRAPH");
+  const char* gb = knob("PIDM_GRAPH_BWD");        // (the backward plan depends on the side stream too)
+  const char* gw = knob("PIDM_GRAPH_BWD_WIDE");
   return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0);
 }
 static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
@@ -879,16 +879,23 @@ static int conv_dgrad(Run& r, const ConvLayer& L, const float* dy, const float* 
 }
 
 // g_out [B,HW,Co] -> g_x [B,HW,C0+C1]
-static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, float* dss) {
+// pc2_in > 0: the kernel that produced g_out already left the per-channel sums GroupNorm 2's backward starts with in r.scratch
+// (pc2_in 32-pixel chunks per image) - its own reduction pass is skipped.  next / pc_next: the block whose GroupNorm 2 will consume
+// THIS block's g_x as its g_out (the previous block of the level in forward order): the input-gradient convolution that finally
+// writes g_x (conv 1's dgrad, which adds the skip / res_conv share as its residual) leaves those sums from its epilogue, and
+// *pc_next says how many chunks it wrote (0: not produced - ineligible shape or a kernel without the epilogue).
+static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, float* dss, int pc2_in = 0, const ResBlock* next = nullptr,
+                        int* pc_next = nullptr) {
   pidm_unet* U = r.U;
   const int B = r.B, HW = m.H * m.H, Co = m.Co, G = U->groups;
   const size_t n = (size_t)B * HW * Co;
   const size_t mk = r.tmp.mark();
+  if (pc_next) *pc_next = 0;
   float* g_c = r.tmp.alloc(n);
   float* dgb2 = r.defer_on ? r.defer.alloc((size_t)B * 2 * Co) : nullptr;   // allocated outside RUN: dry runs size the arena
   float* dgb1 = r.defer_on ? r.defer.alloc((size_t)B * 2 * Co) : nullptr;
   RUN(launch_gn_bwd(m.c, g_out, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, g_c, U->G[m.gn2w],
-                    U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st, dgb2, r.q()));
+                    U->G[m.gn2b], B, HW, Co, G, r.scratch, r.st, dgb2, r.q(), pc2_in));
   if (conv_wgrad(r, m.c2, m.bact, nullptr, g_c)) return -1;
   float* g_b = r.tmp.alloc(n);
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
@@ -898,7 +905,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   // partials of conv2 live in r.scratch, where the sums go.
   int pcb = 0;
   {
-    static const bool off = getenv("PIDM_NO_GN_EPILOGUE") != nullptr || getenv("PIDM_NO_BN_EPILOGUE") != nullptr;
+    static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN_EPILOGUE") != nullptr;
     pidm_conv_desc d = desc_of(m.c2, r.B);
     ConvGeom g;
     int kind;
@@ -923,12 +930,37 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   RUN(launch_gn_bwd(m.a, g_b, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, m.has_mlp ? dss + m.ss_off : nullptr,
                     g_a, U->G[m.gn1w], U->G[m.gn1b], B, HW, Co, G, r.scratch, r.st, dgb1, r.q(), pcb));
   if (conv_wgrad(r, m.c1, m.x0, m.x1, g_a)) return -1;
+  const float* res1 = g_out;
   if (m.has_res) {
     if (conv_wgrad(r, m.cr, m.x0, m.x1, g_out)) return -1;
     if (conv_dgrad(r, m.cr, g_out, nullptr, g_x)) return -1;
-    if (conv_dgrad(r, m.c1, g_a, g_x, g_x)) return -1;
-  } else {
-    if (conv_dgrad(r, m.c1, g_a, g_out, g_x)) return -1;
+    res1 = g_x;
+  }
+  {
+    // conv 1's input gradient (+ the skip share as residual) = g_x; with `next` its epilogue also sums for next's GroupNorm 2
+    static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN2_EPILOGUE") != nullptr;
+    pidm_conv_desc d = desc_of(m.c1, r.B);
+    ConvGeom g;
+    int kind;
+    if (geom_dgrad(&d, m.c1.Cout, m.c1.C0 + m.c1.C1, &g, &kind)) return -1;
+    bool ok = false;
+    if (next && !off && r.defer_on) {
+      const int Cn = next->Co, cpg = (G > 0 && Cn % G == 0) ? Cn / G : 0;
+      ok = next->H == m.H && g.Cout == Cn && Cn % 32 == 0 && cpg >= 1 && HW % 32 == 0 && g.nz == 1 && g.nph == 1 && g.os == 1 && g.soc == 1 &&
+           g.KH == 3 && g.Ho * g.Wo == HW;
+      if (ok) {
+        g.bn_part = reinterpret_cast<double*>(r.scratch);
+        g.bn_x = next->c; g.bn_stats = next->st2; g.bn_gamma = U->P[next->gn2w]; g.bn_beta = U->P[next->gn2b];
+        g.bn_ss = nullptr; g.bn_ssb = nullptr; g.bn_ldss = 0;
+        g.bn_cpg = cpg; g.bn_G = G; g.bn_nchunk = HW / 32;
+        g.bn_res = 1;
+      }
+    }
+    if (!r.dry) {
+      const int rc = launch_conv(g, g_a, nullptr, r.wpack + m.c1.off_d, nullptr, res1, g_x, 0, r.st);
+      if (rc < 0) return rc;
+      if (ok && rc == 0 && pc_next) *pc_next = HW / 32;
+    }
   }
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
   // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
@@ -1116,7 +1148,7 @@ static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase
     if (!same && r.cap) {
       r.cap->failed = true;      // a table upload is never captured: host and device table stay as they are, the pass is re-run eagerly
     } else if (!same) {
-      if (getenv("PIDM_REDUCE_STATS")) {   // one line per table change: what the deferred reduction reads
+      if (knob("PIDM_REDUCE_STATS")) {   // one line per table change: what the deferred reduction reads
         double bytes = 0, outs = 0;
         for (size_t i = first; i < n; ++i) {
           const ReduceDesc& d = r.rq.v[i];
@@ -1205,9 +1237,11 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     float* g1 = r.tmp.alloc(npix * din);
     if (attn_bwd(r, U->attn[iat--], g_x, g1)) return -1;
     float* g2 = r.tmp.alloc(npix * din);
-    if (resblock_bwd(r, U->rb[irb--], g1, g2, dss)) return -1;
+    int pc_b1 = 0;             // block 2's final input-gradient convolution sums for block 1's GroupNorm 2
+    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, 0, &U->rb[irb - 1], &pc_b1)) return -1;
+    --irb;
     float* gc = r.tmp.alloc(npix * 2 * dout);
-    if (resblock_bwd(r, U->rb[irb--], g2, gc, dss)) return -1;
+    if (resblock_bwd(r, U->rb[irb--], g2, gc, dss, pc_b1)) return -1;
     g_skip[lvl] = gc + dout;
     g_skip_ld[lvl] = 2 * dout;
     if (j > 0) {
@@ -1246,9 +1280,11 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     float* g1 = r.tmp.alloc(npix * dout);
     if (attn_bwd(r, U->attn[iat--], g_la, g1)) return -1;
     float* g2 = r.tmp.alloc(npix * dout);
-    if (resblock_bwd(r, U->rb[irb--], g1, g2, dss)) return -1;
+    int pc_b1 = 0;
+    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, 0, &U->rb[irb - 1], &pc_b1)) return -1;
+    --irb;
     float* g3 = r.tmp.alloc(npix * din);
-    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss)) return -1;
+    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss, pc_b1)) return -1;
     g_x = g3;
   }
   // encoder half done: downs.* / mid_* gradients are final after this flush
@@ -1440,21 +1476,10 @@ static uint64_t hash_words(const uint64_t* w, size_t n, uint64_t h = 14695981039
   }
   return h;
 }
-// every PIDM_* environment variable (the launchers read their knobs per call; a replayed graph has them frozen in)
-static uint64_t env_signature() {
-  uint64_t h = 1469598103934665603ull;
-  for (char** e = ::environ; e && *e; ++e) {
-    if (strncmp(*e, "PIDM_", 5) != 0) continue;
-    for (const char* c = *e; *c; ++c) {
-      h ^= (unsigned char)*c;
-      h *= 1099511628211ull;
-    }
-    h ^= h >> 31;
-  }
-  return h;
-}
+// every PIDM_* environment variable as the knob snapshot saw it (pidm_api.cpp: one read per process until pidm_reload_knobs())
+static uint64_t env_signature() { return knob_signature(); }
 static bool graphs_enabled() {
-  const char* e = getenv("PIDM_GRAPH");        // 0: every pass is enqueued launch by launch (A/B measurements)
+  const char* e = knob("PIDM_GRAPH");        // 0: every pass is enqueued launch by launch (A/B measurements)
   return !(e && !atoi(e)) && !prof_enabled();  // per-launch event timing needs individual launches
 }
 static GraphEntry* graph_find(pidm_unet* h, int kind, const std::vector<uint64_t>& key) {
@@ -1543,7 +1568,7 @@ static void touch_arena(pidm_unet* h, int B, bool train, const void* workspace, 
     const size_t packed_b = packed_region_bytes(h) + io_region(h, B, nullptr).total;
     const bool planned = plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b) == 0;
     const bool inside = tab >= ws && tab < ws + workspace_bytes;
-    if (getenv("PIDM_DEBUG_ARENA")) fprintf(stderr, "[pidm] arena touch B=%d train=%d: extent %zu, table at %zu\n", B, (int)train, packed_b + tape_b + tmp_b, (size_t)(tab - ws));
+    if (knob("PIDM_DEBUG_ARENA")) fprintf(stderr, "[pidm] arena touch B=%d train=%d: extent %zu, table at %zu\n", B, (int)train, packed_b + tape_b + tmp_b, (size_t)(tab - ws));
     if (!planned || !inside || ws + packed_b + tape_b + tmp_b > tab) h->red_table_dev = nullptr;
   }
   h->arena_sig = sig;
@@ -1661,7 +1686,7 @@ extern "C" int pidm_unet_backward(pidm_unet* h, const float* grad_out_nchw, floa
   const hipStream_t st = as_stream(stream);
   if (!h->side_ok && !h->side) {
     // created once per handle; PIDM_NO_OVERLAP=1 keeps the whole backward on the caller's stream (A/B measurements)
-    const char* e = getenv("PIDM_NO_OVERLAP");
+    const char* e = knob("PIDM_NO_OVERLAP");
     if (!(e && atoi(e))) {
       h->side_ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
                    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&

@@ -37,8 +37,49 @@ def flat_gradient_buffers(model):
     return [e.flat_grad for k, e in model.__dict__.get("_engines", {}).items() if e.flat_grad is not None and k[2] == 0]
 
 
-def _allreduce_avg(buf, world, group):
-    if dist.get_backend(group) == "nccl":
+class NativeComm:
+    """The C-ABI communicator (include/pidm.h: pidm_comm_*): RCCL bound inside the library, no torch collective on the data path.
+    Rank 0's 128-byte id reaches the other ranks through the process group the caller already has (one broadcast at set-up);
+    `allreduce_avg` then takes a raw pointer, a count and the current stream.  Opt-in (`PIDM_DP_NATIVE=1`, or pass one to
+    GradientExchange): torch.distributed's own RCCL path stays the default."""
+
+    def __init__(self, lib, device, group=None):
+        self.lib, self.device = lib, torch.device(device)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            lib.check(lib.pidm_comm_unique_id(buf), "pidm_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        carrier = ident.to(self.device) if dist.get_backend(group) == "nccl" else ident
+        dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(carrier.cpu().tolist())
+        self.handle = vp()
+        with torch.cuda.device(self.device):
+            lib.check(lib.pidm_comm_init(rank, world, raw, C.byref(self.handle)), "pidm_comm_init")
+        self.world = world
+
+    def allreduce_avg(self, buf):
+        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        st = torch.cuda.current_stream(buf.device).cuda_stream
+        self.lib.check(self.lib.pidm_allreduce_f32(self.handle, vp(buf.data_ptr()), buf.numel(), 1, vp(st)), "pidm_allreduce_f32")
+
+    def close(self):
+        if self.handle:
+            self.lib.pidm_comm_destroy(self.handle)
+            self.handle = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _allreduce_avg(buf, world, group, native=None):
+    if native is not None:
+        native.allreduce_avg(buf)                                   # RCCL through the library's own C entry point
+    elif dist.get_backend(group) == "nccl":
         dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)     # RCCL over xGMI
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
@@ -71,8 +112,10 @@ class GradientExchange:
     data-parallel exact (it needs the world size for one scalar all-reduce)."""
 
     def __init__(self, model, world_size: int | None = None, image_size: int = 64, buckets: int = 3, group=None, lib=None,
-                 diffusion=None, force: bool = False):
+                 diffusion=None, force: bool = False, native: bool | None = None):
         self.model, self.group = model, group
+        self.native = None
+        self._want_native = (os.environ.get("PIDM_DP_NATIVE") == "1") if native is None else bool(native)
         self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         # force: run the collectives even with one rank (exercises RCCL, the side stream and the phase events on a single-GPU box)
         self.active = self.world > 1 or (force and dist.is_initialized())
@@ -103,6 +146,8 @@ class GradientExchange:
         self.ranges.append(rest)
         dev = eng.params[0].device
         self.on_gpu = dev.type == "cuda"
+        if self._want_native and self.active and self.on_gpu:
+            self.native = NativeComm(eng.lib, dev, group)
         self.events, self.stream = None, None
         self._closed = True                # until the engine has been told about this object
         handles = None
@@ -143,6 +188,9 @@ class GradientExchange:
             pass
         self.events = self.stream = None
         self.active = False
+        if self.native is not None:
+            self.native.close()
+            self.native = None
 
     def __del__(self):
         try:
@@ -173,7 +221,7 @@ class GradientExchange:
                 timing[0].record()
             for rs in self.ranges:
                 for lo, hi in rs:
-                    _allreduce_avg(flat[lo:hi], self.world, self.group)
+                    _allreduce_avg(flat[lo:hi], self.world, self.group, self.native)
             if timing:
                 timing[1].record()
             return
@@ -184,7 +232,7 @@ class GradientExchange:
                 if timing and k == 0:
                     timing[0].record()          # first phase's gradients are final: the exchange starts here
                 for lo, hi in rs:
-                    _allreduce_avg(flat[lo:hi], self.world, self.group)
+                    _allreduce_avg(flat[lo:hi], self.world, self.group, self.native)
                 if timing and k == len(self.ranges) - 1:
                     timing[1].record()
         cur.wait_stream(self.stream)

@@ -32,3 +32,30 @@ def backend(request):
     L = get_lib()
     assert L.backend == "hip"
     return L, torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_knobs():
+    """The native library reads each PIDM_* knob once per process; tests flip knobs, so every test starts (and leaves) with a fresh
+    snapshot."""
+    from physicsinformeddiffusionmodels_amd._lib import reload_knobs
+    reload_knobs()
+    yield
+    reload_knobs()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch whose setenv / delenv also drop the native library's knob snapshot (see _fresh_knobs)."""
+    from physicsinformeddiffusionmodels_amd._lib import reload_knobs
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        set_(name, value, prepend)
+        reload_knobs()
+
+    def delenv(name, raising=True):
+        del_(name, raising)
+        reload_knobs()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    return monkeypatch

@@ -9,6 +9,8 @@ import ctypes as C
 import pytest
 import torch
 
+from physicsinformeddiffusionmodels_amd._lib import reload_knobs
+
 from oracle import pidm_oracle as O
 from physicsinformeddiffusionmodels_amd._engine import get_engine
 from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
@@ -79,10 +81,12 @@ def test_replay_survives_interleaved_passes_and_rebinding(backend):
     import os
     for i, d in enumerate(data):
         os.environ["PIDM_GRAPH"] = "0"
+        reload_knobs()
         try:
             o_ref, g_ref = _train_step(ref_m, *d)
         finally:
             del os.environ["PIDM_GRAPH"]
+            reload_knobs()
         o, g = _train_step(m, *d)
         assert torch.equal(o, o_ref) and torch.equal(g, g_ref), i
         if i == 2:
@@ -113,10 +117,12 @@ def test_changed_weights_are_seen_by_the_replayed_forward(backend):
     data = _inputs(dev, 4)
     for i, d in enumerate(data):
         os.environ["PIDM_GRAPH"] = "0"
+        reload_knobs()
         try:
             o_ref, g_ref = _train_step(ma, *d)
         finally:
             del os.environ["PIDM_GRAPH"]
+            reload_knobs()
         o, g = _train_step(mb, *d)
         assert torch.equal(o, o_ref) and torch.equal(g, g_ref), i
         with torch.no_grad():
@@ -172,10 +178,12 @@ def test_conditioning_branch_replay(backend):
     for i, d in enumerate(data):
         c = conds[i] if i % 2 == 0 else None
         os.environ["PIDM_GRAPH"] = "0"
+        reload_knobs()
         try:
             o_ref, g_ref = _train_step(ma, *d, cond=c)
         finally:
             del os.environ["PIDM_GRAPH"]
+            reload_knobs()
         o, gg = _train_step(mb, *d, cond=c)
         assert torch.equal(o, o_ref) and torch.equal(gg, g_ref), i
 

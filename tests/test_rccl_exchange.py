@@ -113,3 +113,43 @@ def test_exchange_object_lifetime(nccl_single_rank):
     del ex2
     gc.collect()
     assert torch.equal(_step(m, diff, res, x0, eps, t), ref)    # no dangling event handles: backward records nothing
+
+
+def test_c_abi_communicator_single_rank(nccl_single_rank):
+    """include/pidm.h pidm_comm_unique_id / pidm_comm_init / pidm_allreduce_f32 / pidm_comm_destroy: RCCL bound inside the library
+    (no torch collective on the data path).  One rank: mean and sum are the identity, enqueued on the current (non-default) stream."""
+    import ctypes as C
+    from physicsinformeddiffusionmodels_amd._lib import get_lib, vp
+    lib = get_lib()
+    ident = (C.c_ubyte * 128)()
+    lib.check(lib.pidm_comm_unique_id(ident), "pidm_comm_unique_id")
+    assert any(ident)
+    comm = vp()
+    lib.check(lib.pidm_comm_init(0, 1, bytes(ident), C.byref(comm)), "pidm_comm_init")
+    assert comm.value
+    x = torch.randn(1 << 20, device="cuda:0")
+    ref = x.clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for avg in (1, 0):
+            lib.check(lib.pidm_allreduce_f32(comm, vp(x.data_ptr()), x.numel(), avg, vp(st.cuda_stream)), "pidm_allreduce_f32")
+    st.synchronize()
+    assert torch.equal(x, ref)
+    assert lib.pidm_allreduce_f32(None, vp(x.data_ptr()), 4, 1, None) != 0            # null communicator: an error, not a crash
+    assert lib.pidm_comm_init(3, 2, bytes(ident), C.byref(vp())) != 0                # rank outside the world
+    lib.check(lib.pidm_comm_destroy(comm), "pidm_comm_destroy")
+
+
+def test_gradient_exchange_over_the_c_abi_communicator(nccl_single_rank):
+    """GradientExchange(native=True): the three overlapped range all-reduces go through pidm_allreduce_f32 on the side stream
+    instead of torch.distributed.all_reduce - same bit-identical result with one rank, id hand-off over the process group."""
+    from physicsinformeddiffusionmodels_amd.parallel import GradientExchange
+    m, diff, res, x0, eps, t = _setup(False)
+    ref = _step(m, diff, res, x0, eps, t)
+    ex = GradientExchange(m, image_size=32, diffusion=diff, force=True, native=True)
+    assert ex.native is not None and ex.native.world == 1
+    for _ in range(4):
+        assert torch.equal(_step(m, diff, res, x0, eps, t, ex), ref) and ex.last_overlapped
+    ex.close()
+    assert ex.native is None
+    assert torch.equal(_step(m, diff, res, x0, eps, t), ref)

@@ -15,7 +15,7 @@ for (H, C0, C1, Cout) in SHAPES:
     d = ConvDesc(B=B, Hi=H, Wi=H, C0=C0, C1=C1, ld0=C0, ld1=C1, Cout=Cout, KH=1, KW=1, stride=1, pad=0, transposed=0, out_nchw=0, ldo=Cout)
     res_us = []
     for split in ("1", "0"):
-        os.environ["PIDM_CONV_SPLIT"] = split
+        os.environ["PIDM_CONV_SPLIT"] = split; L.pidm_reload_knobs()
         wp = torch.empty(L.pidm_conv_packed_weight_floats(d), device=dev)
         L.check(L.pidm_conv_pack_weights(d, ptr(w), ptr(wp), 0, st))
         f = lambda: L.check(L.pidm_conv_forward(d, ptr(x0), ptr(x1), ptr(wp), ptr(bias), ptr(res), ptr(out), st))

@@ -498,7 +498,9 @@ def main():
         exch = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ms_per_exchange": None if ems is None else round(ems, 3),
                 "overlapped_with_backward": bool(exchange.last_overlapped), "ranges": [len(r) for r in exchange.ranges],
                 "payload_MB": round(sum(hi - lo for rs in exchange.ranges for lo, hi in rs) * 4 / 1e6, 2),
-                "forced_single_rank": bool(force_dp and world == 1)}
+                "forced_single_rank": bool(force_dp and world == 1),
+                "collective": ("pidm_allreduce_f32 (C-ABI communicator over RCCL, PIDM_DP_NATIVE=1)" if exchange.native is not None
+                               else "torch.distributed.all_reduce")}
 
     roofline = None
     if not args.no_roofline:

@@ -30,6 +30,23 @@ int launch_split_reduce(const float* partial, float* dst, const float* bias_part
 int make_geom(ConvGeom* g, int kind, int B, int Hi, int Wi, int C0, int C1, int ld0, int ld1, int Cout, int KH, int KW,
               int stride, int pad, int out_nchw, int ldo, int ldr);
 int geom_dgrad(const pidm_conv_desc* d, int ld_dy, int ld_dx, ConvGeom* g, int* pack_kind);
+int geom_fwd(const pidm_conv_desc* d, ConvGeom* g);   // geometry of the forward op described by a public pidm_conv_desc
+// re-tile a stride-1 geometry for a bm-pixel workgroup tile (bm = 256: two m-tiles per wave)
+inline bool retile_bm(ConvGeom* g, int bm) {
+  if (g->Wv > bm || g->nz != 1 || g->nph != 1) return false;
+  const int TH = bm / g->Wv < g->Hv ? bm / g->Wv : g->Hv;
+  if (g->Hv % TH) return false;
+  int tsh = 0;
+  while ((1 << tsh) < TH) ++tsh;
+  if ((1 << tsh) != TH) return false;
+  const int NI = bm / (g->Wv * TH);
+  if (NI * g->Wv * TH != bm) return false;
+  g->TH = TH; g->tsh = tsh; g->NI = NI;
+  g->IHt = (TH - 1) * g->stride + g->KH;
+  g->mIHt = g->IHt > 1 ? (unsigned)((0x100000000ULL + g->IHt - 1) / g->IHt) : 0;
+  g->tiles_m = (NI > 1) ? cdiv(g->B, NI) : g->B * (g->Hv / TH);
+  return true;
+}
 size_t packed_floats(const ConvGeom& g);
 int packed_kp(const ConvGeom& g);
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,

@@ -1179,6 +1179,10 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   const int smode = wgrad_stream_mode(g, ld_dy);
   if (smode == 2) blocks_mn = cdiv(wg->MP, 128) * (wg->NP / 32);
   if (smode == 3) blocks_mn = cdiv(wg->NP, 128) * (wg->MP / 32);
+  // the 4x4 / stride-2 layers on the row-streaming bf16 kernel (k_wgrad_rs.hip): one workgroup per (split, 32 x 32 block) and CU
+  const char* rse = knob("PIDM_WGRAD_RS");
+  const bool rs4 = !(rse && !atoi(rse)) && wgrad_rs4_eligible(g, ld_dy);
+  if (rs4) blocks_mn = (wg->MP / 32) * (wg->NP / 32);
   // two workgroups per CU are resident: pick tiles-per-split so that the number of workgroup "rounds" over the
   // 512 slots times the per-workgroup work (+ ~1 tile-equivalent of prologue / epilogue) is minimal
   int best_tps = g.tiles_m;
@@ -1186,7 +1190,7 @@ static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   for (int tps = 1; tps <= g.tiles_m; ++tps) {
     const long wgs = (long)blocks_mn * cdiv(g.tiles_m, tps);
     if (wgs > 4096 && tps < g.tiles_m) continue;
-    const double cost = (T == 9)   ? (double)((wgs + 255) / 256) * (tps + 1.5)      // 3x3: 144 accumulators, 1 workgroup per CU
+    const double cost = (T == 9 || rs4) ? (double)((wgs + 255) / 256) * (tps + 1.5) // 3x3 (and 4x4/s2 row-streaming): 1 workgroup per CU
                         : (T == 1) ? (double)((wgs + 1023) / 1024) * (tps + 1.0)    // 1x1: <= 128 registers, 4 workgroups per CU
                                    : (double)((wgs + 511) / 512) * (tps + 1.0);     // 2x2 (phased 4x4/s2): two per CU
     if (cost < best_cost - 1e-9) { best_cost = cost; best_tps = tps; }
@@ -1303,6 +1307,8 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<1>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<4>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
+  } else if (g.nph > 1 && launch_wgrad_rs4(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
+    if (prof) prof_reclass_last(3);   // split form on the bf16 pipe
   } else if (g.nph > 1) {
     if (!aligned || g.NI * g.IHt * g.IWt * 8 > 9 * 256) return fail("wgrad: phased 4x4/s2 geometry not eligible for the pipelined kernel");
     const dim3 gridp(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 4);

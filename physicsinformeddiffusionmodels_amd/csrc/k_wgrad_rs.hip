@@ -238,6 +238,151 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs_kernel(WgradGeom wg, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 4x4 / stride-2 / pad-1 layers (`Downsample`, src/unet_model.py:197; and - with the operands swapped by the caller - the
+// transposed `Upsample`, :163) in the same row-streaming form:  dW[m][ky][kx][n] = sum dY[b,y,x][m] X[b, 2y + ky - 1, 2x + kx - 1][n].
+// A k-step is again one row of 8 + 8 OUTPUT pixels; the 8 input pixels a tap needs lie two apart, so a row of X is loaded as its
+// even-column fragment E[j] = X[r][2(x0 + j)], j = 0..8, and its odd-column fragment O[j] = X[r][2(x0 + j) + 1], j = -1..7 (18 dword
+// loads, each two whole 128-byte lines), and   kx = 0: O[j - 1]   kx = 1: E[j]   kx = 2: O[j]   kx = 3: E[j + 1]
+// - the shifted forms are the same registers moved by one bf16, as for the 3x3 taps.  A wave owns the 8 taps of two kernel rows
+// (128 accumulator registers: ky = 2 kp, 2 kp + 1 read the input rows 2y + 2kp - 1 and 2y + 2kp); waves 0 / 1 of a workgroup take
+// kp = 0 / 1 of the same strips, waves 2 / 3 the same for the workgroup's other strips; the two partners of a kernel-row pair
+// are summed through LDS.  No rows are shared between consecutive k-steps of a wave (stride 2), so there is no rolling window:
+// ~330 vector instructions per 48 MFMAs - vector-bound, and still 2x the fp32-MFMA kernel it replaces (conv_wgrad_pipe_kernel<2,2,..>).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_wgrad_rs4_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                             const float* __restrict__ dy, float* __restrict__ partial,
+                                                             float* __restrict__ bias_partial) {
+  const ConvGeom& g = wg.g;
+  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][8 taps][32][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = wg.NP / 32;
+  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int split = blockIdx.x;
+  const int kp = wave & 1, pw = wave >> 1;                 // kernel-row pair, pixel share of the workgroup
+  const int Ho = g.Hv, Wo = g.Wv, Hi = g.Hi, R = wg.rs_R;
+  const int wsh = g.wsh;                                   // log2 Wo
+  const unsigned ldxb = (unsigned)g.ld0 * 4u, ldyb = (unsigned)wg.ld_dy * 4u;
+  const unsigned rowxb = ldxb << (wsh + 1), rowyb = ldyb << wsh;              // bytes between rows of X (2 Wo pixels) / of dY
+  const unsigned tot_x = (unsigned)g.B * (unsigned)Hi * rowxb, tot_y = (unsigned)g.B * (unsigned)Ho * rowyb;
+  const float* xsrc = (n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0);
+  const pidm_rsrc rx = pidm_make_rsrc(xsrc, tot_x), ry = pidm_make_rsrc(dy + m0, tot_y);
+  const bool do_bias = (bias_partial != nullptr) && (tn == 0) && (kp == 0);
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bacc = 0.f;
+
+  const int wv = split * 2 + pw;                           // this pixel share among the 2 * nsplit of the block
+  const int npairs = (wg.rs_S + 1) >> 1;
+  int pair_lo = wv * wg.rs_ppw, pair_hi = pair_lo + wg.rs_ppw;
+  if (pair_hi > npairs) pair_hi = npairs;
+
+  for (int pair = pair_lo; pair < pair_hi; ++pair) {
+    const int s = 2 * pair + half;
+    const bool s_ok = s < wg.rs_S;
+    const int xs = s & ((1 << wg.rs_xsh) - 1), t1 = s >> wg.rs_xsh;
+    const int chunk = t1 & ((1 << wg.rs_csh) - 1), b = t1 >> wg.rs_csh;
+    const int x0 = xs << 3, y0 = chunk * R;
+    const bool left_ok = x0 > 0, right_ok = x0 + 8 < Wo;
+    // X: (image b, input row 2 y0 + 2 kp - 1, input column 2 x0, this lane's channel); dY: (b, y0, x0, channel)
+    int yx = 2 * y0 + 2 * kp - 1;
+    unsigned offx = ((unsigned)(b * Hi + yx) << (wsh + 1)) * ldxb + (unsigned)(2 * x0) * ldxb + (unsigned)l31 * 4u;
+    unsigned offy = ((unsigned)(b * Ho + y0) << wsh) * ldyb + (unsigned)x0 * ldyb + (unsigned)l31 * 4u;
+
+    // one input row: E (even columns, + the one after) and O (odd columns, + the one before), as rs_split_row operands
+    float re[2][2][10], ro[2][2][10], rawy[2][8];           // [buffer][row of the pair][...]
+#define PIDM_RS4_LOAD_ROW(e_, o_, row_, voff_)                                                                      \
+  {                                                                                                                 \
+    const bool ok__ = s_ok & ((row_) >= 0) & ((row_) < Hi);                                                         \
+    const unsigned vc__ = ok__ ? (voff_) : kRsInv, vp__ = (ok__ & left_ok) ? (voff_) - ldxb : kRsInv,               \
+                   vn__ = (ok__ & right_ok) ? (voff_) : kRsInv;                                                     \
+    e_[0] = 0.f;                                                                                                    \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) e_[1 + j__] = pidm_buf_load_f32(rx, vc__, (unsigned)(2 * j__) * ldxb); \
+    e_[9] = pidm_buf_load_f32(rx, vn__, 16u * ldxb);                                                                \
+    o_[0] = pidm_buf_load_f32(rx, vp__, 0u);                                                                        \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) o_[1 + j__] = pidm_buf_load_f32(rx, vc__, (unsigned)(2 * j__ + 1) * ldxb); \
+    o_[9] = 0.f;                                                                                                    \
+  }
+#define PIDM_RS4_LOAD(buf_)                                                                                         \
+  {                                                                                                                 \
+    PIDM_RS4_LOAD_ROW(re[buf_][0], ro[buf_][0], yx, offx)                                                           \
+    PIDM_RS4_LOAD_ROW(re[buf_][1], ro[buf_][1], yx + 1, offx + rowxb)                                               \
+    const unsigned vy__ = (s_ok & (ny < R)) ? offy : kRsInv;                                                        \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) rawy[buf_][j__] = pidm_buf_load_f32(ry, vy__, (unsigned)j__ * ldyb); \
+    offx += 2u * rowxb;                                                                                             \
+    yx += 2;                                                                                                        \
+    offy += rowyb;                                                                                                  \
+    ++ny;                                                                                                           \
+  }
+    int ny = 0;
+    PIDM_RS4_LOAD(0)
+    int i = 0;
+    while (i < R) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (i >= R) break;         // wave-uniform
+        PIDM_RS4_LOAD(u ^ 1)                          // the next output row's operands (zeros past the chunk)
+        RsRow e0, o0, e1, o1;
+        u32x4 ya[3];
+        rs_split_row(re[u][0], e0);
+        rs_split_row(ro[u][0], o0);
+        rs_split_row(re[u][1], e1);
+        rs_split_row(ro[u][1], o1);
+        const float sb = rs_split_dy(rawy[u], ya);
+        if (do_bias) bacc += sb;
+        PIDM_RS_SIX(acc[0], ya, o0.l)                // ky = 2 kp:     kx = 0 .. 3
+        PIDM_RS_SIX(acc[1], ya, e0.c)
+        PIDM_RS_SIX(acc[2], ya, o0.c)
+        PIDM_RS_SIX(acc[3], ya, e0.r)
+        PIDM_RS_SIX(acc[4], ya, o1.l)                // ky = 2 kp + 1
+        PIDM_RS_SIX(acc[5], ya, e1.c)
+        PIDM_RS_SIX(acc[6], ya, o1.c)
+        PIDM_RS_SIX(acc[7], ya, e1.r)
+        ++i;
+      }
+    }
+#undef PIDM_RS4_LOAD
+#undef PIDM_RS4_LOAD_ROW
+  }
+
+  // ---- the two pixel shares of each kernel-row pair summed through LDS, then the split's partial slab [split][m][16 taps][n] ----
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[((wave * 8 + t) * 32 + row) * 32 + l31] = acc[t][r];
+    }
+  __syncthreads();
+  {
+    const int mrow = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int kpt = tap >> 3, t = tap & 7;           // tap = ky * 4 + kx = (2 kp + (t >> 2)) * 4 + (t & 3) = 8 kp + t
+      const float* rp = red + (((kpt) * 8 + t) * 32 + mrow) * 32 + c4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp), a1 = *reinterpret_cast<const f32x4*>(rp + 2 * 8 * 1024);
+      const f32x4 sv = a0 + a1;
+      *reinterpret_cast<f32x4*>(partial + (((size_t)split * wg.MP + (m0 + mrow)) * 16 + tap) * wg.NP + n0 + c4) = sv;
+    }
+  }
+  if ((bias_partial != nullptr) && (tn == 0)) {
+    __syncthreads();
+    red[tid] = bacc;               // zero in the kp = 1 waves
+    __syncthreads();
+    if (tid < 32) {
+      float sb = 0.f;
+      for (int k = 0; k < 8; ++k) sb += red[k * 32 + tid];
+      bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
+    }
+  }
+}
+
 // Plan: rows per strip chunk R (power of two <= H) such that the waves of a block (4 per split) get whole items and the longest
 // wave - items x (R rows + the three rows of prologue) - is shortest.
 static void rs_plan(WgradGeom* wg, int nsplit) {
@@ -258,6 +403,62 @@ static void rs_plan(WgradGeom* wg, int nsplit) {
     }
   }
   wg->nsplit = nsplit;
+}
+
+static void rs4_plan(WgradGeom* wg, int nsplit) {
+  const ConvGeom& g = wg->g;
+  const int shares = 2 * nsplit;                 // pixel shares of a block: two per workgroup
+  int xsh = 0;
+  while ((8 << xsh) < g.Wv) ++xsh;
+  long best_cost = -1;
+  for (int R = g.Hv; R >= 1; R >>= 1) {
+    const int cpi = g.Hv / R;
+    const long S = (long)g.B * cpi * (g.Wv / 8), pairs = (S + 1) / 2, ppw = (pairs + shares - 1) / shares;
+    const long cost = ppw * (R + 1);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      int csh = 0;
+      while ((1 << csh) < cpi) ++csh;
+      wg->rs_R = R; wg->rs_csh = csh; wg->rs_xsh = xsh; wg->rs_S = (int)S; wg->rs_ppw = (int)ppw;
+    }
+  }
+  wg->nsplit = nsplit;
+}
+
+bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const size_t pix_x = (size_t)g.B * g.Hi * g.Wi, pix_y = (size_t)g.B * g.Hv * g.Wv;
+  return g.nph == 4 && g.nz == 1 && g.KH == 2 && g.KW == 2 && g.in_step == 2 && 2 * g.Wv == g.Wi && 2 * g.Hv == g.Hi && g.Wv >= 8 &&
+         pow2(g.Wv) && pow2(g.Hv) && (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && (g.Cout % 32 == 0) && (g.C1 == 0 || g.ld1 == g.ld0) &&
+         pix_x * (size_t)g.ld0 * 4 < 0x7ff00000ull && pix_y * (size_t)ld_dy * 4 < 0x7ff00000ull;
+}
+
+// the 4x4 / stride-2 layers (phased geometry, ConvGeom::nph == 4); same contract as launch_wgrad_rs
+bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
+                      float* bias_partial, hipStream_t st, WgradGeom* used) {
+  const ConvGeom& g = plan.g;
+  const char* off = knob("PIDM_WGRAD_RS");
+  if (off && !atoi(off)) return false;
+  if (!wgrad_rs4_eligible(g, ld_dy) || (reinterpret_cast<size_t>(src0) & 3) || (reinterpret_cast<size_t>(dy) & 3)) return false;
+  WgradGeom wg = plan;
+  wg.ld_dy = ld_dy;
+  int ns = plan.nsplit;
+  const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");
+  if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+  rs4_plan(&wg, ns);
+  const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
+  const size_t lds = 4 * 8 * 1024 * sizeof(float);
+  static bool attr_ = false;
+  if (!attr_) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_ = true;
+  }
+  if (knob("PIDM_TRACE_CONV"))
+    fprintf(stderr, "[pidm]   -> conv_wgrad_rs4_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per pixel share\n", wg.nsplit,
+            grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
+  hipLaunchKernelGGL(conv_wgrad_rs4_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  *used = wg;
+  return true;
 }
 
 // true: launched (and *used holds the split actually written); false: geometry not eligible (the caller goes on to the LDS-staged

@@ -66,6 +66,9 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
 // k_wgrad_rs.hip: 3x3 / stride-1 weight gradient, row-streaming split form (false: geometry not eligible)
 bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
                      float* bias_partial, hipStream_t st, WgradGeom* used);
+bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy);
+bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
+                      float* bias_partial, hipStream_t st, WgradGeom* used);
 size_t colsum_ws_bytes(size_t rows, int C);
 int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st,
                   ReduceQueue* defer = nullptr);

@@ -1291,7 +1291,9 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   const bool aligned = ((g.ld0 & 3) == 0) && ((g.ld1 & 3) == 0) && ((g.C0 & 3) == 0) && ((g.Cin & 3) == 0) &&
                        ((ld_dy & 3) == 0) && ((g.Cout & 3) == 0);
   const int smode = wgrad_stream_mode(g, ld_dy);
-  if (wgrad_smallc(g)) {
+  if (wgrad_smallc(g) && launch_wgrad_rs7(wg, src0, dy, ld_dy, partial, bias_partial, st, &wg)) {
+    if (prof) prof_reclass_last(3);   // split form on the bf16 pipe (row-streaming, k_wgrad_rs.hip)
+  } else if (wgrad_smallc(g)) {
     // few input channels, many taps (init conv): (tap, channel) flattened into the GEMM N dimension
     const int NJ = T * g.Cin, ntl = cdiv(NJ, 32), maxn = cdiv(ntl, 4);
     const size_t lds2 = ((((size_t)g.NI * g.IHt * g.IWt * g.Cin + 3) & ~(size_t)3) + kBM * 32) * sizeof(float);

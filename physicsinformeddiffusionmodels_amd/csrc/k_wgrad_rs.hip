@@ -383,6 +383,128 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs4_kernel(WgradGeom wg, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Few input channels, many taps (the 7x7 `init_conv`, src/unet_model.py:453: Cin = 2, or 10 for the mechanics model): the GEMM N
+// dimension is the flattened (tap, channel) index, as in conv_wgrad_smallc_kernel (98 columns for 7x7x2 instead of 49 taps x a
+// 32-channel tile that is 94 % padding).  Row-streaming form: lane j of an n-tile IS column (ky, kx, c) and loads its own 8 pixels
+// X[y + ky - pad][x0 + kx - pad + 0..7][c] (neighbouring lanes read neighbouring floats: a tile's loads are a few contiguous
+// runs); rows / columns outside the image are never fetched (per-load offset select).  The 4 waves of a workgroup walk the SAME
+// pixels and own different n-tiles (wave w: tiles w, w + 4, ..), so the epilogue needs no cross-wave sum; the dY fragment is
+// split by every wave (48 vector instructions).  Vector-bound (~120 instructions per 6 MFMAs and n-tile) - and 3-5x the fp32-MFMA
+// LDS kernel it replaces, whose 64 two-deep k-steps per 128 pixels were the cost.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MAXN>
+__global__ void __launch_bounds__(256) conv_wgrad_rs7_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ dy,
+                                                             float* __restrict__ partial, float* __restrict__ bias_partial) {
+  const ConvGeom& g = wg.g;
+  __shared__ float red[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = g.KH * g.KW, Cin = g.Cin, NJ = T * Cin;
+  const int m0 = blockIdx.y * 32;
+  const int split = blockIdx.x;
+  const int H = g.Hi, W = g.Wi, R = wg.rs_R;
+  const int wsh = g.wsh;
+  const unsigned ldxb = (unsigned)g.ld0 * 4u, ldyb = (unsigned)wg.ld_dy * 4u;
+  const unsigned rowxb = ldxb << wsh, rowyb = ldyb << wsh;
+  const unsigned tot_x = (unsigned)g.B * (unsigned)H * rowxb, tot_y = (unsigned)g.B * (unsigned)H * rowyb;
+  const pidm_rsrc rx = pidm_make_rsrc(src0, tot_x), ry = pidm_make_rsrc(dy + m0, tot_y);
+  const bool do_bias = (bias_partial != nullptr) && (wave == 0);
+
+  // this lane's column of each of the wave's n-tiles: (tap row, tap column, channel) -> (dy, dx, c)
+  int jdy[MAXN], jdx[MAXN], jt[MAXN], jc[MAXN];
+  bool jok[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) {
+    const int j = (wave + 4 * i) * 32 + l31;
+    jok[i] = j < NJ;
+    const int t = jok[i] ? j / Cin : 0, c = jok[i] ? j - t * Cin : 0;
+    jt[i] = t; jc[i] = c;
+    jdy[i] = t / g.KW - g.pad_y[0];
+    jdx[i] = t % g.KW - g.pad_x[0];
+  }
+  f32x16 acc[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bacc = 0.f;
+
+  const int npairs = (wg.rs_S + 1) >> 1;
+  int pair_lo = split * wg.rs_ppw, pair_hi = pair_lo + wg.rs_ppw;
+  if (pair_hi > npairs) pair_hi = npairs;
+  for (int pair = pair_lo; pair < pair_hi; ++pair) {
+    const int s = 2 * pair + half;
+    const bool s_ok = s < wg.rs_S;
+    const int xs = s & ((1 << wg.rs_xsh) - 1), t1 = s >> wg.rs_xsh;
+    const int chunk = t1 & ((1 << wg.rs_csh) - 1), b = t1 >> wg.rs_csh;
+    const int x0 = xs << 3, y0 = chunk * R;
+    unsigned offy = ((unsigned)(b * H + y0) << wsh) * ldyb + (unsigned)x0 * ldyb + (unsigned)l31 * 4u;
+    unsigned offx[MAXN];
+    bool cok[MAXN][8];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+      offx[i] = (unsigned)(((b * H + y0 + jdy[i]) << wsh) + x0 + jdx[i]) * ldxb + (unsigned)jc[i] * 4u;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) cok[i][jj] = s_ok & jok[i] & ((unsigned)(x0 + jdx[i] + jj) < (unsigned)W);
+    }
+    // rows of the chunk, the next row's operands in flight while the current one is split and multiplied (two register sets)
+    float vy[2][8], vx[2][MAXN][8];
+    int yl = y0;                   // row the next load reads
+#define PIDM_RS7_LOAD(buf_)                                                                                         \
+  {                                                                                                                 \
+    const unsigned voy__ = (s_ok & (yl < y0 + R)) ? offy : kRsInv;                                                  \
+    _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) vy[buf_][jj] = pidm_buf_load_f32(ry, voy__, (unsigned)jj * ldyb); \
+    offy += rowyb;                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MAXN; ++i) {                                                              \
+      const bool rok__ = ((unsigned)(yl + jdy[i]) < (unsigned)H) & (yl < y0 + R);                                   \
+      _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)                                                              \
+          vx[buf_][i][jj] = pidm_buf_load_f32(rx, (rok__ & cok[i][jj]) ? offx[i] + (unsigned)jj * ldxb : kRsInv, 0u); \
+      offx[i] += rowxb;                                                                                             \
+    }                                                                                                               \
+    ++yl;                                                                                                           \
+  }
+    PIDM_RS7_LOAD(0)
+    int y = y0;
+    while (y < y0 + R) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (y >= y0 + R) break;          // wave-uniform
+        PIDM_RS7_LOAD(u ^ 1)
+        u32x4 ya[3];
+        const float sb = rs_split_dy(vy[u], ya);
+        if (do_bias) bacc += sb;
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) {
+          if ((wave + 4 * i) * 32 < NJ) {          // wave-uniform
+            u32x4 xb[3];
+            rs_split_dy(vx[u][i], xb);
+            PIDM_RS_SIX(acc[i], ya, xb)
+          }
+        }
+        ++y;
+      }
+    }
+#undef PIDM_RS7_LOAD
+  }
+  // results: column j = (t, c) of this lane, rows = 32 dY channels: the split's slab [split][m][T][Cin] (conv_wgrad_smallc_kernel's)
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) {
+    if (jok[i]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        partial[(((size_t)split * wg.MP + (m0 + row)) * T + jt[i]) * wg.NP + jc[i]] = acc[i][r];
+      }
+    }
+  }
+  if (bias_partial != nullptr) {
+    red[tid] = bacc;               // zero outside wave 0
+    __syncthreads();
+    if (tid < 32) bias_partial[(size_t)split * wg.MP + m0 + tid] = red[tid] + red[32 + tid];
+  }
+}
+
 // Plan: rows per strip chunk R (power of two <= H) such that the waves of a block (4 per split) get whole items and the longest
 // wave - items x (R rows + the three rows of prologue) - is shortest.
 static void rs_plan(WgradGeom* wg, int nsplit) {
@@ -457,6 +579,64 @@ bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src
     fprintf(stderr, "[pidm]   -> conv_wgrad_rs4_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per pixel share\n", wg.nsplit,
             grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
   hipLaunchKernelGGL(conv_wgrad_rs4_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  *used = wg;
+  return true;
+}
+
+bool wgrad_rs7_eligible(const ConvGeom& g, int ld_dy) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const size_t pix = (size_t)g.B * g.Hi * g.Wi;
+  const int NJ = g.KH * g.KW * g.Cin;
+  return g.nph == 1 && g.nz == 1 && g.C1 == 0 && g.stride == 1 && g.Cin <= 16 && g.KH * g.KW > 1 && NJ <= 16 * 32 && g.Wv == g.Wi &&
+         g.Hv == g.Hi && g.Wi >= 8 && pow2(g.Wi) && pow2(g.Hi) && (g.Cout % 32 == 0) && pix * (size_t)g.ld0 * 4 < 0x7ff00000ull &&
+         pix * (size_t)ld_dy * 4 < 0x7ff00000ull;
+}
+
+// few input channels, many taps (wgrad_smallc geometry); same contract as launch_wgrad_rs, partial layout of conv_wgrad_smallc_kernel
+bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy, int ld_dy, float* partial, float* bias_partial,
+                      hipStream_t st, WgradGeom* used) {
+  const ConvGeom& g = plan.g;
+  const char* off = knob("PIDM_WGRAD_RS");
+  if (off && !atoi(off)) return false;
+  if (!wgrad_rs7_eligible(g, ld_dy) || (reinterpret_cast<size_t>(src0) & 3) || (reinterpret_cast<size_t>(dy) & 3)) return false;
+  WgradGeom wg = plan;
+  wg.ld_dy = ld_dy;
+  int ns = plan.nsplit;
+  const int blocks = wg.MP / 32;
+  const int ntl0 = (g.KH * g.KW * g.Cin + 31) / 32;
+  // no software prefetch in this kernel: the load latency is covered by residency - 82 registers with one n-tile per wave
+  // (4 workgroups per CU), 173 with four (2 per CU)
+  const int slots = ntl0 <= 4 ? 1024 : 512;
+  if (ns * blocks > slots) ns = slots / blocks > 0 ? slots / blocks : 1;
+  const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");
+  if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+  // every wave of a workgroup walks the workgroup's pairs: `shares` = workgroups of a block
+  {
+    int xsh = 0;
+    while ((8 << xsh) < g.Wi) ++xsh;
+    long best_cost = -1;
+    for (int R = g.Hi; R >= 1; R >>= 1) {
+      const int cpi = g.Hi / R;
+      const long S = (long)g.B * cpi * (g.Wi / 8), pairs = (S + 1) / 2, ppw = (pairs + ns - 1) / ns;
+      const long cost = ppw * (R + 1);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        int csh = 0;
+        while ((1 << csh) < cpi) ++csh;
+        wg.rs_R = R; wg.rs_csh = csh; wg.rs_xsh = xsh; wg.rs_S = (int)S; wg.rs_ppw = (int)ppw;
+      }
+    }
+    wg.nsplit = ns;
+  }
+  const int ntl = (g.KH * g.KW * g.Cin + 31) / 32, maxn = (ntl + 3) / 4;
+  const dim3 grid(wg.nsplit, blocks, 1);
+  if (knob("PIDM_TRACE_CONV"))
+    fprintf(stderr, "[pidm]   -> conv_wgrad_rs7_kernel<%d>, %d splits x %d blocks, %d strips of %d rows, %d pairs per workgroup\n", maxn <= 1 ? 1 : 4,
+            wg.nsplit, grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
+  if (maxn <= 1)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_rs7_kernel<1>), grid, dim3(256), 0, st, wg, src0, dy, partial, bias_partial);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_rs7_kernel<4>), grid, dim3(256), 0, st, wg, src0, dy, partial, bias_partial);
   *used = wg;
   return true;
 }

@@ -69,6 +69,8 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
 bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy);
 bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
                       float* bias_partial, hipStream_t st, WgradGeom* used);
+bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy, int ld_dy, float* partial, float* bias_partial,
+                      hipStream_t st, WgradGeom* used);
 size_t colsum_ws_bytes(size_t rows, int C);
 int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* workspace, hipStream_t st,
                   ReduceQueue* defer = nullptr);

@@ -982,6 +982,136 @@ __global__ void __launch_bounds__(256) mid_attn_kernel(const float* __restrict__
 
 #undef sS
 #undef sdS
+
+// The same for exactly 64 tokens (the 8 x 8 bottleneck of every 64 x 64 configuration), with every product on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 products) instead of scalar FMA loops over LDS, and the row softmax / Jacobian spread over all
+// 256 threads (4 per row).  A 32 x 32 output tile per wave; operands are read from the padded LDS images as one scalar per lane and
+// k-step (A: row l & 31, k = lane >> 5; B: column l & 31).  Round 4: 62 -> ~25 us (backward) per launch at batch 64.
+template <bool BWD>
+__global__ void __launch_bounds__(256) mid_attn64_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                         float* __restrict__ out, int heads, float scale) {
+  constexpr int N = 64, LS = 65;
+  HIP_DYNAMIC_SHARED(float, smem)
+  float (*sq)[33] = reinterpret_cast<float (*)[33]>(smem);
+  float (*sk)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)N * 33);
+  float (*sv)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)2 * N * 33);
+  float (*sdo)[33] = reinterpret_cast<float (*)[33]>(smem + (size_t)3 * N * 33);
+  float* sS_ = smem + (size_t)4 * N * 33;
+  float* sdS_ = sS_ + (size_t)N * LS;
+  const int HD = heads * DH;
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  const int lane = tid & 63, half = lane >> 5, l31 = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < N * 32; e += 256) {
+    const int n = e >> 5, d = e & 31;
+    const float* row = qkv + ((size_t)b * N + n) * 3 * HD + h * DH + d;
+    sq[n][d] = row[0] * scale;
+    sk[n][d] = row[HD];
+    sv[n][d] = row[2 * HD];
+    if (BWD) sdo[n][d] = dO[((size_t)b * N + n) * HD + h * DH + d];
+  }
+  __syncthreads();
+  const int ti = wave >> 1, tj = wave & 1;
+  // S = (scale q) k^T: wave (ti, tj) owns tile rows 32 ti.., columns 32 tj..
+  {
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[32 * ti + l31][2 * s2 + half], sk[32 * tj + l31][2 * s2 + half], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sS_[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * half) * LS + 32 * tj + l31] = acc[r];
+  }
+  __syncthreads();
+  // row softmax: 4 threads per row, 16 columns each
+  {
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    float* pr = sS_ + row * LS + c0;
+    float m = pr[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m = fmaxf(m, pr[j]);
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    float ex[16], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ex[j] = fexp(pr[j] - m); sum += ex[j]; }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pr[j] = ex[j] * inv;
+  }
+  __syncthreads();
+  if (!BWD) {
+    // O = P v: 64 x 32, K = 64: waves 0 / 1 take the two row tiles
+    if (wave < 2) {
+      f32x16 acc;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sS_[(32 * wave + l31) * LS + 2 * s2 + half], sv[2 * s2 + half][l31], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[((size_t)b * N + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half) * HD + h * DH + l31] = acc[r];
+    }
+    return;
+  }
+  // dP = dO v^T (all four waves, one tile each), then dV = P^T dO (64 x 32, K = 64: waves 0 / 1)
+  {
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sdo[32 * ti + l31][2 * s2 + half], sv[32 * tj + l31][2 * s2 + half], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sdS_[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * half) * LS + 32 * tj + l31] = acc[r];
+  }
+  if (wave < 2) {
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int s2 = 0; s2 < 32; ++s2)    // A[j][i] = P[i][j]: a column of P per lane (LS is odd: conflict-free)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sS_[(2 * s2 + half) * LS + 32 * wave + l31], sdo[2 * s2 + half][l31], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[((size_t)b * N + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half) * 3 * HD + 2 * HD + h * DH + l31] = acc[r];
+  }
+  __syncthreads();
+  // dS = P (dP - sum_j dP P), 4 threads per row
+  {
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    const float* pp = sS_ + row * LS + c0;
+    float* pd = sdS_ + row * LS + c0;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dot = fmaf(pd[j], pp[j], dot);
+    dot += __shfl_xor(dot, 1);
+    dot += __shfl_xor(dot, 2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pd[j] = pp[j] * (pd[j] - dot);
+  }
+  __syncthreads();
+  // dq = scale dS k (waves 0 / 1), dk = dS^T (scale q) (waves 2 / 3): 64 x 32, K = 64 each
+  {
+    const int t = wave & 1;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (wave < 2) {
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sdS_[(32 * t + l31) * LS + 2 * s2 + half], sk[2 * s2 + half][l31], acc, 0, 0, 0);
+    } else {
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sdS_[(2 * s2 + half) * LS + 32 * t + l31], sq[2 * s2 + half][l31], acc, 0, 0, 0);
+    }
+    const float f = wave < 2 ? scale : 1.f;
+    const size_t col = (wave < 2 ? 0 : HD) + h * DH + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[((size_t)b * N + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half) * 3 * HD + col] = acc[r] * f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
@@ -1147,6 +1277,19 @@ int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_done = true;
+  }
+  static const bool mfma_off = [] { const char* e = knob("PIDM_MID_ATTN_MFMA"); return e && !atoi(e); }();
+  if (N == 64 && !mfma_off) {
+    static bool attr64 = false;
+    if (!attr64) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr64 = true;
+    }
+    if (bwd) hipLaunchKernelGGL(HIP_KERNEL_NAME(mid_attn64_kernel<true>), dim3(B * heads), dim3(256), lds, st, qkv, dO, out, heads, scale);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(mid_attn64_kernel<false>), dim3(B * heads), dim3(256), lds, st, qkv, dO, out, heads, scale);
+    PIDM_CHECK_LAUNCH("mid_attn64_kernel");
+    return 0;
   }
   if (bwd)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(mid_attn_kernel<true>), dim3(B * heads), dim3(256), lds, st, qkv, dO, out, N, heads, scale);

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ q
   const size_t p = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;   // global pixel index (b*N + n)
   const bool valid = p < npix;
   const size_t b = valid ? p / N : 0;
-  for (int h = 0; h < heads; ++h) {
+  for (int h = blockIdx.y; h < heads; h += gridDim.y) {     // gridDim.y = heads where the pixel grid alone leaves CUs idle
     float qv[16];
     float m = -3.0e38f;
     if (valid) {
@@ -388,19 +388,22 @@ __global__ void __launch_bounds__(256) la_bwd_pix_mfma_kernel(const float* __res
                                                               const float* __restrict__ qstat, const float* __restrict__ ctx,
                                                               const float* __restrict__ dctx, const float* __restrict__ rowdot,
                                                               const float* __restrict__ dA, float* __restrict__ dqkv, int N,
-                                                              int heads, float scale) {
+                                                              int heads, float scale, int ppb) {
+  // ppb = pixels per block = 32 x its waves (128 / 64 / 32, chosen by the launcher), N % ppb == 0: one image per block
   __shared__ float sc[32][33], sd[32][33], srd[32], skm[32], skis[32];
   const int HD = heads * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const size_t pblk = (size_t)blockIdx.x * 128;          // first pixel (b*N + n) of the block; one image per block
+  const size_t pblk = (size_t)blockIdx.x * ppb;          // first pixel (b*N + n) of the block; one image per block
   const int b = (int)(pblk / N);
   const size_t pw = pblk + wave * 32;                     // first pixel of this wave
   const size_t pa = pw + l31;                             // this lane's A-layout pixel
   const float invN = 1.f / (float)N;
-  for (int h = 0; h < heads; ++h) {
+  // one head per block (blockIdx.y): with the heads walked one after the other inside a block the launch was a serial chain of
+  // 8 x (stage, 48 MFMAs, epilogue) on a grid that left most of the chip idle at batch 64 - ~70 us for the 16x16 AND the 8x8 level
+  {
+    const int h = blockIdx.y;
     const int bh = b * heads + h;
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
+    for (int e = tid; e < 1024; e += 2 * ppb) {
       sc[e >> 5][e & 31] = ctx[(size_t)bh * 1024 + e];
       sd[e >> 5][e & 31] = dctx[(size_t)bh * 1024 + e];
     }
@@ -1152,10 +1155,10 @@ int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, f
   PIDM_CHECK_LAUNCH("la_context_final");
   const size_t npix = (size_t)B * N;
   if (N % 32 == 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<true>), dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<true>), dim3((unsigned)((npix + 127) / 128), (npix + 127) / 128 < 1024 ? heads : 1), dim3(256), 0, st, qkv, ctx, attn,
                        qstat, N, heads, npix, scale);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<false>), dim3((unsigned)((npix + 127) / 128)), dim3(256), 0, st, qkv, ctx, attn,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<false>), dim3((unsigned)((npix + 127) / 128), (npix + 127) / 128 < 1024 ? heads : 1), dim3(256), 0, st, qkv, ctx, attn,
                        qstat, N, heads, npix, scale);
   PIDM_CHECK_LAUNCH("la_out_kernel");
   return 0;
@@ -1171,9 +1174,13 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
   PIDM_CHECK_LAUNCH("la_dctx");
   hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<1>), dim3(B * heads), dim3(256), 0, st, dpart, ctx, dctx, rowdot, NS, 1.f);
   PIDM_CHECK_LAUNCH("la_dctx_final");
-  if (N % 128 == 0) {
-    hipLaunchKernelGGL(la_bwd_pix_mfma_kernel, dim3((unsigned)((size_t)B * N / 128)), dim3(256), 0, st, qkv, kstat, qstat, ctx,
-                       dctx, rowdot, dA, dqkv, N, heads, scale);
+  if (N % 32 == 0 && N >= 64) {        // whole 32-pixel waves of one image per block: 4 waves, or fewer while that leaves CUs idle
+    const size_t npix = (size_t)B * N;
+    int ppb = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
+    (void)npix;
+    if (const char* pe = knob("PIDM_LA_PPB")) { const int v = atoi(pe); if ((v == 32 || v == 64 || v == 128) && N % v == 0) ppb = v; }
+    hipLaunchKernelGGL(la_bwd_pix_mfma_kernel, dim3((unsigned)((size_t)B * N / ppb), heads), dim3(2 * ppb), 0, st, qkv, kstat, qstat, ctx,
+                       dctx, rowdot, dA, dqkv, N, heads, scale, ppb);
   } else {
     hipLaunchKernelGGL(la_bwd_pix_kernel, dim3(cdiv(N, 256), B * heads), dim3(256), 0, st, qkv, kstat, qstat, ctx, dctx, rowdot,
                        dA, dqkv, N, heads, scale);

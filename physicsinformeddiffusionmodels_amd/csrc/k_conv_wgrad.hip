@@ -1056,6 +1056,38 @@ __global__ void __launch_bounds__(256) reduce_multi_kernel(const ReduceDesc* __r
     }
     return;
   }
+  if (d.mode == 2) {
+    __shared__ f32x4 red4[8][32];
+    const int tid = threadIdx.x, ql = tid & 31, sl = tid >> 5;
+    const size_t flat = (size_t)d.MP * d.T * d.NP;
+    const size_t f0 = ((size_t)(bid - d.blk0) * 32 + ql) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (f0 < flat) {
+      const float* p = d.src + f0;
+      int sp = sl;
+      for (; sp + 24 < d.nsplit; sp += 32) {
+        s0 += *reinterpret_cast<const f32x4*>(p + (size_t)sp * d.sstride);
+        s1 += *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 8) * d.sstride);
+        s2 += *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 16) * d.sstride);
+        s3 += *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 24) * d.sstride);
+      }
+      for (; sp < d.nsplit; sp += 8) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)sp * d.sstride);
+    }
+    red4[sl][ql] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && f0 < flat) {
+      f32x4 a = red4[0][ql];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) a += red4[k][ql];
+      const unsigned tn = (unsigned)d.T * (unsigned)d.NP;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned f = (unsigned)f0 + k, m = f / tn, rem = f - m * tn, t = rem / (unsigned)d.NP, n = rem - t * (unsigned)d.NP;
+        if ((int)m < d.M && (int)n < d.N) d.dst[((size_t)m * d.N + n) * d.T + t] = a[k];
+      }
+    }
+    return;
+  }
   const int tid = threadIdx.x, ol = tid & 31, sl = tid >> 5;
   const long nw = (long)d.M * d.T * d.N;
   const long o = (long)(bid - d.blk0) * 32 + ol;

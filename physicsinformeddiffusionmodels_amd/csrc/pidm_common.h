@@ -232,7 +232,8 @@ struct ReduceDesc {
   size_t sstride;
   int nsplit, M, N, T, MP, NP;
   unsigned blk0, nblk;
-  int mode;   // 0: 32 outputs x 8 split lanes per block (many small splits); 1: one row m x 64 columns x all taps per block,
+  int mode;   // 2: 128 consecutive floats of the flat slab as 16-byte pieces x 8 split lanes per block (many splits of a large slab);
+              // 0: 32 outputs x 8 split lanes per block (many small splits); 1: one row m x 64 columns x all taps per block,
               //    transposed through LDS so that both the partial rows and the [m][n][t] result move as whole lines (large tensors
               //    with few splits: the 130 M-parameter mechanics model spent 4.2 ms per step in the scattered form)
 };

@@ -16,8 +16,22 @@ struct ReduceQueue {
     d.src = src; d.dst = dst; d.bsrc = bsrc; d.bdst = bdst; d.sstride = sstride;
     d.nsplit = nsplit; d.M = M; d.N = N; d.T = T; d.MP = MP; d.NP = NP;
     const size_t total = (size_t)M * N * T + (bdst ? M : 0);
+    const size_t flat = (size_t)MP * T * NP;
     d.blk0 = nblocks;
     d.mode = (nsplit <= 8 && T <= 16 && (size_t)M * N * T >= 32768) ? 1 : 0;
+    // mode 2 (round 4): many splits of a large contiguous slab (the 3x3 weight gradients: 64-256 slabs of 36 KB - 2.4 MB): the slab is
+    // walked as a flat array in 16-byte pieces (512 contiguous bytes per split and quarter wave instead of 128), the [m][t][n] ->
+    // [m][n][t] turn happens on the way out; the bias column sums become a small descriptor of their own
+    if (d.mode == 0 && nsplit > 8 && flat >= 4096 && (flat & 3) == 0 && (sstride & 3) == 0 && (reinterpret_cast<size_t>(src) & 15) == 0) {
+      d.mode = 2;
+      d.bsrc = nullptr;
+      d.bdst = nullptr;
+      d.nblk = (unsigned)((flat / 4 + 31) / 32);
+      nblocks += d.nblk;
+      v.push_back(d);
+      if (bdst) push(bsrc, bdst, nullptr, nullptr, (size_t)MP, nsplit, 1, M, 1, 1, MP);
+      return;
+    }
     d.nblk = d.mode ? (unsigned)M * (unsigned)((N + 63) / 64) : (unsigned)((total + 31) / 32);
     nblocks += d.nblk;
     v.push_back(d);

@@ -532,8 +532,10 @@ def main():
             "frac_fp32_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             "frac_bf16_peak": round((6.0 * sp_fl / (conv_ms * 1e-3) / 1e12) / PEAK_BF16_MFMA_TFLOPS, 4) if conv_ms > 0 else None,
             "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
-            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3 and 4x4/s2: conv3x3_split_kernel / conv_wgrad_split_kernel, 6 bf16 "
-                      "MFMAs per fp32 product on 3-piece split operands; 1x1, 7x7, 4x4/s2 wgrad: fp32 MFMA)",
+            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3, 4x4/s2, 7x7 and the compute-bound 1x1: conv3x3_split*_kernel / "
+                      "conv1x1_split_kernel / conv7x7_split_kernel forward + input gradient, conv_wgrad_rs*_kernel weight gradient - 6 bf16 "
+                      "MFMAs per fp32 product on 3-piece split operands; memory-bound 1x1 layers, their weight gradients and the linears: "
+                      "fp32 MFMA)",
             "peak_note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = the fp32 MFMA's dense peak, the rate an fp32 "
                          "contraction is priced at; frac_bf16_pipe prices the split-form launches alone against the pipe they run on",
             # the split-form launches against THEIR pipe: 6 bf16 MFMA terms per fp32 product / their HIP-event time / 2500 TFLOP/s dense
@@ -644,7 +646,7 @@ def main():
             workload = ("sample.py DDPM sampling, Darcy 64x64, 1000-step schedule, Unet3D dim=32; a step = one p_sample step of the "
                         "whole batch (a full chain = 1000 steps; sample.py:145-150)")
         cfg = {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-               "arithmetic": "fp32 tensors and accumulation; 3x3 / 4x4-stride-2 / 7x7 convolution contractions (fwd, dgrad, 3x3 wgrad), the "
+               "arithmetic": "fp32 tensors and accumulation; 3x3 / 4x4-stride-2 / 7x7 convolution contractions (fwd, dgrad, wgrad), the "
                              "compute-bound 1x1 convolutions (fwd, dgrad) and the pixel sums / projections of the projected attention "
                              "as 6 bf16 MFMA terms on "
                              "round-to-nearest 3-piece splits of both operands (24 mantissa bits; error <= the fp32 MFMA's own, "

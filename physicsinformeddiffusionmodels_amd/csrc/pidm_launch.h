@@ -61,6 +61,13 @@ inline bool retile_bm(ConvGeom* g, int bm) {
   g->tiles_m = (NI > 1) ? cdiv(g->B, NI) : g->B * (g->Hv / TH);
   return true;
 }
+int pick_kc(int Cin);                         // K-chunk of the fp32 packing (k_conv.hip)
+int pick_nt(int Cout, int tiles_m);
+int packed_np(int Cout);
+bool conv_nt4_ok(const ConvGeom& g, int KC);   // k_conv_fp32.hip: the permuted 128-channel tile of 1x1 convolutions applies
+// k_conv_fp32.hip: the fp32-MFMA kernels behind launch_conv
+int launch_conv_fp32(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias, const float* residual,
+                     float* out, int sigmoid_last, hipStream_t st, int KC, int NT, bool nt4);
 size_t packed_floats(const ConvGeom& g);
 int packed_kp(const ConvGeom& g);
 int launch_pack(const ConvGeom& g, int kind, const float* w_ref, float* w_packed, int srcKH, int srcKW, int n_off, int k_off,

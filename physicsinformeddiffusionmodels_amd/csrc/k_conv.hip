@@ -1602,6 +1602,11 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         (!src1 || (reinterpret_cast<size_t>(src1) & 15) == 0) &&
         (!residual || ((g.ldr & 3) == 0 && (reinterpret_cast<size_t>(residual) & 15) == 0)) &&
         (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0 < 4.0e9) {
+      // rows of 32 / 64 pixels with 32 / 64 input channels: the row-streaming kernel (k_conv_rs.hip)
+      if (!knob("PIDM_STREAM_TRACE") && !knob("PIDM_SPLIT_NW")) {
+        const int rc = launch_conv_rs(g, src0, src1, reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g)), bias, residual, out, st);
+        if (rc <= 0) return rc;
+      }
       // 8 waves on a 256-pixel tile, or - when that leaves CUs without a work item - 4 waves on 128 pixels (PIDM_SPLIT_NW forces one)
       const char* fe = knob("PIDM_SPLIT_NW");
       const int force = fe ? atoi(fe) : 0;

@@ -139,6 +139,16 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef PIDM_HAVE_BUFLOAD4
+// 16 bytes per lane through the same descriptor (buffer_load_dwordx4; offsets multiples of 16)
+__device__ __forceinline__ f32x4 pidm_buf_load_f32x4(pidm_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#endif
+// register budget of a kernel as waves per SIMD (512 unified registers / n); the host emulator ignores it
+#ifndef PIDM_WAVES_PER_SIMD
+#define PIDM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Geometry of one implicit-GEMM convolution launch (see k_conv.hip).  "Virtual" output pixels

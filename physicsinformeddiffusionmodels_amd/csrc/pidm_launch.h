@@ -66,6 +66,9 @@ int pick_nt(int Cout, int tiles_m);
 int packed_np(int Cout);
 bool conv_nt4_ok(const ConvGeom& g, int KC);   // k_conv_fp32.hip: the permuted 128-channel tile of 1x1 convolutions applies
 // k_conv_fp32.hip: the fp32-MFMA kernels behind launch_conv
+// k_conv_rs.hip: the row-streaming 3x3 kernel of the wide levels (0: launched, 1: not its shape, < 0: error)
+int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, const unsigned short* wsplit, const float* bias,
+                   const float* residual, float* out, hipStream_t st);
 int launch_conv_fp32(const ConvGeom& g, const float* src0, const float* src1, const float* wp, const float* bias, const float* residual,
                      float* out, int sigmoid_last, hipStream_t st, int KC, int NT, bool nt4);
 size_t packed_floats(const ConvGeom& g);

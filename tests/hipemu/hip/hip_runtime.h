@@ -259,6 +259,15 @@ static inline float pidm_buf_load_f32(pidm_rsrc r, unsigned voff, unsigned soff)
   memcpy(&f, r.base + o, 4);
   return f;
 }
+#define PIDM_HAVE_BUFLOAD4 1
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 pidm_buf_load_f32x4(pidm_rsrc r, unsigned voff, unsigned soff) {
+  const uint64_t o = (uint64_t)voff + soff;
+  hipemu_f32x4 f = {0.f, 0.f, 0.f, 0.f};
+  if (voff < r.bytes && o + 16 <= r.bytes) memcpy(&f, r.base + o, 16);   // (the hardware checks the per-lane offset only)
+  return f;
+}
+#define PIDM_WAVES_PER_SIMD(n)
 // global_load_lds_dwordx4 (pidm_common.h): synchronous here
 #define PIDM_HAVE_GLDS 1
 static inline void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {

@@ -154,6 +154,46 @@ def test_conv_3x3_split_forms(backend, monkeypatch, ws, nw, wgs, p, maxns, B, H,
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+RS_CASES = [   # the row-streaming forward / dgrad kernel (k_conv_rs.hip): rows of 32 / 64 pixels, 32 / 64 input channels
+    (1, 64, 32, 0, 32, 3, 1, 1, 0),      # two strips per row, one n-tile; dgrad the same
+    (3, 32, 32, 32, 64, 3, 1, 1, 0),     # concat source = 4 chunks, two n-groups, odd batch; dgrad: 64 -> 64
+    (2, 32, 32, 0, 64, 3, 1, 1, 0),      # two n-tiles per wave; dgrad: 4 chunks -> 32
+    (2, 64, 64, 0, 32, 3, 1, 1, 0),      # 4 chunks from one source; dgrad: two n-tiles per wave
+]
+
+
+@pytest.mark.parametrize("wps", ["1", "2"])
+@pytest.mark.parametrize("waves", ["1", "24", "100000"])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", RS_CASES)
+def test_conv_3x3_row_streaming(backend, monkeypatch, wps, waves, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """Strips of the whole image height (waves = 1: R = 64 or 32, both values of R % 3), of a few rows, and of 4 rows (every row an
+    edge row); ragged last workgroup; both register budgets."""
+    monkeypatch.setenv("PIDM_CONV_RS_WAVES", waves)
+    monkeypatch.setenv("PIDM_CONV_RS_MINR", "4")
+    monkeypatch.setenv("PIDM_CONV_RS_WPS", wps)
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+def test_conv_3x3_row_streaming_is_taken(backend, monkeypatch, capfd):
+    """The launcher picks the row-streaming kernel for the wide levels (and PIDM_CONV_RS=0 turns it off)."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    d = ConvDesc(B=1, Hi=32, Wi=32, C0=32, C1=0, ld0=32, ld1=0, Cout=32, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=32)
+    x = torch.randn(1, 32, 32, 32, device=dev)
+    w = torch.randn(32, 32, 3, 3, device=dev)
+    wp = torch.zeros(L.pidm_conv_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(w), ptr(wp), 0, st))
+    out = torch.empty(1, 32, 32, 32, device=dev)
+    monkeypatch.setenv("PIDM_CONV_RS_WAVES", "8")
+    for off, expect in (("1", True), ("0", False)):
+        monkeypatch.setenv("PIDM_CONV_RS", off)
+        monkeypatch.setenv("PIDM_TRACE_CONV", "1")
+        L.check(L.pidm_conv_forward(d, ptr(x), None, ptr(wp), None, None, ptr(out), st))
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        assert ("conv3x3_rs_kernel" in capfd.readouterr().err) == expect
+
+
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM3_CASES[:2])
 def test_conv_3x3_streaming_off_matches(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
     """PIDM_CONV_STREAM=0 keeps the older tilings reachable (A/B measurements)."""

@@ -24,6 +24,8 @@
 // instead of chunk-major - equal to it within fp32 rounding of the accumulation order, not bit for bit.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "pidm_launch.h"
 #include "k_conv_epilogue.h"
@@ -34,6 +36,38 @@ static constexpr int kRsRow = 112;                  // bytes per LDS weight row 
 static constexpr int kRsSlab = 9 * 32 * kRsRow;     // pre-split weights of one (n-tile, 16-channel chunk)
 static constexpr unsigned kRsOob = 0x80000000u;     // a byte offset no tensor reaches (the launcher checks): reads as 0
 
+// order of the tap rows inside a (kx, chunk) step: ky = 1, 2, 0 - the slot of ky = 0 is the one the previous input row finished, and
+// its sums are taken out during the first two groups; km = the tap rows present (bit ky)
+__host__ __device__ constexpr int rs_nk(int km) { return (km & 1) + ((km >> 1) & 1) + ((km >> 2) & 1); }
+__host__ __device__ constexpr int rs_ord(int km, int oi) {
+  int n = 0;
+  if (km & 2) { if (n == oi) return 1; ++n; }
+  if (km & 4) { if (n == oi) return 2; ++n; }
+  if (km & 1) { if (n == oi) return 0; ++n; }
+  return 0;
+}
+// group slot (of nslot in the row, sps per (kx, chunk) step) in which epilogue piece k of np runs: the two halves of the take in the
+// first step, before its ky = 0 group adds to the slot they read; the others evenly behind them
+__host__ __device__ constexpr int rs_slot(int k, int np, int nslot, int sps) {
+  if (k < 2) return k < sps ? k : sps - 1;
+  const int first = sps < 2 ? sps : 2, s = first + (k - 2) * (nslot - first) / (np - 2);
+  return s < nslot ? s : nslot - 1;
+}
+// compile-time loops: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) - every index a constant the front end folds
+// (as unrolled loops the dead alternatives of every iteration reached the optimiser, the unroller gave up on the size and the
+// accumulators ended up in scratch memory; as nested macros the translation unit ran out of source locations)
+template <int N> using rs_ic = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void rs_for_impl(F& f, std::integer_sequence<int, I...>) { (f(rs_ic<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void rs_for(F&& f) { rs_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// piece number of the k-th epilogue piece in running order: take, loads, GroupNorm sums, [sums of the backward], quarters
+__host__ __device__ constexpr int rs_piece(int k, int bnp) {
+  if (!bnp) return k;
+  return k <= 2 ? k : (k == 3 ? 9 : (k <= 5 ? k - 1 : (k <= 9 ? k + 4 : k - 5)));
+}
+#define PIDM_RSF_PIN(x_) asm volatile("" : "+v"(x_))   // the value exists here: computations on it neither start before nor end after
+
 #define PIDM_RSF_MFMA6(acc_, a_, b_)                          \
   acc_ = pidm_mfma_bf16_32x32x16(a_[2], b_[0], acc_);         \
   acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[2], acc_);         \
@@ -42,13 +76,17 @@ static constexpr unsigned kRsOob = 0x80000000u;     // a byte offset no tensor r
   acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[1], acc_);         \
   acc_ = pidm_mfma_bf16_32x32x16(a_[0], b_[0], acc_);
 
-// NCH = Cin / 16 (2 or 4), NT = n-tiles of 32 output channels per wave (1 or 2), WPS = waves per SIMD the register budget is cut for,
-// RM = R % 3 (1 or 2: R is a power of two >= 4; it fixes which accumulator slot the last rows of a strip use)
-template <int NCH, int NT, int WPS, int RM>
-__global__ void __launch_bounds__(256) PIDM_WAVES_PER_SIMD(WPS)
+// NCH = Cin / 16 (2 or 4), NT = n-tiles of 32 output channels per wave (1 or 2), RM = R % 3 (1 or 2: R is a power of two >= 4; it
+// fixes which accumulator slot the last rows of a strip use), BNP = 1: the launch also leaves the GroupNorm-backward sums
+// (ConvGeom::bn_part; ~200 vector instructions per output row and n-tile that the other launches do not carry).
+// One wave per SIMD (512 registers): what overlaps the matrix instructions is this wave's own vector work, interleaved by the
+// compiler inside each fenced group - so the row code has NO branch: optional operands (residual, GroupNorm partials) go through
+// buffer descriptors of size 0 when absent (loads return 0, stores are dropped), lane predicates through out-of-range offsets.
+template <int NCH, int NT, int RM, int BNP>
+__global__ void __launch_bounds__(256) PIDM_WAVES_PER_SIMD(1)
 conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1, const unsigned short* __restrict__ ws,
                   const float* __restrict__ bias, const float* __restrict__ residual, float* __restrict__ out, int R, int n_units,
-                  unsigned src_bytes) {
+                  unsigned src_bytes, unsigned res_bytes) {
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
@@ -74,9 +112,34 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
   pidm_rsrc rsc[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) rsc[ch] = pidm_make_rsrc((ch * 16 < g.C0) ? src0 + ch * 16 : src1 + (ch * 16 - g.C0), src_bytes);
+  // optional operands of the epilogue: size 0 when absent
+  const pidm_rsrc rs_res = pidm_make_rsrc(residual, residual ? res_bytes : 0u);
+  const pidm_rsrc rs_gn = pidm_make_rsrc(g.gn_part, g.gn_part ? (unsigned)g.B * (unsigned)g.gn_nchunk * (unsigned)g.gn_G * 16u : 0u);
+  const pidm_rsrc rs_bn = pidm_make_rsrc(g.bn_part, (BNP && g.bn_part) ? (unsigned)g.B * (unsigned)g.bn_nchunk * (unsigned)g.Cout * 16u : 0u);
+  const pidm_rsrc rs_bnres = pidm_make_rsrc(residual, (BNP && g.bn_res && residual) ? res_bytes : 0u);
+  const int HW = g.Ho * g.Wo;
   float bvs[NT];
+  // per lane and n-tile: constants of the GroupNorm-backward sums (the wave's image and the lane's channel never change)
+  float bn_mean[NT], bn_rstd[NT], bn_gm[NT], bn_bt[NT], bn_sc[NT], bn_sh[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bvs[nt] = bias ? bias[(ng * NT + nt) * 32 + l31] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = (ng * NT + nt) * 32 + l31;
+    bvs[nt] = bias ? bias[c] : 0.f;
+    bn_mean[nt] = bn_rstd[nt] = bn_gm[nt] = bn_bt[nt] = 0.f;
+    bn_sc[nt] = 1.f;
+    bn_sh[nt] = 0.f;
+    if (BNP && g.bn_part) {
+      const int gI = c / g.bn_cpg;
+      bn_mean[nt] = g.bn_stats[((size_t)b * g.bn_G + gI) * 2];
+      bn_rstd[nt] = g.bn_stats[((size_t)b * g.bn_G + gI) * 2 + 1];
+      bn_gm[nt] = g.bn_gamma[c];
+      bn_bt[nt] = g.bn_beta[c];
+      if (g.bn_ss) {
+        bn_sc[nt] = 1.f + (g.bn_ss[(size_t)b * g.bn_ldss + c] + g.bn_ssb[c]);
+        bn_sh[nt] = g.bn_ss[(size_t)b * g.bn_ldss + g.Cout + c] + g.bn_ssb[g.Cout + c];
+      }
+    }
+  }
   // per-lane byte offset of the lane's 8 channels inside a row, per kx (out-of-image columns: out of range)
   unsigned voff[3];
 #pragma unroll
@@ -86,6 +149,14 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
   }
   const unsigned img_off = (unsigned)b * (unsigned)g.Hi * (unsigned)g.Wi * ldb, row_b = (unsigned)g.Wi * ldb;
   const char* bl = smem + l31 * kRsRow + 48 * half;   // this lane's B fragments: + ((nt * NCH + ch) * 9 + tap) * 32 * 112 + 16 * piece
+  // epilogue addressing.  Accumulator register r of a lane is pixel (r & 3) + 8 (r >> 2) + 4 half of the wave's 32, channel l31;
+  // after the 4x4 transposes a lane holds channels 4 (l31 >> 2) .. + 3 of pixel 8 q + 4 half + (l31 & 3), q = 0..3.
+  const int tp = 4 * half + (l31 & 3);                                        // the lane's pixel inside a quarter after the transposes
+  const unsigned lres = (unsigned)(tp * g.ldr + 4 * (l31 >> 2)) * 4u;          // its bytes inside the residual row block
+  const size_t lout = (size_t)tp * g.sox + 4 * (l31 >> 2);
+  const int gn_cpg = g.gn_part ? g.gn_cpg : 1;                                 // (no partials: any valid divisor)
+  const unsigned gn_lane = (half == 0 && (l31 & (gn_cpg - 1)) == 0) ? 0u : kRsOob;   // the lane of a group that writes its sums
+  const unsigned bn_lane = (half == 0) ? 0u : kRsOob;
 
   f32x4 raw[3][NCH][2];
   f32x16 acc[3][NT][2];
@@ -114,106 +185,194 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
   __syncthreads();                                   // the weights are in LDS (the only barrier)
   if (!live) return;
 
-  // the finished output row o_ (slot s_): bias, GroupNorm sums, transposes, residual, stores; the slot restarts at zero
-#define PIDM_RSF_EPILOGUE(s_, o_)                                                                                     \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                                 \
-    f32x16 av = acc[s_][nt][0];                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) av[r] += acc[s_][nt][1][r];                                       \
-    const int n0 = (ng * NT + nt) * 32, c = n0 + l31;                                                                 \
-    const float bv = bvs[nt];                                                                                         \
-    const int pin = (y0 + (o_)) * g.Wv + x0;                                                                          \
-    float v[16];                                                                                                      \
-    float gs1 = 0.f, gs2 = 0.f;                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
-      v[r] = av[r] + bv;                                                                                              \
-      gs1 += v[r];                                                                                                    \
-      gs2 += v[r] * v[r];                                                                                             \
-    }                                                                                                                 \
-    if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)                                                               \
-    if (g.bn_part) {                                                                                                  \
-      const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;                                      \
-      PIDM_BN_PARTIAL(av, bv, b, pin, c, xrow, g.Cout,                                                                \
-                      (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr) \
-    }                                                                                                                 \
-    const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;                                                          \
-    const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);                                \
-    const size_t rpix = ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + n0 + 4 * (l31 >> 2);                                \
-    _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                                \
-      float e0 = v[4 * q4], e1 = v[4 * q4 + 1], e2 = v[4 * q4 + 2], e3 = v[4 * q4 + 3];                               \
-      const float r01 = pidm_quad_xor1(odd1 ? e0 : e1), r23 = pidm_quad_xor1(odd1 ? e2 : e3);                         \
-      e0 = odd1 ? r01 : e0; e1 = odd1 ? e1 : r01;                                                                     \
-      e2 = odd1 ? r23 : e2; e3 = odd1 ? e3 : r23;                                                                     \
-      const float r02 = pidm_quad_xor2(odd2 ? e0 : e2), r13 = pidm_quad_xor2(odd2 ? e1 : e3);                         \
-      e0 = odd2 ? r02 : e0; e2 = odd2 ? e2 : r02;                                                                     \
-      e1 = odd2 ? r13 : e1; e3 = odd2 ? e3 : r13;                                                                     \
-      const int prow = 8 * q4 + 4 * half + (l31 & 3);                                                                 \
-      f32x4 o = {e0, e1, e2, e3};                                                                                     \
-      if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);                     \
-      *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;                                               \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc[s_][nt][0][r] = 0.f; acc[s_][nt][1][r] = 0.f; }             \
-  }
+  // ---- the epilogue of a finished output row, in pieces that ride inside the NEXT input row's groups -------------------------
+  // pend = the row's sums (both chains + bias), taken out of the accumulators during the first groups of the next input row (the
+  // slot is that row's ky = 0 slot, which the order 1, 2, 0 touches last).  Every piece pins its inputs and outputs
+  // (PIDM_RSF_PIN) or ends in a store: unpinned arithmetic floats out of the group it is written in - into the fragment-read region,
+  // where no matrix instruction covers it.
+  float pend[NT][16], gsa[NT][2];
+  f32x4 rres[NT][4];                 // residual rows, loaded a few groups ahead of their use
+  float bxv[BNP ? NT : 1][16], brv[BNP ? NT : 1][16], ba1[BNP ? NT : 1], ba2[BNP ? NT : 1];
+  // pieces: 0 / 1 take the sums (halves), 2 residual loads, 3 / 4 GroupNorm partial sums (sum, butterfly + store), 5-8 the four
+  // quarters (transposes, residual, stores); BNP: 9 loads of x (and of the residual as dy's second term), 10-13 the sums' quarters
+  auto piece = [&](auto P_, auto S_, int o_) __attribute__((always_inline)) {
+    constexpr int p = decltype(P_)::value, sl = decltype(S_)::value;
+    const int pin = (y0 + o_) * g.Wv + x0;                          // first pixel of the row inside the image
+    const unsigned pixb = (unsigned)b * (unsigned)HW + (unsigned)pin;
+    if constexpr (p == 0 || p == 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = (p == 0 ? 0 : 8); r < (p == 0 ? 8 : 16); ++r) {
+          pend[nt][r] = (acc[sl][nt][0][r] + acc[sl][nt][1][r]) + bvs[nt];
+          PIDM_RSF_PIN(pend[nt][r]);
+          acc[sl][nt][0][r] = 0.f;
+          acc[sl][nt][1][r] = 0.f;
+        }
+      }
+    } else if constexpr (p == 2) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          rres[nt][q4] = pidm_buf_load_f32x4(rs_res, lres, ((pixb + 8u * q4) * (unsigned)g.ldr + (unsigned)((ng * NT + nt) * 32)) * 4u);
+    } else if constexpr (p == 3) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        PIDM_RSF_PIN(pend[nt][0]);
+        float a1 = pend[nt][0], a2 = pend[nt][0] * pend[nt][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { a1 += pend[nt][r]; a2 += pend[nt][r] * pend[nt][r]; }
+        gsa[nt][0] = a1;
+        gsa[nt][1] = a2;
+        PIDM_RSF_PIN(gsa[nt][0]);
+        PIDM_RSF_PIN(gsa[nt][1]);
+      }
+    } else if constexpr (p == 4) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float a1 = gsa[nt][0], a2 = gsa[nt][1];
+        PIDM_RSF_PIN(a1);
+        PIDM_RSF_PIN(a2);
+        // the gn_cpg (4, 8 or 16) lanes of a group: the leader (lane % gn_cpg == 0) ends up with the group's sum
+        a1 += pidm_quad_xor1(a1); a2 += pidm_quad_xor1(a2);
+        a1 += pidm_quad_xor2(a1); a2 += pidm_quad_xor2(a2);
+        { const float t1 = pidm_row_shl4(a1), t2 = pidm_row_shl4(a2); a1 += (gn_cpg > 4) ? t1 : 0.f; a2 += (gn_cpg > 4) ? t2 : 0.f; }
+        { const float t1 = pidm_row_shl8(a1), t2 = pidm_row_shl8(a2); a1 += (gn_cpg > 8) ? t1 : 0.f; a2 += (gn_cpg > 8) ? t2 : 0.f; }
+        a1 += pidm_other_half(a1);
+        a2 += pidm_other_half(a2);
+        const double d1 = (double)a1, d2 = (double)a2;
+        const unsigned long long w1 = __builtin_bit_cast(unsigned long long, d1), w2 = __builtin_bit_cast(unsigned long long, d2);
+        const int c = (ng * NT + nt) * 32 + l31;
+        const unsigned go = (((unsigned)b * (unsigned)g.gn_nchunk + (unsigned)(pin >> 5)) * (unsigned)g.gn_G + (unsigned)(c / gn_cpg)) * 16u;
+        pidm_buf_store_u32x4(rs_gn, gn_lane + go, 0u, u32x4{(unsigned)w1, (unsigned)(w1 >> 32), (unsigned)w2, (unsigned)(w2 >> 32)});
+      }
+    } else if constexpr (p >= 5 && p <= 8) {
+      constexpr int q4 = p - 5;
+      const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float e0 = pend[nt][4 * q4], e1 = pend[nt][4 * q4 + 1], e2 = pend[nt][4 * q4 + 2], e3 = pend[nt][4 * q4 + 3];
+        PIDM_RSF_PIN(e0); PIDM_RSF_PIN(e1); PIDM_RSF_PIN(e2); PIDM_RSF_PIN(e3);
+        const float r01 = pidm_quad_xor1(odd1 ? e0 : e1), r23 = pidm_quad_xor1(odd1 ? e2 : e3);
+        e0 = odd1 ? r01 : e0; e1 = odd1 ? e1 : r01;
+        e2 = odd1 ? r23 : e2; e3 = odd1 ? e3 : r23;
+        const float r02 = pidm_quad_xor2(odd2 ? e0 : e2), r13 = pidm_quad_xor2(odd2 ? e1 : e3);
+        e0 = odd2 ? r02 : e0; e2 = odd2 ? e2 : r02;
+        e1 = odd2 ? r13 : e1; e3 = odd2 ? e3 : r13;
+        f32x4 o = {e0, e1, e2, e3};
+        o += rres[nt][q4];
+        *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + (size_t)(pin + 8 * q4) * g.sox + (ng * NT + nt) * 32 + lout) = o;
+      }
+    } else if constexpr (BNP && p == 9) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = (ng * NT + nt) * 32 + l31;
+        const float* xrow = g.bn_x + ((size_t)pixb) * g.Cout + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int prow = (r & 3) + 8 * (r >> 2) + 4 * half;
+          bxv[nt][r] = xrow[(size_t)prow * g.Cout];
+          brv[nt][r] = pidm_buf_load_f32(rs_bnres, (unsigned)(prow * g.ldr + l31) * 4u, (pixb * (unsigned)g.ldr + (unsigned)((ng * NT + nt) * 32)) * 4u);
+        }
+        ba1[nt] = 0.f;
+        ba2[nt] = 0.f;
+      }
+    } else if constexpr (BNP && p >= 10 && p <= 13) {
+      constexpr int k4 = p - 10;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        PIDM_RSF_PIN(ba1[nt]);
+        PIDM_RSF_PIN(ba2[nt]);
+#pragma unroll
+        for (int r = 4 * k4; r < 4 * k4 + 4; ++r) {
+          const float xh = (bxv[nt][r] - bn_mean[nt]) * bn_rstd[nt];
+          const float v = (xh * bn_gm[nt] + bn_bt[nt]) * bn_sc[nt] + bn_sh[nt];
+          const float sg = pidm_sigmoid(v);
+          const float dv = (pend[nt][r] + brv[nt][r]) * (sg * (1.f + v * (1.f - sg)));
+          ba1[nt] += dv;
+          ba2[nt] += dv * xh;
+        }
+        PIDM_RSF_PIN(ba1[nt]);
+        PIDM_RSF_PIN(ba2[nt]);
+        if constexpr (k4 == 3) {
+          float a1 = ba1[nt], a2 = ba2[nt];
+          a1 += pidm_other_half(a1);
+          a2 += pidm_other_half(a2);
+          const double d1 = (double)a1, d2 = (double)a2;
+          const unsigned long long w1 = __builtin_bit_cast(unsigned long long, d1), w2 = __builtin_bit_cast(unsigned long long, d2);
+          const unsigned bo = (((unsigned)b * (unsigned)g.bn_nchunk + (unsigned)(pin >> 5)) * (unsigned)g.Cout + (unsigned)((ng * NT + nt) * 32 + l31)) * 16u;
+          pidm_buf_store_u32x4(rs_bn, bn_lane + bo, 0u, u32x4{(unsigned)w1, (unsigned)(w1 >> 32), (unsigned)w2, (unsigned)(w2 >> 32)});
+        }
+      }
+    }
+  };
+  constexpr int NP = BNP ? 14 : 9;
 
-  // One input row (index i_, i_ % 3 == J_): groups of six MFMAs in the order (kx, chunk, ky, n-tile); the output row of tap row ky
-  // is o = i_ - ky in slot (J_ + 3 - ky) % 3.  KM_ = the tap rows whose output row exists (bit ky; compile time): 1 and 3 for the
-  // first two rows of a strip, 7 in between, 6 and 4 for the last two.  The pipeline runs across groups, steps and rows: a group
-  // reads the weight fragments of the NEXT group before its own MFMAs (NKY_ = tap row of the next row's first group), the groups of
-  // a (kx, chunk) step split the registers of the next step into its pieces - which are then re-loaded with the next input row -
-  // and a scheduling fence closes every group, so that the compiler neither hoists a row's worth of fragment reads nor sinks them.
-  // No branch inside a row: the matrix instructions of a group and the vector work around them share a scheduling region.
+  // One input row (index i, i % 3 == J): groups of six MFMAs in the order (kx, chunk, ky in the order 1, 2, 0, n-tile); the
+  // output row of tap row ky is o = i - ky in slot (J + 3 - ky) % 3.  KM = the tap rows whose output row exists (bit ky): 1 and 3
+  // for the first two rows of a strip, 7 in between, 6 and 4 for the last two.  PEND = 1: output row i - 3 - slot J, finished by
+  // the previous input row - is waiting: its epilogue pieces are spread over this row's groups (all but the last of every
+  // (kx, chunk) step, which carries the split).
+  // The pipeline runs across groups, steps and rows.  A group = [reads of the NEXT group's weight fragments (NKY = tap row of the
+  // next row's first group)] fence [its six MFMAs + its share of vector work, which the compiler interleaves] fence; the last
+  // group of a step splits the registers of the next step into its pieces and re-loads them with the next input row.
 #define PIDM_RSF_FRAGS(dst_, bl_, kx_, ch_, ky_, nt_)                                                                 \
   {                                                                                                                   \
     const u32x4* bp__ = reinterpret_cast<const u32x4*>((bl_) + (((nt_) * NCH + (ch_)) * 9 + (ky_) * 3 + (kx_)) * (32 * kRsRow)); \
     dst_[0] = bp__[0]; dst_[1] = bp__[1]; dst_[2] = bp__[2];                                                          \
   }
-#define PIDM_RSF_ROW(J_, i_, KM_, NKY_)                                                                               \
-  {                                                                                                                   \
-    constexpr int NK__ = ((KM_) & 1) + (((KM_) >> 1) & 1) + (((KM_) >> 2) & 1);                                       \
-    constexpr int KF__ = ((KM_) & 1) ? 0 : (((KM_) & 2) ? 1 : 2);                      /* first tap row of the mask */  \
-    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                                            \
-        const int sn = (kx * NCH + ch + 1) % (3 * NCH), kxn = sn / NCH, chn = sn % NCH;   /* next step (of the next row after the last) */ \
-        const f32x4 a0 = raw[kxn][chn][0], a1 = raw[kxn][chn][1];                                                     \
-        unsigned q0[4], q1[4], q2[4];                                                                                 \
-        int z__ = 0;                       /* the fragment reads are loop-invariant: keep them where they are written */ \
-        PIDM_OPAQUE_I32(z__);                                                                                         \
-        const char* blz = bl + z__;                                                                                   \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                            \
-          if (((KM_) >> ky) & 1) {                                                                                    \
-            const int kidx = ((KM_) & ((1 << ky) - 1) & 1) + (((KM_) & ((1 << ky) - 1)) >> 1);                        \
-            const int kyn = (ky < 1 && ((KM_) & 2)) ? 1 : ((ky < 2 && ((KM_) & 4)) ? 2 : -1);    /* next tap row of the mask */ \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                       \
-              const int gi = ((kx * NCH + ch) * NK__ + kidx) * NT + nt;                                               \
-              if (nt + 1 < NT) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, ky, nt + 1)                              \
-              else if (kyn >= 0) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, kyn, 0)                                \
-              else if (sn != 0) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kxn, chn, KF__, 0)                              \
-              else PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, 0, 0, (NKY_), 0)                                             \
-              PIDM_RSF_MFMA6(acc[((J_) + 3 - ky) % 3][nt][(ky * 3 + kx) & 1], pc, fb[gi & 1])                         \
-              if (nt == 0) {                                                                                          \
-                if (kidx == 0) {                                                                                      \
-                  pidm_split3_pk(a0[0], a0[1], q0[0], q1[0], q2[0]);                                                  \
-                  pidm_split3_pk(a0[2], a0[3], q0[1], q1[1], q2[1]);                                                  \
-                }                                                                                                     \
-                if (kidx == (NK__ > 1 ? 1 : 0)) pidm_split3_pk(a1[0], a1[1], q0[2], q1[2], q2[2]);                    \
-                if (kidx == NK__ - 1) pidm_split3_pk(a1[2], a1[3], q0[3], q1[3], q2[3]);                              \
-              }                                                                                                       \
-              if (kidx == NK__ - 1 && nt == NT - 1) {                                                                 \
-                pc[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};                                                            \
-                pc[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};                                                            \
-                pc[2] = u32x4{q2[0], q2[1], q2[2], q2[3]};                                                            \
-                PIDM_RSF_LOAD((i_) + (sn == 0 ? 2 : 1), kxn, chn)                                                     \
-              }                                                                                                       \
-              __builtin_amdgcn_sched_barrier(0);                                                                      \
-            }                                                                                                         \
-          }                                                                                                           \
-        }                                                                                                             \
-      }                                                                                                               \
-    }                                                                                                                 \
-    if ((i_) >= 2) PIDM_RSF_EPILOGUE(((J_) + 1) % 3, (i_) - 2)                                                        \
-  }
+  u32x4 pc[3], fb[2][3];
+  auto row = [&](auto J_, auto KM_, auto NKY_, auto PEND_, int i) __attribute__((always_inline)) {
+    constexpr int J = decltype(J_)::value, KM = decltype(KM_)::value, NKY = decltype(NKY_)::value, PEND = decltype(PEND_)::value;
+    constexpr int NK = rs_nk(KM), GPS = NK * NT;                          // tap rows present, groups per step
+    constexpr int SPS = GPS > 1 ? GPS - 1 : 1, NSLOT = 3 * NCH * SPS;     // epilogue slots per step / row
+    rs_for<3 * NCH>([&](auto ST_) __attribute__((always_inline)) {
+      constexpr int st = decltype(ST_)::value, kx = st / NCH, ch = st % NCH;
+      constexpr int sn = (st + 1) % (3 * NCH), kxn = sn / NCH, chn = sn % NCH;   // next step (of the next row after the last)
+      int z = 0;                         // the fragment reads are loop-invariant: keep them where they are written
+      PIDM_OPAQUE_I32(z);
+      const char* blz = bl + z;
+      rs_for<GPS>([&](auto GS_) __attribute__((always_inline)) {
+        constexpr int gs = decltype(GS_)::value, oi = gs / NT, nt = gs % NT, ky = rs_ord(KM, oi);
+        constexpr int gi = st * GPS + gs;                                   // group inside the row
+        if constexpr (nt + 1 < NT) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, ky, nt + 1)
+        else if constexpr (oi + 1 < NK) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, rs_ord(KM, oi + 1), 0)
+        else if constexpr (sn != 0) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kxn, chn, rs_ord(KM, 0), 0)
+        else PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, 0, 0, NKY, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        PIDM_RSF_MFMA6(acc[(J + 3 - ky) % 3][nt][(ky * 3 + kx) & 1], pc, fb[gi & 1])
+        if constexpr (PEND && (GPS == 1 || gs < GPS - 1)) {
+          constexpr int slot = st * SPS + (GPS == 1 ? 0 : gs);
+          rs_for<NP>([&](auto K_) __attribute__((always_inline)) {
+            constexpr int k = decltype(K_)::value;
+            if constexpr (rs_slot(k, NP, NSLOT, SPS) == slot) piece(rs_ic<rs_piece(k, BNP)>{}, rs_ic<J>{}, i - 3);
+          });
+        }
+        if constexpr (gs == GPS - 1) {
+          float e[8] = {raw[kxn][chn][0][0], raw[kxn][chn][0][1], raw[kxn][chn][0][2], raw[kxn][chn][0][3],
+                        raw[kxn][chn][1][0], raw[kxn][chn][1][1], raw[kxn][chn][1][2], raw[kxn][chn][1][3]};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) PIDM_RSF_PIN(e[k]);
+          unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pidm_split3_pk(e[2 * k], e[2 * k + 1], q0[k], q1[k], q2[k]);
+            PIDM_RSF_PIN(q0[k]); PIDM_RSF_PIN(q1[k]); PIDM_RSF_PIN(q2[k]);
+          }
+          pc[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+          pc[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+          pc[2] = u32x4{q2[0], q2[1], q2[2], q2[3]};
+          PIDM_RSF_LOAD(i + (sn == 0 ? 2 : 1), kxn, chn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+#define PIDM_RSF_ROW(J_, i_, KM_, NKY_, PEND_) row(rs_ic<J_>{}, rs_ic<KM_>{}, rs_ic<NKY_>{}, rs_ic<PEND_>{}, (i_));
+#define PIDM_RSF_FLUSH(s_) rs_for<NP>([&](auto K_) __attribute__((always_inline)) { piece(rs_ic<rs_piece(decltype(K_)::value, BNP)>{}, rs_ic<s_>{}, R - 1); });
 
   // pipeline prologue: pieces of the first step of the first row (its registers go on to the second row), fragments of the first group
-  u32x4 pc[3], fb[2][3];
   {
     const f32x4 a0 = raw[0][0][0], a1 = raw[0][0][1];
     unsigned q0[4], q1[4], q2[4];
@@ -227,32 +386,39 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
     PIDM_RSF_LOAD(1, 0, 0)
     PIDM_RSF_FRAGS(fb[0], bl, 0, 0, 0, 0)
   }
-  // rows 0 and 1 feed one and two output rows, rows 2 .. R - 1 three, rows R and R + 1 two and one (R >= 4, R % 3 == RM)
-  PIDM_RSF_ROW(0, 0, 1, 0)
-  PIDM_RSF_ROW(1, 1, 3, 0)
-  int i0 = 2;
+  // rows 0 and 1 feed one and two output rows, rows 2 .. R - 1 three, rows R and R + 1 two and one (R >= 4, R % 3 == RM); the
+  // first finished row appears after row 2, so rows 3 ... carry a pending epilogue and the last one is flushed behind the loop
+  PIDM_RSF_ROW(0, 0, 1, 1, 0)
+  PIDM_RSF_ROW(1, 1, 3, 1, 0)
+  PIDM_RSF_ROW(2, 2, 7, 1, 0)
+  int i0 = 3;
   for (; i0 + 2 < R; i0 += 3) {
-    PIDM_RSF_ROW(2, i0, 7, 0)
-    PIDM_RSF_ROW(0, i0 + 1, 7, 0)
-    PIDM_RSF_ROW(1, i0 + 2, 7, (i0 + 3 < R ? 0 : 1))
+    PIDM_RSF_ROW(0, i0, 7, 1, 1)
+    PIDM_RSF_ROW(1, i0 + 1, 7, 1, 1)
+    PIDM_RSF_ROW(2, i0 + 2, 7, 1, 1)
   }
-  if (RM == 1) {                     // (R - 2) % 3 == 2 rows left
-    PIDM_RSF_ROW(2, R - 2, 7, 0)
-    PIDM_RSF_ROW(0, R - 1, 7, 1)
-    PIDM_RSF_ROW(1, R, 6, 2)
-    PIDM_RSF_ROW(2, R + 1, 4, 0)
-  } else {
-    PIDM_RSF_ROW(2, R, 6, 2)
-    PIDM_RSF_ROW(0, R + 1, 4, 0)
+  // (RM is a template parameter because a run-time choice between the two tails - both reading every accumulator - makes the
+  // register allocator copy accumulators around the diamond and spill: 801 registers for <2, 2>)
+  if (RM == 1) {                     // (R - 3) % 3 == 1 row left; the last output row R - 1 sits in slot 0
+    PIDM_RSF_ROW(0, R - 1, 7, 1, 1)
+    PIDM_RSF_ROW(1, R, 6, 2, 1)
+    PIDM_RSF_ROW(2, R + 1, 4, 0, 1)
+    PIDM_RSF_FLUSH(0)
+  } else {                           // two; slot 1
+    PIDM_RSF_ROW(0, R - 2, 7, 1, 1)
+    PIDM_RSF_ROW(1, R - 1, 7, 1, 1)
+    PIDM_RSF_ROW(2, R, 6, 2, 1)
+    PIDM_RSF_ROW(0, R + 1, 4, 0, 1)
+    PIDM_RSF_FLUSH(1)
   }
 #undef PIDM_RSF_FRAGS
+#undef PIDM_RSF_FLUSH
 #undef PIDM_RSF_ROW
-#undef PIDM_RSF_EPILOGUE
 #undef PIDM_RSF_LOAD
 }
 
 // PIDM_CONV_RS=0: off (conv3x3_split_kernel takes the launch).  PIDM_CONV_RS_WAVES: waves a launch should have at least before rows
-// per strip are doubled (default 1024 = one per SIMD of an MI355X).  PIDM_CONV_RS_WPS = 2: the two-waves-per-SIMD register budget.
+// per strip are doubled (default 1024 = one per SIMD of an MI355X).  PIDM_CONV_RS_MINR: fewest rows per strip (8).
 static int rs_fwd_knob(const char* name, int dflt) {
   const char* e = knob(name);
   return e ? atoi(e) : dflt;
@@ -270,7 +436,9 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   const double bytes = (double)g.B * g.Hi * g.Wi * g.ld0 * 4.0;
   if (bytes >= 2147483648.0) return 1;               // 32-bit offsets, and kRsOob must stay out of range
   const int NCH = g.Cin / 16, ntn = g.Cout / 32;
-  const int NT = (NCH == 2 && (ntn % 2) == 0) ? 2 : 1;
+  const int bnp = g.bn_part ? 1 : 0;
+  // two n-tiles per wave where the weights fit in LDS and the registers hold (the GroupNorm-backward sums need 64 more per n-tile)
+  const int NT = (NCH == 2 && (ntn % 2) == 0 && !bnp) ? 2 : 1;
   const int ngr = ntn / NT;
   const int want = rs_fwd_knob("PIDM_CONV_RS_WAVES", 1024);
   int R = g.Hv;
@@ -281,14 +449,17 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   if (R < rs_fwd_knob("PIDM_CONV_RS_MINR", 8) && (long)g.B * (g.Wv / 32) * (g.Hv / R) * ngr < want) return 1;
   const int n_units = g.B * (g.Wv / 32) * (g.Hv / R);
   const size_t lds = (size_t)NT * NCH * kRsSlab;
-  const int wps = rs_fwd_knob("PIDM_CONV_RS_WPS", 1) == 2 ? 2 : 1;
+  const double rbytes = (double)g.B * g.Ho * g.Wo * g.ldr * 4.0;
+  if (residual && rbytes >= 2147483648.0) return 1;
+  if (g.gn_part && (g.gn_cpg < 1 || g.gn_cpg > 32 || (g.gn_cpg & (g.gn_cpg - 1)))) return 1;
   if (knob("PIDM_TRACE_CONV"))
-    fprintf(stderr, "[pidm]   -> conv3x3_rs_kernel<%d, %d, %d, %d>, %d strips of %d rows, %d n-groups, %zu B LDS\n", NCH, NT, wps, R % 3, n_units, R, ngr, lds);
+    fprintf(stderr, "[pidm]   -> conv3x3_rs_kernel<%d, %d, %d, %d>, %d strips of %d rows, %d n-groups, %zu B LDS\n", NCH, NT, R % 3, bnp, n_units, R, ngr, lds);
   const bool prof = prof_enabled();
   if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 9, st);
   const dim3 grid(cdiv(n_units, 4), ngr), block(256);
   const float* s1 = src1 ? src1 : src0;
   const unsigned sb = (unsigned)bytes;
+  const unsigned rb = residual ? (unsigned)rbytes : 0u;
 #define PIDM_RSF_GO(a, b, c, d)                                                                                                   \
   {                                                                                                                               \
     static bool attr__ = false;                                                                                                   \
@@ -296,14 +467,14 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rs_kernel<a, b, c, d>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
       attr__ = true;                                                                                                              \
     }                                                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb); \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb, rb); \
   }
-#define PIDM_RSF_GO_RM(a, b, c) if (R % 3 == 1) PIDM_RSF_GO(a, b, c, 1) else PIDM_RSF_GO(a, b, c, 2)
-  if (NCH == 2 && NT == 2) PIDM_RSF_GO_RM(2, 2, 1)
-  else if (NCH == 2 && wps == 2) PIDM_RSF_GO_RM(2, 1, 2)
-  else if (NCH == 2) PIDM_RSF_GO_RM(2, 1, 1)
-  else if (wps == 2) PIDM_RSF_GO_RM(4, 1, 2)
-  else PIDM_RSF_GO_RM(4, 1, 1)
+#define PIDM_RSF_GO_RM(a, b, d) if (R % 3 == 1) PIDM_RSF_GO(a, b, 1, d) else PIDM_RSF_GO(a, b, 2, d)
+  if (NCH == 2 && NT == 2) PIDM_RSF_GO_RM(2, 2, 0)
+  else if (NCH == 2 && bnp) PIDM_RSF_GO_RM(2, 1, 1)
+  else if (NCH == 2) PIDM_RSF_GO_RM(2, 1, 0)
+  else if (bnp) PIDM_RSF_GO_RM(4, 1, 1)
+  else PIDM_RSF_GO_RM(4, 1, 0)
 #undef PIDM_RSF_GO_RM
 #undef PIDM_RSF_GO
   if (prof) prof_end_launch(st);

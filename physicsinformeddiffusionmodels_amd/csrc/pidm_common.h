@@ -67,6 +67,22 @@ __device__ __forceinline__ float pidm_quad_xor2(float v) {
 }
 #endif
 
+// value of lane + 4 / lane + 8 inside the lane's row of 16 (0 past the row's end; one DPP move: row_shl), and of lane ^ 32
+// (v_permlane32_swap): sums over groups of 8 / 16 lanes and over the two halves of a wave without a trip through LDS
+#ifndef PIDM_HAVE_ROW_SHL
+__device__ __forceinline__ float pidm_row_shl4(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104 /* row_shl:4 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pidm_row_shl8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108 /* row_shl:8 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pidm_other_half(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (__lane_id() < 32) ? sw[1] : sw[0]);
+}
+#endif
+
 // logistic function on the hardware's exp2 and reciprocal units (v_exp_f32, v_rcp_f32: ~1 ulp each; relative error of the result
 // <= 2e-7 + |v| * 6e-8 * min(1, e^v)) instead of libm expf + a correctly rounded division (~5x the VALU instructions, which made
 // the GroupNorm kernels - one or two SiLUs per element - and the dgrad epilogue sums instruction-bound rather than HBM-bound).
@@ -143,6 +159,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 16 bytes per lane through the same descriptor (buffer_load_dwordx4; offsets multiples of 16)
 __device__ __forceinline__ f32x4 pidm_buf_load_f32x4(pidm_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#endif
+#ifndef PIDM_HAVE_BUFSTORE4
+// 16-byte store through a descriptor: a per-lane offset at or beyond the descriptor's size drops the lane's store (predication
+// without a branch; a descriptor of size 0 drops them all)
+__device__ __forceinline__ void pidm_buf_store_u32x4(pidm_rsrc r, unsigned voff, unsigned soff, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 #endif
 // register budget of a kernel as waves per SIMD (512 unified registers / n); the host emulator ignores it

@@ -148,6 +148,11 @@ static inline int __any(int pred) {
 static inline float pidm_quad_xor1(float v) { return __shfl_xor(v, 1); }
 static inline float pidm_quad_xor2(float v) { return __shfl_xor(v, 2); }
 
+#define PIDM_HAVE_ROW_SHL 1
+static inline float pidm_row_shl4(float v) { const float o = __shfl(v, (hipemu::lane_id() + 4) & 63); return ((hipemu::lane_id() & 15) + 4 < 16) ? o : 0.f; }
+static inline float pidm_row_shl8(float v) { const float o = __shfl(v, (hipemu::lane_id() + 8) & 63); return ((hipemu::lane_id() & 15) + 8 < 16) ? o : 0.f; }
+static inline float pidm_other_half(float v) { return __shfl_xor(v, 32); }
+
 // ---- MFMA (f32 in / f32 acc), lane layouts per cdna_hip_programming.md section 3 -----------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
@@ -268,6 +273,12 @@ static inline hipemu_f32x4 pidm_buf_load_f32x4(pidm_rsrc r, unsigned voff, unsig
   return f;
 }
 #define PIDM_WAVES_PER_SIMD(n)
+#define PIDM_HAVE_BUFSTORE4 1
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+static inline void pidm_buf_store_u32x4(pidm_rsrc r, unsigned voff, unsigned soff, hipemu_u32x4 v) {
+  const uint64_t o = (uint64_t)voff + soff;
+  if (voff < r.bytes && o + 16 <= r.bytes) memcpy(const_cast<char*>(r.base) + o, &v, 16);
+}
 // global_load_lds_dwordx4 (pidm_common.h): synchronous here
 #define PIDM_HAVE_GLDS 1
 static inline void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {

@@ -162,15 +162,13 @@ RS_CASES = [   # the row-streaming forward / dgrad kernel (k_conv_rs.hip): rows 
 ]
 
 
-@pytest.mark.parametrize("wps", ["1", "2"])
 @pytest.mark.parametrize("waves", ["1", "24", "100000"])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", RS_CASES)
-def test_conv_3x3_row_streaming(backend, monkeypatch, wps, waves, B, H, C0, C1, Cout, K, stride, pad, transposed):
+def test_conv_3x3_row_streaming(backend, monkeypatch, waves, B, H, C0, C1, Cout, K, stride, pad, transposed):
     """Strips of the whole image height (waves = 1: R = 64 or 32, both values of R % 3), of a few rows, and of 4 rows (every row an
-    edge row); ragged last workgroup; both register budgets."""
+    edge row); ragged last workgroup.  The weight gradient and the GroupNorm-backward sums of the input gradient ride along."""
     monkeypatch.setenv("PIDM_CONV_RS_WAVES", waves)
     monkeypatch.setenv("PIDM_CONV_RS_MINR", "4")
-    monkeypatch.setenv("PIDM_CONV_RS_WPS", wps)
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 

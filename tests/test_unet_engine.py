@@ -91,6 +91,9 @@ def test_unet_dim32_p64_emulated(monkeypatch, form):
     from tests.emu_util import emu_lib
     for k, v in ATTN_FORMS[form].items():
         monkeypatch.setenv(k, v)
+    # (two images are too little work for the row-streaming 3x3 kernel's default: let it take the 64- and 32-wide levels - strips
+    # of 16 and 4 rows - with the epilogues the engine asks for: GroupNorm partials, GroupNorm-backward sums, residuals)
+    monkeypatch.setenv("PIDM_CONV_RS_WAVES", "16")
     run_case((emu_lib(), torch.device("cpu")), "g6_unet_dim32_p64", 32, False)
 
 

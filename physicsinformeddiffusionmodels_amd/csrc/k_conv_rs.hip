@@ -32,6 +32,12 @@
 
 namespace pidm {
 
+#ifndef PIDM_RSF_ABLATE
+#define PIDM_RSF_ABLATE 0   // measurement builds only (tools/rs_ablate.py; wrong results): 1 = no epilogue pieces, 2 = no split, 4 = no activation loads in the row loop, 8 = no fragment reads, 16 = no matrix instructions
+#endif
+// PIDM_RS_TRACE=1: shader-clock and 100 MHz real-time stamps of workgroup 0 / wave 0 around its row loop (launch_conv_rs prints the
+// clock the kernel ran at and the cycles per row)
+__device__ unsigned long long g_rs_trace[4];
 static constexpr int kRsRow = 112;                  // bytes per LDS weight row (k_conv.hip: kSplitRow)
 static constexpr int kRsSlab = 9 * 32 * kRsRow;     // pre-split weights of one (n-tile, 16-channel chunk)
 static constexpr unsigned kRsOob = 0x80000000u;     // a byte offset no tensor reaches (the launcher checks): reads as 0
@@ -86,7 +92,7 @@ template <int NCH, int NT, int RM, int BNP>
 __global__ void __launch_bounds__(256) PIDM_WAVES_PER_SIMD(1)
 conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1, const unsigned short* __restrict__ ws,
                   const float* __restrict__ bias, const float* __restrict__ residual, float* __restrict__ out, int R, int n_units,
-                  unsigned src_bytes, unsigned res_bytes) {
+                  unsigned src_bytes, unsigned res_bytes, int trace) {
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
@@ -336,20 +342,24 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
       rs_for<GPS>([&](auto GS_) __attribute__((always_inline)) {
         constexpr int gs = decltype(GS_)::value, oi = gs / NT, nt = gs % NT, ky = rs_ord(KM, oi);
         constexpr int gi = st * GPS + gs;                                   // group inside the row
-        if constexpr (nt + 1 < NT) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, ky, nt + 1)
+        if constexpr ((PIDM_RSF_ABLATE & 8) != 0) { }
+        else if constexpr (nt + 1 < NT) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, ky, nt + 1)
         else if constexpr (oi + 1 < NK) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kx, ch, rs_ord(KM, oi + 1), 0)
         else if constexpr (sn != 0) PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, kxn, chn, rs_ord(KM, 0), 0)
         else PIDM_RSF_FRAGS(fb[(gi + 1) & 1], blz, 0, 0, NKY, 0)
         __builtin_amdgcn_sched_barrier(0);
-        PIDM_RSF_MFMA6(acc[(J + 3 - ky) % 3][nt][(ky * 3 + kx) & 1], pc, fb[gi & 1])
-        if constexpr (PEND && (GPS == 1 || gs < GPS - 1)) {
+        if constexpr (!(PIDM_RSF_ABLATE & 16)) PIDM_RSF_MFMA6(acc[(J + 3 - ky) % 3][nt][(ky * 3 + kx) & 1], pc, fb[gi & 1])
+        if constexpr (PEND && (GPS == 1 || gs < GPS - 1) && !(PIDM_RSF_ABLATE & 1)) {
           constexpr int slot = st * SPS + (GPS == 1 ? 0 : gs);
           rs_for<NP>([&](auto K_) __attribute__((always_inline)) {
             constexpr int k = decltype(K_)::value;
             if constexpr (rs_slot(k, NP, NSLOT, SPS) == slot) piece(rs_ic<rs_piece(k, BNP)>{}, rs_ic<J>{}, i - 3);
           });
         }
-        if constexpr (gs == GPS - 1) {
+        if constexpr (gs == GPS - 1 && (PIDM_RSF_ABLATE & 2)) {
+          if (!(PIDM_RSF_ABLATE & 4)) PIDM_RSF_LOAD(i + (sn == 0 ? 2 : 1), kxn, chn)
+        }
+        if constexpr (gs == GPS - 1 && !(PIDM_RSF_ABLATE & 2)) {
           float e[8] = {raw[kxn][chn][0][0], raw[kxn][chn][0][1], raw[kxn][chn][0][2], raw[kxn][chn][0][3],
                         raw[kxn][chn][1][0], raw[kxn][chn][1][1], raw[kxn][chn][1][2], raw[kxn][chn][1][3]};
 #pragma unroll
@@ -363,7 +373,7 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
           pc[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
           pc[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
           pc[2] = u32x4{q2[0], q2[1], q2[2], q2[3]};
-          PIDM_RSF_LOAD(i + (sn == 0 ? 2 : 1), kxn, chn)
+          if (!(PIDM_RSF_ABLATE & 4)) PIDM_RSF_LOAD(i + (sn == 0 ? 2 : 1), kxn, chn)
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -385,7 +395,10 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
     pc[2] = u32x4{q2[0], q2[1], q2[2], q2[3]};
     PIDM_RSF_LOAD(1, 0, 0)
     PIDM_RSF_FRAGS(fb[0], bl, 0, 0, 0, 0)
+    if (PIDM_RSF_ABLATE & 8) PIDM_RSF_FRAGS(fb[1], bl, 0, 0, 1, 0)
   }
+  const bool tr = trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  if (tr) { g_rs_trace[0] = __builtin_readcyclecounter(); g_rs_trace[1] = __builtin_amdgcn_s_memrealtime(); }
   // rows 0 and 1 feed one and two output rows, rows 2 .. R - 1 three, rows R and R + 1 two and one (R >= 4, R % 3 == RM); the
   // first finished row appears after row 2, so rows 3 ... carry a pending epilogue and the last one is flushed behind the loop
   PIDM_RSF_ROW(0, 0, 1, 1, 0)
@@ -411,6 +424,7 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
     PIDM_RSF_ROW(0, R + 1, 4, 0, 1)
     PIDM_RSF_FLUSH(1)
   }
+  if (tr) { g_rs_trace[2] = __builtin_readcyclecounter(); g_rs_trace[3] = __builtin_amdgcn_s_memrealtime(); }
 #undef PIDM_RSF_FRAGS
 #undef PIDM_RSF_FLUSH
 #undef PIDM_RSF_ROW
@@ -440,6 +454,9 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   // two n-tiles per wave where the weights fit in LDS and the registers hold (the GroupNorm-backward sums need 64 more per n-tile)
   const int NT = (NCH == 2 && (ntn % 2) == 0 && !bnp) ? 2 : 1;
   const int ngr = ntn / NT;
+  // One wave per SIMD.  Two (the <2, 1, *, 0> kernel fits 243 registers) ran at the same speed, 64x64 32 -> 32 at batch 256: 100 vs 103
+  // us - the chip lowers its clock to fit its power budget (PIDM_RS_TRACE: 1.47-1.52 GHz in this kernel at batch 256, 1.70-1.78 at
+  // batch 64), and what the second wave wins in issue slots the clock takes back (profiles/r04_m_conv_rs_clock.txt)
   const int want = rs_fwd_knob("PIDM_CONV_RS_WAVES", 1024);
   int R = g.Hv;
   if (R < 4 || (R & (R - 1))) return 1;             // (a power of two: R % 3 is 1 or 2)
@@ -460,6 +477,7 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   const float* s1 = src1 ? src1 : src0;
   const unsigned sb = (unsigned)bytes;
   const unsigned rb = residual ? (unsigned)rbytes : 0u;
+  const int trace = knob("PIDM_RS_TRACE") ? 1 : 0;
 #define PIDM_RSF_GO(a, b, c, d)                                                                                                   \
   {                                                                                                                               \
     static bool attr__ = false;                                                                                                   \
@@ -467,7 +485,7 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rs_kernel<a, b, c, d>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
       attr__ = true;                                                                                                              \
     }                                                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb, rb); \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb, rb, trace); \
   }
 #define PIDM_RSF_GO_RM(a, b, d) if (R % 3 == 1) PIDM_RSF_GO(a, b, 1, d) else PIDM_RSF_GO(a, b, 2, d)
   if (NCH == 2 && NT == 2) PIDM_RSF_GO_RM(2, 2, 0)
@@ -479,6 +497,12 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
 #undef PIDM_RSF_GO
   if (prof) prof_end_launch(st);
   PIDM_CHECK_LAUNCH("conv3x3_rs_kernel");
+  if (trace) {
+    unsigned long long t[4] = {0, 0, 0, 0};
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rs_trace), sizeof(t)) == hipSuccess && t[3] > t[1])
+      fprintf(stderr, "[pidm] conv3x3_rs_kernel<%d, %d, %d, %d> R=%d: row loop %.2f us, shader clock %.3f GHz, %.0f cycles per input row\n", NCH, NT, R % 3, bnp,
+              R, (double)(t[3] - t[1]) * 0.01, (double)(t[2] - t[0]) / ((double)(t[3] - t[1]) * 10.0), (double)(t[2] - t[0]) / (R + 2));
+  }
   return 0;
 }
 

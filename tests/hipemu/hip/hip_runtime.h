@@ -148,6 +148,9 @@ static inline int __any(int pred) {
 static inline float pidm_quad_xor1(float v) { return __shfl_xor(v, 1); }
 static inline float pidm_quad_xor2(float v) { return __shfl_xor(v, 2); }
 
+// cycle / real-time counters (trace builds of the kernels only)
+static inline unsigned long long hipemu_counter() { return 0ull; }
+#define __builtin_amdgcn_s_memrealtime() hipemu_counter()
 #define PIDM_HAVE_ROW_SHL 1
 static inline float pidm_row_shl4(float v) { const float o = __shfl(v, (hipemu::lane_id() + 4) & 63); return ((hipemu::lane_id() & 15) + 4 < 16) ? o : 0.f; }
 static inline float pidm_row_shl8(float v) { const float o = __shfl(v, (hipemu::lane_id() + 8) & 63); return ((hipemu::lane_id() & 15) + 8 < 16) ? o : 0.f; }

@@ -532,12 +532,15 @@ def main():
             "frac_fp32_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             "frac_bf16_peak": round((6.0 * sp_fl / (conv_ms * 1e-3) / 1e12) / PEAK_BF16_MFMA_TFLOPS, 4) if conv_ms > 0 else None,
             "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
-            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3, 4x4/s2, 7x7 and the compute-bound 1x1: conv3x3_split*_kernel / "
-                      "conv1x1_split_kernel / conv7x7_split_kernel forward + input gradient, conv_wgrad_rs*_kernel weight gradient - 6 bf16 "
+            "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3, 4x4/s2, 7x7 and the compute-bound 1x1: conv3x3_rs_kernel (rows of 32 / 64 "
+                      "pixels) / conv3x3_split*_kernel / conv1x1_split_kernel / conv7x7_split_kernel forward + input gradient, "
+                      "conv_wgrad_rs*_kernel weight gradient - 6 bf16 "
                       "MFMAs per fp32 product on 3-piece split operands; memory-bound 1x1 layers, their weight gradients and the linears: "
                       "fp32 MFMA)",
             "peak_note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = the fp32 MFMA's dense peak, the rate an fp32 "
-                         "contraction is priced at; frac_bf16_pipe prices the split-form launches alone against the pipe they run on",
+                         "contraction is priced at; frac_bf16_pipe prices the split-form launches alone against the pipe they run on.  Both "
+                         "peaks assume the nominal 2.4 GHz; stamps inside conv3x3_rs_kernel (PIDM_RS_TRACE, profiles/r04_m_conv_rs_clock.txt) "
+                         "show a shader clock of 1.5-1.9 GHz while these kernels run and 76-83 % of the matrix pipe busy in cycles",
             # the split-form launches against THEIR pipe: 6 bf16 MFMA terms per fp32 product / their HIP-event time / 2500 TFLOP/s dense
             "frac_bf16_pipe": round(6.0 * sp_fl / (sp_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if sp_ms > 0 else None,
             "split_form": {"launches_per_step": sp_n // nprof, "ms_per_step": round(sp_ms / nprof, 3),

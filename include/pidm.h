@@ -232,8 +232,10 @@ int pidm_conv_pack_weights(const pidm_conv_desc* d, const float* w_ref, float* w
 int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
                       const float* bias, const float* residual, float* out, void* stream);
 /* forward convolution feeding a GroupNorm (Block: proj -> norm, src/unet_model.py:227-241): besides `out`, the epilogue leaves
- * per-(image, 32-pixel chunk, group) sums and sums of squares of the output in partial[B][chunks][groups][2] (doubles);
- * returns chunks per image (H*W/32), 0 when the shape has no statistics epilogue (then only `out` is written), < 0 on error. */
+ * per-(image, chunk, group) sums and sums of squares of the output in partial[B][chunks][groups][2] (doubles; size it for H*W/32
+ * chunks).  A chunk is a set of pixels of one image, the chunks of an image cover it once: 32 consecutive pixels behind the tile
+ * kernels (H*W/32 chunks), a strip of 32 pixels x R rows behind the row-streaming kernel.  Returns the chunks per image
+ * written, 0 when the shape has no statistics epilogue (then only `out` is written), < 0 on error. */
 int pidm_conv_forward_gn_partials(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
                                   const float* bias, float* out, int groups, double* partial, void* stream);
 /* adjoint wrt the input: dx[B,Hi,Wi,Cin] (+ residual) from dy[B,Ho,Wo,Cout]; weights packed with mode 1 */

@@ -1743,13 +1743,15 @@ extern "C" int pidm_conv_forward(const pidm_conv_desc* d, const float* src0, con
 }
 
 // forward convolution that also leaves GroupNorm partial statistics of its output (ConvGeom::gn_part): returns the number of
-// 32-pixel chunks per image written to `partial` [B][chunks][groups][2] doubles, 0 if this shape / kernel has no statistics
+// chunks per image written to `partial` [B][chunks][groups][2] doubles (32-pixel chunks behind the tile kernels, whole strips
+// behind the row-streaming kernel: ConvGeom::part_chunks_out), 0 if this shape / kernel has no statistics
 // epilogue (the convolution itself is done either way), < 0 on error
 extern "C" int pidm_conv_forward_gn_partials(const pidm_conv_desc* d, const float* src0, const float* src1, const float* w_packed,
                                              const float* bias, float* out, int groups, double* partial, void* stream) {
   ConvGeom g;
   if (geom_fwd(d, &g)) return -1;
   const int HW = g.Ho * g.Wo, cpg = (groups > 0 && g.Cout % groups == 0) ? g.Cout / groups : 0;
+  int chunks = HW / 32;
   const bool ok = partial && g.Cout % 32 == 0 && cpg >= 4 && cpg <= 32 && (cpg & (cpg - 1)) == 0 && HW % 32 == 0 && g.nz == 1 &&
                   g.nph == 1 && g.os == 1 && g.soc == 1 && g.KH == 3;
   if (ok) {
@@ -1757,10 +1759,11 @@ extern "C" int pidm_conv_forward_gn_partials(const pidm_conv_desc* d, const floa
     g.gn_cpg = cpg;
     g.gn_G = groups;
     g.gn_nchunk = HW / 32;
+    g.part_chunks_out = &chunks;
   }
   const int rc = launch_conv(g, src0, src1, w_packed, bias, nullptr, out, 0, as_stream(stream));
   if (rc < 0) return rc;
-  return (ok && rc == 0) ? HW / 32 : 0;
+  return (ok && rc == 0) ? chunks : 0;
 }
 
 extern "C" int pidm_conv_dgrad(const pidm_conv_desc* d, const float* dy, int ld_dy, const float* w_packed_dgrad,

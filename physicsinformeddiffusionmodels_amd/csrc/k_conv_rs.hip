@@ -70,7 +70,7 @@ __device__ __forceinline__ void rs_for(F&& f) { rs_for_impl(f, std::make_integer
 // piece number of the k-th epilogue piece in running order: take, loads, GroupNorm sums, [sums of the backward], quarters
 __host__ __device__ constexpr int rs_piece(int k, int bnp) {
   if (!bnp) return k;
-  return k <= 2 ? k : (k == 3 ? 9 : (k <= 5 ? k - 1 : (k <= 9 ? k + 4 : k - 5)));
+  return k <= 2 ? k : (k == 3 ? 8 : (k == 4 ? 3 : (k <= 8 ? k + 4 : k - 5)));
 }
 #define PIDM_RSF_PIN(x_) asm volatile("" : "+v"(x_))   // the value exists here: computations on it neither start before nor end after
 
@@ -92,7 +92,7 @@ template <int NCH, int NT, int RM, int BNP>
 __global__ void __launch_bounds__(256) PIDM_WAVES_PER_SIMD(1)
 conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1, const unsigned short* __restrict__ ws,
                   const float* __restrict__ bias, const float* __restrict__ residual, float* __restrict__ out, int R, int n_units,
-                  unsigned src_bytes, unsigned res_bytes, int trace) {
+                  unsigned src_bytes, unsigned res_bytes, int pch, int trace) {
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
@@ -120,8 +120,11 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
   for (int ch = 0; ch < NCH; ++ch) rsc[ch] = pidm_make_rsrc((ch * 16 < g.C0) ? src0 + ch * 16 : src1 + (ch * 16 - g.C0), src_bytes);
   // optional operands of the epilogue: size 0 when absent
   const pidm_rsrc rs_res = pidm_make_rsrc(residual, residual ? res_bytes : 0u);
-  const pidm_rsrc rs_gn = pidm_make_rsrc(g.gn_part, g.gn_part ? (unsigned)g.B * (unsigned)g.gn_nchunk * (unsigned)g.gn_G * 16u : 0u);
-  const pidm_rsrc rs_bn = pidm_make_rsrc(g.bn_part, (BNP && g.bn_part) ? (unsigned)g.B * (unsigned)g.bn_nchunk * (unsigned)g.Cout * 16u : 0u);
+  // partial sums: ONE chunk per strip (pch = strips per image; chunk = the unit's index inside its image), summed over the strip's
+  // rows in double per lane - the consumers (k_norm.hip) total H*W/32 chunks per image behind the tile kernels, 8-32x fewer here
+  const pidm_rsrc rs_gn = pidm_make_rsrc(g.gn_part, g.gn_part ? (unsigned)g.B * (unsigned)pch * (unsigned)g.gn_G * 16u : 0u);
+  const pidm_rsrc rs_bn = pidm_make_rsrc(g.bn_part, (BNP && g.bn_part) ? (unsigned)g.B * (unsigned)pch * (unsigned)g.Cout * 16u : 0u);
+  const int chunk = sx * nrb + rb;
   const pidm_rsrc rs_bnres = pidm_make_rsrc(residual, (BNP && g.bn_res && residual) ? res_bytes : 0u);
   const int HW = g.Ho * g.Wo;
   float bvs[NT];
@@ -196,11 +199,14 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
   // slot is that row's ky = 0 slot, which the order 1, 2, 0 touches last).  Every piece pins its inputs and outputs
   // (PIDM_RSF_PIN) or ends in a store: unpinned arithmetic floats out of the group it is written in - into the fragment-read region,
   // where no matrix instruction covers it.
-  float pend[NT][16], gsa[NT][2];
+  float pend[NT][16];
+  double gd[NT][2], bd[BNP ? NT : 1][2];     // GroupNorm / GroupNorm-backward sums of the strip so far
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { gd[nt][0] = gd[nt][1] = 0.0; bd[BNP ? nt : 0][0] = bd[BNP ? nt : 0][1] = 0.0; }
   f32x4 rres[NT][4];                 // residual rows, loaded a few groups ahead of their use
   float bxv[BNP ? NT : 1][16], brv[BNP ? NT : 1][16], ba1[BNP ? NT : 1], ba2[BNP ? NT : 1];
-  // pieces: 0 / 1 take the sums (halves), 2 residual loads, 3 / 4 GroupNorm partial sums (sum, butterfly + store), 5-8 the four
-  // quarters (transposes, residual, stores); BNP: 9 loads of x (and of the residual as dy's second term), 10-13 the sums' quarters
+  // pieces: 0 / 1 take the sums (halves), 2 residual loads, 3 GroupNorm sums of the row (added to the strip's), 4-7 the four
+  // quarters (transposes, residual, stores); BNP: 8 loads of x (and of the residual as dy's second term), 9-12 the sums' quarters
   auto piece = [&](auto P_, auto S_, int o_) __attribute__((always_inline)) {
     constexpr int p = decltype(P_)::value, sl = decltype(S_)::value;
     const int pin = (y0 + o_) * g.Wv + x0;                          // first pixel of the row inside the image
@@ -229,32 +235,13 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
         float a1 = pend[nt][0], a2 = pend[nt][0] * pend[nt][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) { a1 += pend[nt][r]; a2 += pend[nt][r] * pend[nt][r]; }
-        gsa[nt][0] = a1;
-        gsa[nt][1] = a2;
-        PIDM_RSF_PIN(gsa[nt][0]);
-        PIDM_RSF_PIN(gsa[nt][1]);
+        gd[nt][0] += (double)a1;
+        gd[nt][1] += (double)a2;
+        PIDM_RSF_PIN(gd[nt][0]);
+        PIDM_RSF_PIN(gd[nt][1]);
       }
-    } else if constexpr (p == 4) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float a1 = gsa[nt][0], a2 = gsa[nt][1];
-        PIDM_RSF_PIN(a1);
-        PIDM_RSF_PIN(a2);
-        // the gn_cpg (4, 8 or 16) lanes of a group: the leader (lane % gn_cpg == 0) ends up with the group's sum
-        a1 += pidm_quad_xor1(a1); a2 += pidm_quad_xor1(a2);
-        a1 += pidm_quad_xor2(a1); a2 += pidm_quad_xor2(a2);
-        { const float t1 = pidm_row_shl4(a1), t2 = pidm_row_shl4(a2); a1 += (gn_cpg > 4) ? t1 : 0.f; a2 += (gn_cpg > 4) ? t2 : 0.f; }
-        { const float t1 = pidm_row_shl8(a1), t2 = pidm_row_shl8(a2); a1 += (gn_cpg > 8) ? t1 : 0.f; a2 += (gn_cpg > 8) ? t2 : 0.f; }
-        a1 += pidm_other_half(a1);
-        a2 += pidm_other_half(a2);
-        const double d1 = (double)a1, d2 = (double)a2;
-        const unsigned long long w1 = __builtin_bit_cast(unsigned long long, d1), w2 = __builtin_bit_cast(unsigned long long, d2);
-        const int c = (ng * NT + nt) * 32 + l31;
-        const unsigned go = (((unsigned)b * (unsigned)g.gn_nchunk + (unsigned)(pin >> 5)) * (unsigned)g.gn_G + (unsigned)(c / gn_cpg)) * 16u;
-        pidm_buf_store_u32x4(rs_gn, gn_lane + go, 0u, u32x4{(unsigned)w1, (unsigned)(w1 >> 32), (unsigned)w2, (unsigned)(w2 >> 32)});
-      }
-    } else if constexpr (p >= 5 && p <= 8) {
-      constexpr int q4 = p - 5;
+    } else if constexpr (p >= 4 && p <= 7) {
+      constexpr int q4 = p - 4;
       const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -270,7 +257,7 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
         o += rres[nt][q4];
         *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + (size_t)(pin + 8 * q4) * g.sox + (ng * NT + nt) * 32 + lout) = o;
       }
-    } else if constexpr (BNP && p == 9) {
+    } else if constexpr (BNP && p == 8) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int c = (ng * NT + nt) * 32 + l31;
@@ -284,8 +271,8 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
         ba1[nt] = 0.f;
         ba2[nt] = 0.f;
       }
-    } else if constexpr (BNP && p >= 10 && p <= 13) {
-      constexpr int k4 = p - 10;
+    } else if constexpr (BNP && p >= 9 && p <= 12) {
+      constexpr int k4 = p - 9;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         PIDM_RSF_PIN(ba1[nt]);
@@ -302,18 +289,15 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
         PIDM_RSF_PIN(ba1[nt]);
         PIDM_RSF_PIN(ba2[nt]);
         if constexpr (k4 == 3) {
-          float a1 = ba1[nt], a2 = ba2[nt];
-          a1 += pidm_other_half(a1);
-          a2 += pidm_other_half(a2);
-          const double d1 = (double)a1, d2 = (double)a2;
-          const unsigned long long w1 = __builtin_bit_cast(unsigned long long, d1), w2 = __builtin_bit_cast(unsigned long long, d2);
-          const unsigned bo = (((unsigned)b * (unsigned)g.bn_nchunk + (unsigned)(pin >> 5)) * (unsigned)g.Cout + (unsigned)((ng * NT + nt) * 32 + l31)) * 16u;
-          pidm_buf_store_u32x4(rs_bn, bn_lane + bo, 0u, u32x4{(unsigned)w1, (unsigned)(w1 >> 32), (unsigned)w2, (unsigned)(w2 >> 32)});
+          bd[nt][0] += (double)ba1[nt];
+          bd[nt][1] += (double)ba2[nt];
+          PIDM_RSF_PIN(bd[nt][0]);
+          PIDM_RSF_PIN(bd[nt][1]);
         }
       }
     }
   };
-  constexpr int NP = BNP ? 14 : 9;
+  constexpr int NP = BNP ? 13 : 8;
 
   // One input row (index i, i % 3 == J): groups of six MFMAs in the order (kx, chunk, ky in the order 1, 2, 0, n-tile); the
   // output row of tap row ky is o = i - ky in slot (J + 3 - ky) % 3.  KM = the tap rows whose output row exists (bit ky): 1 and 3
@@ -424,6 +408,43 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
     PIDM_RSF_ROW(0, R + 1, 4, 0, 1)
     PIDM_RSF_FLUSH(1)
   }
+  // the strip's partial sums: lanes of a group / the two halves added in a fixed order (64-bit values as two DPP / swap moves), one
+  // 16-byte store per (group leader | channel) - dropped through the size-0 descriptor when the launch has no such epilogue
+  {
+    auto shuf = [&](double v, auto f) __attribute__((always_inline)) {
+      const unsigned long long w = __builtin_bit_cast(unsigned long long, v);
+      const unsigned lo = __builtin_bit_cast(unsigned, f(__builtin_bit_cast(float, (unsigned)w)));
+      const unsigned hi = __builtin_bit_cast(unsigned, f(__builtin_bit_cast(float, (unsigned)(w >> 32))));
+      return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    auto x1 = [](float v) { return pidm_quad_xor1(v); };
+    auto x2 = [](float v) { return pidm_quad_xor2(v); };
+    auto s4 = [](float v) { return pidm_row_shl4(v); };
+    auto s8 = [](float v) { return pidm_row_shl8(v); };
+    auto oh = [](float v) { return pidm_other_half(v); };
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = (ng * NT + nt) * 32 + l31;
+      double a1 = gd[nt][0], a2 = gd[nt][1];
+      a1 += shuf(a1, x1); a2 += shuf(a2, x1);
+      a1 += shuf(a1, x2); a2 += shuf(a2, x2);
+      { const double t1 = shuf(a1, s4), t2 = shuf(a2, s4); a1 += (gn_cpg > 4) ? t1 : 0.0; a2 += (gn_cpg > 4) ? t2 : 0.0; }
+      { const double t1 = shuf(a1, s8), t2 = shuf(a2, s8); a1 += (gn_cpg > 8) ? t1 : 0.0; a2 += (gn_cpg > 8) ? t2 : 0.0; }
+      a1 += shuf(a1, oh);
+      a2 += shuf(a2, oh);
+      const unsigned long long w1 = __builtin_bit_cast(unsigned long long, a1), w2 = __builtin_bit_cast(unsigned long long, a2);
+      const unsigned go = (((unsigned)b * (unsigned)pch + (unsigned)chunk) * (unsigned)g.gn_G + (unsigned)(c / gn_cpg)) * 16u;
+      pidm_buf_store_u32x4(rs_gn, gn_lane + go, 0u, u32x4{(unsigned)w1, (unsigned)(w1 >> 32), (unsigned)w2, (unsigned)(w2 >> 32)});
+      if constexpr (BNP != 0) {
+        double e1 = bd[nt][0], e2 = bd[nt][1];
+        e1 += shuf(e1, oh);
+        e2 += shuf(e2, oh);
+        const unsigned long long v1 = __builtin_bit_cast(unsigned long long, e1), v2 = __builtin_bit_cast(unsigned long long, e2);
+        const unsigned bo = (((unsigned)b * (unsigned)pch + (unsigned)chunk) * (unsigned)g.Cout + (unsigned)c) * 16u;
+        pidm_buf_store_u32x4(rs_bn, bn_lane + bo, 0u, u32x4{(unsigned)v1, (unsigned)(v1 >> 32), (unsigned)v2, (unsigned)(v2 >> 32)});
+      }
+    }
+  }
   if (tr) { g_rs_trace[2] = __builtin_readcyclecounter(); g_rs_trace[3] = __builtin_amdgcn_s_memrealtime(); }
 #undef PIDM_RSF_FRAGS
 #undef PIDM_RSF_FLUSH
@@ -465,6 +486,11 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   // 32x32 level 20-30 us there, 28-33 us here with strips of 4 rows, where every row is an edge row)
   if (R < rs_fwd_knob("PIDM_CONV_RS_MINR", 8) && (long)g.B * (g.Wv / 32) * (g.Hv / R) * ngr < want) return 1;
   const int n_units = g.B * (g.Wv / 32) * (g.Hv / R);
+  const int pch = (g.Wv / 32) * (g.Hv / R);           // partial chunks per image: one per strip
+  if (g.gn_part || g.bn_part) {
+    if (!g.part_chunks_out) return 1;                 // the caller counts on Ho*Wo/32 chunks: a tile kernel's layout
+    *g.part_chunks_out = pch;
+  }
   const size_t lds = (size_t)NT * NCH * kRsSlab;
   const double rbytes = (double)g.B * g.Ho * g.Wo * g.ldr * 4.0;
   if (residual && rbytes >= 2147483648.0) return 1;
@@ -485,7 +511,7 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rs_kernel<a, b, c, d>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); \
       attr__ = true;                                                                                                              \
     }                                                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb, rb, trace); \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_rs_kernel<a, b, c, d>), grid, block, lds, st, g, src0, s1, wsplit, bias, residual, out, R, n_units, sb, rb, pch, trace); \
   }
 #define PIDM_RSF_GO_RM(a, b, d) if (R % 3 == 1) PIDM_RSF_GO(a, b, 1, d) else PIDM_RSF_GO(a, b, 2, d)
   if (NCH == 2 && NT == 2) PIDM_RSF_GO_RM(2, 2, 0)

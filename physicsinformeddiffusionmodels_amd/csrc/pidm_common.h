@@ -226,6 +226,10 @@ struct ConvGeom {
   double* bn_part;
   int bn_ldss, bn_cpg, bn_G, bn_nchunk;
   int bn_res;             // 1: dy = result + residual (the sums are those of the tensor the launch WRITES; split-form 3x3 epilogues only)
+  // host side only: where the launcher reports how many partial chunks per image the kernel it picked writes to gn_part / bn_part
+  // (Ho*Wo/32 for the tile kernels - one per wave tile; one per strip for the row-streaming kernel, k_conv_rs.hip, which sums over the
+  // rows of a strip first).  A caller that passes null gets Ho*Wo/32 chunks or no epilogue.
+  int* part_chunks_out;
 };
 
 // Geometry of one weight-gradient launch (k_conv.hip, k_wgrad_rs.hip): dW[m][t][n] = sum_p dY[p][m] * X[p (+tap)][n]

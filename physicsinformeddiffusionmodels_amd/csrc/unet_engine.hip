@@ -619,6 +619,7 @@ static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float*
   ConvGeom g;
   if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
   const int HW = g.Ho * g.Wo, cpg = (G > 0 && L.Cout % G == 0) ? L.Cout / G : 0;
+  int chunks = HW / 32;               // (the row-streaming kernel writes one chunk per strip: ConvGeom::part_chunks_out)
   const bool ok = !off && L.Cout % 32 == 0 && cpg >= 4 && cpg <= 32 && (cpg & (cpg - 1)) == 0 && HW % 32 == 0 && g.nz == 1 &&
                   g.nph == 1 && g.os == 1 && g.soc == 1 && g.KH == 3 && (32 % g.Wv == 0 || g.Wv % 32 == 0);
   if (ok) {
@@ -626,11 +627,12 @@ static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float*
     g.gn_cpg = cpg;
     g.gn_G = G;
     g.gn_nchunk = HW / 32;
+    g.part_chunks_out = &chunks;
   }
   if (r.dry) return 0;
   const int rc = launch_conv(g, x0, x1, r.wpack + L.off_f, L.b >= 0 ? r.U->P[L.b] : nullptr, nullptr, out, 0, r.st);
   if (rc < 0) return rc;
-  if (ok && rc == 0) *part_chunks = HW / 32;
+  if (ok && rc == 0) *part_chunks = chunks;
   return 0;
 }
 
@@ -911,6 +913,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
     int kind;
     if (geom_dgrad(&d, m.c2.Cout, m.c2.C0 + m.c2.C1, &g, &kind)) return -1;
     const int cpg = (G > 0 && Co % G == 0) ? Co / G : 0;
+    int chunks = HW / 32;
     const bool ok = !off && r.defer_on && g.Cout == Co && Co % 32 == 0 && cpg >= 1 && HW % 32 == 0 && g.nz == 1 && g.nph == 1 && g.os == 1 &&
                     g.soc == 1 && g.KH == 3 && g.Ho * g.Wo == HW;
     if (ok) {
@@ -918,11 +921,12 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
       g.bn_x = m.a; g.bn_stats = m.st1; g.bn_gamma = U->P[m.gn1w]; g.bn_beta = U->P[m.gn1b];
       g.bn_ss = ss; g.bn_ssb = ssb; g.bn_ldss = U->ss_total;
       g.bn_cpg = cpg; g.bn_G = G; g.bn_nchunk = HW / 32;
+      g.part_chunks_out = &chunks;
     }
     if (!r.dry) {
       const int rc = launch_conv(g, g_c, nullptr, r.wpack + m.c2.off_d, nullptr, nullptr, g_b, 0, r.st);
       if (rc < 0) return rc;
-      if (ok && rc == 0) pcb = HW / 32;
+      if (ok && rc == 0) pcb = chunks;
     }
   }
   // g_c is dead on THIS stream after the two uses above, but the side-stream wgrad of c2 may still be reading it
@@ -944,6 +948,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
     int kind;
     if (geom_dgrad(&d, m.c1.Cout, m.c1.C0 + m.c1.C1, &g, &kind)) return -1;
     bool ok = false;
+    int chunks = HW / 32;
     if (next && !off && r.defer_on) {
       const int Cn = next->Co, cpg = (G > 0 && Cn % G == 0) ? Cn / G : 0;
       ok = next->H == m.H && g.Cout == Cn && Cn % 32 == 0 && cpg >= 1 && HW % 32 == 0 && g.nz == 1 && g.nph == 1 && g.os == 1 && g.soc == 1 &&
@@ -954,12 +959,13 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
         g.bn_ss = nullptr; g.bn_ssb = nullptr; g.bn_ldss = 0;
         g.bn_cpg = cpg; g.bn_G = G; g.bn_nchunk = HW / 32;
         g.bn_res = 1;
+        g.part_chunks_out = &chunks;
       }
     }
     if (!r.dry) {
       const int rc = launch_conv(g, g_a, nullptr, r.wpack + m.c1.off_d, nullptr, res1, g_x, 0, r.st);
       if (rc < 0) return rc;
-      if (ok && rc == 0 && pc_next) *pc_next = HW / 32;
+      if (ok && rc == 0 && pc_next) *pc_next = chunks;
     }
   }
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply

@@ -7,7 +7,7 @@ bash tools/pmc.sh sp64 $R/tools/bench_one.py 64 32 0 32 3 1 1 0 64 3 > /dev/null
 bash tools/pmc.sh sp16 $R/tools/bench_one.py 16 128 0 128 3 1 1 0 64 3 > /dev/null 2>&1
 bash tools/pmc.sh sp8 $R/tools/bench_one.py 8 256 0 256 3 1 1 0 64 3 > /dev/null 2>&1
 bash tools/pmc.sh sp64b256 $R/tools/bench_one.py 64 32 0 32 3 1 1 0 256 3 > /dev/null 2>&1
-for n in sp64 sp16 sp8 sp64b256; do echo "#### $n"; python tools/pmc_report.py gpurun_out/pmc_$n conv3x3_split conv_wgrad_rs conv_wgrad_split; done > $o/pmc_split_kernels.txt
+for n in sp64 sp16 sp8 sp64b256; do echo "#### $n"; python tools/pmc_report.py gpurun_out/pmc_$n conv3x3_rs conv3x3_split conv_wgrad_rs conv_wgrad_split; done > $o/pmc_split_kernels.txt
 rm -rf gpurun_out/pmc_sp64 gpurun_out/pmc_sp16 gpurun_out/pmc_sp8 gpurun_out/pmc_sp64b256
 grep -E "####|==|waves=" $o/pmc_split_kernels.txt | cut -c1-260
 # ---- PMC traffic, all four workloads ----

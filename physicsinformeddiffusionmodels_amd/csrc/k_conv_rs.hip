@@ -7,21 +7,27 @@
 // Why: at these levels a tile of conv3x3_split_kernel has only 2-4 stages of 16 input channels, so its per-stage staging (global ->
 // registers -> split -> LDS -> barrier -> fragment reads: ~1950 of a stage's ~5800 cycles, profiles/r02_split_conv_notes.txt) and
 // its per-tile epilogue with both waves of a SIMD lined up by the barrier (~2200 cycles every 2-4 stages) keep the matrix pipe at
-// 0.32-0.45 occupancy (profiles/r04_pmc_split_kernels.txt).  The operand fragment of the 32x32x16 MFMA is "lane = pixel, 8
+// 0.32-0.45 occupancy by the PMC measure (profiles/r04_pmc_split_kernels.txt).  The operand fragment of the 32x32x16 MFMA is "lane = pixel, 8
 // consecutive channels" - in a channels-last image that is 32 contiguous bytes of the lane's own pixel - so a wave can load its
 // fragments straight from global memory, split them in registers and keep going: no staging buffer, no barrier, no tile.
 //
 // A wave owns a strip of 32 pixels x R output rows of one image and walks the R + 2 input rows top to bottom.  For input row r it
 // loads the row three times (shifted by -1 / 0 / +1 pixels: the kx taps; the re-reads hit L1), splits each 16-channel chunk into its
 // pieces and issues, for ky = 0..2, the six MFMAs of tap (ky, kx) into the accumulators of output row r + 1 - ky: three output rows
-// are live (x 2 chains x NT n-tiles x 16 registers), the one that received its last row (ky = 2) is finished, stored and zeroed.
-// Zero padding comes from the buffer descriptor: out-of-image columns use an out-of-range offset (reads as 0, pidm_common.h),
-// out-of-image rows are skipped.  The pre-split weights of the workgroup's n-tiles (the packing of conv3x3_split_kernel: an image of
-// 112-byte LDS rows) are copied to LDS once per workgroup by global_load_lds; a wave reads each tap's fragments once per input row.
-// The only barrier of the kernel publishes the weights.  Epilogue per output row = the tile epilogue of conv3x3_split_kernel (bias,
-// GroupNorm partial sums, GroupNorm-backward sums, 4x4 register transposes, residual, 16-byte stores).
+// are live (x 2 chains x NT n-tiles x 16 registers), the one that received its last row (ky = 2) is finished.
+// Zero padding comes from the buffer descriptor: out-of-image columns and rows use an out-of-range offset (reads as 0 without a memory
+// access, pidm_common.h).  The pre-split weights of the workgroup's n-tiles (the packing of conv3x3_split_kernel: an image of 112-byte
+// LDS rows) are copied to LDS once per workgroup by global_load_lds; a wave reads each tap's fragments once per input row.  The only
+// barrier of the kernel publishes the weights.
+// Epilogue of a finished row = the tile epilogue of conv3x3_split_kernel (bias, GroupNorm partial sums, GroupNorm-backward sums, 4x4
+// register transposes, residual, 16-byte stores), but (i) cut into 8-13 pieces that ride between the matrix instructions of the NEXT
+// input row - with one wave per SIMD nothing else can fill the gaps between a wave's MFMAs -, (ii) without a branch (absent operands =
+// buffer descriptors of size 0), (iii) with the GroupNorm sums accumulated over the strip's rows and written once per strip
+// (ConvGeom::part_chunks_out tells the caller how many chunks per image to total).
 // Results: same pieces, same products, same two chains per output element as conv3x3_split_kernel, but the chains run tap-major
 // instead of chunk-major - equal to it within fp32 rounding of the accumulation order, not bit for bit.
+// Measured (PIDM_RS_TRACE, profiles/r04_m_conv_rs_clock.txt): 76-83 % of the matrix pipe busy in shader cycles; the shader clock under
+// this kernel is 1.5-1.87 GHz.
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>

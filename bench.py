@@ -160,6 +160,62 @@ def cpu_baseline(workload, batch, steps, threads):
                       f"(host has {os.cpu_count()} logical cores), {dt:.2f} s/step"}
 
 
+def rs_clock_probe(lib, dev, B):
+    """The clock the matrix-pipe kernels actually run at.  The 3x3 forward convolution of the 64x64 level (32 -> 32 channels, this
+    batch) through the C ABI with PIDM_RS_TRACE=1: workgroup 0 / wave 0 of conv3x3_rs_kernel stamps the shader-clock counter and the
+    100 MHz real-time counter around its row loop (k_conv_rs.hip).  Outside the timed region; knobs restored afterwards."""
+    import torch
+    from physicsinformeddiffusionmodels_amd._lib import ConvDesc, ptr, stream_ptr
+    try:
+        st = stream_ptr(dev)
+        H, Cc = 64, 32
+        d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cc, C1=0, ld0=Cc, ld1=0, Cout=Cc, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=Cc)
+        x = torch.randn(B, H, H, Cc, device=dev)
+        w = torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05
+        wp = torch.zeros(lib.pidm_conv_packed_weight_floats(d), device=dev)
+        lib.check(lib.pidm_conv_pack_weights(d, ptr(w), ptr(wp), 0, st))
+        out = torch.empty(B, H, H, Cc, device=dev)
+        for _ in range(20):                               # the clock settles under load
+            lib.check(lib.pidm_conv_forward(d, ptr(x), None, ptr(wp), None, None, ptr(out), st))
+        os.environ["PIDM_RS_TRACE"] = "1"
+        lib.pidm_reload_knobs()
+        samples = []
+        t = (C.c_ulonglong * 4)()
+        try:
+            with open(os.devnull, "w") as devnull:
+                saved = os.dup(2)
+                os.dup2(devnull.fileno(), 2)              # (the traced launch also prints its line)
+                try:
+                    for _ in range(8):
+                        lib.check(lib.pidm_conv_forward(d, ptr(x), None, ptr(wp), None, None, ptr(out), st))
+                        torch.cuda.synchronize()
+                        if lib.pidm_debug_conv_rs_trace(t) == 0 and t[3] > t[1]:
+                            samples.append((t[2] - t[0], t[3] - t[1]))
+                finally:
+                    os.dup2(saved, 2)
+                    os.close(saved)
+        finally:
+            del os.environ["PIDM_RS_TRACE"]
+            lib.pidm_reload_knobs()
+        if not samples:
+            return None
+        cyc = sum(s_[0] for s_ in samples) / len(samples)
+        ticks = sum(s_[1] for s_ in samples) / len(samples)
+        # rows per strip: the launcher halves the image height until 1024 waves exist (k_conv_rs.hip: launch_conv_rs)
+        R = H
+        while R > 4 and B * (H // 32) * (H // R) < 1024:
+            R //= 2
+        mfma_rows = R                                     # input rows 0,1 and R, R+1 carry 1/3 + 2/3 of a row's MFMAs each
+        return {"kernel": "conv3x3_rs_kernel, 64x64 32->32 forward at this batch, row loop of workgroup 0 / wave 0",
+                "shader_clock_ghz": round(cyc / (ticks * 10.0), 3), "nominal_clock_ghz": 2.4,
+                "row_loop_us": round(ticks * 0.01, 2), "rows_per_strip": R,
+                "mfma_pipe_busy_in_cycles": round(mfma_rows * 108 * 32 / cyc, 3),
+                "what": "108 MFMAs of 32 cycles per full input row; busy = MFMA cycles / shader cycles of the row loop.  The two MFMA peaks "
+                        "of this object assume the nominal clock: at the measured one the matrix pipe is this busy in cycles"}
+    except Exception as e:  # noqa: BLE001 - a probe must not take the bench line down
+        return {"error": repr(e)}
+
+
 def pmc_traffic(workload, batch):
     """(HBM bytes per launch of the conv class, where the figure comes from).  The PMC counters need rocprofv3 around the
     process, so they cannot be read live: the figure is the committed pass of tools/pmc_traffic.sh under profiles/ for this
@@ -559,6 +615,8 @@ def main():
         }
         if wl == "darcy":
             roofline["step_hbm_fraction"] = round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+        if wl == "darcy":
+            roofline["clock_probe"] = rs_clock_probe(lib, dev, B)
         st_bytes = pmc_step_traffic(wl, B)
         if st_bytes is not None:
             # every kernel class of the step from the same PMC pass; for darcy next to the SURVEY 8(d) contract bytes

@@ -287,6 +287,9 @@ int pidm_lap_backward(const float* xn, const float* dy, const float* w_qkv, cons
 
 /* measurement aid (tools/conv_trace.py): cycle stamps of the streaming 3x3 convolution kernel, written when PIDM_STREAM_TRACE is set */
 int pidm_debug_stream_trace(unsigned long long* out256);
+/* measurement aid (bench.py roofline.clock_probe): stamps of the last conv3x3_rs_kernel launch made with PIDM_RS_TRACE set -
+ * out4 = {shader-clock counter, 100 MHz real-time counter} before and {.., ..} after the row loop of workgroup 0 / wave 0 */
+int pidm_debug_conv_rs_trace(unsigned long long* out4);
 /* test aid: host-to-device uploads of the deferred-reduction descriptor table since the library was loaded (a second identical
  * backward pass must not upload anything: the table is compared with what the device already holds) */
 long long pidm_debug_reduce_table_uploads(void);

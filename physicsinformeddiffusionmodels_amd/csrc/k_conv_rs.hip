@@ -539,3 +539,10 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
 }
 
 }  // namespace pidm
+
+// measurement aid: the four stamps the last traced launch of conv3x3_rs_kernel left (PIDM_RS_TRACE=1): shader-clock counter and
+// 100 MHz real-time counter of workgroup 0 / wave 0 before and after its row loop
+extern "C" int pidm_debug_conv_rs_trace(unsigned long long* out4) {
+  if (!out4) return pidm::fail("debug_conv_rs_trace: null argument");
+  return hipMemcpyFromSymbol(out4, HIP_SYMBOL(pidm::g_rs_trace), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -1;
+}

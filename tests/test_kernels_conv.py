@@ -386,12 +386,17 @@ def test_warp_specialised_kernel_is_bit_identical(backend, monkeypatch, B, H, C0
     assert torch.isfinite(outs["1"][0]).all() and torch.isfinite(outs["1"][1]).all()
 
 
-def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
+@pytest.mark.parametrize("fwd_kernel", ["tile", "row_streaming"])
+def test_split_form_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch, fwd_kernel):
     """The 3-piece / 6-term bf16 form against a float64 convolution, next to the fp32-MFMA kernels on the same data (K = 576):
     forward, input-gradient and weight-gradient errors of the split form stay within 1.25x of the fp32-MFMA kernels' and below
-    2e-6 of the result's scale (measured on an MI355X: see profiles/r02_split_conv_notes.txt)."""
+    2e-6 of the result's scale (measured on an MI355X: see profiles/r02_split_conv_notes.txt).  fwd_kernel: forward / input
+    gradient on conv3x3_split_kernel (chunk-major accumulation) or on conv3x3_rs_kernel (tap-major; k_conv_rs.hip)."""
     L, dev = backend
     st = stream_ptr(dev)
+    monkeypatch.setenv("PIDM_CONV_RS", "1" if fwd_kernel == "row_streaming" else "0")
+    monkeypatch.setenv("PIDM_CONV_RS_WAVES", "8")
+    monkeypatch.setenv("PIDM_CONV_RS_MINR", "4")
     g = torch.Generator().manual_seed(99)
     B, H, Cin, Cout = 2, 32, 64, 64
     x = torch.randn(B, Cin, H, H, generator=g)
@@ -460,8 +465,9 @@ def test_1x1_split_gemm_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
         assert e_split < 2e-6, (what, errs)
 
 
+@pytest.mark.parametrize("H", [16, 32])       # 32: rows wide enough for the row-streaming forward / input-gradient kernel
 @pytest.mark.parametrize("form", ["split", "fp32"])
-def test_conv_extreme_magnitudes(backend, monkeypatch, form):
+def test_conv_extreme_magnitudes(backend, monkeypatch, form, H):
     """Non-finite and extreme inputs through the 3x3 kernels, split form next to the fp32-MFMA form (same expectations for both):
     * +-inf / NaN in the input make exactly the outputs of their 3x3 footprint non-finite (the split form turns inf into NaN -
       x - bf16(x) = inf - inf - where the fp32 kernels keep +-inf; a fp32 value above the bf16 maximum 3.3895e38 rounds its
@@ -474,8 +480,10 @@ def test_conv_extreme_magnitudes(backend, monkeypatch, form):
     st = stream_ptr(dev)
     monkeypatch.setenv("PIDM_CONV_SPLIT", "1" if form == "split" else "0")
     monkeypatch.setenv("PIDM_WGRAD_SPLIT", "1" if form == "split" else "0")
+    monkeypatch.setenv("PIDM_CONV_RS_WAVES", "8")        # (two images: let conv3x3_rs_kernel take the 32-wide case)
+    monkeypatch.setenv("PIDM_CONV_RS_MINR", "4")
     g = torch.Generator().manual_seed(7)
-    B, H, Cin, Cout = 2, 16, 32, 32
+    B, Cin, Cout = 2, 32, 32
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     w = torch.where(w.abs() < 1e-3, torch.full_like(w, 1e-3), w)          # no zero weight: inf * w is never NaN in the reference
     specials = [((0, 3, 2, 2), float("inf")), ((0, 7, 2, 8), float("-inf")), ((0, 1, 2, 13), float("nan")),

@@ -224,14 +224,14 @@ __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ q
       for (int k = 0; k < 16; ++k) qv[k] = 0.f;
       m = 0.f;
     }
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = fmaxf(m, pidm_other_half(m));
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       qv[k] = fexp(qv[k] - m);
       s += qv[k];
     }
-    s += __shfl_xor(s, 32);
+    s += pidm_other_half(s);
     const float inv = 1.f / s;
     if (valid && half == 0) {
       qstat[(p * heads + h) * 2] = m;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) la_out_kernel(const float* __restrict__ q
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const float mine = qv[k] * inv * scale;
-        const float other = __shfl_xor(mine, 32);
+        const float other = pidm_other_half(mine);
         qfull[k] = half ? other : mine;        // static indices keep the array in registers
         qfull[16 + k] = half ? mine : other;
       }
@@ -526,14 +526,14 @@ __global__ void __launch_bounds__(256) la_out_proj_kernel(const float* __restric
     float m = qv[0];
 #pragma unroll
     for (int k = 1; k < 16; ++k) m = fmaxf(m, qv[k]);
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = fmaxf(m, pidm_other_half(m));
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       qv[k] = fexp(qv[k] - m);
       sum += qv[k];
     }
-    sum += __shfl_xor(sum, 32);
+    sum += pidm_other_half(sum);
     const float inv = 1.f / sum;
     if (half == 0) *reinterpret_cast<float2*>(qstat + (p * heads + h) * 2) = make_float2(m, inv);
     f32x16 accT;
@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(256, 3) la_bwd_dq_kernel(const float* __restri
         qs4[j][c] = fexp(q4[j][c] - qst.x) * qst.y;
         dot = fmaf(qs4[j][c], acc1[4 * j + c], dot);
       }
-    dot += __shfl_xor(dot, 32);
+    dot += pidm_other_half(dot);
     // one pixel per lane -> whole 128-byte lines through the wave's LDS tile (see la_bwd_dkdv_kernel)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1032,13 +1032,13 @@ __global__ void __launch_bounds__(256) mid_attn64_kernel(const float* __restrict
     float m = pr[0];
 #pragma unroll
     for (int j = 1; j < 16; ++j) m = fmaxf(m, pr[j]);
-    m = fmaxf(m, __shfl_xor(m, 1));
-    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, pidm_quad_xor1(m));
+    m = fmaxf(m, pidm_quad_xor2(m));
     float ex[16], sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { ex[j] = fexp(pr[j] - m); sum += ex[j]; }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
+    sum += pidm_quad_xor1(sum);
+    sum += pidm_quad_xor2(sum);
     const float inv = 1.f / sum;
 #pragma unroll
     for (int j = 0; j < 16; ++j) pr[j] = ex[j] * inv;
@@ -1087,8 +1087,8 @@ __global__ void __launch_bounds__(256) mid_attn64_kernel(const float* __restrict
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) dot = fmaf(pd[j], pp[j], dot);
-    dot += __shfl_xor(dot, 1);
-    dot += __shfl_xor(dot, 2);
+    dot += pidm_quad_xor1(dot);
+    dot += pidm_quad_xor2(dot);
 #pragma unroll
     for (int j = 0; j < 16; ++j) pd[j] = pp[j] * (pd[j] - dot);
   }

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
     float tm = kt[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
-    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    tm = fmaxf(tm, pidm_other_half(tm));
     if (__any(tm > mrun)) {     // wave-uniform: the max of some column grew - rescale what has been accumulated (rare after the first tiles)
       const float mn = fmaxf(mrun, tm);
       const float f = lap_exp(mrun - mn);
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
       for (int cb = 0; cb < CB; ++cb) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], brow[32 * cb], M[cb], 0, 0, 0);
     }
   }
-  const float z = zp + __shfl_xor(zp, 32);
+  const float z = zp + pidm_other_half(zp);
   float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C + 64);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(512) lap_kctx_split_kernel(const float* __rest
     float tm = kt[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
-    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    tm = fmaxf(tm, pidm_other_half(tm));
     if (__any(tm > mrun)) {
       const float mn = fmaxf(mrun, tm);
       const float f = lap_exp(mrun - mn);
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(512) lap_kctx_split_kernel(const float* __rest
     }
   }
 #undef PIDM_LAP_SIX
-  const float z = zp + __shfl_xor(zp, 32);
+  const float z = zp + pidm_other_half(zp);
   float* o = part + ((size_t)blockIdx.x * heads + h) * (size_t)(32 * C + 64);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -446,14 +446,14 @@ __global__ void __launch_bounds__(256) lap_out_kernel(const float* __restrict__ 
       float mx = qt[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, pidm_other_half(mx));
       float sm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         qt[r] = lap_exp(qt[r] - mx);
         sm += qt[r];
       }
-      sm += __shfl_xor(sm, 32);
+      sm += pidm_other_half(sm);
       const float inv = 1.f / sm;
       if (half == 0) *reinterpret_cast<float2*>(qstat + (pix * heads + h) * 2) = make_float2(mx, inv);
       const float sc = inv * scale;
@@ -575,14 +575,14 @@ __global__ void __launch_bounds__(512) lap_out_split_kernel(const float* __restr
       float mx = qt[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, pidm_other_half(mx));
       float sm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         qt[r] = lap_exp(qt[r] - mx);
         sm += qt[r];
       }
-      sm += __shfl_xor(sm, 32);
+      sm += pidm_other_half(sm);
       const float inv = 1.f / sm;
       if (half == 0) *reinterpret_cast<float2*>(qstat + (pix * heads + h) * 2) = make_float2(mx, inv);
       const float sc = inv * scale;
@@ -1147,14 +1147,14 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       float mx = qt[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, pidm_other_half(mx));
       float sm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         qt[r] = lap_exp(qt[r] - mx);
         sm += qt[r];
       }
-      sm += __shfl_xor(sm, 32);
+      sm += pidm_other_half(sm);
       const float sc = scale / sm;
       float jd = 0.f;
 #pragma unroll
@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
         qt[r] *= sc;                     // qs
         jd += qt[r] * dq[r];
       }
-      jd = (jd + __shfl_xor(jd, 32)) * rscale;
+      jd = (jd + pidm_other_half(jd)) * rscale;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = qt[r] * (dq[r] - jd);
       // d_xn^T[c][px] += Wq_h^T[c][d] dq^T[d][px]  (operand rows fetched as one batch, then the MFMAs)

@@ -13,8 +13,8 @@ namespace pidm {
       a1__ += __shfl_xor(a1__, off__);                                                                              \
       a2__ += __shfl_xor(a2__, off__);                                                                              \
     }                                                                                                               \
-    a1__ += __shfl_xor(a1__, 32);                                                                                   \
-    a2__ += __shfl_xor(a2__, 32);                                                                                   \
+    a1__ += pidm_other_half(a1__);                                                                                   \
+    a2__ += pidm_other_half(a2__);                                                                                   \
     if (half == 0 && (l31 & (g.gn_cpg - 1)) == 0) {                                                                 \
       double* o__ = g.gn_part + (((size_t)(b_) * g.gn_nchunk + ((pix_in_img_) >> 5)) * g.gn_G + (c_) / g.gn_cpg) * 2; \
       o__[0] = (double)a1__;                                                                                        \
@@ -49,8 +49,8 @@ namespace pidm {
       a1__ += dv__;                                                                                                 \
       a2__ += dv__ * xh__;                                                                                          \
     }                                                                                                               \
-    a1__ += __shfl_xor(a1__, 32);                                                                                   \
-    a2__ += __shfl_xor(a2__, 32);                                                                                   \
+    a1__ += pidm_other_half(a1__);                                                                                   \
+    a2__ += pidm_other_half(a2__);                                                                                   \
     if (half == 0) {                                                                                                \
       double* o__ = g.bn_part + (((size_t)(b_) * g.bn_nchunk + ((pix_in_img_) >> 5)) * g.Cout + (c_)) * 2;          \
       o__[0] = (double)a1__;                                                                                        \

@@ -509,7 +509,12 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   const float* s1 = src1 ? src1 : src0;
   const unsigned sb = (unsigned)bytes;
   const unsigned rb = residual ? (unsigned)rbytes : 0u;
-  const int trace = knob("PIDM_RS_TRACE") ? 1 : 0;
+  // (the read-back below synchronises the stream: never while it is being captured into a hipGraph)
+  int trace = knob("PIDM_RS_TRACE") ? 1 : 0;
+  if (trace) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) trace = 0;
+  }
 #define PIDM_RSF_GO(a, b, c, d)                                                                                                   \
   {                                                                                                                               \
     static bool attr__ = false;                                                                                                   \

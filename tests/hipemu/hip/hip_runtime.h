@@ -353,6 +353,11 @@ static inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMo
   hipemu::capturing_graph() = new hipemu::Graph();
   return hipSuccess;
 }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) {
+  *st = hipemu::capturing_graph() ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+  return hipSuccess;
+}
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
   if (!hipemu::capturing_graph()) return hipErrorInvalidValue;
   *g = hipemu::capturing_graph();

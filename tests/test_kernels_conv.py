@@ -282,6 +282,8 @@ GN_EPILOGUE_CASES = [
     (3, 32, 32, 32, 64, 8),     # concat source, two 32-channel accumulators per wave, 8 channels per group
     (2, 16, 64, 0, 128, 8),     # 16-wide rows: a wave = two rows; 16 channels per group
     (5, 8, 128, 0, 256, 8),     # two 8x8 images per tile (ragged last tile); a whole 32-channel tile per group
+    (2, 32, 32, 0, 64, 4),      # 16 channels per group on 32-wide rows: the row-streaming kernel's widest in-row group sum
+    (1, 64, 64, 0, 32, 2),      # the same with 64 input channels and 64-wide rows
 ]
 
 

@@ -23,6 +23,10 @@ CASES = {
     # 32 / 64 channels at 32x32 / 16x16: the projected linear attention, whose backward runs two tile groups when attn_heads <= 4
     "heads_4_projected_attention": (32, 1, dict(dim=32, dim_mults=(1, 2, 4), attn_heads=4)),
     "groups_4": (16, 2, dict(dim=8, resnet_groups=4)),
+    # 32 channels on 32-wide rows with 8 / 16 channels per GroupNorm group: the row-streaming 3x3 kernel (k_conv_rs.hip) with its
+    # wider in-row group sums, forward partials and backward sums (PIDM_CONV_RS_* below lets one image be enough work for it)
+    "row_streaming_groups_4": (32, 1, dict(dim=32, dim_mults=(1, 2, 4), resnet_groups=4)),
+    "row_streaming_groups_2": (32, 2, dict(dim=32, dim_mults=(1, 2, 4), resnet_groups=2)),
     "init_kernel_5": (16, 2, dict(dim=8, init_kernel_size=5)),
     "init_kernel_3": (16, 2, dict(dim=8, init_kernel_size=3)),
     "sigmoid_last_channel": (16, 2, dict(dim=8, sigmoid_last_channel=True)),
@@ -35,8 +39,11 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_unusual_configuration_matches_the_oracle(backend, name):
+def test_unusual_configuration_matches_the_oracle(backend, monkeypatch, name):
     L, dev = backend
+    if name.startswith("row_streaming"):
+        monkeypatch.setenv("PIDM_CONV_RS_WAVES", "4")
+        monkeypatch.setenv("PIDM_CONV_RS_MINR", "4")
     P, B, kw = CASES[name]
     torch.manual_seed(7)
     m = Unet3D(**kw)

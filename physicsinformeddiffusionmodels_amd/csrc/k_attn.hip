@@ -32,8 +32,10 @@ __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 
 // ---- k softmax statistics over pixels: kstat[b][j] = (max_n, 1/sum_n exp(k - max)) -----------------
 // stage 1: online (max, sum) over one segment of pixels per block; stage 2 merges the segments.
+// kstat != null (one segment: every level of the Darcy and mechanics models): the statistics are final - (max, 1 / sum) go straight
+// to kstat and la_kstats_final_kernel is not launched (the same values: it would multiply the sum by exp(0) = 1)
 __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict__ qkv, int N, int HD, int nseg,
-                                                        float* __restrict__ kpart) {
+                                                        float* __restrict__ kpart, float* __restrict__ kstat) {
   __shared__ float sm[4][64], ssum[4][64];
   const int b = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
   const int j = blockIdx.x * 64 + cl;
@@ -73,8 +75,13 @@ __global__ void __launch_bounds__(256) la_kstats_kernel(const float* __restrict_
     float M = fmaxf(fmaxf(sm[0][cl], sm[1][cl]), fmaxf(sm[2][cl], sm[3][cl]));
     float S = 0.f;
     for (int r = 0; r < 4; ++r) S += ssum[r][cl] * fexp(sm[r][cl] - M);
-    kpart[(((size_t)b * nseg + seg) * HD + j) * 2] = M;
-    kpart[(((size_t)b * nseg + seg) * HD + j) * 2 + 1] = S;
+    if (kstat) {
+      kstat[((size_t)b * HD + j) * 2] = M;
+      kstat[((size_t)b * HD + j) * 2 + 1] = 1.f / S;
+    } else {
+      kpart[(((size_t)b * nseg + seg) * HD + j) * 2] = M;
+      kpart[(((size_t)b * nseg + seg) * HD + j) * 2 + 1] = S;
+    }
   }
 }
 __global__ void la_kstats_final_kernel(const float* __restrict__ kpart, int B, int HD, int nseg, float* __restrict__ kstat) {
@@ -99,7 +106,8 @@ __global__ void la_kstats_final_kernel(const float* __restrict__ kpart, int B, i
 template <int MODE>
 __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict__ qkv, const float* __restrict__ stat,
                                                          const float* __restrict__ dA, const float* __restrict__ ctx,
-                                                         float* __restrict__ Dpart, int N, int heads, float scale) {
+                                                         float* __restrict__ Dpart, int N, int heads, float scale,
+                                                         float* __restrict__ Dfinal, float* __restrict__ rowdot, float alpha) {
   __shared__ float red[4][1024];
   const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
   const int ns = blockIdx.y, NS = gridDim.y;
@@ -166,6 +174,29 @@ __global__ void __launch_bounds__(256) la_nreduce_kernel(const float* __restrict
     red[wave][row * 32 + l31] = acc[r];
   }
   __syncthreads();
+  if (Dfinal) {
+    // one pixel range per (image, head) (gridDim.y == 1: images of <= 512 pixels): this block's sum IS the result - what
+    // la_nreduce_final_kernel would make of the single partial (alpha * (0 + sum); MODE 1: the row dots in the same order)
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + 256 * k;
+      v[k] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * alpha;
+      Dfinal[(size_t)bh * 1024 + e] = v[k];
+    }
+    if (MODE == 1) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[0][tid + 256 * k] = v[k] * ctx[(size_t)bh * 1024 + tid + 256 * k];
+      __syncthreads();
+      if (tid < 32) {
+        float sacc = 0.f;
+        for (int j = 0; j < 32; ++j) sacc += red[0][tid * 32 + j];
+        rowdot[(size_t)bh * 32 + tid] = sacc;
+      }
+    }
+    return;
+  }
   float* out = Dpart + ((size_t)bh * NS + ns) * 1024;
   for (int e = tid; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
@@ -1143,16 +1174,20 @@ int launch_la_forward(const float* qkv, float* kstat, float* ctx, float* attn, f
   const int nseg = la_kseg(N), NS = la_nsplit(N);
   float* kpart = scratch;
   float* dpart = scratch + (size_t)B * nseg * HD * 2;
-  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart);
+  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart, nseg == 1 ? kstat : nullptr);
   PIDM_CHECK_LAUNCH("la_kstats_kernel");
-  hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
-  PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  if (nseg > 1) {
+    hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
+    PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads, NS), dim3(256), 0, st, qkv, kstat, nullptr, nullptr,
-                     dpart, N, heads, scale);
+                     dpart, N, heads, scale, NS == 1 ? ctx : nullptr, nullptr, 1.f / (float)N);
   PIDM_CHECK_LAUNCH("la_context");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
-                     1.f / (float)N);
-  PIDM_CHECK_LAUNCH("la_context_final");
+  if (NS > 1) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
+                       1.f / (float)N);
+    PIDM_CHECK_LAUNCH("la_context_final");
+  }
   const size_t npix = (size_t)B * N;
   if (N % 32 == 0)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(la_out_kernel<true>), dim3((unsigned)((npix + 127) / 128), (npix + 127) / 128 < 1024 ? heads : 1), dim3(256), 0, st, qkv, ctx, attn,
@@ -1170,10 +1205,12 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
   const int NS = la_nsplit(N);
   float* dpart = scratch;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<1>), dim3(B * heads, NS), dim3(256), 0, st, qkv, qstat, dA, ctx, dpart, N, heads,
-                     scale);
+                     scale, NS == 1 ? dctx : nullptr, rowdot, 1.f);
   PIDM_CHECK_LAUNCH("la_dctx");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<1>), dim3(B * heads), dim3(256), 0, st, dpart, ctx, dctx, rowdot, NS, 1.f);
-  PIDM_CHECK_LAUNCH("la_dctx_final");
+  if (NS > 1) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<1>), dim3(B * heads), dim3(256), 0, st, dpart, ctx, dctx, rowdot, NS, 1.f);
+    PIDM_CHECK_LAUNCH("la_dctx_final");
+  }
   if (N % 32 == 0 && N >= 64) {        // whole 32-pixel waves of one image per block: 4 waves, or fewer while that leaves CUs idle
     const size_t npix = (size_t)B * N;
     int ppb = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
@@ -1204,16 +1241,20 @@ int launch_la_forward_fused(const float* qkv, float* kstat, float* ctx, float* q
   const int nseg = la_kseg(N), NS = la_nsplit(N);
   float* kpart = scratch;
   float* dpart = scratch + (size_t)B * nseg * HD * 2;
-  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart);
+  hipLaunchKernelGGL(la_kstats_kernel, dim3(cdiv(HD, 64), B, nseg), dim3(256), 0, st, qkv, N, HD, nseg, kpart, nseg == 1 ? kstat : nullptr);
   PIDM_CHECK_LAUNCH("la_kstats_kernel");
-  hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
-  PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  if (nseg > 1) {
+    hipLaunchKernelGGL(la_kstats_final_kernel, dim3(cdiv(B * HD, 256)), dim3(256), 0, st, kpart, B, HD, nseg, kstat);
+    PIDM_CHECK_LAUNCH("la_kstats_final_kernel");
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_kernel<0>), dim3(B * heads, NS), dim3(256), 0, st, qkv, kstat, nullptr, nullptr,
-                     dpart, N, heads, scale);
+                     dpart, N, heads, scale, NS == 1 ? ctx : nullptr, nullptr, 1.f / (float)N);
   PIDM_CHECK_LAUNCH("la_context");
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
-                     1.f / (float)N);
-  PIDM_CHECK_LAUNCH("la_context_final");
+  if (NS > 1) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(la_nreduce_final_kernel<0>), dim3(B * heads), dim3(256), 0, st, dpart, nullptr, ctx, nullptr, NS,
+                       1.f / (float)N);
+    PIDM_CHECK_LAUNCH("la_context_final");
+  }
   float* wt = dpart + (size_t)B * heads * NS * 1024;
   hipLaunchKernelGGL(la_wt_kernel, dim3(cdiv(Cout * HD, 256)), dim3(256), 0, st, w_out, wt, Cout, HD);
   PIDM_CHECK_LAUNCH("la_wt_kernel");

@@ -1229,7 +1229,7 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
 // backward of attention + to_out projection; dy [B][N][Cout] (leading dimension ld_dy), w_out [Cout][HD] (reference layout);
 // dwpart [B][Cout][HD]: per-image shares of the to_out weight gradient.  Eligibility: la_fused_ok.
 bool la_fused_ok(int N, int heads, int Cout, int ld_dy) {
-  static const bool off = knob("PIDM_NO_LA_FUSED") != nullptr;
+  const bool off = knob("PIDM_NO_LA_FUSED") != nullptr;
   return !off && N % 128 == 0 && (Cout == 32 || Cout == 64 || Cout == 128) && (ld_dy & 3) == 0 && heads >= 1 && heads <= 14;
 }
 // forward: k statistics, context, then attention output x projection (+ bias + residual) in one kernel; y [B][N][Cout]
@@ -1326,7 +1326,7 @@ int launch_mid_attn(const float* qkv, const float* dO, float* out, int B, int N,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mid_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_done = true;
   }
-  static const bool mfma_off = [] { const char* e = knob("PIDM_MID_ATTN_MFMA"); return e && !atoi(e); }();
+  const bool mfma_off = [] { const char* e = knob("PIDM_MID_ATTN_MFMA"); return e && !atoi(e); }();
   if (N == 64 && !mfma_off) {
     static bool attr64 = false;
     if (!attr64) {

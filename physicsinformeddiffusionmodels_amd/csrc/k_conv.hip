@@ -56,7 +56,7 @@ __device__ unsigned long long g_stream_trace[4 * 64];
 static constexpr int kSplitRow = 112;                 // bytes per LDS row
 // extra bytes per halo-tile row (ConvGeom::rpad): see conv3x3_split_kernel; PIDM_SPLIT_ROWPAD=0: off (A/B measurements)
 static int split_row_pad(int Wv) {
-  static const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
+  const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
   return (on && Wv <= 16) ? 32 : 0;
 }
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
@@ -1041,7 +1041,7 @@ static int split_ntg(const ConvGeom& g) {
   if (!(g.KH == 1 && g.KW == 1 && g.stride == 1 && g.nz == 1 && g.nph == 1 && g.os == 1 && (g.Cin % 32 == 0) && (g.Cout % 64 == 0) &&
         g.Cin >= 64 && g.Hv * g.Wv > 1))
     return 0;
-  static const bool on = [] { const char* e = knob("PIDM_CONV1X1_SPLIT"); return !(e && !atoi(e)); }();
+  const bool on = [] { const char* e = knob("PIDM_CONV1X1_SPLIT"); return !(e && !atoi(e)); }();
   if (!on) return 0;
   return (g.Cout % 128 == 0) ? 4 : 2;
 }

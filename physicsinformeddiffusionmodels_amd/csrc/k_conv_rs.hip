@@ -428,6 +428,7 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
     auto s4 = [](float v) { return pidm_row_shl4(v); };
     auto s8 = [](float v) { return pidm_row_shl8(v); };
     auto oh = [](float v) { return pidm_other_half(v); };
+    auto x16 = [](float v) { return __shfl_xor(v, 16); };   // the other row of 16 of the lane's half (groups of 32 channels only)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int c = (ng * NT + nt) * 32 + l31;
@@ -436,6 +437,8 @@ conv3x3_rs_kernel(ConvGeom g, const float* __restrict__ src0, const float* __res
       a1 += shuf(a1, x2); a2 += shuf(a2, x2);
       { const double t1 = shuf(a1, s4), t2 = shuf(a2, s4); a1 += (gn_cpg > 4) ? t1 : 0.0; a2 += (gn_cpg > 4) ? t2 : 0.0; }
       { const double t1 = shuf(a1, s8), t2 = shuf(a2, s8); a1 += (gn_cpg > 8) ? t1 : 0.0; a2 += (gn_cpg > 8) ? t2 : 0.0; }
+      // a DPP row is 16 lanes: a group of 32 channels spans two rows, whose leaders (lanes 0 and 16 of the half) are added here
+      if (gn_cpg > 16) { const double t1 = shuf(a1, x16), t2 = shuf(a2, x16); a1 += t1; a2 += t2; }
       a1 += shuf(a1, oh);
       a2 += shuf(a2, oh);
       const unsigned long long w1 = __builtin_bit_cast(unsigned long long, a1), w2 = __builtin_bit_cast(unsigned long long, a2);
@@ -493,14 +496,14 @@ int launch_conv_rs(const ConvGeom& g, const float* src0, const float* src1, cons
   if (R < rs_fwd_knob("PIDM_CONV_RS_MINR", 8) && (long)g.B * (g.Wv / 32) * (g.Hv / R) * ngr < want) return 1;
   const int n_units = g.B * (g.Wv / 32) * (g.Hv / R);
   const int pch = (g.Wv / 32) * (g.Hv / R);           // partial chunks per image: one per strip
-  if (g.gn_part || g.bn_part) {
-    if (!g.part_chunks_out) return 1;                 // the caller counts on Ho*Wo/32 chunks: a tile kernel's layout
-    *g.part_chunks_out = pch;
-  }
+  if ((g.gn_part || g.bn_part) && !g.part_chunks_out) return 1;   // the caller counts on Ho*Wo/32 chunks: a tile kernel's layout
   const size_t lds = (size_t)NT * NCH * kRsSlab;
   const double rbytes = (double)g.B * g.Ho * g.Wo * g.ldr * 4.0;
   if (residual && rbytes >= 2147483648.0) return 1;
   if (g.gn_part && (g.gn_cpg < 1 || g.gn_cpg > 32 || (g.gn_cpg & (g.gn_cpg - 1)))) return 1;
+  // (only now - behind every `return 1` - does the caller learn this kernel's chunk count: a tile kernel that takes the launch
+  // after a fall-through writes Ho*Wo/32 chunks per image)
+  if (g.gn_part || g.bn_part) *g.part_chunks_out = pch;
   if (knob("PIDM_TRACE_CONV"))
     fprintf(stderr, "[pidm]   -> conv3x3_rs_kernel<%d, %d, %d, %d>, %d strips of %d rows, %d n-groups, %zu B LDS\n", NCH, NT, R % 3, bnp, n_units, R, ngr, lds);
   const bool prof = prof_enabled();

@@ -1182,8 +1182,8 @@ static int wgrad_taps(const ConvGeom& g) { return g.nph > 1 ? 16 : g.KH * g.KW; 
 
 // 0: LDS-staged kernels, 1: LDS-free stream with 32x32 tiles, 2: stream with a 128-wide dY operand, 3: 128-wide X operand
 static int wgrad_stream_mode(const ConvGeom& g, int ld_dy) {
-  static const bool off = knob("PIDM_NO_WGRAD_STREAM") != nullptr;
-  static const bool off4 = knob("PIDM_NO_WGRAD_STREAM4") != nullptr;
+  const bool off = knob("PIDM_NO_WGRAD_STREAM") != nullptr;
+  const bool off4 = knob("PIDM_NO_WGRAD_STREAM4") != nullptr;
   if (off || g.KH != 1 || g.KW != 1 || g.stride != 1 || g.nph != 1 || g.nz != 1 || wgrad_smallc(g)) return 0;
   if (g.C1 != 0 && g.C0 % 32 != 0) return 0;
   if (off4) return 1;

@@ -646,7 +646,7 @@ static int ew_blocks(size_t n_threads) {
 
 static int gn_chunks(int HW, int B) {
   // enough blocks to fill the chip, at least 64 pixels per block (PIDM_GN_BLOCKS: the block budget, A/B measurements)
-  static const int budget = [] { const char* e = knob("PIDM_GN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  const int budget = [] { const char* e = knob("PIDM_GN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
   int nchunk = (budget + B - 1) / B;
   if (nchunk > HW / 64) nchunk = HW / 64;
   if (nchunk < 1) nchunk = 1;

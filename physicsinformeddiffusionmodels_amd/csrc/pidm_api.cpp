@@ -37,6 +37,7 @@ extern "C" const char* pidm_backend(void) {
 // ---------------------------------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline figures)
 // ---------------------------------------------------------------------------------------------------------
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -64,9 +65,19 @@ void prof_reclass_last(int cls) { if (!g_prof.empty()) g_prof.back().cls = cls; 
 
 // ---- knobs: one environment read per name and process ------------------------------------------------------------------------
 namespace {
-struct KnobEntry { bool set; std::string val; };
+// `val` points into g_knob_strings, which only ever grows: a pointer knob() handed out stays valid across pidm_reload_knobs()
+// (a launcher on another thread may still be reading it), at the price of a few leaked bytes per CHANGED value
+struct KnobEntry { bool set; const std::string* val; };
 std::mutex g_knob_mu;
 std::map<std::string, KnobEntry>* g_knobs = nullptr;     // leaked on purpose: launchers may run during static destruction
+std::deque<std::string>* g_knob_strings = nullptr;
+KnobEntry read_env(const char* name) {
+  const char* v = getenv(name);
+  if (!v) return KnobEntry{false, nullptr};
+  if (!g_knob_strings) g_knob_strings = new std::deque<std::string>();
+  g_knob_strings->emplace_back(v);
+  return KnobEntry{true, &g_knob_strings->back()};
+}
 uint64_t g_knob_sig = 0;
 bool g_knob_sig_valid = false;
 }  // namespace
@@ -75,10 +86,9 @@ const char* knob(const char* name) {
   if (!g_knobs) g_knobs = new std::map<std::string, KnobEntry>();
   auto it = g_knobs->find(name);
   if (it == g_knobs->end()) {
-    const char* v = getenv(name);
-    it = g_knobs->emplace(name, KnobEntry{v != nullptr, v ? std::string(v) : std::string()}).first;
+    it = g_knobs->emplace(name, read_env(name)).first;
   }
-  return it->second.set ? it->second.val.c_str() : nullptr;
+  return it->second.set ? it->second.val->c_str() : nullptr;
 }
 uint64_t knob_signature() {
   std::lock_guard<std::mutex> lk(g_knob_mu);
@@ -101,7 +111,13 @@ uint64_t knob_signature() {
 
 extern "C" int pidm_reload_knobs(void) {
   std::lock_guard<std::mutex> lk(pidm::g_knob_mu);
-  if (pidm::g_knobs) pidm::g_knobs->clear();
+  // entries are re-read in place, never erased: see KnobEntry
+  if (pidm::g_knobs)
+    for (auto& kv : *pidm::g_knobs) {
+      const char* v = getenv(kv.first.c_str());
+      const bool same = kv.second.set ? (v && *kv.second.val == v) : (v == nullptr);
+      if (!same) kv.second = pidm::read_env(kv.first.c_str());
+    }
   pidm::g_knob_sig_valid = false;
   return 0;
 }

@@ -8,6 +8,7 @@
 // caller has (parallel.py broadcasts it over the process group it already owns).
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
 
 #include "pidm_common.h"
 
@@ -28,6 +29,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+std::string g_rccl_why;        // why the binding failed (dlerror() is read once, right after the failing call: reading it clears it)
 
 const Rccl& rccl() {
   std::call_once(g_rccl_once, [] {
@@ -36,6 +38,7 @@ const Rccl& rccl() {
     for (const char* n : names) {
       g_rccl.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (g_rccl.so) break;
+      if (const char* e = dlerror()) g_rccl_why = e;
     }
     if (!g_rccl.so) return;
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.so, "ncclGetUniqueId"));
@@ -44,6 +47,7 @@ const Rccl& rccl() {
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.so, "ncclCommDestroy"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.so, "ncclGetErrorString"));
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
+    if (!g_rccl.ok) g_rccl_why = "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy: symbol missing";
 #endif
   });
   return g_rccl;
@@ -53,7 +57,7 @@ int need(const Rccl& r) {
 #ifdef PIDM_BACKEND_NAME
   return pidm::fail("pidm_comm: the host-emulated build has no RCCL (gloo carries the multi-rank tests)");
 #else
-  return pidm::fail("pidm_comm: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  return pidm::fail("pidm_comm: librccl.so could not be bound (%s)", g_rccl_why.empty() ? "unknown reason" : g_rccl_why.c_str());
 #endif
 }
 int check(const Rccl& r, ncclResult_i rc, const char* what) {

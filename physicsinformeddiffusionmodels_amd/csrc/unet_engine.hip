@@ -614,7 +614,7 @@ static int conv_fwd(Run& r, const ConvLayer& L, const float* x0, const float* x1
 // *part_chunks = chunks per image written (0: not produced - shape not eligible or kernel without the epilogue; the caller
 // then runs launch_gn_stats).
 static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float* x1, float* out, int G, int* part_chunks) {
-  static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr;
+  const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr;
   *part_chunks = 0;
   ConvGeom g;
   if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
@@ -907,7 +907,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   // partials of conv2 live in r.scratch, where the sums go.
   int pcb = 0;
   {
-    static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN_EPILOGUE") != nullptr;
+    const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN_EPILOGUE") != nullptr;
     pidm_conv_desc d = desc_of(m.c2, r.B);
     ConvGeom g;
     int kind;
@@ -942,7 +942,7 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
   }
   {
     // conv 1's input gradient (+ the skip share as residual) = g_x; with `next` its epilogue also sums for next's GroupNorm 2
-    static const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN2_EPILOGUE") != nullptr;
+    const bool off = knob("PIDM_NO_GN_EPILOGUE") != nullptr || knob("PIDM_NO_BN2_EPILOGUE") != nullptr;
     pidm_conv_desc d = desc_of(m.c1, r.B);
     ConvGeom g;
     int kind;
@@ -951,8 +951,10 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
     int chunks = HW / 32;
     if (next && !off && r.defer_on) {
       const int Cn = next->Co, cpg = (G > 0 && Cn % G == 0) ? Cn / G : 0;
+      // (res1 != g_x: with a res_conv the residual is the output buffer itself, and the row-streaming kernel re-reads the residual
+      // for the GroupNorm-backward sums AFTER it stored the output row - in place it would sum result + residual + result)
       ok = next->H == m.H && g.Cout == Cn && Cn % 32 == 0 && cpg >= 1 && HW % 32 == 0 && g.nz == 1 && g.nph == 1 && g.os == 1 && g.soc == 1 &&
-           g.KH == 3 && g.Ho * g.Wo == HW;
+           g.KH == 3 && g.Ho * g.Wo == HW && res1 != g_x;
       if (ok) {
         g.bn_part = reinterpret_cast<double*>(r.scratch);
         g.bn_x = next->c; g.bn_stats = next->st2; g.bn_gamma = U->P[next->gn2w]; g.bn_beta = U->P[next->gn2b];

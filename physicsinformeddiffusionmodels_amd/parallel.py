@@ -40,29 +40,43 @@ def flat_gradient_buffers(model):
 class NativeComm:
     """The C-ABI communicator (include/pidm.h: pidm_comm_*): RCCL bound inside the library, no torch collective on the data path.
     Rank 0's 128-byte id reaches the other ranks through the process group the caller already has (one broadcast at set-up);
-    `allreduce_avg` then takes a raw pointer, a count and the current stream.  Opt-in (`PIDM_DP_NATIVE=1`, or pass one to
-    GradientExchange): torch.distributed's own RCCL path stays the default."""
+    `allreduce_avg` then takes a raw pointer, a count and the current stream.  Construct it through `negotiate_native_comm`
+    (every rank of the group, collectively): that is what `GradientExchange` does by default with more than one rank on GPUs."""
 
-    def __init__(self, lib, device, group=None):
+    def __init__(self, lib, device, group=None, ident: bytes | None = None):
         self.lib, self.device = lib, torch.device(device)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_ubyte * 128)()
-            lib.check(lib.pidm_comm_unique_id(buf), "pidm_comm_unique_id")
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
-        carrier = ident.to(self.device) if dist.get_backend(group) == "nccl" else ident
-        dist.broadcast(carrier, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        raw = bytes(carrier.cpu().tolist())
+        if ident is None:
+            ident = _broadcast_id(lib, self.device, group, _new_id(lib) if rank == 0 else None)
         self.handle = vp()
-        with torch.cuda.device(self.device):
-            lib.check(lib.pidm_comm_init(rank, world, raw, C.byref(self.handle)), "pidm_comm_init")
-        self.world = world
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                lib.check(lib.pidm_comm_init(rank, world, ident, C.byref(self.handle)), "pidm_comm_init")
+        else:
+            lib.check(lib.pidm_comm_init(rank, world, ident, C.byref(self.handle)), "pidm_comm_init")
+        self.rank, self.world = rank, world
+
+    def allreduce(self, buf, average: bool):
+        assert buf.dtype == torch.float32 and buf.is_contiguous()
+        st = torch.cuda.current_stream(buf.device).cuda_stream if buf.is_cuda else 0
+        self.lib.check(self.lib.pidm_allreduce_f32(self.handle, vp(buf.data_ptr()), buf.numel(), 1 if average else 0, vp(st)), "pidm_allreduce_f32")
 
     def allreduce_avg(self, buf):
-        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
-        st = torch.cuda.current_stream(buf.device).cuda_stream
-        self.lib.check(self.lib.pidm_allreduce_f32(self.handle, vp(buf.data_ptr()), buf.numel(), 1, vp(st)), "pidm_allreduce_f32")
+        self.allreduce(buf, True)
+
+    def self_check(self):
+        """One float per rank through the communicator: the sum of rank + 1 must be N (N + 1) / 2 and the mean (N + 1) / 2 - a
+        communicator that initialised but moves nothing (or adds where it should average) is caught before the first step."""
+        n = self.world
+        x = torch.full((2,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+        self.allreduce(x[:1], False)
+        self.allreduce(x[1:], True)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        got = x.cpu().tolist()
+        want = [n * (n + 1) / 2.0, (n + 1) / 2.0]
+        if got != want:
+            raise RuntimeError(f"pidm_allreduce_f32 self-check: got sum {got[0]}, mean {got[1]}; expected {want[0]}, {want[1]} (rank {self.rank} of {n})")
 
     def close(self):
         if self.handle:
@@ -74,6 +88,71 @@ class NativeComm:
             self.close()
         except Exception:
             pass
+
+
+def _new_id(lib) -> bytes:
+    buf = (C.c_ubyte * 128)()
+    lib.check(lib.pidm_comm_unique_id(buf), "pidm_comm_unique_id")
+    return bytes(buf)
+
+
+def _carrier_device(device, group):
+    return torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def _broadcast_id(lib, device, group, ident: bytes | None) -> bytes:
+    t = torch.tensor(list(ident), dtype=torch.uint8) if ident is not None else torch.zeros(128, dtype=torch.uint8)
+    t = t.to(_carrier_device(device, group))
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return bytes(t.cpu().tolist())
+
+
+def _all_ranks_ok(ok: bool, device, group) -> bool:
+    """Logical AND over the ranks of the group, through the torch process group (the channel that is known to work)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_carrier_device(device, group))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def negotiate_native_comm(lib, device, group=None):
+    """COLLECTIVE over the group: try to bring up the C-ABI communicator on every rank, check it, and agree on the outcome.
+
+    Returns (NativeComm, None) when every rank initialised it and passed the one-float self-check, else (None, reason) on EVERY
+    rank - never a mixture (a mixture would deadlock the first step: some ranks in ncclAllReduce of one communicator, the rest in
+    torch.distributed's).  The caller falls back to torch.distributed.all_reduce and reports `reason`.  What cannot be caught
+    here: a rank that dies INSIDE ncclCommInitRank leaves the others waiting in it (RCCL's own time-out applies)."""
+    rank = dist.get_rank(group)
+    why = None
+    ident = None
+    # 1. is the binding there on every rank?  (rank 0's id is the one that is used; the others only probe the binding)
+    try:
+        probe = _new_id(lib)
+        if rank == 0:
+            ident = probe
+    except Exception as e:  # noqa: BLE001 - any failure means "fall back", the reason is reported
+        why = f"rank {rank}: {e}"
+    if not _all_ranks_ok(why is None, device, group):
+        return None, why or "pidm_comm_unique_id failed on another rank"
+    ident = _broadcast_id(lib, device, group, ident)
+    # 2. every rank enters pidm_comm_init (ncclCommInitRank is itself collective)
+    comm = None
+    try:
+        comm = NativeComm(lib, device, group, ident=ident)
+    except Exception as e:  # noqa: BLE001
+        why = f"rank {rank}: {e}"
+    if not _all_ranks_ok(comm is not None, device, group):
+        if comm is not None:
+            comm.close()
+        return None, why or "pidm_comm_init failed on another rank"
+    # 3. one float through it
+    try:
+        comm.self_check()
+    except Exception as e:  # noqa: BLE001
+        why = f"rank {rank}: {e}"
+    if not _all_ranks_ok(why is None, device, group):
+        comm.close()
+        return None, why or "the pidm_allreduce_f32 self-check failed on another rank"
+    return comm, None
 
 
 def _allreduce_avg(buf, world, group, native=None):
@@ -109,13 +188,23 @@ class GradientExchange:
 
     buckets: 1..3 phases of the engine's deferred reduction (PIDM_DP_BUCKETS overrides; 1 = a single collective after
     backward, the round-1 behaviour).  diffusion: the DenoisingDiffusion whose mechanics inequality term should be made
-    data-parallel exact (it needs the world size for one scalar all-reduce)."""
+    data-parallel exact (it needs the world size for one scalar all-reduce).
+
+    Which collective carries the gradients (`self.collective`): on GPUs the library's own communicator (`pidm_allreduce_f32`,
+    RCCL behind the C ABI - torch is a container here, not the data path) after `negotiate_native_comm` brought it up on every rank
+    and its self-check passed; `torch.distributed.all_reduce` otherwise (CPU / gloo, `native=False`, `PIDM_DP_NATIVE=0`, or any
+    failure of the negotiation - then `self.collective_note` says why).  `native=True` asks for the C-ABI communicator on any
+    device; `native=<NativeComm>` uses a communicator the caller negotiated (the CPU tests bring one up over a library whose
+    pidm_comm_* entries they control)."""
 
     def __init__(self, model, world_size: int | None = None, image_size: int = 64, buckets: int = 3, group=None, lib=None,
                  diffusion=None, force: bool = False, native: bool | None = None):
         self.model, self.group = model, group
         self.native = None
-        self._want_native = (os.environ.get("PIDM_DP_NATIVE") == "1") if native is None else bool(native)
+        env_native = os.environ.get("PIDM_DP_NATIVE")
+        # None = default: the C-ABI communicator on GPUs, torch.distributed elsewhere; a NativeComm object = use this one
+        given = native if isinstance(native, NativeComm) else None
+        self._want_native = (None if env_native is None else env_native == "1") if native is None else bool(native)
         self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         # force: run the collectives even with one rank (exercises RCCL, the side stream and the phase events on a single-GPU box)
         self.active = self.world > 1 or (force and dist.is_initialized())
@@ -146,8 +235,20 @@ class GradientExchange:
         self.ranges.append(rest)
         dev = eng.params[0].device
         self.on_gpu = dev.type == "cuda"
-        if self._want_native and self.active and self.on_gpu:
-            self.native = NativeComm(eng.lib, dev, group)
+        self.collective_note = None
+        if given is not None:
+            self.native = given if self.active else None
+        elif self.active and (self._want_native is True or (self._want_native is None and self.on_gpu)):
+            self.native, self.collective_note = negotiate_native_comm(eng.lib, dev, group)
+            if self.native is None:
+                print(f"GradientExchange: C-ABI communicator not used ({self.collective_note}); falling back to torch.distributed.all_reduce",
+                      flush=True)
+        if self.native is not None:
+            self.collective = "pidm_allreduce_f32 (C-ABI communicator over RCCL)"
+        elif dist.is_initialized():
+            self.collective = f"torch.distributed.all_reduce ({dist.get_backend(group)})"
+        else:
+            self.collective = "none (one rank)"
         self.events, self.stream = None, None
         self._closed = True                # until the engine has been told about this object
         handles = None

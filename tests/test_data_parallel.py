@@ -74,6 +74,53 @@ def _step(m, diff, res, x0, eps, t, case):
     return loss.item()
 
 
+class _CommStubLib:
+    """TEST DOUBLE for the four pidm_comm_* entries of include/pidm.h (the host-emulated build has no RCCL): same signatures and
+    return codes, gloo underneath.  Lets parallel.negotiate_native_comm / NativeComm / GradientExchange run their multi-rank C-ABI
+    path on CPU: id hand-off (every rank must receive rank 0's bytes), the self-check, averaged values, and the agreed fall-back
+    when one rank's init fails (`init_fails_on`) or the collective moves nothing (`dead`)."""
+
+    def __init__(self, lib, init_fails_on=None, dead=False, no_binding_on=None):
+        self._lib, self._init_fails_on, self._dead, self._no_binding_on = lib, init_fails_on, dead, no_binding_on
+        self._err = ""
+        self.ident_seen = None
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._err}")
+
+    def pidm_comm_unique_id(self, buf):
+        if dist.get_rank() == self._no_binding_on:
+            self._err = "librccl.so could not be bound (stub)"
+            return -1
+        for k in range(128):
+            buf[k] = (37 * k + 11) & 0xFF
+        return 0
+
+    def pidm_comm_init(self, rank, world, ident, handle_ref):
+        self.ident_seen = bytes(ident)
+        if rank == self._init_fails_on:
+            self._err = "ncclCommInitRank: RCCL error 5 (stub)"
+            return -1
+        handle_ref._obj.value = 0x1000 + rank
+        return 0
+
+    def pidm_allreduce_f32(self, handle, ptr, count, average, stream):
+        import ctypes as C
+        t = torch.frombuffer((C.c_float * count).from_address(ptr.value), dtype=torch.float32)
+        if not self._dead:
+            dist.all_reduce(t)
+            if average:
+                t.mul_(1.0 / dist.get_world_size())
+        return 0
+
+    def pidm_comm_destroy(self, handle):
+        return 0
+
+
 def _worker(rank, world, port, outdir, case):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -84,9 +131,24 @@ def _worker(rank, world, port, outdir, case):
     from physicsinformeddiffusionmodels_amd.parallel import GradientExchange, shard_batch
     from tests.emu_util import emu_lib
     lib = emu_lib()
+    case, _, comm_mode = case.partition("+")
     m, diff, res, P = _setup(lib, case)
-    ex = GradientExchange(m, world, image_size=P, buckets=3, lib=lib, diffusion=diff)
+    native = None
+    if comm_mode:
+        from physicsinformeddiffusionmodels_amd.parallel import negotiate_native_comm
+        stub = _CommStubLib(lib, init_fails_on=1 if comm_mode == "init_fails" else None, dead=comm_mode == "dead",
+                            no_binding_on=1 if comm_mode == "no_binding" else None)
+        native, why = negotiate_native_comm(stub, torch.device("cpu"))
+        if comm_mode == "native":
+            assert native is not None and why is None and native.world == world
+            assert stub.ident_seen == bytes((37 * k + 11) & 0xFF for k in range(128))     # rank 0's id reached this rank
+        else:
+            # one rank failed (init / binding) or the collective is dead: EVERY rank must come back without a communicator
+            assert native is None and why, (comm_mode, why)
+            native = False
+    ex = GradientExchange(m, world, image_size=P, buckets=3, lib=lib, diffusion=diff, native=native)
     assert [len(r) for r in ex.ranges] == [1, 1, 2]        # decoder | encoder | head + conditioning tail
+    assert ex.collective == ("pidm_allreduce_f32 (C-ABI communicator over RCCL)" if comm_mode == "native" else "torch.distributed.all_reduce (gloo)")
     x0, eps, t = _inputs(case)
     loss = _step(m, diff, res, shard_batch(x0, rank, world), shard_batch(eps, rank, world), shard_batch(t, rank, world), case)
     ex.allreduce()
@@ -99,7 +161,7 @@ def _worker(rank, world, port, outdir, case):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("case", ["darcy", "two_tape", "mechanics"])
+@pytest.mark.parametrize("case", ["darcy", "two_tape", "mechanics", "darcy+native", "darcy+init_fails", "darcy+dead", "darcy+no_binding"])
 def test_two_rank_step_equals_global_batch_step(tmp_path, case):
     from physicsinformeddiffusionmodels_amd._engine import get_engine
     from tests.emu_util import emu_lib
@@ -109,6 +171,7 @@ def test_two_rank_step_equals_global_batch_step(tmp_path, case):
     g0 = np.load(tmp_path / "grad_0.npy")
     g1 = np.load(tmp_path / "grad_1.npy")
     np.testing.assert_array_equal(g0, g1)          # every rank holds the same averaged gradient
+    case = case.partition("+")[0]                  # (+mode: which collective carried the exchange - the result must not depend on it)
     m, diff, res, P = _setup(lib, case)
     x0, eps, t = _inputs(case)
     loss = _step(m, diff, res, x0, eps, t, case)

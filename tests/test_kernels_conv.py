@@ -284,6 +284,9 @@ GN_EPILOGUE_CASES = [
     (5, 8, 128, 0, 256, 8),     # two 8x8 images per tile (ragged last tile); a whole 32-channel tile per group
     (2, 32, 32, 0, 64, 4),      # 16 channels per group on 32-wide rows: the row-streaming kernel's widest in-row group sum
     (1, 64, 64, 0, 32, 2),      # the same with 64 input channels and 64-wide rows
+    (2, 32, 32, 0, 32, 1),      # 32 channels per group: a group spans both 16-lane DPP rows of the row-streaming kernel's half wave
+    (2, 32, 32, 0, 64, 2),      # the same with two n-tiles per wave
+    (1, 64, 64, 0, 32, 1),      # 64-wide rows, 64 input channels
 ]
 
 

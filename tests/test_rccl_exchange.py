@@ -74,14 +74,21 @@ def test_forced_single_rank_exchange_is_the_identity(nccl_single_rank, monkeypat
     m, diff, res, x0, eps, t = _setup(two_tape)
     ref = _step(m, diff, res, x0, eps, t)                      # no exchange object: one deferred reduction, no events
     assert torch.isfinite(ref).all() and ref.abs().max().item() > 0
-    for env, want_overlap, want_ranges in (({}, not two_tape, [1, 1, 2]), ({"PIDM_DP_NO_OVERLAP": "1"}, False, [1, 1, 2]),
-                                           ({"PIDM_DP_BUCKETS": "1"}, not two_tape, [1])):
-        for k in ("PIDM_DP_NO_OVERLAP", "PIDM_DP_BUCKETS"):
+    # (default on GPUs: the library's own communicator, negotiated and self-checked; native=False / PIDM_DP_NATIVE=0: torch.distributed)
+    for env, want_overlap, want_ranges, native in (({}, not two_tape, [1, 1, 2], None), ({}, not two_tape, [1, 1, 2], False),
+                                                   ({"PIDM_DP_NO_OVERLAP": "1"}, False, [1, 1, 2], None),
+                                                   ({"PIDM_DP_BUCKETS": "1"}, not two_tape, [1], None),
+                                                   ({"PIDM_DP_NATIVE": "0"}, not two_tape, [1, 1, 2], None)):
+        for k in ("PIDM_DP_NO_OVERLAP", "PIDM_DP_BUCKETS", "PIDM_DP_NATIVE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        ex = GradientExchange(m, image_size=32, diffusion=diff, force=True)
+        ex = GradientExchange(m, image_size=32, diffusion=diff, force=True, native=native)
         assert ex.active and ex.world == 1 and [len(r) for r in ex.ranges] == want_ranges
+        if native is False or env.get("PIDM_DP_NATIVE") == "0":
+            assert ex.native is None and ex.collective == "torch.distributed.all_reduce (nccl)"
+        else:
+            assert ex.native is not None and ex.collective.startswith("pidm_allreduce_f32") and ex.collective_note is None
         ex.measure = True
         for _ in range(5):                                      # steady state: from the third step on the backward is a replayed hipGraph
                                                                 # cut at the phase events (recorded for real between the segments)

@@ -27,6 +27,7 @@ CASES = {
     # wider in-row group sums, forward partials and backward sums (PIDM_CONV_RS_* below lets one image be enough work for it)
     "row_streaming_groups_4": (32, 1, dict(dim=32, dim_mults=(1, 2, 4), resnet_groups=4)),
     "row_streaming_groups_2": (32, 2, dict(dim=32, dim_mults=(1, 2, 4), resnet_groups=2)),
+    "row_streaming_groups_1": (32, 2, dict(dim=32, dim_mults=(1, 2, 4), resnet_groups=1)),   # 32 channels per group at the first level
     "init_kernel_5": (16, 2, dict(dim=8, init_kernel_size=5)),
     "init_kernel_3": (16, 2, dict(dim=8, init_kernel_size=3)),
     "sigmoid_last_channel": (16, 2, dict(dim=8, sigmoid_last_channel=True)),

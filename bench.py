@@ -57,7 +57,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA pea
 LOG_FREQ = 20                         # main.py:153
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -74,13 +74,9 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra run with the 3x3 convolutions on the fp32 MFMA")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="use torch clip_grad_norm_ + torch.optim.Adam instead of the fused flat clip+Adam kernel (same math)")
-    ap.add_argument("--selftest-emu", action="store_true",
-                    help="TEST HOOK (tests/test_bench_multirank.py), not a measurement: run this script's control flow - rank set-up, "
-                         "sharding, gradient exchange, max-over-ranks timing, JSON - on CPU tensors with the host-emulated kernel build "
-                         "(tests/hipemu) over gloo at a tiny size; the JSON line says so (`selftest`)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="also run one 1 GiB device copy (known byte count for the PMC traffic passes, tools/pmc_traffic.sh)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def _oracle_params(m):
@@ -277,10 +273,11 @@ def residual_only_rates(lib, residuals, diffusion, dev):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         nbytes = B * (32 + 48 + 32) * 1024
-        out[f"b{B}"] = {"us_per_launch_pair": round(us, 2), "GB/s": round(nbytes / us / 1e3, 1),
+        out[f"b{B}"] = {"us_per_launch": round(us, 2), "GB/s": round(nbytes / us / 1e3, 1),
                         "frac_of_hbm_peak": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
-    out["what"] = ("darcy_kernel<loss> + darcy_loss_finalize (residual, loss terms, d loss/d x0_pred), algorithmic 112 KiB per sample, "
-                   "back-to-back launches timed with events on the launch stream")
+    out["what"] = ("darcy_quad_kernel<loss>: residual, loss terms, d loss/d x0_pred and - by its last-arriving workgroup - the loss scalars in ONE "
+                   "launch (round 5; before: + darcy_loss_finalize), algorithmic 112 KiB per sample, back-to-back launches timed with events "
+                   "on the launch stream")
     return out
 
 
@@ -292,8 +289,9 @@ def respawn_under_torchrun(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # (the script that was started: bench.py itself, or the test driver that calls bench.main with an injected library)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
     raise SystemExit(subprocess.call(cmd))
 
@@ -318,8 +316,11 @@ def child_leg(workload, steps, warmup):
             "workload": d["config"]["workload"], "how": "child process of this run: " + " ".join(cmd[1:])}
 
 
-def main():
-    args = parse()
+def main(argv=None, test_env=None):
+    """test_env (tests/bench_on_emulator.py only - never a measurement): {"lib": a PidmLib, "image": P, "dim": d, "batch": B} runs
+    this function's control flow - rank set-up, sharding, gradient exchange, max-over-ranks timing, JSON - on CPU tensors over gloo
+    with the library the test hands in; the JSON line says so (`selftest`)."""
+    args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -328,11 +329,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}: "
                          f"launch with --nproc-per-node {args.gpus} (or let bench.py spawn the ranks: unset WORLD_SIZE)")
-    selftest = args.selftest_emu
+    selftest = test_env is not None
     if selftest:
-        # TEST HOOK: CPU tensors + the host-emulated kernel build (tests/hipemu, test infrastructure) over gloo.  Never a measurement.
-        from tests.emu_util import emu_lib
-        lib = emu_lib()
+        lib = test_env["lib"]
         dev = torch.device("cpu")
         args.no_cpu_baseline = args.no_alt = args.no_roofline = True
     elif not torch.cuda.is_available():
@@ -383,9 +382,9 @@ def main():
         args.eager_scalars = True
     wl = args.workload
     B = args.batch or {"darcy": 64, "mechanics": 32, "sampling": 1024}[wl]
-    P_img, dim_darcy = (16, 8) if selftest else (64, 32)      # selftest: a 16x16 / dim 8 model the emulator steps in seconds
+    P_img, dim_darcy = (test_env["image"], test_env["dim"]) if selftest else (64, 32)
     if selftest:
-        B = args.batch or 2
+        B = args.batch or test_env["batch"]
     torch.manual_seed(0)                      # identical initial weights on every rank
     train = wl != "sampling"
     if wl == "mechanics":
@@ -511,10 +510,21 @@ def main():
                 "loop, where the launch queue is full and the host is held to the GPU's pace - the unloaded cost (queue drained: 1.2 ms per step "
                 "with graphs, 2.7-3.4 without) is in profiles/r03_graph_ab.txt",
     }
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own time for the K steps (barrier + sync on both sides): the job's time is the slowest rank's; the list makes a
+        # straggler visible in the line the driver keeps
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        times = [float(t_.item()) for t_ in every]
+        elapsed = max(times)
+        per_rank = {"ms_per_step": [round(t_ / args.steps * 1e3, 3) for t_ in times],
+                    "value": [round(B * args.steps / t_, 2) for t_ in times],
+                    "slowest_rank": times.index(max(times)), "ms_per_step_min": round(min(times) / args.steps * 1e3, 3),
+                    "ms_per_step_max": round(max(times) / args.steps * 1e3, 3),
+                    "what": "each rank's wall time for the timed steps between the two fences and its own shard's samples/s; "
+                            "`value` = global batch x steps / the slowest rank's time"}
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
 
@@ -555,24 +565,34 @@ def main():
                 "overlapped_with_backward": bool(exchange.last_overlapped), "ranges": [len(r) for r in exchange.ranges],
                 "payload_MB": round(sum(hi - lo for rs in exchange.ranges for lo, hi in rs) * 4 / 1e6, 2),
                 "forced_single_rank": bool(force_dp and world == 1),
-                "collective": ("pidm_allreduce_f32 (C-ABI communicator over RCCL, PIDM_DP_NATIVE=1)" if exchange.native is not None
-                               else "torch.distributed.all_reduce")}
+                "collective": exchange.collective, "collective_note": exchange.collective_note}
 
     roofline = None
     if not args.no_roofline:
         # same steps again with HIP events around every launch of the dominant kernel class (recorded on the
         # launch stream inside the library); kept out of the timed region so the events do not perturb `value`
         nprof = min(args.steps, 5)
-        lib.pidm_prof_enable(1)
+        from physicsinformeddiffusionmodels_amd._lib import stream_ptr
+        lib.check(lib.pidm_prof_kernels_begin(stream_ptr(dev)), "pidm_prof_kernels_begin")
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
-        lib.pidm_prof_enable(0)
-        ms = (C.c_double * 4)()
-        cnt = (C.c_longlong * 4)()
-        work = (C.c_double * 4)()
-        lib.pidm_prof_collect(ms, cnt, work)
-        # classes: 0 / 1 = forward+dgrad / wgrad on the fp32 MFMA, 2 / 3 = the same in split form on the bf16 pipe
+        kbuf = C.create_string_buffer(1 << 16)
+        if lib.pidm_prof_kernels_collect(kbuf, len(kbuf)) < 0:
+            raise SystemExit("pidm_prof_kernels_collect failed")
+        # one line per kernel name: name, launches, total ms, declared work (conv FLOPs), class (0 / 1 = forward+dgrad / wgrad on the fp32
+        # MFMA, 2 / 3 = the same in split form on the bf16 pipe, -1 = not a convolution)
+        kernels = []
+        for ln in kbuf.value.decode().splitlines():
+            nm, n_, ms_, wk_, cl_ = ln.split("\t")
+            kernels.append({"name": nm, "n": int(n_), "ms": float(ms_), "work": float(wk_), "cls": int(cl_)})
+        ms, cnt, work = [0.0] * 4, [0] * 4, [0.0] * 4
+        for k_ in kernels:
+            if 0 <= k_["cls"] < 4:
+                ms[k_["cls"]] += k_["ms"]
+                cnt[k_["cls"]] += k_["n"]
+                work[k_["cls"]] += k_["work"]
+        all_ms = sum(k_["ms"] for k_ in kernels)
         conv_ms, conv_fl, conv_n = sum(ms), sum(work), sum(cnt)
         fd_ms, fd_fl = ms[0] + ms[2], work[0] + work[2]
         wg_ms, wg_fl = ms[1] + ms[3], work[1] + work[3]
@@ -586,7 +606,7 @@ def main():
             # the same achieved rate against BOTH matrix peaks: fp32 FLOPs / 157.3 (= frac) and the bf16 terms they are executed as
             # (6 per fp32 product for the split-form launches, 1 for the rest) / 2500
             "frac_fp32_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-            "frac_bf16_peak": round((6.0 * sp_fl / (conv_ms * 1e-3) / 1e12) / PEAK_BF16_MFMA_TFLOPS, 4) if conv_ms > 0 else None,
+            "frac_bf16_peak": round(((6.0 * sp_fl + (conv_fl - sp_fl)) / (conv_ms * 1e-3) / 1e12) / PEAK_BF16_MFMA_TFLOPS, 4) if conv_ms > 0 else None,
             "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
             "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3, 4x4/s2, 7x7 and the compute-bound 1x1: conv3x3_rs_kernel (rows of 32 / 64 "
                       "pixels) / conv3x3_split*_kernel / conv1x1_split_kernel / conv7x7_split_kernel forward + input gradient, "
@@ -604,9 +624,11 @@ def main():
                            "bf16_tflops": round(6.0 * sp_fl / max(sp_ms, 1e-9) / 1e9, 2), "bf16_peak": PEAK_BF16_MFMA_TFLOPS},
             "fp32_mfma_form": {"launches_per_step": (cnt[0] + cnt[1]) // nprof, "ms_per_step": round((ms[0] + ms[1]) / nprof, 3),
                                "tflops": round((work[0] + work[1]) / max(ms[0] + ms[1], 1e-9) / 1e9, 2)},
-            "timing": "HIP events per launch in extra steps after the timed region; the library keeps the weight-gradient "
-                      "side-stream overlap OFF while these hooks are on (a kernel that shares the chip has no duration of its own); "
-                      "`value` is measured with the overlap on",
+            "timing": "one HIP event per library launch (pidm_prof_kernels_begin / _collect) in extra steps after the timed region: a "
+                      "launch's time = the interval since the previous launch's event, launch by launch on one stream - graph replay and "
+                      "the weight-gradient side-stream overlap are OFF while the hooks are on (a kernel that shares the chip has no "
+                      "duration of its own); `value` is measured with both on",
+            "all_kernels_ms_per_step": round(all_ms / nprof, 3),
             "launches_per_step": conv_n // nprof, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "kernel_ms_per_step": round(conv_ms / nprof, 3),
             "fwd_dgrad": {"ms_per_step": round(fd_ms / nprof, 3), "tflops": round(fd_fl / max(fd_ms, 1e-9) / 1e9, 2)},
@@ -617,6 +639,48 @@ def main():
             roofline["step_hbm_fraction"] = round(B * BYTES_PER_SAMPLE / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         if wl == "darcy":
             roofline["clock_probe"] = rs_clock_probe(lib, dev, B)
+        # ---- the step priced against the pipe it runs on ----
+        # split form = 6 bf16 MFMA terms per fp32 product, so 2500 / 6 TFLOP/s of fp32-equivalent work is the most this engine's
+        # convolutions can do at the nominal clock; the contract FLOPs of the whole step and the split-form launches against that, and
+        # both again at the shader clock the probe measured (peaks scale with the clock)
+        ceil_sp = PEAK_BF16_MFMA_TFLOPS / 6.0
+        step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
+        sp_tf = sp_fl / max(sp_ms, 1e-9) / 1e9
+        roofline["ceiling_split_form_tflops"] = round(ceil_sp, 1)
+        roofline["step_frac_of_split_ceiling"] = round(step_tf / ceil_sp, 4)
+        roofline["conv_split_frac_of_split_ceiling"] = round(sp_tf / ceil_sp, 4)
+        clk = (roofline.get("clock_probe") or {}).get("shader_clock_ghz")
+        if clk:
+            scale = clk / 2.4
+            roofline["frac_at_measured_clock"] = {
+                "shader_clock_ghz": clk,
+                "conv_class_vs_fp32_peak": round(achieved / (PEAK_FP32_MFMA_TFLOPS * scale), 4),
+                "step_vs_fp32_peak": round(step_tf / (PEAK_FP32_MFMA_TFLOPS * scale), 4),
+                "step_vs_split_ceiling": round(step_tf / (ceil_sp * scale), 4),
+                "conv_split_vs_split_ceiling": round(sp_tf / (ceil_sp * scale), 4),
+                "what": "the same fractions with both peaks scaled by measured / nominal clock (the chip clocks to its power budget; "
+                        "the probe reads the clock inside conv3x3_rs_kernel at this batch)"}
+        top = []
+        for k_ in kernels[:5]:
+            e = {"name": k_["name"], "launches_per_step": round(k_["n"] / nprof, 1), "us_per_step": round(k_["ms"] / nprof * 1e3, 1),
+                 "avg_us": round(k_["ms"] / max(k_["n"], 1) * 1e3, 2), "share_of_kernel_time": round(k_["ms"] / max(all_ms, 1e-9), 4)}
+            if k_["work"] > 0:
+                tf = k_["work"] / (k_["ms"] * 1e-3) / 1e12
+                e["fp32_equiv_tflops"] = round(tf, 1)
+                e["frac_fp32_peak"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 3)
+                if k_["cls"] in (2, 3):
+                    e["frac_bf16_pipe"] = round(6.0 * tf / PEAK_BF16_MFMA_TFLOPS, 3)
+            else:
+                e["fp32_equiv_tflops"] = None     # no FLOP contract declared for this kernel (attention / normalisation / reductions)
+            top.append(e)
+        roofline["top_kernels"] = top
+        roofline["kernel_classes_ms_per_step"] = {
+            "conv": round(conv_ms / nprof, 3),
+            "attention": round(sum(k_["ms"] for k_ in kernels if k_["name"].startswith(("lap_", "la_", "mid_attn"))) / nprof, 3),
+            "groupnorm": round(sum(k_["ms"] for k_ in kernels if k_["name"].startswith("gn_")) / nprof, 3),
+            "layernorm": round(sum(k_["ms"] for k_ in kernels if k_["name"].startswith("layernorm")) / nprof, 3),
+            "reductions_and_pack": round(sum(k_["ms"] for k_ in kernels if k_["name"].startswith(("reduce_multi", "pack_", "wgrad_reduce", "colsum"))) / nprof, 3),
+        }
         st_bytes = pmc_step_traffic(wl, B)
         if st_bytes is not None:
             # every kernel class of the step from the same PMC pass; for darcy next to the SURVEY 8(d) contract bytes
@@ -725,15 +789,15 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
             "fp32_mfma_only": alt, "eager_scalars": eager, "dropin_main_py": dropin, "north_star_b256": b256,
-            "residual_only": resonly, "exchange": exch, "launches": launches,
+            "residual_only": resonly, "exchange": exch, "per_rank": per_rank, "launches": launches,
             # contract FLOPs of the step (SURVEY 8(d) / FlopCounterMode on the reference) over the measured step time against the
             # fp32 MFMA peak - also present when the roofline legs are skipped
             "step_flop_fraction": round(B * flops_per_unit / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
         out.update(legs)
         if selftest:
-            out["selftest"] = ("NOT A MEASUREMENT: --selftest-emu ran this script's control flow on CPU tensors with the host-emulated "
-                               "kernels (tests/hipemu) over gloo, 16x16 fields, Unet3D dim=8")
+            out["selftest"] = ("NOT A MEASUREMENT: bench.main(test_env=...) ran this script's control flow on CPU tensors over gloo with "
+                               f"the library the test handed in ({lib.backend}), {P_img}x{P_img} fields, Unet3D dim={dim_darcy}")
             out["data"] = "synthetic (selftest)"
     if dist is not None:
         dist.destroy_process_group()

@@ -34,6 +34,13 @@ const char* pidm_backend(void);
  * class 2 / 3 = the same two in split form on the bf16 pipe (each launch is in exactly one class). */
 int pidm_prof_enable(int on);
 int pidm_prof_collect(double* ms4, long long* launches4, double* work4);
+/* bench-only, per KERNEL: between _begin and _collect every launch of the library records one event on `stream` (graph replay and
+ * the side-stream overlap are off meanwhile, so launches are back to back on that stream); a launch's time is the interval since
+ * the previous launch's event.  _collect writes one line per kernel name, largest total first:
+ *   name \t launches \t total_ms \t work \t class \n   (work: FLOPs the launcher declared, 0 = none; class as above, -1 = none)
+ * and returns the bytes the table needs incl. the terminating 0 (the text is truncated to `cap`), or -1. */
+int pidm_prof_kernels_begin(void* stream);
+long long pidm_prof_kernels_collect(char* buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Darcy PDE residual                    replaces ResidualsDarcy.compute_residual's stencil part

@@ -55,6 +55,8 @@ class PidmLib:
         self._sig("pidm_debug_launch_counts", [C.POINTER(C.c_longlong)])
         self._sig("pidm_prof_enable", [i])
         self._sig("pidm_prof_collect", [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)])
+        self._sig("pidm_prof_kernels_begin", [vp])
+        self._sig("pidm_prof_kernels_collect", [C.c_char_p, sz], C.c_longlong)
         self._sig("pidm_darcy_residual_fwd", [vp, vp, f, f, vp, i, i, vp])
         self._sig("pidm_darcy_residual_bwd", [vp, vp, f, f, vp, i, i, vp])
         self._sig("pidm_darcy_loss_ws", [i, i], sz)

@@ -1216,6 +1216,7 @@ int launch_la_backward(const float* qkv, const float* kstat, const float* qstat,
     int ppb = N % 128 == 0 ? 128 : (N % 64 == 0 ? 64 : 32);
     (void)npix;
     if (const char* pe = knob("PIDM_LA_PPB")) { const int v = atoi(pe); if ((v == 32 || v == 64 || v == 128) && N % v == 0) ppb = v; }
+    PIDM_PROF_NAME("la_bwd_pix_mfma_kernel");
     hipLaunchKernelGGL(la_bwd_pix_mfma_kernel, dim3((unsigned)((size_t)B * N / ppb), heads), dim3(2 * ppb), 0, st, qkv, kstat, qstat, ctx,
                        dctx, rowdot, dA, dqkv, N, heads, scale, ppb);
   } else {

@@ -1370,6 +1370,7 @@ static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kctx_split_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_s = true;
     }
+    PIDM_PROF_NAME("lap_kctx_split_kernel");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_split_kernel<CB>), dim3(B * NS), dim3(512), ldss, st, xn, wqkv, scratch, N, heads, nper);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_kctx_kernel<CB>), dim3(B * NS), dim3(512), lds1, st, xn, wqkv, scratch, N, heads, nper);
@@ -1395,6 +1396,7 @@ static int lap_forward_t(const float* xn, const float* wqkv, const float* wout, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_out_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_o = true;
     }
+    PIDM_PROF_NAME("lap_out_split_kernel");
     hipLaunchKernelGGL(lap_out_split_kernel, dim3(wg8), dim3(512), ldso, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tp8, 0.17677669529663687f);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_out_kernel<CB>), dim3(wgs), dim3(256), lds3, st, xn, wqkv, P, bias, resid, y, qstat, N, heads, tpw,
@@ -1441,6 +1443,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_g_split_kernel<CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_s = true;
     }
+    PIDM_PROF_NAME("lap_g_split_kernel");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_split_kernel<CB>), dim3(B * NS2), dim3(512), ldss, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_g_kernel<CB>), dim3(B * NS2), dim3(512), lds1, st, xn, dy, wqkv, qstat, scratch, N, heads, np2, scale);
@@ -1469,6 +1472,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_bwd_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       attr_p = true;
     }
+    PIDM_PROF_NAME("lap_bwd_kernel<1, true>");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<1, true>), dim3(B * NS3), dim3(512), lds3p, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn,
                        dwqk_part, N, heads, nslab, nsl, scale, 1 | oflip, G3);
     PIDM_CHECK_LAUNCH("lap_bwd_kernel");

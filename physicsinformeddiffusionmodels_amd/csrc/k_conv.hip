@@ -1576,15 +1576,18 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
             attr_w = true;
           }
           const dim3 bw(64 * nw + 256);
+          PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 2x2>" : "conv3x3_split_ws_kernel<4, 2x2>");
           if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
           else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
           else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
-        } else
+        } else {
+        PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_kernel<8, 2x2>" : "conv3x3_split_kernel<4, 2x2>");
         if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 2>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 2>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+        }
         if (prof) prof_end_launch(st);
         PIDM_CHECK_LAUNCH("conv3x3_split_kernel(2x2)");
         return 0;
@@ -1645,19 +1648,22 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             attr_w0 = true;
           }
+          PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 0>" : "conv3x3_split_ws_kernel<4, 0>");
           if (nw == 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 0>), dim3(wgs), dim3(768), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
                                out, n_items, ipw);
           else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
                                out, n_items, ipw);
-        } else
+        } else {
+        PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_kernel<8, 0>" : "conv3x3_split_kernel<4, 0>");
         if (nw == 8)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);
         else
           hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<4, 0>), dim3(wgs), dim3(256), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out,
                              n_items, ipw, trace);
+        }
         if (prof) prof_end_launch(st);
         PIDM_CHECK_LAUNCH("conv3x3_split_kernel");
         return 0;

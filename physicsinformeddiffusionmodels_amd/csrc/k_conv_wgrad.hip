@@ -1283,6 +1283,7 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
       attr_ = true;
     }
     if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv_wgrad_split_kernel<%d>, %d splits x %d blocks, %d tiles each, %zu B LDS\n", P, wg.nsplit, grid.y, wg.tiles_per_split, lds);
+    PIDM_PROF_NAME("conv_wgrad_split_kernel");
     if (P == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_split_kernel<256>), grid, dim3(768), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
     else
@@ -1354,6 +1355,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
       attr_ = true;                                                                                                        \
     }                                                                                                                      \
+    PIDM_PROF_NAME("conv_wgrad_pipe_kernel");                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pipe_kernel<KH_, KW_, PH_, WIDE_, MINW_, ROWST_>), grid_, dim3(256), lds, st, wg, \
                        src0, src1 ? src1 : src0, dy, partial, bias_partial);                                              \
   }
@@ -1361,12 +1363,15 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     if (g.Wv >= 32) PIDM_LAUNCH_WG(2, 2, true, true, 2, gridp)
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
   } else if (smode == 1) {
+    PIDM_PROF_NAME("conv_wgrad_1x1_stream_kernel");
     hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, grid, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (smode == 2) {
     const dim3 grid4(cdiv(wg.MP, 128) * (wg.NP / 32), wg.nsplit, 1);
+    PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<true>");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<true>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (smode == 3) {
     const dim3 grid4(cdiv(wg.NP, 128) * (wg.MP / 32), wg.nsplit, 1);
+    PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<false>");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<false>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 &&
              g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {

@@ -578,6 +578,7 @@ bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src
   if (knob("PIDM_TRACE_CONV"))
     fprintf(stderr, "[pidm]   -> conv_wgrad_rs4_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per pixel share\n", wg.nsplit,
             grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
+  PIDM_PROF_NAME("conv_wgrad_rs4_kernel");
   hipLaunchKernelGGL(conv_wgrad_rs4_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   *used = wg;
   return true;
@@ -633,6 +634,7 @@ bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy,
   if (knob("PIDM_TRACE_CONV"))
     fprintf(stderr, "[pidm]   -> conv_wgrad_rs7_kernel<%d>, %d splits x %d blocks, %d strips of %d rows, %d pairs per workgroup\n", maxn <= 1 ? 1 : 4,
             wg.nsplit, grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
+  PIDM_PROF_NAME("conv_wgrad_rs7_kernel");
   if (maxn <= 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_rs7_kernel<1>), grid, dim3(256), 0, st, wg, src0, dy, partial, bias_partial);
   else
@@ -671,6 +673,7 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
   if (knob("PIDM_TRACE_CONV"))
     fprintf(stderr, "[pidm]   -> conv_wgrad_rs_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per wave\n", wg.nsplit, grid.y,
             wg.rs_S, wg.rs_R, wg.rs_ppw);
+  PIDM_PROF_NAME("conv_wgrad_rs_kernel");
   hipLaunchKernelGGL(conv_wgrad_rs_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   *used = wg;
   return true;

@@ -37,6 +37,7 @@ extern "C" const char* pidm_backend(void) {
 // ---------------------------------------------------------------------------------------------------------
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline figures)
 // ---------------------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -50,9 +51,31 @@ struct ProfRec { hipEvent_t a, b; int cls; double work; std::string label; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::string g_prof_label;
-bool prof_enabled() { return g_prof_on; }
+// per-kernel marks (see pidm_common.h): one event per launch, durations are intervals between consecutive events
+struct MarkRec { hipEvent_t e; const char* name; int cls; double work; };
+bool g_prof_marks = false;
+const char* g_prof_name = nullptr;
+static std::vector<MarkRec> g_marks;
+static hipStream_t g_mark_stream = nullptr;
+static struct { bool valid; int cls; double work; } g_mark_pending = {false, -1, 0.0};
+void prof_mark(const char* what) {
+  MarkRec m;
+  m.name = g_prof_name ? g_prof_name : what;
+  g_prof_name = nullptr;
+  m.cls = g_mark_pending.valid ? g_mark_pending.cls : -1;
+  m.work = g_mark_pending.valid ? g_mark_pending.work : 0.0;
+  g_mark_pending.valid = false;
+  (void)hipEventCreate(&m.e);
+  (void)hipEventRecord(m.e, g_mark_stream);
+  g_marks.push_back(m);
+}
+bool prof_enabled() { return g_prof_on || g_prof_marks; }
 void prof_set_label(const char* label) { g_prof_label = label ? label : ""; }
 void prof_begin_launch(int cls, double work, hipStream_t st) {
+  if (g_prof_marks) {            // the launch's own mark (PIDM_CHECK_LAUNCH) carries class and work
+    g_mark_pending.valid = true; g_mark_pending.cls = cls; g_mark_pending.work = work;
+    return;
+  }
   ProfRec r;
   r.cls = cls; r.work = work; r.label = g_prof_label;
   (void)hipEventCreate(&r.a);
@@ -60,8 +83,18 @@ void prof_begin_launch(int cls, double work, hipStream_t st) {
   (void)hipEventRecord(r.a, st);
   g_prof.push_back(r);
 }
-void prof_end_launch(hipStream_t st) { (void)hipEventRecord(g_prof.back().b, st); }
-void prof_reclass_last(int cls) { if (!g_prof.empty()) g_prof.back().cls = cls; }
+void prof_end_launch(hipStream_t st) {
+  if (g_prof_marks) return;
+  (void)hipEventRecord(g_prof.back().b, st);
+}
+void prof_reclass_last(int cls) {
+  if (g_prof_marks) {
+    if (g_mark_pending.valid) g_mark_pending.cls = cls;
+    else if (!g_marks.empty()) g_marks.back().cls = cls;
+    return;
+  }
+  if (!g_prof.empty()) g_prof.back().cls = cls;
+}
 
 // ---- knobs: one environment read per name and process ------------------------------------------------------------------------
 namespace {
@@ -120,6 +153,54 @@ extern "C" int pidm_reload_knobs(void) {
     }
   pidm::g_knob_sig_valid = false;
   return 0;
+}
+
+extern "C" int pidm_prof_kernels_begin(void* stream) {
+  using namespace pidm;
+  if (g_prof_marks) return fail("pidm_prof_kernels_begin: already on");
+  g_mark_stream = as_stream(stream);
+  g_marks.clear();
+  g_mark_pending.valid = false;
+  g_prof_name = nullptr;
+  MarkRec m{nullptr, "(begin)", -1, 0.0};
+  if (hipEventCreate(&m.e) != hipSuccess || hipEventRecord(m.e, g_mark_stream) != hipSuccess) return fail("pidm_prof_kernels_begin: no event");
+  g_marks.push_back(m);
+  g_prof_marks = true;
+  return 0;
+}
+// Ends the per-kernel timing and writes one line per kernel name, largest total first:
+//   name \t launches \t total_ms \t work \t class \n     (work = what the launcher declared: conv FLOPs; 0 = not declared; class -1 = none)
+// Returns the number of bytes the table needs (incl. the terminating 0; truncated to cap when larger), or -1.
+extern "C" long long pidm_prof_kernels_collect(char* buf, size_t cap) {
+  using namespace pidm;
+  if (!g_prof_marks) return fail("pidm_prof_kernels_collect: not on");
+  g_prof_marks = false;
+  struct Agg { double ms = 0, work = 0; long n = 0; int cls = -1; };
+  std::map<std::string, Agg> by;
+  if (!g_marks.empty()) (void)hipEventSynchronize(g_marks.back().e);
+  for (size_t k = 1; k < g_marks.size(); ++k) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, g_marks[k - 1].e, g_marks[k].e);
+    Agg& a = by[g_marks[k].name];
+    a.ms += t; a.work += g_marks[k].work; a.n += 1;
+    if (g_marks[k].cls >= 0) a.cls = g_marks[k].cls;
+  }
+  for (auto& m : g_marks) (void)hipEventDestroy(m.e);
+  g_marks.clear();
+  std::vector<std::pair<std::string, Agg>> v(by.begin(), by.end());
+  std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
+  std::string out;
+  char line[320];
+  for (auto& kv : v) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.6e\t%d\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work, kv.second.cls);
+    out += line;
+  }
+  if (buf && cap) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (long long)out.size() + 1;
 }
 
 extern "C" int pidm_prof_enable(int on) {

@@ -19,6 +19,14 @@ void prof_set_label(const char* label);   // attached to the next prof_begin_lau
 void prof_begin_launch(int cls, double work, hipStream_t st);
 void prof_end_launch(hipStream_t st);
 void prof_reclass_last(int cls);          // the launcher learned which kernel took the launch (2 / 3 = split form of class 0 / 1)
+// per-KERNEL timing (pidm_prof_kernels_begin / _collect, round 5): while on, every PIDM_CHECK_LAUNCH records one event on the
+// registered stream; a launch's time = the interval since the previous library launch's event (launches are back to back on one
+// stream: graphs and the side-stream overlap are off while any profiling hook is on).  PIDM_PROF_NAME names the kernel a shared
+// launch site is about to enqueue (a family's launch sites end in ONE PIDM_CHECK_LAUNCH).
+extern bool g_prof_marks;
+extern const char* g_prof_name;
+void prof_mark(const char* what);
+#define PIDM_PROF_NAME(n) (::pidm::g_prof_name = (n))
 
 // Tuning / A-B knobs (the PIDM_* environment variables listed in DESIGN.md section 4): read from the environment ONCE per process
 // and name - `knob("PIDM_X")` returns what getenv returned the first time it was asked (or null) - until pidm_reload_knobs()
@@ -38,6 +46,7 @@ extern long long g_kernel_enqueues;
     ++::pidm::g_kernel_enqueues;                                                    \
     hipError_t e__ = hipGetLastError();                                             \
     if (e__ != hipSuccess) return ::pidm::fail("%s: %s", what, hipGetErrorString(e__)); \
+    if (::pidm::g_prof_marks) ::pidm::prof_mark(what);                              \
   } while (0)
 
 // exact n / d for small operands via one mulhi (d == 1 handled by the caller's magic == 0 convention)

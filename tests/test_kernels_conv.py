@@ -543,3 +543,29 @@ def test_conv_extreme_magnitudes(backend, monkeypatch, form, H):
     dy2n = nhwc(dy2).to(dev)
     L.check(L.pidm_conv_wgrad(d, ptr(xn), None, ptr(dy2n), Cout, ptr(dw), None, ptr(ws), st))
     check(dw, dw_ref, "wgrad")
+
+
+def test_per_kernel_profile_table(backend):
+    """pidm_prof_kernels_begin / _collect (bench.py's `roofline.top_kernels`): one line per kernel name with launches, total ms, the
+    FLOPs the launcher declared and its class; the hooks are off again afterwards."""
+    import ctypes as C
+    L, dev = backend
+    st = stream_ptr(dev)
+    B, H, Cin, Cout = 2, 16, 32, 32
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=3, KW=3, stride=1, pad=1, transposed=0, out_nchw=0, ldo=Cout)
+    x = torch.randn(B, H, H, Cin).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.1).to(dev)
+    wp = torch.zeros(L.pidm_conv_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(w), ptr(wp), 0, st))
+    out = torch.empty(B, H, H, Cout, device=dev)
+    L.check(L.pidm_prof_kernels_begin(st))
+    assert L.pidm_prof_kernels_begin(st) != 0                      # already on
+    for _ in range(3):
+        L.check(L.pidm_conv_forward(d, ptr(x), None, ptr(wp), None, None, ptr(out), st))
+    buf = C.create_string_buffer(4096)
+    need = L.pidm_prof_kernels_collect(buf, len(buf))
+    assert 0 < need <= len(buf)
+    rows = [ln.split("\t") for ln in buf.value.decode().splitlines()]
+    assert len(rows) == 1 and rows[0][0].startswith("conv") and int(rows[0][1]) == 3 and float(rows[0][2]) >= 0.0
+    assert abs(float(rows[0][3]) - 3 * 2.0 * B * H * H * Cout * Cin * 9) < 100.0 and int(rows[0][4]) in (0, 2)   # (%.6e text)
+    assert L.pidm_prof_kernels_collect(buf, len(buf)) < 0            # not on any more

@@ -1297,8 +1297,10 @@ static bool launch_wgrad_split(const WgradGeom& plan, const float* src0, const f
 // dW[(m*Cin + n)*T + t] written to dw_ref (m over g.Cout = dY channels, n over g.Cin = X channels)
 // dbias (may be null) = column sums of dy, fused into the same two launches
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer) {
+                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer, WgradQueue* wq) {
   if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
+  if (!defer) wq = nullptr;      // a queued problem's reduction must be a deferred one as well
+  const size_t queued0 = wq ? wq->v.size() : 0;
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
   const int T = wgrad_taps(g);
@@ -1314,7 +1316,8 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr_done = true;
   }
-  const bool prof = prof_enabled();
+  // (a problem that goes to the queue is accounted for by the grouped launch: flush_wgrads declares the FLOPs of its items)
+  const bool prof = prof_enabled() && !(wq && wgrad_rs_queueable(g, src0, dy, ld_dy));
   if (prof) {
     char lab[160];
     snprintf(lab, sizeof(lab), "wgrad B%d %dx%d Cin%d Cout%d k%dx%d nph%d", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH, g.KW, g.nph);
@@ -1378,7 +1381,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
-    } else if (launch_wgrad_rs(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg) ||
+    } else if (launch_wgrad_rs(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg, wq) ||
                launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
       if (prof) prof_reclass_last(3);   // split form: counted with the weight gradients and, separately, against the bf16 pipe
       // taken by the bf16-pipe kernel (wg now holds its tiling / split)
@@ -1403,8 +1406,9 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  const bool queued = wq && wq->v.size() > queued0;      // nothing was enqueued: the problem waits for flush_wgrads
   if (prof) prof_end_launch(st);
-  PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
+  if (!queued) PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
   if (defer) {   // the caller keeps `workspace` alive until its reduce_multi launch
     defer->push(partial, dw_ref, bias_partial, dbias, (size_t)wg.MP * T * wg.NP, wg.nsplit, g.Cout, g.Cin, T, wg.MP, wg.NP);
     return 0;

@@ -90,24 +90,26 @@ constexpr unsigned kRsInv = 0x80000000u;   // a byte offset no tensor reaches (t
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) conv_wgrad_rs_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
-                                                            const float* __restrict__ dy, float* __restrict__ partial,
-                                                            float* __restrict__ bias_partial) {
-  const ConvGeom& g = wg.g;
-  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][9 taps][32 dY channels][32 X channels]
+// The body of the kernel: problem `wg` (by value in scalar registers: kernel arguments of the single-problem kernel, a row of the
+// device table of the grouped one), workgroup (split, by) of its splits x blocks grid.
+__device__ __forceinline__ void conv_wgrad_rs_body(const WgradItem& wg, const int split, const int by, float* __restrict__ red) {
+  const float* __restrict__ src0 = wg.src0;
+  const float* __restrict__ src1 = wg.src1;
+  const float* __restrict__ dy = wg.dy;
+  float* __restrict__ partial = wg.partial;
+  float* __restrict__ bias_partial = wg.bias_partial;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int ntn = wg.NP / 32;
-  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int tn = by % ntn, tm = by / ntn;
   const int m0 = tm * 32, n0 = tn * 32;
-  const int split = blockIdx.x;
-  const int H = g.Hi, W = g.Wi, R = wg.rs_R;
-  const int wsh = g.wsh;                                   // log2 W
-  const unsigned ldxb = (unsigned)g.ld0 * 4u, ldyb = (unsigned)wg.ld_dy * 4u;   // bytes between pixels
+  const int H = wg.Hi, W = wg.Wi, R = wg.rs_R;
+  const int wsh = wg.wsh;                                  // log2 W
+  const unsigned ldxb = (unsigned)wg.ld0 * 4u, ldyb = (unsigned)wg.ld_dy * 4u;  // bytes between pixels
   const unsigned rowxb = ldxb << wsh, rowyb = ldyb << wsh;                      // bytes between rows
-  const unsigned tot_x = (unsigned)g.B * (unsigned)H * rowxb, tot_y = (unsigned)g.B * (unsigned)H * rowyb;
+  const unsigned tot_x = (unsigned)wg.B * (unsigned)H * rowxb, tot_y = (unsigned)wg.B * (unsigned)H * rowyb;
   // the n-tile lies in one source of a concatenation (C0 % 32 == 0, equal channel strides: checked by the launcher)
-  const float* xsrc = (n0 < g.C0) ? src0 + n0 : src1 + (n0 - g.C0);
+  const float* xsrc = (n0 < wg.C0) ? src0 + n0 : src1 + (n0 - wg.C0);
   const pidm_rsrc rx = pidm_make_rsrc(xsrc, tot_x), ry = pidm_make_rsrc(dy + m0, tot_y);
   const bool do_bias = (bias_partial != nullptr) && (tn == 0);
 
@@ -236,6 +238,27 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs_kernel(WgradGeom wg, const 
       bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) conv_wgrad_rs_kernel(WgradItem wg) {
+  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][9 taps][32 dY channels][32 X channels]
+  conv_wgrad_rs_body(wg, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// The same for a TABLE of problems in one launch (round 5; WgradQueue, pidm_launch.h): workgroup blockIdx.x + blk_base belongs to the
+// problem whose [blk0, blk0 + gx * gy) contains it - one load per lane and a ballot (the table has at most 64 rows) - and runs that
+// problem's workgroup (local % gx, local / gx).  Consecutive workgroups of one problem still read neighbouring splits; the
+// launch has no boundary between problems, so the chip drains once per flush instead of once per problem.
+__global__ void __launch_bounds__(256) conv_wgrad_rs_multi_kernel(const WgradItem* __restrict__ table, int n, unsigned blk_base) {
+  HIP_DYNAMIC_SHARED(float, red)
+  const unsigned bid = blockIdx.x + blk_base;
+  // (n <= 64, the queue's flush limit: lane l looks at row l, the rows' first workgroups ascend)
+  const int lane_ = threadIdx.x & 63;
+  const unsigned first_ = lane_ < n ? table[lane_].blk0 : 0xffffffffu;
+  const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(bid >= first_)) - 1);
+  const WgradItem wg = table[p];
+  const unsigned local = bid - wg.blk0;
+  conv_wgrad_rs_body(wg, (int)(local % wg.gx), (int)(local / wg.gx), red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -645,9 +668,21 @@ bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy,
 
 // true: launched (and *used holds the split actually written); false: geometry not eligible (the caller goes on to the LDS-staged
 // kernel).  PIDM_WGRAD_RS=0: off (A/B measurements, tests of the older kernel).
-bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
-                     float* bias_partial, hipStream_t st, WgradGeom* used) {
-  const ConvGeom& g = plan.g;
+static WgradItem rs_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial) {
+  const ConvGeom& g = wg.g;
+  WgradItem it{};
+  it.src0 = src0; it.src1 = src1 ? src1 : src0; it.dy = dy; it.partial = partial; it.bias_partial = bias_partial;
+  it.B = g.B; it.Hi = g.Hi; it.Wi = g.Wi; it.wsh = g.wsh; it.ld0 = g.ld0; it.C0 = g.C0; it.ld_dy = wg.ld_dy;
+  it.MP = wg.MP; it.NP = wg.NP;
+  it.rs_R = wg.rs_R; it.rs_csh = wg.rs_csh; it.rs_xsh = wg.rs_xsh; it.rs_S = wg.rs_S; it.rs_ppw = wg.rs_ppw;
+  it.gx = (unsigned)wg.nsplit; it.gy = (unsigned)((wg.MP / 32) * (wg.NP / 32));
+  return it;
+}
+static constexpr size_t kRsWgradLds = 4 * 9 * 1024 * sizeof(float);
+
+// true: launched - or, with `wq`, queued for the grouped launch - (and *used holds the split actually written); false: geometry not
+// eligible (the caller goes on to the LDS-staged kernel).  PIDM_WGRAD_RS=0: off (A/B measurements, tests of the older kernel).
+bool wgrad_rs_queueable(const ConvGeom& g, const float* src0, const float* dy, int ld_dy) {
   const char* off = knob("PIDM_WGRAD_RS");
   if (off && !atoi(off)) return false;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -656,27 +691,53 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
         (g.C1 == 0 || g.ld1 == g.ld0) && (reinterpret_cast<size_t>(src0) & 3) == 0 && (reinterpret_cast<size_t>(dy) & 3) == 0))
     return false;
   const size_t pix = (size_t)g.B * g.Hi * g.Wi;
-  if (pix * (size_t)g.ld0 * 4 >= 0x7ff00000ull || pix * (size_t)ld_dy * 4 >= 0x7ff00000ull) return false;   // 32-bit byte offsets
+  return pix * (size_t)g.ld0 * 4 < 0x7ff00000ull && pix * (size_t)ld_dy * 4 < 0x7ff00000ull;   // 32-bit byte offsets
+}
+
+bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
+                     float* bias_partial, hipStream_t st, WgradGeom* used, WgradQueue* wq) {
+  const ConvGeom& g = plan.g;
+  if (!wgrad_rs_queueable(g, src0, dy, ld_dy)) return false;
   WgradGeom wg = plan;
   wg.ld_dy = ld_dy;
   int ns = plan.nsplit;                     // never more splits than the workspace was sized for
   const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several items per wave on small problems
   if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+  // grouped launches need not fill the chip problem by problem: PIDM_WGRAD_GROUP_SPLITDIV (default 1) divides the split count -
+  // fewer, longer work items, proportionally fewer partial slabs for the deferred reduction to read
+  if (wq) {
+    const char* de = knob("PIDM_WGRAD_GROUP_SPLITDIV");
+    const int dv = de ? atoi(de) : 1;
+    if (dv > 1 && ns / dv >= 1) ns /= dv;
+  }
   rs_plan(&wg, ns);
-  const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
-  const size_t lds = 4 * 9 * 1024 * sizeof(float);
+  const WgradItem it = rs_item(wg, src0, src1, dy, partial, bias_partial);
   static bool attr_ = false;
   if (!attr_) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsWgradLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsWgradLds);
     attr_ = true;
   }
   if (knob("PIDM_TRACE_CONV"))
-    fprintf(stderr, "[pidm]   -> conv_wgrad_rs_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per wave\n", wg.nsplit, grid.y,
-            wg.rs_S, wg.rs_R, wg.rs_ppw);
-  PIDM_PROF_NAME("conv_wgrad_rs_kernel");
-  hipLaunchKernelGGL(conv_wgrad_rs_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    fprintf(stderr, "[pidm]   -> conv_wgrad_rs_kernel%s, %d splits x %u blocks, %d strips of %d rows, %d pairs per wave\n", wq ? " (queued)" : "",
+            wg.nsplit, it.gy, wg.rs_S, wg.rs_R, wg.rs_ppw);
   *used = wg;
+  if (wq) {
+    wq->push(it, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 9);
+    return true;
+  }
+  PIDM_PROF_NAME("conv_wgrad_rs_kernel");
+  hipLaunchKernelGGL(conv_wgrad_rs_kernel, dim3(it.gx, it.gy, 1), dim3(256), kRsWgradLds, st, it);
   return true;
+}
+
+// rows [first, first + n) of the device table, whose workgroups are [blk_base, blk_base + nblocks) of the queue's flat numbering
+int launch_wgrad_rs_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
+  if (n <= 0 || nblocks == 0) return 0;
+  PIDM_PROF_NAME("conv_wgrad_rs_multi_kernel");
+  hipLaunchKernelGGL(conv_wgrad_rs_multi_kernel, dim3(nblocks), dim3(256), kRsWgradLds, st, table_dev + first, n, blk_base);
+  PIDM_CHECK_LAUNCH("conv_wgrad_rs_multi_kernel");
+  return 0;
 }
 
 }  // namespace pidm

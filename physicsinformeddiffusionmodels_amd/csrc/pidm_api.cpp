@@ -57,11 +57,13 @@ bool g_prof_marks = false;
 const char* g_prof_name = nullptr;
 static std::vector<MarkRec> g_marks;
 static hipStream_t g_mark_stream = nullptr;
+static bool g_mark_trace = false;
 static struct { bool valid; int cls; double work; } g_mark_pending = {false, -1, 0.0};
 void prof_mark(const char* what) {
   MarkRec m;
   m.name = g_prof_name ? g_prof_name : what;
   g_prof_name = nullptr;
+  if (g_mark_trace) fprintf(stderr, "[pidm launch] %s\n", m.name);     // PIDM_TRACE_LAUNCHES=1: the launch sequence of a pass
   m.cls = g_mark_pending.valid ? g_mark_pending.cls : -1;
   m.work = g_mark_pending.valid ? g_mark_pending.work : 0.0;
   g_mark_pending.valid = false;
@@ -159,6 +161,7 @@ extern "C" int pidm_prof_kernels_begin(void* stream) {
   using namespace pidm;
   if (g_prof_marks) return fail("pidm_prof_kernels_begin: already on");
   g_mark_stream = as_stream(stream);
+  g_mark_trace = knob("PIDM_TRACE_LAUNCHES") != nullptr;
   g_marks.clear();
   g_mark_pending.valid = false;
   g_prof_name = nullptr;

@@ -254,6 +254,24 @@ struct WgradGeom {
   int rs_R, rs_csh, rs_xsh, rs_S, rs_ppw;
 };
 
+// one weight-gradient problem of a GROUPED launch (k_wgrad_rs.hip: conv_wgrad_rs_multi_kernel, round 5): what the single-problem
+// kernel receives as arguments, plus the problem's range of workgroups in the flat grid (blk0 .. blk0 + gx * gy)
+// Only the fields conv_wgrad_rs_kernel reads (no host pointers, no padding: tables of these are compared with memcmp).
+struct WgradItem {
+  const float* src0;
+  const float* src1;
+  const float* dy;
+  float* partial;
+  float* bias_partial;
+  int B, Hi, Wi, wsh;      // images, rows, pixels per row (a power of two), log2 Wi
+  int ld0, C0;             // channel stride of X (both sources), channels of src0
+  int ld_dy;               // channel stride of dY
+  int MP, NP;              // padded rows / columns of the partial slab
+  int rs_R, rs_csh, rs_xsh, rs_S, rs_ppw;
+  unsigned blk0, gx, gy;   // first workgroup of the problem in the grouped grid; splits x (32 x 32 blocks)
+  unsigned pad_;
+};
+
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)
 struct PackDesc {
   const float* src;

@@ -37,6 +37,23 @@ struct ReduceQueue {
     v.push_back(d);
   }
 };
+// Weight-gradient problems whose launch is DEFERRED and grouped (round 5): nothing inside a backward pass reads a weight gradient
+// before the deferred reduction, so the 3x3 / stride-1 problems of a pass are collected here and run by ONE
+// conv_wgrad_rs_multi_kernel launch per flush - a launch boundary (drain, dispatch ramp) per ~40 problems instead of per
+// problem.  The operands (taped activations, gradient buffers) and the partial slabs must stay alive until the flush.
+struct WgradQueue {
+  std::vector<WgradItem> v;
+  std::vector<double> fl;  // algorithmic FLOPs per item (profiling hooks)
+  unsigned nblocks = 0;
+  void push(WgradItem it, double flops) {  // `it` value-initialised and filled field by field by the launcher (tables are memcmp'd)
+    it.blk0 = nblocks;
+    nblocks += it.gx * it.gy;
+    v.push_back(it);
+    fl.push_back(flops);
+  }
+  void clear() { v.clear(); fl.clear(); nblocks = 0; }
+};
+int launch_wgrad_rs_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
 int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st, unsigned blk_base = 0);
 int launch_split_reduce(const float* partial, float* dst, const float* bias_partial, float* dbias, int nsplit, int M, int N, int T,
                         int MP, int NP, hipStream_t st);
@@ -85,11 +102,13 @@ size_t smallm_splitk_ws_floats(int M, int N, int K);
 bool smallm_splitk_ok(int M, int N, int K, int lda, int ldw);
 int launch_smallm_splitk(const float* A, int lda, const float* W, int ldw, float* out, int M, int N, int K, float* scratch, hipStream_t st);
 size_t wgrad_ws_bytes(const ConvGeom& g);
+// wq (only together with defer): problems the row-streaming 3x3 kernel takes are queued for a grouped launch instead of launched
 int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const float* dy, int ld_dy, float* dw_ref,
-                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer = nullptr);
+                 float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer = nullptr, WgradQueue* wq = nullptr);
 // k_wgrad_rs.hip: 3x3 / stride-1 weight gradient, row-streaming split form (false: geometry not eligible)
 bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
-                     float* bias_partial, hipStream_t st, WgradGeom* used);
+                     float* bias_partial, hipStream_t st, WgradGeom* used, WgradQueue* wq = nullptr);
+bool wgrad_rs_queueable(const ConvGeom& g, const float* src0, const float* dy, int ld_dy);   // launch_wgrad_rs would take (queue) it
 bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy);
 bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
                       float* bias_partial, hipStream_t st, WgradGeom* used);

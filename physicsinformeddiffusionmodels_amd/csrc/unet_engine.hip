@@ -171,6 +171,8 @@ struct pidm_unet {
   // with them the cached plans) changed in between
   int plan_B = 0;
   size_t plan_tape_b = 0, plan_tmp_b = 0, plan_defer_b = 0;
+  std::vector<WgradItem> wq_table;                       // host copy of the last uploaded grouped-weight-gradient table
+  const void* wq_table_dev = nullptr;                    // (invalidated together with red_table_dev: same arena region)
   std::vector<ReduceDesc> red_table;                     // host copy of the last uploaded reduction table
   const void* red_table_dev = nullptr;
   // data-parallel overlap (pidm_unet_set_grad_events): the deferred gradient reduction runs in up to 3 phases - after the
@@ -202,6 +204,17 @@ static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads()
 // samples/s (main.py's loop unchanged: 750.0 -> 762.6); the Darcy model (256 channels, full launches) ties: 6018 / 6021 / 6037
 // for graph / forward-graph + eager backward / all eager at batch 64, 7999 / 8077 / 7988 at batch 256 - it keeps the replay, which
 // costs the host a third of the launch-by-launch work.
+// Grouped weight gradients (round 5): PIDM_WGRAD_GROUP = problems per grouped launch of the row-streaming 3x3 weight-gradient
+// kernel (0: off - every problem its own launch, as before; default kWgradGroupDefault; at most 64: the kernel's table lookup
+// is one row per lane).  A flush also happens before every deferred reduction (the gradient phases of the data-parallel exchange).
+static const int kWgradGroupDefault = 64;
+static const size_t kMaxWgradItems = 256;      // rows of the device table (problems of one backward pass)
+static int wgrad_group_limit() {
+  const char* e = knob("PIDM_WGRAD_GROUP");
+  int n = e ? atoi(e) : kWgradGroupDefault;
+  if (n < 0) n = 0;
+  return n > 64 ? 64 : n;
+}
 static bool backward_eager(int widest) {
   const char* e = knob("PIDM_GRAPH");
   if (e && !atoi(e)) return true;
@@ -223,18 +236,24 @@ struct Run {
   // fixed-order sums are queued in `rq`, run by ONE reduce_multi launch at the end of backward
   Arena defer;
   ReduceQueue rq;
+  WgradQueue wq;               // weight-gradient problems waiting for their grouped launch (group_on)
+  size_t wq_done = 0;          // rows of wq.v already launched
+  WgradItem* wq_dev = nullptr; // device table (deferred arena, behind the reduction table)
+  bool group_on = false;
   bool defer_on = false;
   bool overlap = false;        // weight gradients on the side stream (real backward runs only)
   // Backward arena frames are kept to the end of the pass while side-stream weight gradients may still read them; the sizing dry
   // run assumes that only where a real pass can take the side stream at all (PIDM_GRAPH=0: captured passes are linear, and with
   // graph replay on - the default - the two eager passes before the capture are linear too), otherwise frames are recycled and
   // the plan is the smaller one.
-  bool keep_frames() const { return overlap || (dry && side_allowed); }
+  // (... and while queued weight-gradient problems may still read them: group_on)
+  bool keep_frames() const { return overlap || group_on || (dry && side_allowed); }
   bool side_allowed = false;   // backward_eager(widest level) of this handle (set by setup / the dry run)
   bool side_pending = false;   // side-stream work issued since the last join
   GraphCapture* cap = nullptr; // non-null while this pass is being stream-captured (r.st is the capture stream then)
   float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
   ReduceQueue* q() { return defer_on ? &rq : nullptr; }
+  WgradQueue* wgq() { return (defer_on && group_on) ? &wq : nullptr; }
 };
 
 #define RUN(call)                 \
@@ -685,7 +704,8 @@ static long lap_knob_signature() {
   const char* g = knob("PIDM_GRAPH");
   const char* gb = knob("PIDM_GRAPH_BWD");        // (the backward plan depends on the side stream too)
   const char* gw = knob("PIDM_GRAPH_BWD_WIDE");
-  return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0);
+  return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0) +
+         7919L * (wgrad_group_limit() > 0 ? 1 : 0);      // (grouped weight gradients keep the backward arena's frames)
 }
 static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
 // decided by the FORWARD (and stored in AttnBlock::projected); the backward replays the stored decision
@@ -845,6 +865,45 @@ static int join_side(Run& r) {
   return 0;
 }
 
+// Launches the weight-gradient problems queued since the previous flush as ONE grouped launch (per 64 table rows).  The table lives
+// behind the reduction table in the deferred arena; as there, only rows that differ from what the device holds are uploaded (steady
+// state: nothing - a captured pass must find the table unchanged).
+static int flush_wgrads(Run& r) {
+  if (r.dry || !r.group_on) return 0;
+  pidm_unet* U = r.U;
+  const size_t n = r.wq.v.size(), first = r.wq_done;
+  if (n <= first) return 0;
+  if (n > kMaxWgradItems) return fail("backward: weight-gradient table overflow (%zu)", n);
+  if (U->wq_table.capacity() < kMaxWgradItems) U->wq_table.reserve(kMaxWgradItems);     // never reallocates: async uploads read it
+  const bool same = U->wq_table_dev == r.wq_dev && U->wq_table.size() >= n &&
+                    memcmp(U->wq_table.data() + first, r.wq.v.data() + first, (n - first) * sizeof(WgradItem)) == 0;
+  if (!same && r.cap) {
+    r.cap->failed = true;        // never captured: the pass is re-run eagerly, which uploads
+  } else if (!same) {
+    if (U->wq_table_dev != r.wq_dev) U->wq_table.clear();
+    U->wq_table.resize(n > U->wq_table.size() ? n : U->wq_table.size());
+    memcpy(U->wq_table.data() + first, r.wq.v.data() + first, (n - first) * sizeof(WgradItem));
+    if (hipMemcpyAsync(r.wq_dev + first, U->wq_table.data() + first, (n - first) * sizeof(WgradItem), hipMemcpyHostToDevice, r.st) != hipSuccess)
+      return fail("backward: weight-gradient table upload failed");
+    ++g_red_table_uploads;           // (counted with the reduction table's: "steady state uploads nothing" covers both)
+    U->wq_table_dev = r.wq_dev;
+  }
+  for (size_t a = first; a < n; a += 64) {
+    const size_t b = a + 64 < n ? a + 64 : n;
+    const unsigned blk0 = r.wq.v[a].blk0, blk1 = (b < n) ? r.wq.v[b].blk0 : r.wq.nblocks;
+    if (prof_enabled()) {
+      double fl = 0.0;
+      for (size_t i = a; i < b; ++i) fl += r.wq.fl[i];
+      prof_begin_launch(3, fl, r.st);
+    }
+    const int rc = launch_wgrad_rs_multi(r.wq_dev, (int)a, (int)(b - a), blk0, blk1 - blk0, r.st);
+    if (prof_enabled()) prof_end_launch(r.st);
+    if (rc) return rc;
+  }
+  r.wq_done = n;
+  return 0;
+}
+
 // ld_dy: channel stride of dy (0 = L.Cout, contiguous): the two halves of a concatenation's gradient are read in place
 static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* dy, int ld_dy = 0) {
   pidm_unet* U = r.U;
@@ -864,7 +923,8 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
   } else {
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
-    RUN(launch_wgrad(g, x0, x1, dy, ld_dy, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q()));
+    RUN(launch_wgrad(g, x0, x1, dy, ld_dy, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q(), r.wgq()));
+    if (r.wgq() && r.wq.v.size() - r.wq_done >= (size_t)wgrad_group_limit() && flush_wgrads(r)) return -1;
   }
   return 0;
 }
@@ -1146,6 +1206,7 @@ static int cap_end_segment(Run& r, hipEvent_t ev_after, bool reopen) {
 static int flush_reductions(Run& r, ReduceDesc* red_dev, size_t* done, int phase, bool final_flush = false) {
   pidm_unet* U = r.U;
   if (r.dry) return 0;
+  if (flush_wgrads(r)) return -1;          // the queued weight-gradient problems write the partial slabs this reduction reads
   if (join_side(r)) return -1;
   const size_t n = r.rq.v.size(), first = *done;
   if (n > kMaxReduceDesc) return fail("backward: reduction table overflow (%zu)", n);
@@ -1201,6 +1262,9 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   r.rq.nblocks = 0;
   ReduceDesc* red_dev = reinterpret_cast<ReduceDesc*>(r.defer.alloc(kMaxReduceDesc * sizeof(ReduceDesc) / 4));
   size_t red_done = 0;
+  r.wq.clear();
+  r.wq_done = 0;
+  r.wq_dev = reinterpret_cast<WgradItem*>(r.defer.alloc(kMaxWgradItems * sizeof(WgradItem) / 4));
   const int n_phases = U->n_phases;
   float* dss = r.tmp.alloc((size_t)B * U->ss_total);
   float* g_o = r.tmp.alloc((size_t)B * HW * od);
@@ -1385,6 +1449,7 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   r.U = U; r.B = B; r.train = training != 0; r.dry = true; r.st = nullptr; r.wpack = nullptr;
   r.tape.dry = r.tmp.dry = r.defer.dry = true;
   r.side_allowed = backward_eager(widest_level(U));
+  r.group_on = wgrad_group_limit() > 0 && !r.side_allowed;      // as backward_body decides it
   // state touched by a dry run is restored afterwards
   pidm_unet saved_ptrs = *U;
   r.scratch_floats = scratch_floats_needed(U, B);
@@ -1577,7 +1642,7 @@ static void touch_arena(pidm_unet* h, int B, bool train, const void* workspace, 
     const bool planned = plan_sizes(h, B, train ? 1 : 0, &tape_b, &tmp_b) == 0;
     const bool inside = tab >= ws && tab < ws + workspace_bytes;
     if (knob("PIDM_DEBUG_ARENA")) fprintf(stderr, "[pidm] arena touch B=%d train=%d: extent %zu, table at %zu\n", B, (int)train, packed_b + tape_b + tmp_b, (size_t)(tab - ws));
-    if (!planned || !inside || ws + packed_b + tape_b + tmp_b > tab) h->red_table_dev = nullptr;
+    if (!planned || !inside || ws + packed_b + tape_b + tmp_b > tab) h->red_table_dev = h->wq_table_dev = nullptr;
   }
   h->arena_sig = sig;
 }
@@ -1609,6 +1674,9 @@ static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x
   // synchronises them with events), while the linear graph equals the eager step with the overlap (11.21 ms).
   r.side_allowed = backward_eager(widest_level(h));
   r.overlap = h->side_ok && !prof_enabled() && !cap && r.side_allowed;
+  // grouped weight gradients for the passes that are linear anyway (graph replay: the Darcy model); the wide models keep their
+  // launch-by-launch backward with the weight gradients on the side stream (measured faster there, see backward_eager)
+  r.group_on = wgrad_group_limit() > 0 && !r.side_allowed;
   if (cap && cap_begin(r)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");

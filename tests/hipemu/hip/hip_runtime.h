@@ -144,6 +144,14 @@ static inline int __any(int pred) {
   return v;
 }
 
+// wave ballot: bit l = lane l's predicate (v_cmp into an SGPR pair on the GPU), and the population count of such a mask
+static inline unsigned long long __ballot(int pred) {
+  unsigned long long v = pred ? (1ull << hipemu::lane_id()) : 0ull;
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off);
+  return v;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
 #define PIDM_HAVE_QUAD_XOR 1
 static inline float pidm_quad_xor1(float v) { return __shfl_xor(v, 1); }
 static inline float pidm_quad_xor2(float v) { return __shfl_xor(v, 2); }

@@ -152,68 +152,6 @@ __device__ __forceinline__ FdTaps5 fd_taps_T(const FdAxis& ax, int m, int P, int
   return t;
 }
 
-// ---- the loss scalars from the LAST-ARRIVING workgroup (round 5: darcy_loss_finalize folded into the residual kernel) --------------
-// Every workgroup leaves its three partial sums in `partial` and counts itself in; the one that finds all others counted totals
-// the partials - samples and bands in a fixed order, so the result does not depend on which workgroup that is (run-to-run
-// bit-identical) - and writes out[0..3].  __threadfence() is an agent-scope fence: release (L2 write-back: the XCDs' L2s are not
-// coherent with each other) before the arrival is counted, acquire (invalidate) before the partials are read.  The counter lives
-// in a small pool of self-resetting device globals, one per launch in flight (the host hands out tickets round-robin): no memset
-// launch, and two streams running the loss concurrently do not share one.
-constexpr int kDarcyTickets = 64;
-__device__ unsigned g_darcy_arrivals[kDarcyTickets];
-
-// out[0] = loss, out[1] = c_data*data_loss, out[2] = mean|r|, out[3] = 0
-__device__ __forceinline__ void darcy_loss_total(const double* __restrict__ partial, const float* __restrict__ p2w,
-                                                 const float* __restrict__ inv_var, const long long* __restrict__ tsteps, float c_data,
-                                                 float c_res, int B, int N, int nb, float* __restrict__ out, double (*red)[8]) {
-  const int tid = threadIdx.x, nthr = blockDim.x, nw = (nthr + 63) >> 6;
-  double v[3] = {0.0, 0.0, 0.0};
-  for (int b = tid; b < B; b += nthr) {
-    double d = 0.0, r = 0.0, a = 0.0;
-    for (int k = 0; k < nb; ++k) {
-      const double* pp = partial + ((size_t)b * nb + k) * 4;
-      d += pp[0];
-      r += pp[1];
-      a += pp[2];
-    }
-    v[0] += d / (2.0 * N) * (double)darcy_p2w(p2w, tsteps, b);
-    v[1] += r * (double)darcy_inv_var(inv_var, tsteps, b);
-    v[2] += a;
-  }
-  for (int q = 0; q < 3; ++q) {
-    double x = v[q];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if ((tid & 63) == 0) red[q][tid >> 6] = x;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double data = 0.0, res = 0.0, rabs = 0.0;
-    for (int w = 0; w < nw; ++w) { data += red[0][w]; res += red[1][w]; rabs += red[2][w]; }     // fixed order
-    data = data / B * c_data;
-    res = 0.5 * c_res * res / ((double)B * N * 3.0);
-    out[0] = (float)(data + res);
-    out[1] = (float)data;
-    out[2] = (float)(rabs / ((double)B * N * 3.0));
-    out[3] = 0.f;
-  }
-}
-
-// called by ALL threads of every workgroup after its partial sums were stored by threads 0..2 (red: 3 x 8 doubles of LDS, free)
-__device__ __forceinline__ void darcy_arrive_and_total(const double* __restrict__ partial, const float* __restrict__ p2w,
-                                                       const float* __restrict__ inv_var, const long long* __restrict__ tsteps,
-                                                       float c_data, float c_res, int B, int N, int nb, float* __restrict__ out,
-                                                       int ticket, double (*red)[8]) {
-  __shared__ int s_last;
-  if (threadIdx.x < 3) __threadfence();          // the writers of `partial`: visible device-wide before the arrival counts
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&g_darcy_arrivals[ticket], 1u) == gridDim.x - 1u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  darcy_loss_total(partial, p2w, inv_var, tsteps, c_data, c_res, B, N, nb, out, red);
-  if (threadIdx.x == 0) g_darcy_arrivals[ticket] = 0u;      // ready for the ticket's next launch (a kernel boundary away)
-}
-
 // dynamic LDS: MODE 0: 2 fields; MODE 1/2: 8 fields of darcy_lds_rows(P, R) x P floats
 template <int MODE>
 __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0,       // target (MODE 2) [B,2,P,P]
@@ -225,8 +163,7 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
                                                     float c_data, float c_res, float bc1_sign, FdAxis ax0, FdAxis ax1,
                                                     float* __restrict__ residual, float* __restrict__ grad_pred,
                                                     double* __restrict__ partial,       // MODE 2: [B][nb][4]
-                                                    int B, int P, int R, int nb, int lds_rows,
-                                                    float* __restrict__ out_scalars, int ticket) {   // MODE 2, non-null: totals by the last arriver
+                                                    int B, int P, int R, int nb, int lds_rows) {
   HIP_DYNAMIC_SHARED(float, smem)
   const int N = P * P;
   const int b = blockIdx.x / nb, band = blockIdx.x - b * nb;
@@ -380,7 +317,7 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
 
   if (MODE == DARCY_LOSS) {
     // deterministic block reduction of the three partial sums
-    __shared__ double red[3][8];
+    __shared__ double red[3][4];
     double v[3] = {acc_data, acc_r2, acc_rabs};
     for (int q = 0; q < 3; ++q) {
       double x = v[q];
@@ -392,7 +329,6 @@ __global__ void __launch_bounds__(256) darcy_kernel(const float* __restrict__ x0
       double s = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
       partial[(size_t)blockIdx.x * 4 + tid] = s;
     }
-    if (out_scalars) darcy_arrive_and_total(partial, p2w, inv_var, tsteps, c_data, c_res, B, N, nb, out_scalars, ticket, red);
   }
 }
 
@@ -467,8 +403,7 @@ __global__ void __launch_bounds__(512) darcy_quad_kernel(const float* __restrict
                                                          const float* __restrict__ p2w, const float* __restrict__ inv_var,
                                                          const long long* __restrict__ tsteps, float c_data, float c_res, float bc1_sign,
                                                          FdAxis ax0, FdAxis ax1, float* __restrict__ residual, float* __restrict__ grad_pred,
-                                                         double* __restrict__ partial, int B, int P, int R, int nb, int lds_rows,
-                                                         float* __restrict__ out_scalars, int ticket) {
+                                                         double* __restrict__ partial, int B, int P, int R, int nb, int lds_rows) {
   HIP_DYNAMIC_SHARED(float, smem)
   const int N = P * P, QP = P >> 2;           // quads per row (a power of two <= 256)
   const int b = blockIdx.x / nb, band = blockIdx.x - b * nb;
@@ -662,7 +597,6 @@ __global__ void __launch_bounds__(512) darcy_quad_kernel(const float* __restrict
       for (int w = 0; w < (int)blockDim.x >> 6; ++w) sv += red[tid][w];     // fixed order
       partial[(size_t)blockIdx.x * 4 + tid] = sv;
     }
-    if (out_scalars) darcy_arrive_and_total(partial, p2w, inv_var, tsteps, c_data, c_res, B, N, nb, out_scalars, ticket, red);
   }
 }
 
@@ -766,11 +700,8 @@ __global__ void __launch_bounds__(256) darcy_jacmax_kernel(const float* __restri
 template <int MODE>
 static int launch_darcy(const float* x0, const float* pred, const float* f_s, const float* grad_res, const float* p2w,
                         const float* inv_var, const long long* tsteps, float c_data, float c_res, float inv_h0, float inv_h1,
-                        float* residual, float* grad_pred, double* partial, int B, int P, hipStream_t st,
-                        float* out_scalars = nullptr) {
+                        float* residual, float* grad_pred, double* partial, int B, int P, hipStream_t st) {
   if (B <= 0 || P < 5) return fail("darcy: need B>0 and P>=5 (got B=%d P=%d)", B, P);
-  static int next_ticket = 0;
-  const int ticket = out_scalars ? (next_ticket++ % kDarcyTickets) : 0;
   const DarcyBands bd = darcy_bands(B, P);
   const int rows = darcy_lds_rows(P, bd.R);
   size_t lds = (size_t)(MODE == DARCY_RES_ONLY ? 2 : 8) * rows * P * sizeof(float);
@@ -802,13 +733,13 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
     if (nt < 64) nt = 64;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_quad_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(nt), lds, st, x0, pred, f_s, grad_res, p2w,
                        inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,
-                       grad_pred, partial, B, P, bd.R, bd.nb, rows, out_scalars, ticket);
+                       grad_pred, partial, B, P, bd.R, bd.nb, rows);
     PIDM_CHECK_LAUNCH("darcy_quad_kernel");
     return 0;
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_kernel<MODE>), dim3((unsigned)B * bd.nb), dim3(256), lds, st, x0, pred, f_s, grad_res, p2w,
                      inv_var, tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual,
-                     grad_pred, partial, B, P, bd.R, bd.nb, rows, out_scalars, ticket);
+                     grad_pred, partial, B, P, bd.R, bd.nb, rows);
   PIDM_CHECK_LAUNCH("darcy_kernel");
   return 0;
 }
@@ -817,12 +748,9 @@ static int darcy_loss_impl(const float* x0, const float* x0_pred, const float* f
                            const long long* tsteps, float c_data, float c_residual, float inv_h0, float inv_h1, float* residual,
                            float* grad_x0_pred, float* out_scalars, void* workspace, int B, int P, hipStream_t st) {
   double* partial = reinterpret_cast<double*>(workspace);
-  // PIDM_DARCY_FUSED_FINALIZE=0: the totals by a second launch (darcy_loss_finalize), as before round 5 (A/B measurements)
-  const char* fe = knob("PIDM_DARCY_FUSED_FINALIZE");
-  const bool fused = !(fe && !atoi(fe));
   int rc = launch_darcy<DARCY_LOSS>(x0, x0_pred, f_s, nullptr, p2w, inv_var, tsteps, c_data, c_residual, inv_h0, inv_h1, residual,
-                                    grad_x0_pred, partial, B, P, st, fused ? out_scalars : nullptr);
-  if (rc || fused) return rc;
+                                    grad_x0_pred, partial, B, P, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(darcy_loss_finalize, dim3(1), dim3(256), 0, st, partial, p2w, inv_var, tsteps, c_data, c_residual, B, P * P,
                      darcy_bands(B, P).nb, out_scalars);
   PIDM_CHECK_LAUNCH("darcy_loss_finalize");

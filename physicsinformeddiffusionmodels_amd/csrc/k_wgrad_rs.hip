@@ -703,11 +703,14 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
   int ns = plan.nsplit;                     // never more splits than the workspace was sized for
   const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");   // tests: several items per wave on small problems
   if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
-  // grouped launches need not fill the chip problem by problem: PIDM_WGRAD_GROUP_SPLITDIV (default 1) divides the split count -
-  // fewer, longer work items, proportionally fewer partial slabs for the deferred reduction to read
+  // Grouped launches need not fill the chip problem by problem - the ~40 problems of a pass do it together: PIDM_WGRAD_GROUP_SPLITDIV
+  // (default 4) divides the split count: fewer, longer work items (a workgroup's prologue, its 147 KB cross-wave sum and its 36 KB
+  // partial slab are per item), proportionally fewer partial slabs for the deferred reduction to read.  Measured per step, same box
+  // (profiles/r05_b_wgrad_group_splitdiv.txt): batch 16 5.08 -> 4.80 / 4.74 / 4.80 / 4.85 ms for 2 / 4 / 8 / 16, batch 64 8.28 ->
+  // 8.07 / 8.03 / 8.09 / 8.13, batch 256 24.81 -> 24.85 / 24.78 / 25.07 / 25.17 (32: slower everywhere).
   if (wq) {
     const char* de = knob("PIDM_WGRAD_GROUP_SPLITDIV");
-    const int dv = de ? atoi(de) : 1;
+    const int dv = de ? atoi(de) : 4;
     if (dv > 1 && ns / dv >= 1) ns /= dv;
   }
   rs_plan(&wg, ns);

@@ -102,39 +102,3 @@ def test_darcy_one_pixel_kernel_at_64(backend, monkeypatch):
     test_darcy_residual_fwd_bwd(backend, 64, 2)
     test_darcy_fused_loss(backend, 16, 4)
 
-
-@pytest.mark.parametrize("P,B,quad", [(64, 70, "1"), (16, 5, "1"), (21, 4, "0")])
-def test_darcy_loss_totals_by_the_last_arriving_workgroup(backend, monkeypatch, P, B, quad):
-    """Round 5: the loss scalars are totalled by the last-arriving workgroup of the residual kernel (one launch instead of two).
-    Same values as the separate darcy_loss_finalize launch (PIDM_DARCY_FUSED_FINALIZE=0) up to the summation tree, identical
-    residual / gradient, bit-identical from launch to launch - more launches than the pool has arrival counters, so every
-    counter is found reset (reference: the .mean() / loss algebra of src/denoising_utils.py:666-692)."""
-    L, dev = backend
-    st = stream_ptr(dev)
-    monkeypatch.setenv("PIDM_DARCY_QUAD", quad)
-    g = torch.Generator().manual_seed(5 + P)
-    x0 = torch.randn(B, 2, P, P, generator=g).to(dev)
-    pred = (x0.cpu() + 0.1 * torch.randn(B, 2, P, P, generator=g)).to(dev)
-    fs = torch.randn(P * P, generator=g).to(dev)
-    tables = O.diffusion_tables(100)
-    t = torch.randint(0, 100, (B,), generator=g).to(dev)
-    tab_w, tab_v = tables["p2_loss_weight"].to(dev), tables["posterior_variance_clipped"].to(dev)
-    inv_h = float(P - 1)
-    ws = torch.empty(L.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
-
-    def run():
-        res, gp, out = torch.empty(B, P * P, 3, device=dev), torch.empty(B, 2, P, P, device=dev), torch.full((4,), -1.0, device=dev)
-        L.check(L.pidm_darcy_loss_fwd_bwd_t(ptr(x0), ptr(pred), ptr(fs), ptr(t), ptr(tab_w), ptr(tab_v), 1.0, 1e-3, inv_h, -inv_h,
-                                            ptr(res), ptr(gp), ptr(out), ptr(ws), B, P, st))
-        return res, gp, out.cpu()
-    monkeypatch.setenv("PIDM_DARCY_FUSED_FINALIZE", "0")
-    res0, gp0, out0 = run()
-    monkeypatch.delenv("PIDM_DARCY_FUSED_FINALIZE")
-    n = 70 if dev.type == "cuda" else 3
-    first = None
-    for _ in range(n):
-        res1, gp1, out1 = run()
-        assert torch.equal(res1, res0) and torch.equal(gp1, gp0)
-        assert out1[3].item() == 0.0 and torch.allclose(out1, out0, rtol=2e-6, atol=0.0)
-        first = out1 if first is None else first
-        assert torch.equal(out1, first)

@@ -381,11 +381,18 @@ def test_grouped_weight_gradients(backend, monkeypatch):
         return out
     ref = grads({"PIDM_WGRAD_GROUP": "0"})
     assert len(ref) > 50
-    for env, phases, steps in (({}, 1, 4), ({"PIDM_WGRAD_GROUP": "3"}, 1, 1), ({}, 3, 4), ({"PIDM_WGRAD_GROUP": "1"}, 3, 1)):
+    same_splits = {"PIDM_WGRAD_GROUP_SPLITDIV": "1"}
+    for env, phases, steps in ((same_splits, 1, 4), (dict(same_splits, PIDM_WGRAD_GROUP="3"), 1, 1), (same_splits, 3, 4),
+                               (dict(same_splits, PIDM_WGRAD_GROUP="1"), 3, 1)):
         got = grads(env, phases, steps)
         assert got.keys() == ref.keys()
         for k in ref:
             assert torch.equal(got[k], ref[k]), (env, phases, k)
-    got = grads({"PIDM_WGRAD_GROUP_SPLITDIV": "2"})
+    # the default (a quarter of the splits per problem) and another divisor: the same sums in another order
+    for env, steps in (({}, 4), ({"PIDM_WGRAD_GROUP_SPLITDIV": "2"}, 1)):
+        got = grads(env, 1, steps)
+        for k in ref:
+            assert (got[k] - ref[k]).abs().max().item() <= 2e-5 * max(ref[k].abs().max().item(), 1e-6), k
+    a, b = grads({}, 1, 2), grads({}, 3, 2)                  # and the default is bit-identical run to run, one phase or three
     for k in ref:
-        assert (got[k] - ref[k]).abs().max().item() <= 2e-5 * max(ref[k].abs().max().item(), 1e-6), k
+        assert torch.equal(a[k], b[k]), k

@@ -834,16 +834,19 @@ int launch_smallm_splitk(const float* A, int lda, const float* W, int ldw, float
 // operand in flight.  The LDS-staged kernel did 16 MFMAs per wave between two barriers and ran at half the byte rate.
 // Pixel range of a workgroup: tiles [split*tps, ...) of 128 pixels, one contiguous quarter per wave; cross-wave sum
 // through LDS at the end, split-K partials as everywhere else.
-__global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg, const float* __restrict__ src0,
-                                                                    const float* __restrict__ src1, const float* __restrict__ dy,
-                                                                    float* __restrict__ partial, float* __restrict__ bias_partial) {
-  __shared__ float red[4][1024];
-  const ConvGeom& g = wg.g;
+// (problem `wg` by value in scalar registers - kernel arguments or a row of the grouped launch's table -, workgroup (split, by) of its
+// splits x tiles grid, 4 x 1024 floats of LDS)
+__device__ __forceinline__ void conv_wgrad_1x1_stream_body(const WgradItem& wg, const int split, const int by, float (*red)[1024]) {
+  const WgradItem& g = wg;
+  const float* __restrict__ src0 = wg.src0;
+  const float* __restrict__ src1 = wg.src1;
+  const float* __restrict__ dy = wg.dy;
+  float* __restrict__ partial = wg.partial;
+  float* __restrict__ bias_partial = wg.bias_partial;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int ntn = wg.NP / 32;
-  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int tn = by % ntn, tm = by / ntn;
   const int m0 = tm * 32, n0 = tn * 32;
-  const int split = blockIdx.x;
   const size_t ptot = (size_t)g.B * g.Hv * g.Wv;
   size_t p_lo = (size_t)split * wg.tiles_per_split * 128, p_hi = p_lo + (size_t)wg.tiles_per_split * 128;
   if (p_hi > ptot) p_hi = ptot;
@@ -911,18 +914,24 @@ __global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradGeom wg
 // component t of the wide fragment (channel 4*lane + t - the permuted-tile trick of the NT=4 forward kernel) with the narrow
 // fragment, so the narrow operand is re-read four times less often than with 32x32 tiles.  WIDE_DY: the wide side is dY
 // (GEMM M), otherwise X (GEMM N).
-template <bool WIDE_DY>
-__global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradGeom wg, const float* __restrict__ src0,
-                                                                     const float* __restrict__ src1, const float* __restrict__ dy,
-                                                                     float* __restrict__ partial, float* __restrict__ bias_partial) {
+__global__ void __launch_bounds__(256) conv_wgrad_1x1_stream_kernel(WgradItem wg) {
   __shared__ float red[4][1024];
-  const ConvGeom& g = wg.g;
+  conv_wgrad_1x1_stream_body(wg, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+template <bool WIDE_DY>
+__device__ __forceinline__ void conv_wgrad_1x1_stream4_body(const WgradItem& wg, const int bx, const int split, float (*red)[1024]) {
+  const WgradItem& g = wg;
+  const float* __restrict__ src0 = wg.src0;
+  const float* __restrict__ src1 = wg.src1;
+  const float* __restrict__ dy = wg.dy;
+  float* __restrict__ partial = wg.partial;
+  float* __restrict__ bias_partial = wg.bias_partial;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int n_nar = WIDE_DY ? wg.NP / 32 : wg.MP / 32;          // 32-channel tiles of the narrow operand
   // tile index fastest: workgroups launched together read neighbouring channel groups of the same pixel rows
-  const int t_nar = blockIdx.x % n_nar, t_wid = blockIdx.x / n_nar;
+  const int t_nar = bx % n_nar, t_wid = bx / n_nar;
   const int w0 = t_wid * 128, r0 = t_nar * 32;
-  const int split = blockIdx.y;
   const size_t ptot = (size_t)g.B * g.Hv * g.Wv;
   size_t p_lo = (size_t)split * wg.tiles_per_split * 128, p_hi = p_lo + (size_t)wg.tiles_per_split * 128;
   if (p_hi > ptot) p_hi = ptot;
@@ -1017,6 +1026,28 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradGeo
       }
     }
   }
+}
+
+template <bool WIDE_DY>
+__global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradItem wg) {
+  __shared__ float red[4][1024];
+  conv_wgrad_1x1_stream4_body<WIDE_DY>(wg, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// The three 1x1 stream kernels for a TABLE of problems in one launch (round 5; WgradQueue, pidm_launch.h; the lookup of
+// conv_wgrad_rs_multi_kernel): a problem's `kind` - wave-uniform - picks the body, its own grid is gx x gy.
+__global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_multi_kernel(const WgradItem* __restrict__ table, int n, unsigned blk_base) {
+  __shared__ float red[4][1024];
+  const unsigned bid = blockIdx.x + blk_base;
+  const int lane_ = threadIdx.x & 63;
+  const unsigned first_ = lane_ < n ? table[lane_].blk0 : 0xffffffffu;
+  const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(bid >= first_)) - 1);
+  const WgradItem wg = table[p];
+  const unsigned local = bid - wg.blk0;
+  const int bx = (int)(local % wg.gx), by = (int)(local / wg.gx);
+  if (wg.kind == kWgKindStream4Dy) conv_wgrad_1x1_stream4_body<true>(wg, bx, by, red);
+  else if (wg.kind == kWgKindStream4X) conv_wgrad_1x1_stream4_body<false>(wg, bx, by, red);
+  else conv_wgrad_1x1_stream_body(wg, bx, by, red);
 }
 
 // all deferred reductions of one backward pass in ONE launch (descriptor table on the device, binary search per block
@@ -1165,6 +1196,14 @@ int launch_split_reduce(const float* partial, float* dst, const float* bias_part
   return 0;
 }
 
+int launch_wgrad_1x1_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
+  if (n <= 0 || nblocks == 0) return 0;
+  PIDM_PROF_NAME("conv_wgrad_1x1_multi_kernel");
+  hipLaunchKernelGGL(conv_wgrad_1x1_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev + first, n, blk_base);
+  PIDM_CHECK_LAUNCH("conv_wgrad_1x1_multi_kernel");
+  return 0;
+}
+
 int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st, unsigned blk_base) {
   if (ndesc <= 0 || nblocks == 0) return 0;
   hipLaunchKernelGGL(reduce_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev, ndesc, blk_base);
@@ -1300,7 +1339,13 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
                  float* dbias, void* workspace, hipStream_t st, ReduceQueue* defer, WgradQueue* wq) {
   if (g.nz != 1) return fail("wgrad: transposed problems must be passed with swapped operands");
   if (!defer) wq = nullptr;      // a queued problem's reduction must be a deferred one as well
-  const size_t queued0 = wq ? wq->v.size() : 0;
+  const size_t queued0 = wq ? wq->size() : 0;
+  // PIDM_WGRAD_GROUP_FAMS (A/B measurements): bit 0 / 1 / 2 = the 3x3 row-streaming / 4x4-stride-2 row-streaming / 1x1 stream family may queue
+  const char* fe = knob("PIDM_WGRAD_GROUP_FAMS");
+  const int fams = fe ? atoi(fe) : 7;
+  WgradQueue* const wq_rs = (fams & 1) ? wq : nullptr;
+  WgradQueue* const wq_rs4 = (fams & 2) ? wq : nullptr;
+  WgradQueue* const wq_1x1 = (fams & 4) ? wq : nullptr;
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
   const int T = wgrad_taps(g);
@@ -1317,7 +1362,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     attr_done = true;
   }
   // (a problem that goes to the queue is accounted for by the grouped launch: flush_wgrads declares the FLOPs of its items)
-  const bool prof = prof_enabled() && !(wq && wgrad_rs_queueable(g, src0, dy, ld_dy));
+  const bool prof = prof_enabled() && !wq;
   if (prof) {
     char lab[160];
     snprintf(lab, sizeof(lab), "wgrad B%d %dx%d Cin%d Cout%d k%dx%d nph%d", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH, g.KW, g.nph);
@@ -1345,7 +1390,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<1>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_smallc_kernel<4>), grid2, dim3(256), lds2, st, wg, src0, dy, partial, bias_partial);
-  } else if (g.nph > 1 && launch_wgrad_rs4(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
+  } else if (g.nph > 1 && launch_wgrad_rs4(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg, wq_rs4)) {
     if (prof) prof_reclass_last(3);   // split form on the bf16 pipe
   } else if (g.nph > 1) {
     if (!aligned || g.NI * g.IHt * g.IWt * 8 > 9 * 256) return fail("wgrad: phased 4x4/s2 geometry not eligible for the pipelined kernel");
@@ -1365,23 +1410,39 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
 #define PIDM_LAUNCH_WG(KH_, KW_, PH_, WIDE_, MINW_, grid_) PIDM_LAUNCH_WG6(KH_, KW_, PH_, WIDE_, MINW_, false, grid_)
     if (g.Wv >= 32) PIDM_LAUNCH_WG(2, 2, true, true, 2, gridp)
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
-  } else if (smode == 1) {
-    PIDM_PROF_NAME("conv_wgrad_1x1_stream_kernel");
-    hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, grid, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-  } else if (smode == 2) {
-    const dim3 grid4(cdiv(wg.MP, 128) * (wg.NP / 32), wg.nsplit, 1);
-    PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<true>");
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<true>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-  } else if (smode == 3) {
-    const dim3 grid4(cdiv(wg.NP, 128) * (wg.MP / 32), wg.nsplit, 1);
-    PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<false>");
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<false>), grid4, dim3(256), 0, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+  } else if (smode >= 1 && smode <= 3) {
+    // the LDS-free pixel streams; grouped (wq): queued with a quarter of the splits (launch_wgrad_rs)
+    if (wq_1x1) {
+      const int dv = wgrad_group_splitdiv();
+      if (dv > 1) {
+        wg.tiles_per_split *= dv;
+        if (wg.tiles_per_split > g.tiles_m) wg.tiles_per_split = g.tiles_m;
+        wg.nsplit = cdiv(g.tiles_m, wg.tiles_per_split);
+      }
+    }
+    const dim3 gr = smode == 1   ? dim3(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1)
+                    : smode == 2 ? dim3(cdiv(wg.MP, 128) * (wg.NP / 32), wg.nsplit, 1)
+                                 : dim3(cdiv(wg.NP, 128) * (wg.MP / 32), wg.nsplit, 1);
+    const WgradItem it = wgrad_item(wg, src0, src1, dy, partial, bias_partial, gr.x, gr.y,
+                                    smode == 1 ? kWgKindStream : smode == 2 ? kWgKindStream4Dy : kWgKindStream4X);
+    if (wq_1x1) {
+      wq_1x1->push(kWgFam1x1, it, 0.0);
+    } else if (smode == 1) {
+      PIDM_PROF_NAME("conv_wgrad_1x1_stream_kernel");
+      hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, gr, dim3(256), 0, st, it);
+    } else if (smode == 2) {
+      PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<true>");
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<true>), gr, dim3(256), 0, st, it);
+    } else {
+      PIDM_PROF_NAME("conv_wgrad_1x1_stream4_kernel<false>");
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_stream4_kernel<false>), gr, dim3(256), 0, st, it);
+    }
   } else if (aligned && ((g.KH == 3 && g.KW == 3) || (g.KH == 1 && g.KW == 1)) && wg.ntg == 1 &&
              g.NI * g.IHt * g.IWt * 8 <= (g.KH == 1 ? 4 : 9) * 256 && g.IHt < 1024 && g.IWt < 1024) {
     if (g.KH == 1) {
       if (g.Wv >= 32) PIDM_LAUNCH_WG(1, 1, false, true, 4, grid)
       else PIDM_LAUNCH_WG(1, 1, false, false, 3, grid)   // per-step pixel decode: 3 waves per SIMD without spilling
-    } else if (launch_wgrad_rs(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg, wq) ||
+    } else if (launch_wgrad_rs(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg, wq_rs) ||
                launch_wgrad_split(wg, src0, src1, dy, ld_dy, partial, bias_partial, st, &wg)) {
       if (prof) prof_reclass_last(3);   // split form: counted with the weight gradients and, separately, against the bf16 pipe
       // taken by the bf16-pipe kernel (wg now holds its tiling / split)
@@ -1406,7 +1467,10 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<1>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
-  const bool queued = wq && wq->v.size() > queued0;      // nothing was enqueued: the problem waits for flush_wgrads
+  const bool queued = wq && wq->size() > queued0;        // nothing was enqueued: the problem waits for flush_wgrads
+  if (queued)                                            // (what the grouped launch declares to the profiling hooks for this row)
+    for (auto& q : wq->f)
+      if (!q.fl.empty() && q.fl.size() == q.v.size() && q.v.back().partial == partial) q.fl.back() = 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T;
   if (prof) prof_end_launch(st);
   if (!queued) PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
   if (defer) {   // the caller keeps `workspace` alive until its reduce_multi launch

@@ -273,17 +273,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs_multi_kernel(const WgradIte
 // are summed through LDS.  No rows are shared between consecutive k-steps of a wave (stride 2), so there is no rolling window:
 // ~330 vector instructions per 48 MFMAs - vector-bound, and still 2x the fp32-MFMA kernel it replaces (conv_wgrad_pipe_kernel<2,2,..>).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) conv_wgrad_rs4_kernel(WgradGeom wg, const float* __restrict__ src0, const float* __restrict__ src1,
-                                                             const float* __restrict__ dy, float* __restrict__ partial,
-                                                             float* __restrict__ bias_partial) {
-  const ConvGeom& g = wg.g;
-  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][8 taps][32][32]
+__device__ __forceinline__ void conv_wgrad_rs4_body(const WgradItem& wg, const int split, const int by, float* __restrict__ red) {
+  const WgradItem& g = wg;            // (the geometry fields the kernel reads live in the item itself)
+  const float* __restrict__ src0 = wg.src0;
+  const float* __restrict__ src1 = wg.src1;
+  const float* __restrict__ dy = wg.dy;
+  float* __restrict__ partial = wg.partial;
+  float* __restrict__ bias_partial = wg.bias_partial;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int ntn = wg.NP / 32;
-  const int tn = blockIdx.y % ntn, tm = blockIdx.y / ntn;
+  const int tn = by % ntn, tm = by / ntn;
   const int m0 = tm * 32, n0 = tn * 32;
-  const int split = blockIdx.x;
   const int kp = wave & 1, pw = wave >> 1;                 // kernel-row pair, pixel share of the workgroup
   const int Ho = g.Hv, Wo = g.Wv, Hi = g.Hi, R = wg.rs_R;
   const int wsh = g.wsh;                                   // log2 Wo
@@ -404,6 +405,22 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs4_kernel(WgradGeom wg, const
       bias_partial[(size_t)split * wg.MP + m0 + tid] = sb;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) conv_wgrad_rs4_kernel(WgradItem wg) {
+  HIP_DYNAMIC_SHARED(float, red)      // epilogue only: [4 waves][8 taps][32][32]
+  conv_wgrad_rs4_body(wg, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+// a table of problems in one launch (see conv_wgrad_rs_multi_kernel)
+__global__ void __launch_bounds__(256) conv_wgrad_rs4_multi_kernel(const WgradItem* __restrict__ table, int n, unsigned blk_base) {
+  HIP_DYNAMIC_SHARED(float, red)
+  const unsigned bid = blockIdx.x + blk_base;
+  const int lane_ = threadIdx.x & 63;
+  const unsigned first_ = lane_ < n ? table[lane_].blk0 : 0xffffffffu;
+  const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(bid >= first_)) - 1);
+  const WgradItem wg = table[p];
+  const unsigned local = bid - wg.blk0;
+  conv_wgrad_rs4_body(wg, (int)(local % wg.gx), (int)(local / wg.gx), red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -530,6 +547,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_rs7_kernel(WgradGeom wg, const
 
 // Plan: rows per strip chunk R (power of two <= H) such that the waves of a block (4 per split) get whole items and the longest
 // wave - items x (R rows + the three rows of prologue) - is shortest.
+static constexpr size_t kRsWgradLds = 4 * 9 * 1024 * sizeof(float);
+static constexpr size_t kRs4WgradLds = 4 * 8 * 1024 * sizeof(float);
+WgradItem wgrad_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial,
+                     unsigned gx, unsigned gy, int kind);
+int wgrad_group_splitdiv();
+
 static void rs_plan(WgradGeom* wg, int nsplit) {
   const ConvGeom& g = wg->g;
   const int waves = 4 * nsplit;
@@ -580,7 +603,7 @@ bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy) {
 
 // the 4x4 / stride-2 layers (phased geometry, ConvGeom::nph == 4); same contract as launch_wgrad_rs
 bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
-                      float* bias_partial, hipStream_t st, WgradGeom* used) {
+                      float* bias_partial, hipStream_t st, WgradGeom* used, WgradQueue* wq) {
   const ConvGeom& g = plan.g;
   const char* off = knob("PIDM_WGRAD_RS");
   if (off && !atoi(off)) return false;
@@ -590,20 +613,29 @@ bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src
   int ns = plan.nsplit;
   const char* me = knob("PIDM_WGRAD_SPLIT_MAXNS");
   if (me && atoi(me) > 0 && atoi(me) < ns) ns = atoi(me);
+  if (wq) {                                   // grouped: fewer, longer items (see launch_wgrad_rs)
+    const int dv = wgrad_group_splitdiv();
+    if (dv > 1 && ns / dv >= 1) ns /= dv;
+  }
   rs4_plan(&wg, ns);
   const dim3 grid(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1);
-  const size_t lds = 4 * 8 * 1024 * sizeof(float);
   static bool attr_ = false;
   if (!attr_) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRs4WgradLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs4_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRs4WgradLds);
     attr_ = true;
   }
   if (knob("PIDM_TRACE_CONV"))
-    fprintf(stderr, "[pidm]   -> conv_wgrad_rs4_kernel, %d splits x %d blocks, %d strips of %d rows, %d pairs per pixel share\n", wg.nsplit,
-            grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
-  PIDM_PROF_NAME("conv_wgrad_rs4_kernel");
-  hipLaunchKernelGGL(conv_wgrad_rs4_kernel, grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
+    fprintf(stderr, "[pidm]   -> conv_wgrad_rs4_kernel%s, %d splits x %d blocks, %d strips of %d rows, %d pairs per pixel share\n",
+            wq ? " (queued)" : "", wg.nsplit, grid.y, wg.rs_S, wg.rs_R, wg.rs_ppw);
+  const WgradItem it = wgrad_item(wg, src0, src1, dy, partial, bias_partial, grid.x, grid.y, 0);
   *used = wg;
+  if (wq) {
+    wq->push(kWgFamRs4, it, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 16);
+    return true;
+  }
+  PIDM_PROF_NAME("conv_wgrad_rs4_kernel");
+  hipLaunchKernelGGL(conv_wgrad_rs4_kernel, grid, dim3(256), kRs4WgradLds, st, it);
   return true;
 }
 
@@ -668,17 +700,24 @@ bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy,
 
 // true: launched (and *used holds the split actually written); false: geometry not eligible (the caller goes on to the LDS-staged
 // kernel).  PIDM_WGRAD_RS=0: off (A/B measurements, tests of the older kernel).
-static WgradItem rs_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial) {
+WgradItem wgrad_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial,
+                     unsigned gx, unsigned gy, int kind) {
   const ConvGeom& g = wg.g;
   WgradItem it{};
   it.src0 = src0; it.src1 = src1 ? src1 : src0; it.dy = dy; it.partial = partial; it.bias_partial = bias_partial;
-  it.B = g.B; it.Hi = g.Hi; it.Wi = g.Wi; it.wsh = g.wsh; it.ld0 = g.ld0; it.C0 = g.C0; it.ld_dy = wg.ld_dy;
-  it.MP = wg.MP; it.NP = wg.NP;
+  it.B = g.B; it.Hi = g.Hi; it.Wi = g.Wi; it.wsh = g.wsh; it.Hv = g.Hv; it.Wv = g.Wv;
+  it.ld0 = g.ld0; it.ld1 = g.ld1; it.C0 = g.C0; it.Cin = g.Cin; it.Cout = g.Cout; it.ld_dy = wg.ld_dy;
+  it.MP = wg.MP; it.NP = wg.NP; it.tiles_per_split = wg.tiles_per_split;
   it.rs_R = wg.rs_R; it.rs_csh = wg.rs_csh; it.rs_xsh = wg.rs_xsh; it.rs_S = wg.rs_S; it.rs_ppw = wg.rs_ppw;
-  it.gx = (unsigned)wg.nsplit; it.gy = (unsigned)((wg.MP / 32) * (wg.NP / 32));
+  it.kind = kind;
+  it.gx = gx; it.gy = gy;
   return it;
 }
-static constexpr size_t kRsWgradLds = 4 * 9 * 1024 * sizeof(float);
+int wgrad_group_splitdiv() {
+  const char* de = knob("PIDM_WGRAD_GROUP_SPLITDIV");
+  const int dv = de ? atoi(de) : 4;
+  return dv < 1 ? 1 : dv;
+}
 
 // true: launched - or, with `wq`, queued for the grouped launch - (and *used holds the split actually written); false: geometry not
 // eligible (the caller goes on to the LDS-staged kernel).  PIDM_WGRAD_RS=0: off (A/B measurements, tests of the older kernel).
@@ -709,12 +748,11 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
   // (profiles/r05_b_wgrad_group_splitdiv.txt): batch 16 5.08 -> 4.80 / 4.74 / 4.80 / 4.85 ms for 2 / 4 / 8 / 16, batch 64 8.28 ->
   // 8.07 / 8.03 / 8.09 / 8.13, batch 256 24.81 -> 24.85 / 24.78 / 25.07 / 25.17 (32: slower everywhere).
   if (wq) {
-    const char* de = knob("PIDM_WGRAD_GROUP_SPLITDIV");
-    const int dv = de ? atoi(de) : 4;
+    const int dv = wgrad_group_splitdiv();
     if (dv > 1 && ns / dv >= 1) ns /= dv;
   }
   rs_plan(&wg, ns);
-  const WgradItem it = rs_item(wg, src0, src1, dy, partial, bias_partial);
+  const WgradItem it = wgrad_item(wg, src0, src1, dy, partial, bias_partial, (unsigned)ns, (unsigned)((wg.MP / 32) * (wg.NP / 32)), 0);
   static bool attr_ = false;
   if (!attr_) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsWgradLds);
@@ -726,7 +764,7 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
             wg.nsplit, it.gy, wg.rs_S, wg.rs_R, wg.rs_ppw);
   *used = wg;
   if (wq) {
-    wq->push(it, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 9);
+    wq->push(kWgFamRs, it, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * 9);
     return true;
   }
   PIDM_PROF_NAME("conv_wgrad_rs_kernel");
@@ -741,6 +779,20 @@ int launch_wgrad_rs_multi(const WgradItem* table_dev, int first, int n, unsigned
   hipLaunchKernelGGL(conv_wgrad_rs_multi_kernel, dim3(nblocks), dim3(256), kRsWgradLds, st, table_dev + first, n, blk_base);
   PIDM_CHECK_LAUNCH("conv_wgrad_rs_multi_kernel");
   return 0;
+}
+
+int launch_wgrad_rs4_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
+  if (n <= 0 || nblocks == 0) return 0;
+  PIDM_PROF_NAME("conv_wgrad_rs4_multi_kernel");
+  hipLaunchKernelGGL(conv_wgrad_rs4_multi_kernel, dim3(nblocks), dim3(256), kRs4WgradLds, st, table_dev + first, n, blk_base);
+  PIDM_CHECK_LAUNCH("conv_wgrad_rs4_multi_kernel");
+  return 0;
+}
+
+int launch_wgrad_multi(int fam, const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
+  return fam == kWgFamRs    ? launch_wgrad_rs_multi(table_dev, first, n, blk_base, nblocks, st)
+         : fam == kWgFamRs4 ? launch_wgrad_rs4_multi(table_dev, first, n, blk_base, nblocks, st)
+                            : launch_wgrad_1x1_multi(table_dev, first, n, blk_base, nblocks, st);
 }
 
 }  // namespace pidm

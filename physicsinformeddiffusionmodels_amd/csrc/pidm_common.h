@@ -256,20 +256,27 @@ struct WgradGeom {
 
 // one weight-gradient problem of a GROUPED launch (k_wgrad_rs.hip: conv_wgrad_rs_multi_kernel, round 5): what the single-problem
 // kernel receives as arguments, plus the problem's range of workgroups in the flat grid (blk0 .. blk0 + gx * gy)
-// Only the fields conv_wgrad_rs_kernel reads (no host pointers, no padding: tables of these are compared with memcmp).
+// Only the fields the grouped kernels read (no host pointers, no padding: tables of these are compared with memcmp).  Three kernel
+// families, one table and one launch each: the 3x3 / stride-1 row-streaming kernel, its 4x4 / stride-2 sibling (k_wgrad_rs.hip)
+// and the three 1x1 pixel-stream kernels (k_conv_wgrad.hip; `kind` says which).
+enum { kWgFamRs = 0, kWgFamRs4 = 1, kWgFam1x1 = 2, kWgFams = 3 };
+enum { kWgKindStream = 0, kWgKindStream4Dy = 1, kWgKindStream4X = 2 };
 struct WgradItem {
   const float* src0;
   const float* src1;
   const float* dy;
   float* partial;
   float* bias_partial;
-  int B, Hi, Wi, wsh;      // images, rows, pixels per row (a power of two), log2 Wi
-  int ld0, C0;             // channel stride of X (both sources), channels of src0
+  int B, Hi, Wi, wsh;      // images; input rows, pixels per row; log2 of the OUTPUT row length (rs: = Wi)
+  int Hv, Wv;              // output grid (rs4: Hi / 2, Wi / 2; 1x1: the pixel grid)
+  int ld0, ld1, C0;        // channel strides of the two X sources, channels of src0
+  int Cin, Cout;           // channels of X / of dY
   int ld_dy;               // channel stride of dY
   int MP, NP;              // padded rows / columns of the partial slab
+  int tiles_per_split;     // 1x1: 128-pixel tiles per split
   int rs_R, rs_csh, rs_xsh, rs_S, rs_ppw;
-  unsigned blk0, gx, gy;   // first workgroup of the problem in the grouped grid; splits x (32 x 32 blocks)
-  unsigned pad_;
+  int kind;                // 1x1 family: kWgKind*
+  unsigned blk0, gx, gy;   // first workgroup of the problem in the grouped grid; the problem's own grid is gx x gy
 };
 
 // one tensor of the multi-tensor weight re-pack (k_conv.hip: pack_multi_kernel)

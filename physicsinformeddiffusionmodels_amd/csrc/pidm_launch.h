@@ -42,18 +42,34 @@ struct ReduceQueue {
 // conv_wgrad_rs_multi_kernel launch per flush - a launch boundary (drain, dispatch ramp) per ~40 problems instead of per
 // problem.  The operands (taped activations, gradient buffers) and the partial slabs must stay alive until the flush.
 struct WgradQueue {
-  std::vector<WgradItem> v;
-  std::vector<double> fl;  // algorithmic FLOPs per item (profiling hooks)
-  unsigned nblocks = 0;
-  void push(WgradItem it, double flops) {  // `it` value-initialised and filled field by field by the launcher (tables are memcmp'd)
-    it.blk0 = nblocks;
-    nblocks += it.gx * it.gy;
-    v.push_back(it);
-    fl.push_back(flops);
+  struct Fam {
+    std::vector<WgradItem> v;
+    std::vector<double> fl;  // algorithmic FLOPs per item (profiling hooks)
+    unsigned nblocks = 0;
+    size_t done = 0;         // rows already launched
+  } f[kWgFams];
+  void push(int fam, WgradItem it, double flops) {  // `it` value-initialised and filled field by field by the launcher (tables are memcmp'd)
+    Fam& q = f[fam];
+    it.blk0 = q.nblocks;
+    q.nblocks += it.gx * it.gy;
+    q.v.push_back(it);
+    q.fl.push_back(flops);
   }
-  void clear() { v.clear(); fl.clear(); nblocks = 0; }
+  size_t size() const { return f[0].v.size() + f[1].v.size() + f[2].v.size(); }
+  size_t pending() const { return size() - f[0].done - f[1].done - f[2].done; }
+  void clear() {
+    for (auto& q : f) { q.v.clear(); q.fl.clear(); q.nblocks = 0; q.done = 0; }
+  }
 };
+// rows [first, first + n) of the family's device table, whose workgroups are [blk_base, blk_base + nblocks) of its flat numbering
+int launch_wgrad_multi(int fam, const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
 int launch_wgrad_rs_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
+int launch_wgrad_rs4_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
+int launch_wgrad_1x1_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
+int wgrad_group_splitdiv();     // PIDM_WGRAD_GROUP_SPLITDIV (default 4)
+// the device-side description of one problem: the geometry fields the kernels read + operands + its own grid (k_wgrad_rs.hip)
+WgradItem wgrad_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial,
+                     unsigned gx, unsigned gy, int kind);
 int launch_reduce_multi(const ReduceDesc* table_dev, int ndesc, unsigned nblocks, hipStream_t st, unsigned blk_base = 0);
 int launch_split_reduce(const float* partial, float* dst, const float* bias_partial, float* dbias, int nsplit, int M, int N, int T,
                         int MP, int NP, hipStream_t st);
@@ -111,7 +127,7 @@ bool launch_wgrad_rs(const WgradGeom& plan, const float* src0, const float* src1
 bool wgrad_rs_queueable(const ConvGeom& g, const float* src0, const float* dy, int ld_dy);   // launch_wgrad_rs would take (queue) it
 bool wgrad_rs4_eligible(const ConvGeom& g, int ld_dy);
 bool launch_wgrad_rs4(const WgradGeom& plan, const float* src0, const float* src1, const float* dy, int ld_dy, float* partial,
-                      float* bias_partial, hipStream_t st, WgradGeom* used);
+                      float* bias_partial, hipStream_t st, WgradGeom* used, WgradQueue* wq = nullptr);
 bool launch_wgrad_rs7(const WgradGeom& plan, const float* src0, const float* dy, int ld_dy, float* partial, float* bias_partial,
                       hipStream_t st, WgradGeom* used);
 size_t colsum_ws_bytes(size_t rows, int C);

@@ -171,7 +171,7 @@ struct pidm_unet {
   // with them the cached plans) changed in between
   int plan_B = 0;
   size_t plan_tape_b = 0, plan_tmp_b = 0, plan_defer_b = 0;
-  std::vector<WgradItem> wq_table;                       // host copy of the last uploaded grouped-weight-gradient table
+  std::vector<WgradItem> wq_table[kWgFams];              // host copies of the last uploaded grouped-weight-gradient tables
   const void* wq_table_dev = nullptr;                    // (invalidated together with red_table_dev: same arena region)
   std::vector<ReduceDesc> red_table;                     // host copy of the last uploaded reduction table
   const void* red_table_dev = nullptr;
@@ -204,16 +204,29 @@ static long long g_red_table_uploads = 0;   // pidm_debug_reduce_table_uploads()
 // samples/s (main.py's loop unchanged: 750.0 -> 762.6); the Darcy model (256 channels, full launches) ties: 6018 / 6021 / 6037
 // for graph / forward-graph + eager backward / all eager at batch 64, 7999 / 8077 / 7988 at batch 256 - it keeps the replay, which
 // costs the host a third of the launch-by-launch work.
-// Grouped weight gradients (round 5): PIDM_WGRAD_GROUP = problems per grouped launch of the row-streaming 3x3 weight-gradient
-// kernel (0: off - every problem its own launch, as before; default kWgradGroupDefault; at most 64: the kernel's table lookup
-// is one row per lane).  A flush also happens before every deferred reduction (the gradient phases of the data-parallel exchange).
-static const int kWgradGroupDefault = 64;
-static const size_t kMaxWgradItems = 256;      // rows of the device table (problems of one backward pass)
+// Grouped weight gradients (round 5): PIDM_WGRAD_GROUP = queued problems after which the grouped launches run (0: off - every
+// problem its own launch, as before; default kWgradGroupDefault; a launch takes at most 64 rows: the kernels' table lookup is one
+// row per lane).  Three kernel families - 3x3 / stride-1 row-streaming, 4x4 / stride-2 row-streaming, 1x1 pixel streams - with a
+// table and a launch each.  A flush also happens before every deferred reduction (the gradient phases of the data-parallel exchange).
+static const int kWgradGroupDefault = 1 << 20;   // = one flush per deferred reduction (per gradient phase)
+static const size_t kMaxWgradItems = 128;      // rows of a family's device table (problems of one backward pass)
+// Which passes group: the linear (graph-replayed) ones - the wide models keep their launch-by-launch backward with the weight
+// gradients on the side stream (measured faster there, see backward_eager) - up to PIDM_WGRAD_GROUP_MAXWORK batch x image pixels.
+// Measured per step on one box (profiles/r05_d_wgrad_group_maxpix.txt, r05_c_wgrad_group_fams.txt): batch 16 5.07 -> 4.67 ms,
+// batch 64 8.36 -> 7.99, batch 256 24.9 -> 25.1, batch 512 48.3 -> 49.2-49.8: at large batches every problem fills the chip with
+// long work items by itself, runs right behind the kernel that produced its dY (Infinity-Cache hits) and the backward arena's
+// frames are recycled instead of kept to the end of the pass.
+static const long kWgradGroupMaxWork = 128L * 64 * 64;
+static bool wgrad_group_on(int B, int image, bool side_allowed) {
+  const char* e = knob("PIDM_WGRAD_GROUP_MAXWORK");
+  const long maxw = e ? atol(e) : kWgradGroupMaxWork;
+  const char* g = knob("PIDM_WGRAD_GROUP");
+  return !(g && atoi(g) <= 0) && !side_allowed && (long)B * image * image <= maxw;
+}
 static int wgrad_group_limit() {
   const char* e = knob("PIDM_WGRAD_GROUP");
   int n = e ? atoi(e) : kWgradGroupDefault;
-  if (n < 0) n = 0;
-  return n > 64 ? 64 : n;
+  return n < 0 ? 0 : n;
 }
 static bool backward_eager(int widest) {
   const char* e = knob("PIDM_GRAPH");
@@ -236,9 +249,8 @@ struct Run {
   // fixed-order sums are queued in `rq`, run by ONE reduce_multi launch at the end of backward
   Arena defer;
   ReduceQueue rq;
-  WgradQueue wq;               // weight-gradient problems waiting for their grouped launch (group_on)
-  size_t wq_done = 0;          // rows of wq.v already launched
-  WgradItem* wq_dev = nullptr; // device table (deferred arena, behind the reduction table)
+  WgradQueue wq;               // weight-gradient problems waiting for their grouped launch (group_on), per kernel family
+  WgradItem* wq_dev = nullptr; // device tables (deferred arena, behind the reduction table): kWgFams x kMaxWgradItems rows
   bool group_on = false;
   bool defer_on = false;
   bool overlap = false;        // weight gradients on the side stream (real backward runs only)
@@ -705,7 +717,8 @@ static long lap_knob_signature() {
   const char* gb = knob("PIDM_GRAPH_BWD");        // (the backward plan depends on the side stream too)
   const char* gw = knob("PIDM_GRAPH_BWD_WIDE");
   return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0) +
-         7919L * (wgrad_group_limit() > 0 ? 1 : 0);      // (grouped weight gradients keep the backward arena's frames)
+         7919L * (wgrad_group_on(1, 1, false) ? 1 : 0) +  // (grouped weight gradients keep the backward arena's frames)
+         104729L * (knob("PIDM_WGRAD_GROUP_MAXWORK") ? atol(knob("PIDM_WGRAD_GROUP_MAXWORK")) % 65521 : 0);
 }
 static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
 // decided by the FORWARD (and stored in AttnBlock::projected); the backward replays the stored decision
@@ -871,36 +884,43 @@ static int join_side(Run& r) {
 static int flush_wgrads(Run& r) {
   if (r.dry || !r.group_on) return 0;
   pidm_unet* U = r.U;
-  const size_t n = r.wq.v.size(), first = r.wq_done;
-  if (n <= first) return 0;
-  if (n > kMaxWgradItems) return fail("backward: weight-gradient table overflow (%zu)", n);
-  if (U->wq_table.capacity() < kMaxWgradItems) U->wq_table.reserve(kMaxWgradItems);     // never reallocates: async uploads read it
-  const bool same = U->wq_table_dev == r.wq_dev && U->wq_table.size() >= n &&
-                    memcmp(U->wq_table.data() + first, r.wq.v.data() + first, (n - first) * sizeof(WgradItem)) == 0;
-  if (!same && r.cap) {
-    r.cap->failed = true;        // never captured: the pass is re-run eagerly, which uploads
-  } else if (!same) {
-    if (U->wq_table_dev != r.wq_dev) U->wq_table.clear();
-    U->wq_table.resize(n > U->wq_table.size() ? n : U->wq_table.size());
-    memcpy(U->wq_table.data() + first, r.wq.v.data() + first, (n - first) * sizeof(WgradItem));
-    if (hipMemcpyAsync(r.wq_dev + first, U->wq_table.data() + first, (n - first) * sizeof(WgradItem), hipMemcpyHostToDevice, r.st) != hipSuccess)
-      return fail("backward: weight-gradient table upload failed");
-    ++g_red_table_uploads;           // (counted with the reduction table's: "steady state uploads nothing" covers both)
-    U->wq_table_dev = r.wq_dev;
-  }
-  for (size_t a = first; a < n; a += 64) {
-    const size_t b = a + 64 < n ? a + 64 : n;
-    const unsigned blk0 = r.wq.v[a].blk0, blk1 = (b < n) ? r.wq.v[b].blk0 : r.wq.nblocks;
-    if (prof_enabled()) {
-      double fl = 0.0;
-      for (size_t i = a; i < b; ++i) fl += r.wq.fl[i];
-      prof_begin_launch(3, fl, r.st);
+  for (int fam = 0; fam < kWgFams; ++fam) {
+    WgradQueue::Fam& q = r.wq.f[fam];
+    const size_t n = q.v.size(), first = q.done;
+    if (n <= first) continue;
+    if (n > kMaxWgradItems) return fail("backward: weight-gradient table overflow (%zu)", n);
+    WgradItem* dev = r.wq_dev + (size_t)fam * kMaxWgradItems;
+    std::vector<WgradItem>& host = U->wq_table[fam];
+    if (host.capacity() < kMaxWgradItems) host.reserve(kMaxWgradItems);     // never reallocates: async uploads read it
+    const bool same = U->wq_table_dev == r.wq_dev && host.size() >= n &&
+                      memcmp(host.data() + first, q.v.data() + first, (n - first) * sizeof(WgradItem)) == 0;
+    if (!same && r.cap) {
+      r.cap->failed = true;        // never captured: the pass is re-run eagerly, which uploads
+    } else if (!same) {
+      if (U->wq_table_dev != r.wq_dev) {
+        for (auto& h : U->wq_table) h.clear();
+        U->wq_table_dev = r.wq_dev;
+      }
+      host.resize(n > host.size() ? n : host.size());
+      memcpy(host.data() + first, q.v.data() + first, (n - first) * sizeof(WgradItem));
+      if (hipMemcpyAsync(dev + first, host.data() + first, (n - first) * sizeof(WgradItem), hipMemcpyHostToDevice, r.st) != hipSuccess)
+        return fail("backward: weight-gradient table upload failed");
+      ++g_red_table_uploads;       // (counted with the reduction table's: "steady state uploads nothing" covers both)
     }
-    const int rc = launch_wgrad_rs_multi(r.wq_dev, (int)a, (int)(b - a), blk0, blk1 - blk0, r.st);
-    if (prof_enabled()) prof_end_launch(r.st);
-    if (rc) return rc;
+    for (size_t a = first; a < n; a += 64) {
+      const size_t b = a + 64 < n ? a + 64 : n;
+      const unsigned blk0 = q.v[a].blk0, blk1 = (b < n) ? q.v[b].blk0 : q.nblocks;
+      if (prof_enabled()) {
+        double fl = 0.0;
+        for (size_t i = a; i < b; ++i) fl += q.fl[i];
+        prof_begin_launch(fam == kWgFam1x1 ? 1 : 3, fl, r.st);      // (the 1x1 streams run on the fp32 MFMA)
+      }
+      const int rc = launch_wgrad_multi(fam, dev, (int)a, (int)(b - a), blk0, blk1 - blk0, r.st);
+      if (prof_enabled()) prof_end_launch(r.st);
+      if (rc) return rc;
+    }
+    q.done = n;
   }
-  r.wq_done = n;
   return 0;
 }
 
@@ -915,7 +935,7 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
   if (L.transposed) {
     if (make_geom(&g, 0, r.B, 2 * L.H, 2 * L.H, L.Cout, 0, ld_dy, 0, L.C0, 4, 4, 2, 1, 0, 4, 4)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
-    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, wst, r.q()));
+    RUN(launch_wgrad(g, dy, nullptr, x0, L.C0, U->G[L.w], nullptr, part, wst, r.q(), r.wgq()));
     if (L.b >= 0) {
       float* cpart = r.part_alloc(colsum_ws_bytes((size_t)r.B * Ho * Ho, L.Cout));
       RUN(launch_colsum(dy, (size_t)r.B * Ho * Ho, L.Cout, ld_dy, U->G[L.b], cpart, wst, r.q()));
@@ -924,7 +944,7 @@ static int conv_wgrad(Run& r, const ConvLayer& L, const float* x0, const float* 
     if (geom_fwd_layer(L, r.B, 0, &g)) return -1;
     float* part = r.part_alloc(wgrad_ws_bytes(g));
     RUN(launch_wgrad(g, x0, x1, dy, ld_dy, U->G[L.w], L.b >= 0 ? U->G[L.b] : nullptr, part, wst, r.q(), r.wgq()));
-    if (r.wgq() && r.wq.v.size() - r.wq_done >= (size_t)wgrad_group_limit() && flush_wgrads(r)) return -1;
+    if (r.wgq() && r.wq.pending() >= (size_t)wgrad_group_limit() && flush_wgrads(r)) return -1;
   }
   return 0;
 }
@@ -1263,8 +1283,7 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
   ReduceDesc* red_dev = reinterpret_cast<ReduceDesc*>(r.defer.alloc(kMaxReduceDesc * sizeof(ReduceDesc) / 4));
   size_t red_done = 0;
   r.wq.clear();
-  r.wq_done = 0;
-  r.wq_dev = reinterpret_cast<WgradItem*>(r.defer.alloc(kMaxWgradItems * sizeof(WgradItem) / 4));
+  r.wq_dev = reinterpret_cast<WgradItem*>(r.defer.alloc(kWgFams * kMaxWgradItems * sizeof(WgradItem) / 4));
   const int n_phases = U->n_phases;
   float* dss = r.tmp.alloc((size_t)B * U->ss_total);
   float* g_o = r.tmp.alloc((size_t)B * HW * od);
@@ -1449,7 +1468,7 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
   r.U = U; r.B = B; r.train = training != 0; r.dry = true; r.st = nullptr; r.wpack = nullptr;
   r.tape.dry = r.tmp.dry = r.defer.dry = true;
   r.side_allowed = backward_eager(widest_level(U));
-  r.group_on = wgrad_group_limit() > 0 && !r.side_allowed;      // as backward_body decides it
+  r.group_on = wgrad_group_on(B, U->cfg.image_size, r.side_allowed);      // as backward_body decides it
   // state touched by a dry run is restored afterwards
   pidm_unet saved_ptrs = *U;
   r.scratch_floats = scratch_floats_needed(U, B);
@@ -1674,9 +1693,7 @@ static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x
   // synchronises them with events), while the linear graph equals the eager step with the overlap (11.21 ms).
   r.side_allowed = backward_eager(widest_level(h));
   r.overlap = h->side_ok && !prof_enabled() && !cap && r.side_allowed;
-  // grouped weight gradients for the passes that are linear anyway (graph replay: the Darcy model); the wide models keep their
-  // launch-by-launch backward with the weight gradients on the side stream (measured faster there, see backward_eager)
-  r.group_on = wgrad_group_limit() > 0 && !r.side_allowed;
+  r.group_on = wgrad_group_on(B, h->cfg.image_size, r.side_allowed);
   if (cap && cap_begin(r)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");

@@ -16,6 +16,16 @@ from physicsinformeddiffusionmodels_amd._engine import get_engine
 from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
 
 
+@pytest.fixture(autouse=True)
+def _same_split_plan(monkeypatch):
+    """Bit-identity of replay and launch-by-launch execution is a statement about the SAME arithmetic.  A linear (replayed) backward
+    queues its weight-gradient problems for grouped launches with a quarter of the splits per problem by default
+    (PIDM_WGRAD_GROUP_SPLITDIV=4: another fixed summation order - bit-identical run to run, tests/test_unet_engine.py::
+    test_grouped_weight_gradients), the launch-by-launch backward keeps its weight gradients on the side stream with the full
+    split count; with the divisor at 1 both forms run the same split plan and must agree to the bit."""
+    monkeypatch.setenv("PIDM_WGRAD_GROUP_SPLITDIV", "1")
+
+
 def _counts(L):
     a = (C.c_longlong * 4)()
     L.check(L.pidm_debug_launch_counts(a))

@@ -610,7 +610,8 @@ def main(argv=None, test_env=None):
             "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
             "kernel": "implicit-GEMM convolutions: fwd, dgrad, wgrad (3x3, 4x4/s2, 7x7 and the compute-bound 1x1: conv3x3_rs_kernel (rows of 32 / 64 "
                       "pixels) / conv3x3_split*_kernel / conv1x1_split_kernel / conv7x7_split_kernel forward + input gradient, "
-                      "conv_wgrad_rs*_kernel weight gradient - 6 bf16 "
+                      "conv_wgrad_rs*_kernel weight gradient (up to batch 128 the ~60 weight-gradient problems of a pass as three grouped "
+                      "launches: conv_wgrad_rs_multi / _rs4_multi / _1x1_multi_kernel) - 6 bf16 "
                       "MFMAs per fp32 product on 3-piece split operands; memory-bound 1x1 layers, their weight gradients and the linears: "
                       "fp32 MFMA)",
             "peak_note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = the fp32 MFMA's dense peak, the rate an fp32 "
@@ -627,7 +628,9 @@ def main(argv=None, test_env=None):
             "timing": "one HIP event per library launch (pidm_prof_kernels_begin / _collect) in extra steps after the timed region: a "
                       "launch's time = the interval since the previous launch's event, launch by launch on one stream - graph replay and "
                       "the weight-gradient side-stream overlap are OFF while the hooks are on (a kernel that shares the chip has no "
-                      "duration of its own); `value` is measured with both on",
+                      "duration of its own); `value` is measured with both on.  An interval contains the event itself and the launch gap: "
+                      "~3 us per launch more than the kernel-only durations of rocprofv3 (profiles/r05_*kernel_stats*.csv) - "
+                      "all_kernels_ms_per_step exceeds ms_per_step by that",
             "all_kernels_ms_per_step": round(all_ms / nprof, 3),
             "launches_per_step": conv_n // nprof, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "kernel_ms_per_step": round(conv_ms / nprof, 3),

@@ -75,7 +75,7 @@ class NativeComm:
             torch.cuda.synchronize(self.device)
         got = x.cpu().tolist()
         want = [n * (n + 1) / 2.0, (n + 1) / 2.0]
-        if got != want:
+        if any(abs(g - w) > 1e-5 * w for g, w in zip(got, want)):     # (the mean of small integers: exact for 2^k ranks, a rounding away otherwise)
             raise RuntimeError(f"pidm_allreduce_f32 self-check: got sum {got[0]}, mean {got[1]}; expected {want[0]}, {want[1]} (rank {self.rank} of {n})")
 
     def close(self):

@@ -1361,8 +1361,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     attr_done = true;
   }
-  // (a problem that goes to the queue is accounted for by the grouped launch: flush_wgrads declares the FLOPs of its items)
-  const bool prof = prof_enabled() && !wq;
+  const bool prof = prof_enabled();
   if (prof) {
     char lab[160];
     snprintf(lab, sizeof(lab), "wgrad B%d %dx%d Cin%d Cout%d k%dx%d nph%d", g.B, g.Hv, g.Wv, g.Cin, g.Cout, g.KH, g.KW, g.nph);
@@ -1468,11 +1467,15 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<9>), grid, dim3(256), lds, st, wg, src0, src1 ? src1 : src0, dy, partial, bias_partial);
   const bool queued = wq && wq->size() > queued0;        // nothing was enqueued: the problem waits for flush_wgrads
-  if (queued)                                            // (what the grouped launch declares to the profiling hooks for this row)
+  if (queued) {
+    // the grouped launch accounts for this row (flush_wgrads declares the FLOPs of its items to the profiling hooks)
     for (auto& q : wq->f)
       if (!q.fl.empty() && q.fl.size() == q.v.size() && q.v.back().partial == partial) q.fl.back() = 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin * T;
-  if (prof) prof_end_launch(st);
-  if (!queued) PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
+    if (prof) prof_cancel_last();
+  } else {
+    if (prof) prof_end_launch(st);
+    PIDM_CHECK_LAUNCH("conv_wgrad_kernel");
+  }
   if (defer) {   // the caller keeps `workspace` alive until its reduce_multi launch
     defer->push(partial, dw_ref, bias_partial, dbias, (size_t)wg.MP * T * wg.NP, wg.nsplit, g.Cout, g.Cin, T, wg.MP, wg.NP);
     return 0;

@@ -89,6 +89,14 @@ void prof_end_launch(hipStream_t st) {
   if (g_prof_marks) return;
   (void)hipEventRecord(g_prof.back().b, st);
 }
+void prof_cancel_last() {
+  if (g_prof_marks) { g_mark_pending.valid = false; return; }
+  if (!g_prof.empty()) {
+    (void)hipEventDestroy(g_prof.back().a);
+    (void)hipEventDestroy(g_prof.back().b);
+    g_prof.pop_back();
+  }
+}
 void prof_reclass_last(int cls) {
   if (g_prof_marks) {
     if (g_mark_pending.valid) g_mark_pending.cls = cls;

@@ -19,6 +19,7 @@ void prof_set_label(const char* label);   // attached to the next prof_begin_lau
 void prof_begin_launch(int cls, double work, hipStream_t st);
 void prof_end_launch(hipStream_t st);
 void prof_reclass_last(int cls);          // the launcher learned which kernel took the launch (2 / 3 = split form of class 0 / 1)
+void prof_cancel_last();                  // nothing was launched after all (the problem went to a grouped launch's queue)
 // per-KERNEL timing (pidm_prof_kernels_begin / _collect, round 5): while on, every PIDM_CHECK_LAUNCH records one event on the
 // registered stream; a launch's time = the interval since the previous library launch's event (launches are back to back on one
 // stream: graphs and the side-stream overlap are off while any profiling hook is on).  PIDM_PROF_NAME names the kernel a shared

@@ -2,6 +2,12 @@
 # gradient-exchange legs (darcy, mechanics; torch.distributed RCCL and the C-ABI communicator) -> rocprofv3 kernel stats -> batch sweep
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp PYTHONPATH=$R; o=$R/gpurun_out/${1:-r05fin}; rm -rf $o; mkdir -p $o
 timeout 900 python -m pytest tests -m gpu -x -q > $o/pytest.log 2>&1; echo "pytest rc=$?" >> $o/pytest.log; grep -E "passed|failed|rc=" $o/pytest.log | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $o/smoke.log 2>&1; tail -1 $o/smoke.log
+# ---- two ranks on this one GPU over gloo (debug mode of bench.py): the N > 1 control flow on hardware, and the exchange's negotiation for
+# real - RCCL refuses two ranks on one device, so every rank must come back to torch.distributed together (exchange.collective_note)
+PIDM_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --warmup 4 --no-cpu-baseline --no-alt --no-roofline 2>$o/share_gpu.err | tail -1 > $o/bench_two_ranks_one_gpu.json
+python -c "
+import json; d=json.load(open('$o/bench_two_ranks_one_gpu.json')); print('2 ranks / 1 GPU:', d['value'], d['n_gpus'], d['exchange'], d['per_rank'])" 2>&1 | cut -c1-900
 # ---- PMC counters of the split-form 3x3 kernels (three separate --pmc passes each, kernel-trace only) ----
 bash tools/pmc.sh sp64 $R/tools/bench_one.py 64 32 0 32 3 1 1 0 64 3 > /dev/null 2>&1
 bash tools/pmc.sh sp16 $R/tools/bench_one.py 16 128 0 128 3 1 1 0 64 3 > /dev/null 2>&1

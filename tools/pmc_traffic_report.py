@@ -7,7 +7,7 @@ import collections, csv, glob, json, sys
 
 d, batch = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "darcy"
-CLASSES = [("conv7x7", "conv"), ("conv1x1", "conv"), ("conv_igemm", "conv"), ("conv3x3_stream", "conv"), ("conv3x3_split", "conv"), ("conv_wgrad", "conv"), ("lap_", "attn"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
+CLASSES = [("conv7x7", "conv"), ("conv1x1", "conv"), ("conv_igemm", "conv"), ("conv3x3_stream", "conv"), ("conv3x3_split", "conv"), ("conv3x3_rs", "conv"), ("conv_wgrad", "conv"), ("lap_", "attn"), ("wgrad_reduce", "conv_aux"), ("reduce_multi", "conv_aux"),
            ("pack_", "conv_aux"), ("clip_adam", "optimizer"), ("sqsum", "optimizer"),
            ("colsum", "conv_aux"), ("gn_", "norm"), ("layernorm", "norm"), ("la_", "attn"), ("mid_attn", "attn"),
            ("darcy", "darcy"), ("qsample", "darcy"), ("mech_", "mechanics"), ("bilinear", "mechanics"), ("psample", "sampler")]

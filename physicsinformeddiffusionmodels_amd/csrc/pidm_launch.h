@@ -38,9 +38,13 @@ struct ReduceQueue {
   }
 };
 // Weight-gradient problems whose launch is DEFERRED and grouped (round 5): nothing inside a backward pass reads a weight gradient
-// before the deferred reduction, so the 3x3 / stride-1 problems of a pass are collected here and run by ONE
-// conv_wgrad_rs_multi_kernel launch per flush - a launch boundary (drain, dispatch ramp) per ~40 problems instead of per
-// problem.  The operands (taped activations, gradient buffers) and the partial slabs must stay alive until the flush.
+// before the deferred reduction, so the problems of a pass that one of three streaming kernel families takes (kWgFam*: 3x3 /
+// stride-1 row-streaming, 4x4 / stride-2 row-streaming, 1x1 pixel streams) are collected here and run by ONE launch per family
+// and flush (conv_wgrad_rs_multi_kernel, _rs4_multi_, _1x1_multi_).  Together they fill the chip, so each problem is planned with
+// a quarter of the splits it would need alone (wgrad_group_splitdiv): fewer, longer work items and a quarter of the partial slabs
+// - that, not the saved launch boundaries (~1 us each inside a replayed graph), is what pays.  The operands
+// (taped activations, gradient buffers) and the partial slabs must stay alive until the flush: the engine keeps the backward
+// arena's frames while grouping is on.
 struct WgradQueue {
   struct Fam {
     std::vector<WgradItem> v;

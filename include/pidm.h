@@ -309,10 +309,12 @@ int pidm_debug_launch_counts(long long* out4);
  * and averages the gradients with an RCCL all-reduce over xGMI.  One communicator per process (= per GPU).  RCCL is bound with
  * dlopen at first use.  The reference-side binding: parallel.py (`PIDM_DP_NATIVE=1`) or any host with a way to hand rank 0's 128-byte
  * id to the other ranks.
+ *   pidm_comm_available  every rank: 0 when RCCL could be bound, -1 + pidm_last_error() otherwise; starts no bootstrap thread
  *   pidm_comm_unique_id  rank 0: 128 opaque bytes to be sent to every rank (ncclGetUniqueId)
  *   pidm_comm_init       every rank, with the same id; uses the calling thread's current HIP device (ncclCommInitRank)
  *   pidm_allreduce_f32   in place on `buf[0..count)`, enqueued on `stream`; average != 0: mean over ranks, else sum
  *   pidm_comm_destroy    */
+int pidm_comm_available(void);
 int pidm_comm_unique_id(void* out128);
 int pidm_comm_init(int rank, int world, const void* unique_id128, void** comm);
 int pidm_allreduce_f32(void* comm, float* buf, size_t count, int average, void* stream);

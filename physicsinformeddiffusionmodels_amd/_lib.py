@@ -116,6 +116,7 @@ class PidmLib:
         self._sig("pidm_debug_stream_trace", [vp])
         self._sig("pidm_debug_conv_rs_trace", [C.POINTER(C.c_ulonglong)])
         self._sig("pidm_reload_knobs", [])
+        self._sig("pidm_comm_available", [])
         self._sig("pidm_comm_unique_id", [vp])
         self._sig("pidm_comm_init", [i, i, vp, C.POINTER(vp)])
         self._sig("pidm_allreduce_f32", [vp, vp, sz, i, vp])

@@ -13,7 +13,7 @@
 //
 // Kernels in this file (round 4: the fp32-MFMA forward kernels moved to k_conv_fp32.hip, every weight gradient and the deferred
 // reductions to k_conv_wgrad.hip / k_wgrad_rs.hip):
-//   conv3x3_split_kernel<NW,MODE> / conv3x3_split_ws_kernel<NW,MODE>   3x3 and 4x4/s2 forward / dgrad on the bf16 pipe (split form)
+//   conv3x3_split_kernel<NW,MODE> / conv3x3_split_ws_kernel<NW,MODE,NPW>   3x3 and 4x4/s2 forward / dgrad on the bf16 pipe (split form)
 //   conv1x1_split_kernel<NTG,NTGP>, conv7x7_split_kernel<CIN>          compute-bound 1x1 convolutions as a GEMM, the 7x7 init conv
 //   pack_kernel / pack_multi_kernel                reference weight layouts -> [Cout_p][tap][K_p] + bf16 pieces (all tensors in one launch)
 //   make_geom / launch_conv / the C ABI of the convolutions
@@ -59,7 +59,21 @@ static int split_row_pad(int Wv) {
   const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
   return (on && Wv <= 16) ? 32 : 0;
 }
+#ifndef PIDM_WS_LEAVE_FETCH
+#define PIDM_WS_LEAVE_FETCH 1   // 0: the producer waves drain every load before each stage barrier (rounds 3-5; A/B builds)
+#endif
+static constexpr bool kWsLeaveFetch = PIDM_WS_LEAVE_FETCH != 0;
 static constexpr int kSplitSlab = 9 * 32 * kSplitRow; // bytes of pre-split weights per stage (rows padded like the LDS rows)
+
+// Workgroup -> position in the launch's item order.  Hardware places workgroup b on XCD b % 8 (observed, relied on for speed only),
+// and every XCD has its own L2: with the plain order the 32 resident workgroups of an XCD are spread over ALL n-tiles of a layer
+// (every XCD streams every weight slab through its L2), with xcd = a > 0 the workgroups of one XCD take CONSECUTIVE items - one or a
+// few n-tiles' slabs shared by all of them.  Needs a grid that is a multiple of 8 (else: plain order).
+__device__ __forceinline__ int split_vblock(int xcd) {
+  const int b = (int)blockIdx.x, n = (int)gridDim.x;
+  if (xcd <= 0 || (n & 7)) return b;
+  return (b & 7) * (n >> 3) + (b >> 3);
+}
 
 // Position of a stage inside a workgroup's range of work items, kept INCREMENTALLY: stage -> (item, chunk) -> (n-tile, m-tile) ->
 // (image group, row tile) used to be five integer divisions by launch-time values at the top of every stage; the compiler expands
@@ -131,7 +145,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
   const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;     // 16-channel chunks per tile (MODE 1: 4 phases x Cin)
   const int CCH = g.Cin >> 4;
   const int ntn = g.Cout >> 5;
-  const int item0 = blockIdx.x * items_per_wg;
+  const int item0 = split_vblock(g.xcd) * items_per_wg;
   const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
   const int nst = my_items * NCH;
 
@@ -402,15 +416,21 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 // for the whole stage (~900 of ~3850 cycles).  Same buffers, same barrier per stage, same arithmetic in the same order: results
 // are bit-identical to conv3x3_split_kernel.  768 (NW = 8) or 512 (NW = 4) threads.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, int MODE>
-__global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+template <int NW, int MODE, int NPW>
+__global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                                         const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                                         const float* __restrict__ residual, float* __restrict__ out,
-                                                                        int n_items, int items_per_wg) {
+                                                                        int n_items, int items_per_wg, int trace) {
   constexpr int RB = kSplitRow, T = (MODE == 0) ? 9 : 4;
-  constexpr int NPW = 4, NPT = 64 * NPW;                    // producer waves / threads
+  // NPW producer waves (4, or 8 = two per SIMD, round 6): what a producer wave spends per stage is ISSUE time - ~150-185 cycles per
+  // LDS-direct copy and ~7 per vector instruction beside the consumers' MFMAs (stamps: 8 copies + the fetch = 2400-2600 cycles, the
+  // staging arithmetic 600, against 2200-2400 cycles of the consumers' taps): with 4 producers the CONSUMERS waited 700-1100 cycles
+  // per stage at the barrier; 8 halve every producer's share
+  constexpr int NPT = 64 * NPW;                             // producer threads
   constexpr int NB = ((MODE == 0) ? 32 : 16) / NPW;         // 1 KB pieces of the weight slab per producer wave
-  constexpr int KA = NW / 2;                                // staging units (8 channels of one pixel) per producer thread
+  constexpr int KA = 2 * NW / NPW;                          // staging units (8 channels of one pixel) per producer thread
+  static_assert(NPW == 4 || NPW == 8, "producer waves: one or two per SIMD");
+  static_assert(KA >= 1 && NB >= 1, "every producer wave stages something");
   constexpr int SLAB = T * 32 * kSplitRow, BPAD = (MODE == 0) ? 512 : 2048;
   HIP_DYNAMIC_SHARED(float, smemf)
   char* smem = reinterpret_cast<char*>(smemf);
@@ -425,7 +445,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   const int NCH = (MODE == 1 ? g.Kw : g.Cin) >> 4;
   const int CCH = g.Cin >> 4;
   const int ntn = g.Cout >> 5;
-  const int item0 = blockIdx.x * items_per_wg;
+  const int item0 = split_vblock(g.xcd) * items_per_wg;
   const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
   const int nst = my_items * NCH;
 
@@ -469,6 +489,9 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     long long l_rb = 0;
     SplitCursor lc;               // the stage whose activations are being fetched
     split_cursor_init<MODE>(lc, item0, nst, g.tiles_m, tpi, ntn);
+    // PIDM_STREAM_TRACE=1: cycle stamps of workgroup 0 - slot 0: consumer wave 0 [stage top, taps done, epilogue done, past barrier],
+    // slot 1: producer wave 0 [iteration top, set W landed, staging written, past barrier]
+    const int tr_p = (trace && blockIdx.x == 0 && lane == 0 && pw == 0) ? 128 : -1;
 #define PIDM_WS_STAGE()                                                                                            \
   {                                                                                                                \
     const int ch__ = lc.ch, tq__ = lc.tq;                                                                          \
@@ -486,12 +509,21 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   {                                                                                                                \
     const int b__ = l_b0 + a_im[k_], iy__ = l_iy0 + a_hy[k_];                                                      \
     const bool ok__ = (b__ < g.B) & (iy__ >= 0) & (iy__ < (MODE == 1 ? g.Hv : g.Hi));                              \
-    const f32x4* p__ = reinterpret_cast<const f32x4*>(ok__ ? l_sp + l_rb + a_ro[k_] : l_sp + a_vo[k_]);            \
-    ra[set_][k_][0] = p__[0];                                                                                      \
-    ra[set_][k_][1] = p__[1];                                                                                      \
+    const char* p__ = ok__ ? l_sp + l_rb + a_ro[k_] : l_sp + a_vo[k_];                                             \
+    if (kWsLeaveFetch) {                                                                                           \
+      PIDM_UNTRACKED_LOAD_F32X4(ra[set_][k_][0], p__, 0);                                                          \
+      PIDM_UNTRACKED_LOAD_F32X4(ra[set_][k_][1], p__, 16);                                                         \
+    } else {                                                                                                       \
+      ra[set_][k_][0] = reinterpret_cast<const f32x4*>(p__)[0];                                                    \
+      ra[set_][k_][1] = reinterpret_cast<const f32x4*>(p__)[1];                                                    \
+    }                                                                                                              \
     akeep[set_][k_] = ok__ ? 1.f : 0.f;                                                                            \
   }
-#define PIDM_WS_COPY_B(k_, wn_, buf_) pidm_glds_b128((wn_) + 1024 * (pw + NPW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (pw + NPW * (k_)));
+#define PIDM_WS_COPY_B(k_, wn_, buf_)                                                                              \
+  {                                                                                                                \
+    if (kWsLeaveFetch) pidm_glds_b128_untracked((wn_) + 1024 * (pw + NPW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (pw + NPW * (k_))); \
+    else pidm_glds_b128((wn_) + 1024 * (pw + NPW * (k_)) + b_lane, (buf_) + b_reg + 1024 * (pw + NPW * (k_)));      \
+  }
 #define PIDM_WS_WRITE_A(set_, k_, buf_)                                                                            \
   {                                                                                                                \
     const f32x4 v0__ = ra[set_][k_][0] * akeep[set_][k_], v1__ = ra[set_][k_][1] * akeep[set_][k_];                \
@@ -510,13 +542,22 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
 #define PIDM_WS_ITER(s_, setL_, setW_)                                                                             \
   {                                                                                                                \
     const char* wn1__ = l_wn;                                                                                      \
+    if (tr_p >= 0 && (s_) < 32) g_stream_trace[tr_p + 4 * (s_) + 0] = clock64();                                   \
     _Pragma("unroll") for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, wn1__, bufn)                                  \
+    __builtin_amdgcn_sched_barrier(0);   /* (issue order: NB copies, then the 2 KA loads of the fetch - the waits count on it) */ \
     split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);                                                    \
     PIDM_WS_STAGE()                                                                                                \
     _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(setL_, k)                                        \
+    /* set setW_ (fetched by the previous iteration, left in flight over its barrier) has landed once at most this iteration's */ \
+    /* NB copies + 2 KA loads are outstanding */                                                                   \
+    if (kWsLeaveFetch) { PIDM_WAIT_VMEM_LEAVE(NB + 2 * KA); __builtin_amdgcn_sched_barrier(0); }                    \
+    if (tr_p >= 0 && (s_) < 32) g_stream_trace[tr_p + 4 * (s_) + 1] = clock64();                                   \
     _Pragma("unroll") for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(setW_, k, bufn)                                 \
-    PIDM_WAIT_VMEM();                /* the LDS-direct copies (and the fetch) have landed */                       \
+    if (tr_p >= 0 && (s_) < 32) g_stream_trace[tr_p + 4 * (s_) + 2] = clock64();                                   \
+    /* the LDS-direct copies have landed; the 2 KA loads of the fetch (stage s+2, consumed by the NEXT iteration) stay in flight */ \
+    if (kWsLeaveFetch) PIDM_WAIT_VMEM_LEAVE(2 * KA); else PIDM_WAIT_VMEM();                                        \
     __syncthreads();                 /* buffer (s+1)&1 complete (this wave's part), buffer s&1 free */             \
+    if (tr_p >= 0 && (s_) < 32) g_stream_trace[tr_p + 4 * (s_) + 3] = clock64();                                   \
     char* tswap__ = bufc; bufc = bufn; bufn = tswap__;                                                             \
   }
     // prologue: stage 0 into bufc; the activations of stage 1 stay in registers (set 1)
@@ -525,13 +566,14 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
     for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(0, k)
 #pragma unroll
     for (int k = 0; k < NB; ++k) PIDM_WS_COPY_B(k, l_wn, bufc)
+    if (kWsLeaveFetch) { PIDM_WAIT_VMEM_LEAVE(NB); __builtin_amdgcn_sched_barrier(0); }   // set 0 has landed (the copies are behind it)
 #pragma unroll
     for (int k = 0; k < KA; ++k) PIDM_WS_WRITE_A(0, k, bufc)
     split_cursor_next<MODE>(lc, NCH, CCH, g.tiles_m, tpi, ntn);
     PIDM_WS_STAGE()
 #pragma unroll
     for (int k = 0; k < KA; ++k) PIDM_WS_LOAD_A(1, k)
-    PIDM_WAIT_VMEM();
+    if (kWsLeaveFetch) PIDM_WAIT_VMEM_LEAVE(2 * KA); else PIDM_WAIT_VMEM();
     __syncthreads();
     for (int s = 0; s < nst; s += 2) {
       PIDM_WS_ITER(s, 0, 1)
@@ -555,7 +597,9 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
   __syncthreads();                   // stage 0 is in bufc
   f32x16 acc, accb;
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+  const int tr_c = (trace && blockIdx.x == 0 && lane == 0 && wave == 0) ? 0 : -1;
   for (int s = 0; s < nst; ++s) {
+    if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 0] = clock64();
     const float bv_pre = (bias ? bias : reinterpret_cast<const float*>(ws))[cs.tn * 32 + l31];
     int oy0 = 0, ox0 = 0;
     if (MODE == 1) {
@@ -609,6 +653,7 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_WS_FRAGS
+    if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 1] = clock64();
     if (cs.ch == NCH - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += accb[r];
@@ -661,8 +706,10 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
       }
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
     }
+    if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 2] = clock64();
     split_cursor_next<MODE>(cs, NCH, CCH, g.tiles_m, tpi, ntn);
     __syncthreads();               // buffer (s+1)&1 complete, buffer s&1 free
+    if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 3] = clock64();
     char* tswap = bufc; bufc = bufn; bufn = tswap;
   }
 }
@@ -681,16 +728,19 @@ __global__ void __launch_bounds__(64 * NW + 256) conv3x3_split_ws_kernel(ConvGeo
 // ---------------------------------------------------------------------------------------------------
 // NTGP = tiles per group in the PACKED piece layout (4 or 2), NTG <= NTGP the tiles a workgroup takes: launches with fewer than one
 // item per CU at NTG = 4 run with NTG = 2 on the same packing (a stage's weights are then two runs of 7 KB, one per k-step).
-template <int NTG, int NTGP>
-__global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+// NPW = producer waves (4 or 8: see conv3x3_split_ws_kernel; a 1x1 stage has only 12 NTG MFMAs per consumer wave to hide them under).
+template <int NTG, int NTGP, int NPW>
+__global__ void __launch_bounds__(256 + 64 * NPW) conv1x1_split_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                             const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, float* __restrict__ out, int n_items,
                                                             int items_per_wg, int tiles_m) {
-  constexpr int RB = kSplitRow, NW = 4, NPT = 256, KS = 2;
+  constexpr int RB = kSplitRow, NW = 4, NPT = 64 * NPW, KS = 2;
+  constexpr int UA = 512 / NPT;                         // staging units (8 channels of a pixel; 512 per stage) per producer thread
   constexpr int ABYTES = KS * 128 * RB;                 // activation block of a stage
   constexpr int SLAB = KS * NTG * 32 * RB;              // weights of a stage in LDS: [k-step][tile][32 rows]
   constexpr int KRUN = NTG * 32 * RB;                   // ... of one k-step: a whole number of KB (14 / 7), contiguous in the packing
   constexpr int NPIECE = KRUN / 1024;
+  constexpr int NCOPY = KS * ((NPIECE + NPW - 1) / NPW);   // LDS-direct copies per producer wave and stage
   static_assert(NTG == 2 || NTG == 4, "a k-step's run must be a whole number of KB");
   static_assert(NTGP % NTG == 0, "a workgroup's tiles lie inside one packed group");
   constexpr int BUFSZ = ABYTES + SLAB;
@@ -700,7 +750,7 @@ __global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const fl
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int NCH = g.Cin >> 5;                           // stages per item
-  const int item0 = blockIdx.x * items_per_wg;
+  const int item0 = split_vblock(g.xcd) * items_per_wg;
   const int my_items = (item0 + items_per_wg <= n_items) ? items_per_wg : n_items - item0;
   const int nst = my_items * NCH;
   char* bufc = smem;
@@ -719,16 +769,16 @@ __global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const fl
     // =============================== producer waves ===============================
     const int pt = tid - 64 * NW, pw = wave - NW;
     // unit u = pt + 256 k: 8 channels (group q of the stage's 32) of pixel px
-    int a_lds[2];
-    unsigned a_go[2];
+    int a_lds[UA];
+    unsigned a_go[UA];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < UA; ++k) {
       const int u = pt + NPT * k, px = u >> 2, q = u & 3;
       a_lds[k] = ((q >> 1) * 128 + px) * RB + 48 * (q & 1);
       a_go[k] = (unsigned)(px * g.ld0 + 8 * q) * 4u;
     }
     const unsigned b_lane = 16u * lane;
-    f32x4 ra[2][2][2];
+    f32x4 ra[2][UA][2];
     const char* l_sp = reinterpret_cast<const char*>(src0);
     const char* l_wn = reinterpret_cast<const char*>(ws);
 #define PIDM_G1_STAGE()                                                                                            \
@@ -741,19 +791,31 @@ __global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const fl
            ((((size_t)((c_tq * NTG) / NTGP) * (2 * NCH) + 2 * c_ch) * NTGP + (c_tq * NTG) % NTGP) * 32) * RB;       \
   }
 #define PIDM_G1_LOAD_A(set_)                                                                                       \
-  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                  \
-    const f32x4* p__ = reinterpret_cast<const f32x4*>(l_sp + a_go[k]);                                             \
-    ra[set_][k][0] = p__[0];                                                                                       \
-    ra[set_][k][1] = p__[1];                                                                                       \
+  _Pragma("unroll") for (int k = 0; k < UA; ++k) {                                                                  \
+    const char* p__ = l_sp + a_go[k];                                                                              \
+    if (kWsLeaveFetch) {                                                                                           \
+      PIDM_UNTRACKED_LOAD_F32X4(ra[set_][k][0], p__, 0);                                                           \
+      PIDM_UNTRACKED_LOAD_F32X4(ra[set_][k][1], p__, 16);                                                          \
+    } else {                                                                                                       \
+      ra[set_][k][0] = reinterpret_cast<const f32x4*>(p__)[0];                                                     \
+      ra[set_][k][1] = reinterpret_cast<const f32x4*>(p__)[1];                                                     \
+    }                                                                                                              \
   }
+  /* every producer wave issues the SAME number of copies (NCOPY: the waits count them): a wave whose last piece index would  */ \
+  /* lie beyond the run repeats the run's last piece - the same bytes to the same place                                         */ \
 #define PIDM_G1_COPY_B(wn_, buf_)                                                                                  \
   _Pragma("unroll") for (int ks__ = 0; ks__ < KS; ++ks__)                                                          \
-    _Pragma("unroll") for (int k = 0; k < (NPIECE + 3) / 4; ++k)                                                   \
-      if (pw + 4 * k < NPIECE)                                                                                     \
-        pidm_glds_b128((wn_) + (size_t)ks__ * NTGP * 32 * RB + 1024 * (pw + 4 * k) + b_lane,                       \
-                       (buf_) + ABYTES + ks__ * KRUN + 1024 * (pw + 4 * k));
+    _Pragma("unroll") for (int k = 0; k < (NPIECE + NPW - 1) / NPW; ++k) {                                         \
+      const int pc__ = (pw + NPW * k < NPIECE) ? pw + NPW * k : NPIECE - 1;                                        \
+      if (kWsLeaveFetch)                                                                                           \
+        pidm_glds_b128_untracked((wn_) + (size_t)ks__ * NTGP * 32 * RB + 1024 * pc__ + b_lane,                     \
+                                 (buf_) + ABYTES + ks__ * KRUN + 1024 * pc__);                                     \
+      else if (pw + NPW * k < NPIECE)                                                                              \
+        pidm_glds_b128((wn_) + (size_t)ks__ * NTGP * 32 * RB + 1024 * pc__ + b_lane,                               \
+                       (buf_) + ABYTES + ks__ * KRUN + 1024 * pc__);                                               \
+    }
 #define PIDM_G1_WRITE_A(set_, buf_)                                                                                \
-  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                  \
+  _Pragma("unroll") for (int k = 0; k < UA; ++k) {                                                                  \
     const f32x4 v0__ = ra[set_][k][0], v1__ = ra[set_][k][1];                                                      \
     unsigned q0__[4], q1__[4], q2__[4];                                                                            \
     pidm_split3_pk(v0__[0], v0__[1], q0__[0], q1__[0], q2__[0]);                                                   \
@@ -770,22 +832,25 @@ __global__ void __launch_bounds__(512) conv1x1_split_kernel(ConvGeom g, const fl
   {                                                                                                                \
     const char* wn1__ = l_wn;                                                                                      \
     PIDM_G1_COPY_B(wn1__, bufn)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);   /* (issue order: NCOPY copies, then the 2 UA loads of the fetch - as in conv3x3_split_ws_kernel) */ \
     PIDM_G1_NEXT()                                                                                                 \
     PIDM_G1_STAGE()                                                                                                \
     PIDM_G1_LOAD_A(setL_)                                                                                          \
+    if (kWsLeaveFetch) { PIDM_WAIT_VMEM_LEAVE(NCOPY + 2 * UA); __builtin_amdgcn_sched_barrier(0); }   /* set setW_ has landed */ \
     PIDM_G1_WRITE_A(setW_, bufn)                                                                                   \
-    PIDM_WAIT_VMEM();                                                                                              \
+    if (kWsLeaveFetch) PIDM_WAIT_VMEM_LEAVE(2 * UA); else PIDM_WAIT_VMEM();   /* the copies have landed, the fetch stays in flight */ \
     __syncthreads();                                                                                               \
     char* tswap__ = bufc; bufc = bufn; bufn = tswap__;                                                             \
   }
     PIDM_G1_STAGE()
     PIDM_G1_LOAD_A(0)
     PIDM_G1_COPY_B(l_wn, bufc)
+    if (kWsLeaveFetch) { PIDM_WAIT_VMEM_LEAVE(NCOPY); __builtin_amdgcn_sched_barrier(0); }
     PIDM_G1_WRITE_A(0, bufc)
     PIDM_G1_NEXT()
     PIDM_G1_STAGE()
     PIDM_G1_LOAD_A(1)
-    PIDM_WAIT_VMEM();
+    if (kWsLeaveFetch) PIDM_WAIT_VMEM_LEAVE(2 * UA); else PIDM_WAIT_VMEM();
     __syncthreads();
     for (int s = 0; s < nst; s += 2) {
       PIDM_G1_ITER(0, 1)
@@ -1019,6 +1084,30 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
 // for the 4-wave / 128-pixel tile only (one consumer wave per SIMD cannot hide its own staging: 15-19 % faster there, 8x8 level
 // 22.4 -> 18.4 us, 38.3 -> 31.5, 64.1 -> 51.9), the one-role form for the 8-wave tile (two waves per SIMD already overlap each
 // other and the extra producer waves cost 2-3 %: 63.8 -> 65.7 us; profiles/r03_ws_conv.txt); 1 / 0 force one form everywhere.
+// PIDM_SPLIT_XCD: item order of the split-form kernels follows the XCDs (split_vblock); read per launch
+static int split_xcd_order() {
+  const char* e = knob("PIDM_SPLIT_XCD");
+  return e ? atoi(e) : 0;
+}
+// producer waves of the warp-specialised kernels (PIDM_SPLIT_NPW = 4 / 8, read per launch; see conv3x3_split_ws_kernel)
+// default: 8 where the consumers are one wave per SIMD (4-wave tiles, the 1x1 kernel with two tiles per wave); the 8-wave tile and
+// the four-tile 1x1 item keep 4 (16 waves of 128 registers / 12 of 168 would spill their accumulators)
+static int split_npw(bool one_consumer_per_simd) {
+  const char* e = knob("PIDM_SPLIT_NPW");
+  if (!e) return one_consumer_per_simd ? 8 : 4;
+  return atoi(e) == 4 ? 4 : 8;
+}
+template <int NW, int MODE>
+static void launch_split_ws(int wgs, size_t lds, hipStream_t st, const ConvGeom& gs, const float* src0, const float* src1,
+                            const unsigned short* wsplit, const float* bias, const float* residual, float* out, int n_items, int ipw,
+                            int trace) {
+  if (split_npw(NW == 4) == 8)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<NW, MODE, 8>), dim3(wgs), dim3(64 * NW + 512), lds, st, gs, src0, src1, wsplit, bias,
+                       residual, out, n_items, ipw, trace);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<NW, MODE, 4>), dim3(wgs), dim3(64 * NW + 256), lds, st, gs, src0, src1, wsplit, bias,
+                       residual, out, n_items, ipw, trace);
+}
 static bool split_ws_on(int nw) {
   const char* e = knob("PIDM_SPLIT_WS");
   if (!e) return nw == 4;
@@ -1468,18 +1557,29 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
       const unsigned short* wsplit = reinterpret_cast<const unsigned short*>(wp + packed_fp32_floats(g));
       static bool attr_1 = false;
       if (!attr_1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<4, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<2, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         attr_1 = true;
       }
       if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv1x1_split_kernel<%d, %d>, %d items over %d workgroups, %zu B LDS\n", ntr, ntg, n_items, wgs, lds);
       const bool prof = prof_enabled();
       if (prof) prof_begin_launch(2, 2.0 * (double)npix * (double)g.Cout * g.Cin, st);
       const float* s1 = src1 ? src1 : src0;
-      if (ntr == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<4, 4>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
-      else if (ntg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 4>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 2>), dim3(wgs), dim3(512), lds, st, g, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      ConvGeom g1 = g;
+      g1.xcd = split_xcd_order();
+      if (split_npw(ntr == 2) == 8) {
+        if (ntr == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<4, 4, 8>), dim3(wgs), dim3(768), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+        else if (ntg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 4, 8>), dim3(wgs), dim3(768), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 2, 8>), dim3(wgs), dim3(768), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      } else {
+        if (ntr == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<4, 4, 4>), dim3(wgs), dim3(512), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+        else if (ntg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 4, 4>), dim3(wgs), dim3(512), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_split_kernel<2, 2, 4>), dim3(wgs), dim3(512), lds, st, g1, src0, s1, wsplit, bias, residual, out, n_items, ipw, tiles_m);
+      }
       if (prof) prof_end_launch(st);
       PIDM_CHECK_LAUNCH("conv1x1_split_kernel");
       return 0;
@@ -1547,6 +1647,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         gs.tiles_m = (NI > 1) ? cdiv(gs.B, NI) : gs.B * (gs.Hv / TH);
         const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
         gs.rpad = split_row_pad(gs.Wv);
+        gs.xcd = split_xcd_order();
         const size_t lds = (size_t)2 * ((npixA + 4 * 32) * kSplitRow + gs.NI * gs.IHt * gs.rpad + 2048);
         if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
         const int n_items = gs.tiles_m * mult;
@@ -1569,18 +1670,21 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (split_ws_on(nw)) {
           static bool attr_w = false;
           if (!attr_w) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             attr_w = true;
           }
-          const dim3 bw(64 * nw + 256);
           PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 2x2>" : "conv3x3_split_ws_kernel<4, 2x2>");
-          if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
-          else if (nw == 4 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 1>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
-          else if (nw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 2>), dim3(wgs), bw, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw);
+          if (nw == 8 && mode == 1) launch_split_ws<8, 1>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+          else if (nw == 4 && mode == 1) launch_split_ws<4, 1>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+          else if (nw == 8) launch_split_ws<8, 2>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
+          else launch_split_ws<4, 2>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
         } else {
         PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_kernel<8, 2x2>" : "conv3x3_split_kernel<4, 2x2>");
         if (nw == 8 && mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_kernel<8, 1>), dim3(wgs), bd, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
@@ -1625,6 +1729,7 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (!retile_bm(&gs, 32 * nw)) continue;
         const int npixA = gs.NI * gs.IHt * gs.IWt, SEG = gs.NI * gs.IHt * gs.Wv;
         gs.rpad = split_row_pad(gs.Wv);
+        gs.xcd = split_xcd_order();
         const size_t lds = (size_t)2 * ((npixA + 9 * 32) * kSplitRow + gs.NI * gs.IHt * gs.rpad + 512);
         if (!(SEG % 32 == 0 && 2 * SEG >= 64 * nw && 2 * SEG <= 128 * nw && lds <= 160 * 1024 - 256)) continue;
         const int n_items = gs.tiles_m * (g.Cout / 32);
@@ -1641,20 +1746,18 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         const int trace = knob("PIDM_STREAM_TRACE") ? 1 : 0;
         if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
-        if (split_ws_on(nw) && !trace) {
+        if (split_ws_on(nw)) {
           static bool attr_w0 = false;
           if (!attr_w0) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             attr_w0 = true;
           }
           PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 0>" : "conv3x3_split_ws_kernel<4, 0>");
-          if (nw == 8)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<8, 0>), dim3(wgs), dim3(768), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
-                               out, n_items, ipw);
-          else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<4, 0>), dim3(wgs), dim3(512), lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual,
-                               out, n_items, ipw);
+          if (nw == 8) launch_split_ws<8, 0>(wgs, lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out, n_items, ipw, trace);
+          else launch_split_ws<4, 0>(wgs, lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out, n_items, ipw, trace);
         } else {
         PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_kernel<8, 0>" : "conv3x3_split_kernel<4, 0>");
         if (nw == 8)

@@ -67,6 +67,12 @@ int check(const Rccl& r, ncclResult_i rc, const char* what) {
 struct Comm { ncclComm_p c; int rank, world; };
 }  // namespace
 
+// 0: RCCL is bound (dlopen + the four symbols) and the other entries can be used; -1 + message otherwise.  Starts nothing: no
+// bootstrap thread, no socket (ncclGetUniqueId does - only the rank whose id is used should call pidm_comm_unique_id).
+extern "C" int pidm_comm_available(void) {
+  return need(rccl()) ? -1 : 0;
+}
+
 extern "C" int pidm_comm_unique_id(void* out128) {
   const Rccl& r = rccl();
   if (need(r)) return -1;

@@ -130,11 +130,32 @@ __device__ __forceinline__ pidm_f32x16 pidm_mfma_bf16_32x32x16(u32x4 a, u32x4 b,
 // lgkmcnt at their maxima) - global_load_lds writes LDS behind the compiler's back, a barrier that publishes such data says so
 #ifndef PIDM_WAIT_VMEM
 #define PIDM_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+// ... all but the youngest n_ (a compile-time constant < 64; vmcnt = n_: low four bits + bits 15:14).  Vector-memory loads return in
+// issue order, so the n_ loads issued LAST may stay in flight: a producer wave waits for the LDS-direct copies that the barrier
+// publishes without also waiting for the register prefetch of a later stage it issued behind them (round 6).  The issue order the
+// count relies on is pinned with __builtin_amdgcn_sched_barrier(0) at the call sites.
+#define PIDM_WAIT_VMEM_LEAVE(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | ((((n_) >> 4) & 3) << 14))
+// A 16-byte global load the COMPILER DOES NOT TRACK (dst_ = *(f32x4*)((char*)ptr_ + OFF_), OFF_ a literal): hipcc counts the
+// LDS-direct copies and the plain loads of a wave as returning out of order and answers every use of a loaded register that has a
+// global_load_lds behind it with s_waitcnt vmcnt(0) - the producer waves of the split-form kernels then wait for the prefetch they
+// have just issued (ISA of rounds 3-5: a full memory latency in front of the staging arithmetic of every other stage).  The
+// hardware returns loads in issue order, so these kernels count by hand: PIDM_WAIT_VMEM_LEAVE(n) + a sched_barrier before the
+// first use of dst_.  "memory" pins the issue order against the surrounding copies.
+#define PIDM_UNTRACKED_LOAD_F32X4(dst_, ptr_, OFF_) \
+  asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF_ : "=v"(dst_) : "v"(ptr_) : "memory")
 #endif
 #ifndef PIDM_HAVE_GLDS
 __device__ __forceinline__ void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+// The same copy as an instruction the compiler does not track (see PIDM_UNTRACKED_LOAD_F32X4: a wave that counts its vector-memory
+// operations by hand must hide ALL of them from hipcc's own vmcnt bookkeeping, which would otherwise add s_waitcnt vmcnt(0) in front
+// of the barrier for the copies it knows about).  M0 = LDS base of the wave's 1 KB piece; one wait state between the write of M0 and
+// its use, as the compiler emits it.
+__device__ __forceinline__ void pidm_glds_b128_untracked(const void* gsrc_lane, void* lds_base_uniform) {
+  const unsigned la = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_base_uniform);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(la) : "memory", "m0");
 }
 #endif
 // Raw buffer loads (buffer_load_dword through a 128-bit resource descriptor): per-lane 32-bit byte offset + a wave-uniform
@@ -219,6 +240,7 @@ struct ConvGeom {
   int tiles_m;       // number of 128-pixel tiles
   int tpw;           // persistent conv kernels: consecutive m-tiles walked by one workgroup (0/1: one tile per workgroup)
   int rpad;          // split-form 3x3 kernels: extra bytes per halo-tile row in LDS (bank spreading at the 8- / 16-wide levels)
+  int xcd;           // split-form kernels: workgroup -> work-item order that follows the XCDs (split_vblock, k_conv.hip); 0: off
   // GroupNorm statistics of the OUTPUT from the epilogue (k_norm.hip consumes them): per (image, 32-pixel wave chunk, group)
   // sum and sum of squares as doubles at gn_part[((b*gn_nchunk + chunk)*gn_G + g)*2]; gn_part == null: off.
   // Requires Cout % 32 == 0, gn_cpg = Cout/gn_G a power of two in [4, 32], Ho*Wo % 32 == 0, channels-last output, no residual.

@@ -265,7 +265,14 @@ struct Run {
   GraphCapture* cap = nullptr; // non-null while this pass is being stream-captured (r.st is the capture stream then)
   float* part_alloc(size_t bytes) { return defer_on ? defer.alloc(bytes / 4 + 64) : scratch; }
   ReduceQueue* q() { return defer_on ? &rq : nullptr; }
-  WgradQueue* wgq() { return (defer_on && group_on) ? &wq : nullptr; }
+  // (a family's device table holds kMaxWgradItems rows per pass: once one is full the remaining problems of the pass get their own
+  // launches - same decision in the dry run, which queues exactly as the real pass does)
+  WgradQueue* wgq() {
+    if (!(defer_on && group_on)) return nullptr;
+    for (const auto& q : wq.f)
+      if (q.v.size() >= kMaxWgradItems) return nullptr;
+    return &wq;
+  }
 };
 
 #define RUN(call)                 \
@@ -1455,6 +1462,8 @@ static int plan_sizes(pidm_unet* U, int B, int training, size_t* tape_bytes, siz
     U->ws_cache[1].clear();
     U->defer_cache.clear();
     U->knob_sig = sig;
+    U->wq_table_dev = nullptr;   // (the layout the grouped tables were uploaded under is gone with the plans)
+    for (auto& t : U->wq_table) t.clear();
   }
   auto& cache = U->ws_cache[training ? 1 : 0];
   auto it = cache.find(B);
@@ -1694,6 +1703,13 @@ static int backward_body(pidm_unet* h, const float* grad_out_nchw, float* grad_x
   r.side_allowed = backward_eager(widest_level(h));
   r.overlap = h->side_ok && !prof_enabled() && !cap && r.side_allowed;
   r.group_on = wgrad_group_on(B, h->cfg.image_size, r.side_allowed);
+  // A pass WITHOUT grouping recycles the arena's frames and lays its partial slabs out differently: they may overwrite the grouped
+  // tables a previous pass left on the device (grouping toggled on a live handle through pidm_reload_knobs) - the next grouped pass
+  // must upload them again instead of trusting the host copies.
+  if (!r.group_on && h->wq_table_dev) {
+    h->wq_table_dev = nullptr;
+    for (auto& t : h->wq_table) t.clear();
+  }
   if (cap && cap_begin(r)) return -1;
   if (backward_impl(r, grad_out_nchw, grad_x_nhwc)) return -1;
   if (r.tmp.overflow() || r.defer.overflow()) return fail("unet_backward: internal arena overflow");

@@ -124,15 +124,16 @@ def negotiate_native_comm(lib, device, group=None):
     rank = dist.get_rank(group)
     why = None
     ident = None
-    # 1. is the binding there on every rank?  (rank 0's id is the one that is used; the others only probe the binding)
+    # 1. is the binding there on every rank?  pidm_comm_available only binds the symbols; the id comes from rank 0 alone
+    #    (ncclGetUniqueId starts a bootstrap root - a thread and a listening socket - that the other ranks would never use)
     try:
-        probe = _new_id(lib)
+        lib.check(lib.pidm_comm_available(), "pidm_comm_available")
         if rank == 0:
-            ident = probe
+            ident = _new_id(lib)
     except Exception as e:  # noqa: BLE001 - any failure means "fall back", the reason is reported
         why = f"rank {rank}: {e}"
     if not _all_ranks_ok(why is None, device, group):
-        return None, why or "pidm_comm_unique_id failed on another rank"
+        return None, why or "pidm_comm_available / pidm_comm_unique_id failed on another rank"
     ident = _broadcast_id(lib, device, group, ident)
     # 2. every rank enters pidm_comm_init (ncclCommInitRank is itself collective)
     comm = None
@@ -236,9 +237,18 @@ class GradientExchange:
         dev = eng.params[0].device
         self.on_gpu = dev.type == "cuda"
         self.collective_note = None
+        want = self._want_native is True or (self._want_native is None and self.on_gpu)
+        if given is None and self.active and dist.is_initialized():
+            # the wish is per rank (PIDM_DP_NATIVE is read from each rank's own environment): every rank enters this vote, and the
+            # collective negotiation below only runs when ALL of them want it - a rank that skipped it would leave the others waiting
+            agreed = _all_ranks_ok(want, dev, group)
+            if want and not agreed:
+                self.collective_note = "PIDM_DP_NATIVE / native= differ between ranks: another rank asked for torch.distributed"
+                print(f"GradientExchange: C-ABI communicator not used ({self.collective_note})", flush=True)
+            want = agreed
         if given is not None:
             self.native = given if self.active else None
-        elif self.active and (self._want_native is True or (self._want_native is None and self.on_gpu)):
+        elif self.active and want:
             self.native, self.collective_note = negotiate_native_comm(eng.lib, dev, group)
             if self.native is None:
                 print(f"GradientExchange: C-ABI communicator not used ({self.collective_note}); falling back to torch.distributed.all_reduce",

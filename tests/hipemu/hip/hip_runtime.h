@@ -295,6 +295,7 @@ static inline void pidm_buf_store_u32x4(pidm_rsrc r, unsigned voff, unsigned sof
 static inline void pidm_glds_b128(const void* gsrc_lane, void* lds_base_uniform) {
   memcpy(static_cast<char*>(lds_base_uniform) + 16 * hipemu::lane_id(), gsrc_lane, 16);
 }
+static inline void pidm_glds_b128_untracked(const void* gsrc_lane, void* lds_base_uniform) { pidm_glds_b128(gsrc_lane, lds_base_uniform); }
 // v_permlane32_swap / v_permlane16_swap (gfx950): rows (16 lanes) 2,3 of the first operand <-> rows 0,1 of the second; odd rows
 // of the first <-> even rows of the second.  Returns {new first, new second}.
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
@@ -332,6 +333,9 @@ static inline float hipemu_fast_expf(float x) { return exp2f(x * 1.4426950408889
 #define __expf(x) hipemu_fast_expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 #define PIDM_WAIT_VMEM() ((void)0)
+#define PIDM_WAIT_VMEM_LEAVE(n_) ((void)0)
+#define PIDM_UNTRACKED_LOAD_F32X4(dst_, ptr_, OFF_) \
+  memcpy(&(dst_), reinterpret_cast<const char*>(ptr_) + (OFF_), 16)
 #define PIDM_HAVE_FAST_SIGMOID 1
 static inline float pidm_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 static inline float __frcp_rn(float a) { return 1.0f / a; }

@@ -75,7 +75,7 @@ def _step(m, diff, res, x0, eps, t, case):
 
 
 class _CommStubLib:
-    """TEST DOUBLE for the four pidm_comm_* entries of include/pidm.h (the host-emulated build has no RCCL): same signatures and
+    """TEST DOUBLE for the five pidm_comm_* / pidm_allreduce_f32 entries of include/pidm.h (the host-emulated build has no RCCL): same signatures and
     return codes, gloo underneath.  Lets parallel.negotiate_native_comm / NativeComm / GradientExchange run their multi-rank C-ABI
     path on CPU: id hand-off (every rank must receive rank 0's bytes), the self-check, averaged values, and the agreed fall-back
     when one rank's init fails (`init_fails_on`) or the collective moves nothing (`dead`)."""
@@ -92,7 +92,14 @@ class _CommStubLib:
         if rc != 0:
             raise RuntimeError(f"{what}: {self._err}")
 
+    def pidm_comm_available(self):
+        if dist.get_rank() == self._no_binding_on:
+            self._err = "librccl.so could not be bound (stub)"
+            return -1
+        return 0
+
     def pidm_comm_unique_id(self, buf):
+        assert dist.get_rank() == 0, "only the rank whose id is used asks for one (ncclGetUniqueId starts a bootstrap root)"
         if dist.get_rank() == self._no_binding_on:
             self._err = "librccl.so could not be bound (stub)"
             return -1
@@ -134,7 +141,11 @@ def _worker(rank, world, port, outdir, case):
     case, _, comm_mode = case.partition("+")
     m, diff, res, P = _setup(lib, case)
     native = None
-    if comm_mode:
+    if comm_mode == "mixed_wish":
+        # the wish differs between the ranks (one rank's PIDM_DP_NATIVE=0): the vote sends BOTH to torch.distributed before any rank
+        # enters the collective negotiation (which would otherwise wait for the rank that never joins it)
+        native = rank == 0
+    elif comm_mode:
         from physicsinformeddiffusionmodels_amd.parallel import negotiate_native_comm
         stub = _CommStubLib(lib, init_fails_on=1 if comm_mode == "init_fails" else None, dead=comm_mode == "dead",
                             no_binding_on=1 if comm_mode == "no_binding" else None)
@@ -147,6 +158,8 @@ def _worker(rank, world, port, outdir, case):
             assert native is None and why, (comm_mode, why)
             native = False
     ex = GradientExchange(m, world, image_size=P, buckets=3, lib=lib, diffusion=diff, native=native)
+    if comm_mode == "mixed_wish":
+        assert ex.native is None and (ex.collective_note is not None) == (rank == 0), ex.collective_note
     assert [len(r) for r in ex.ranges] == [1, 1, 2]        # decoder | encoder | head + conditioning tail
     assert ex.collective == ("pidm_allreduce_f32 (C-ABI communicator over RCCL)" if comm_mode == "native" else "torch.distributed.all_reduce (gloo)")
     x0, eps, t = _inputs(case)
@@ -161,7 +174,8 @@ def _worker(rank, world, port, outdir, case):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("case", ["darcy", "two_tape", "mechanics", "darcy+native", "darcy+init_fails", "darcy+dead", "darcy+no_binding"])
+@pytest.mark.parametrize("case", ["darcy", "two_tape", "mechanics", "darcy+native", "darcy+init_fails", "darcy+dead", "darcy+no_binding",
+                                  "darcy+mixed_wish"])
 def test_two_rank_step_equals_global_batch_step(tmp_path, case):
     from physicsinformeddiffusionmodels_amd._engine import get_engine
     from tests.emu_util import emu_lib

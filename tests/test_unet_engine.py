@@ -344,11 +344,13 @@ def test_input_form_errors(backend):
 
 
 def test_grouped_weight_gradients(backend, monkeypatch):
-    """Round 5: the 3x3 / stride-1 weight-gradient problems of a backward pass are queued and run by ONE conv_wgrad_rs_multi_kernel
-    launch per flush (PIDM_WGRAD_GROUP, default 64 problems).  Same kernel body, same partial slabs, same fixed-order reduction: the
-    gradients are BIT-identical to the problem-by-problem launches (PIDM_WGRAD_GROUP=0) for any group size, also with the three-phase
-    reduction of the data-parallel exchange; fewer splits per problem (PIDM_WGRAD_GROUP_SPLITDIV) change only the summation order;
-    and a steady-state pass uploads neither table."""
+    """Round 5: the weight-gradient problems of a backward pass that one of the three streaming families takes (3x3 / stride-1,
+    4x4 / stride-2, 1x1 pixel streams) are queued and run by ONE launch per family and flush (conv_wgrad_rs_multi_kernel,
+    conv_wgrad_rs4_multi_kernel, conv_wgrad_1x1_multi_kernel; PIDM_WGRAD_GROUP = problems per flush, default 1 << 20: one flush per
+    reduction phase, 0: off).  Same kernel bodies, same partial slabs, same fixed-order reduction: the gradients are BIT-identical
+    to the problem-by-problem launches (PIDM_WGRAD_GROUP=0) for any group size, also with the three-phase reduction of the
+    data-parallel exchange; fewer splits per problem (PIDM_WGRAD_GROUP_SPLITDIV) change only the summation order; and a
+    steady-state pass uploads neither table."""
     L, dev = backend
     from physicsinformeddiffusionmodels_amd._engine import get_engine
     g = torch.Generator().manual_seed(11)
@@ -396,3 +398,36 @@ def test_grouped_weight_gradients(backend, monkeypatch):
     a, b = grads({}, 1, 2), grads({}, 3, 2)                  # and the default is bit-identical run to run, one phase or three
     for k in ref:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_grouped_weight_gradients_toggled_on_a_live_handle(backend, monkeypatch):
+    """Grouping switched on -> off -> on through pidm_reload_knobs on ONE engine and ONE workspace: the pass without grouping
+    recycles the arena's frames, so its partial slabs may land on the grouped tables the first pass uploaded; the third pass must
+    upload them again (not trust its host copies) and produce the same gradients as the first."""
+    L, dev = backend
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 256, 2, generator=g).to(dev)
+    t = torch.tensor([5, 60, 99], device=dev)
+    w = torch.randn(3, 2, 16, 16, generator=g).to(dev)
+    m = Unet3D(dim=32, channels=2, dim_mults=(1, 2))
+    m.load_state_dict(O.fill_state_dict(m.state_dict()))
+    m = m.to(dev)
+    m._pidm_lib = L if dev.type == "cpu" else None
+
+    def grads(group):
+        monkeypatch.setenv("PIDM_WGRAD_GROUP", group)
+        out = None
+        for _ in range(3):                                   # (the third call with one key replays a graph on the GPU)
+            for p in m.parameters():
+                p.grad = None
+            (m(x, t) * w).sum().backward()
+            out = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        return out
+    on1, up1 = grads("1048576"), L.pidm_debug_reduce_table_uploads()
+    off = grads("0")
+    on2, up2 = grads("1048576"), L.pidm_debug_reduce_table_uploads()
+    assert up2 > up1                                         # the grouped tables were uploaded again
+    assert len(on1) > 50 and on1.keys() == off.keys() == on2.keys()
+    for k in on1:
+        assert torch.equal(on1[k], on2[k]), k
+        assert (off[k] - on1[k]).abs().max().item() <= 2e-5 * max(on1[k].abs().max().item(), 1e-6), k

@@ -59,6 +59,12 @@ static int split_row_pad(int Wv) {
   const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
   return (on && Wv <= 16) ? 32 : 0;
 }
+#ifndef PIDM_WS_INTERLEAVE
+#define PIDM_WS_INTERLEAVE 1    // fragment reads of the warp-specialised consumers pinned one per MFMA (0: the compiler's placement)
+#endif
+#ifndef PIDM_WS_PF
+#define PIDM_WS_PF 2            // fragment prefetch distance of the warp-specialised consumers (taps; 1: rounds 3-5)
+#endif
 #ifndef PIDM_WS_LEAVE_FETCH
 #define PIDM_WS_LEAVE_FETCH 1   // 0: the producer waves drain every load before each stage barrier (rounds 3-5; A/B builds)
 #endif
@@ -416,8 +422,8 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
 // for the whole stage (~900 of ~3850 cycles).  Same buffers, same barrier per stage, same arithmetic in the same order: results
 // are bit-identical to conv3x3_split_kernel.  768 (NW = 8) or 512 (NW = 4) threads.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, int MODE, int NPW>
-__global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
+template <int NW, int MODE, int NPW, int MS>
+__global__ void __launch_bounds__(64 * (NW / MS) + 64 * NPW) conv3x3_split_ws_kernel(ConvGeom g, const float* __restrict__ src0, const float* __restrict__ src1,
                                                                         const unsigned short* __restrict__ ws, const float* __restrict__ bias,
                                                                         const float* __restrict__ residual, float* __restrict__ out,
                                                                         int n_items, int items_per_wg, int trace) {
@@ -429,6 +435,8 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
   constexpr int NPT = 64 * NPW;                             // producer threads
   constexpr int NB = ((MODE == 0) ? 32 : 16) / NPW;         // 1 KB pieces of the weight slab per producer wave
   constexpr int KA = 2 * NW / NPW;                          // staging units (8 channels of one pixel) per producer thread
+  constexpr int NWC = NW / MS;                              // consumer waves (NW = 32-pixel sub-tiles of the workgroup's tile, MS per wave)
+  static_assert(MS == 1 || MS == 2, "sub-tiles per consumer wave");
   static_assert(NPW == 4 || NPW == 8, "producer waves: one or two per SIMD");
   static_assert(KA >= 1 && NB >= 1, "every producer wave stages something");
   constexpr int SLAB = T * 32 * kSplitRow, BPAD = (MODE == 0) ? 512 : 2048;
@@ -436,7 +444,7 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
   char* smem = reinterpret_cast<char*>(smemf);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= NW;
+  const bool producer = wave >= NWC;
   const int half = lane >> 5, l31 = lane & 31;
   const int rowB = g.IWt * RB + g.rpad, nrowsA = g.NI * g.IHt;    // (row pitch: see conv3x3_split_kernel)
   const int b_reg = nrowsA * rowB;
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
   const int nst = my_items * NCH;
 
   // zero halo columns of both buffers (all waves)
-  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 64 * NW + NPT) {
+  for (int e = tid; e < 2 * g.NI * g.IHt * 2 * 6; e += 64 * NWC + NPT) {
     const int q = e % 6, side = (e / 6) & 1, row = (e / 12) % (g.NI * g.IHt), bufi = (e / 12) / (g.NI * g.IHt);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(smem + (size_t)bufi * bufsz + (size_t)row * rowB + (size_t)(side ? g.IWt - 1 : 0) * RB + 16 * q) = zero4;
@@ -460,7 +468,7 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
 
   if (producer) {
     // =============================== producer waves: staging only ===============================
-    const int pt = tid - 64 * NW, pw = wave - NW;           // producer thread / wave index
+    const int pt = tid - 64 * NWC, pw = wave - NWC;         // producer thread / wave index
     const int SEG = g.NI * g.IHt * g.Wv;                    // staged pixels per tile
     const int hh = pt & 1;
     int a_lds[KA], a_im[KA], a_hy[KA];
@@ -588,15 +596,25 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
   }
 
   // =============================== consumer waves: fragments, MFMAs, epilogue ===============================
-  const int pm = wave * 32 + l31;
-  const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
-  const int a_frag = ((a_img < g.NI) ? (a_img * g.IHt + a_ty) * rowB + a_tx * RB : 0) + 48 * half;
+  // MS sub-tiles (32 pixels x 32 output channels, one accumulator pair each) per consumer wave: wave w owns sub-tiles w MS .. w MS + MS - 1.
+  // MS = 2 (round 6): a tap's three weight fragments are read from LDS once for both sub-tiles - 9 instead of 12 KB of fragment reads per
+  // 12 MFMAs (the LDS port is the co-critical resource of these kernels: 65-73 % busy with one sub-tile per wave) - and the 256-pixel
+  // tile runs on ONE consumer wave per SIMD: no second wave's MFMAs in the pipe, a stage long enough (108 MFMAs) for the producers.
+  int a_frag[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    const int pm = (wave * MS + ms) * 32 + l31;
+    const int a_tx = pm & (g.Wv - 1), a_ty = (pm >> g.wsh) & (g.TH - 1), a_img = pm >> (g.wsh + g.tsh);
+    a_frag[ms] = ((a_img < g.NI) ? (a_img * g.IHt + a_ty) * rowB + a_tx * RB : 0) + 48 * half;
+  }
   const int b_frag = b_reg + l31 * RB + 48 * half;
   SplitCursor cs;                    // the stage being computed
   split_cursor_init<MODE>(cs, item0, nst, g.tiles_m, tpi, ntn);
   __syncthreads();                   // stage 0 is in bufc
-  f32x16 acc, accb;
-  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+  f32x16 acc[MS], accb[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+    for (int r = 0; r < 16; ++r) { acc[ms][r] = 0.f; accb[ms][r] = 0.f; }
   const int tr_c = (trace && blockIdx.x == 0 && lane == 0 && wave == 0) ? 0 : -1;
   for (int s = 0; s < nst; ++s) {
     if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 0] = clock64();
@@ -607,47 +625,46 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
     } else if (MODE == 2) {
       oy0 = 1 - g.pad_y[cs.zz]; ox0 = 1 - g.pad_x[cs.zz];
     }
-    const char* afp = bufc + a_frag + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
+    const char* afp = bufc + ((MODE == 0) ? 0 : oy0 * rowB + ox0 * RB);
     const char* bfp = bufc + b_frag;
-    u32x4 fa[2][3], fb[2][3];
+    // PF = taps the fragment reads run ahead of the MFMAs that use them (PF + 1 register sets).  One consumer wave per SIMD has
+    // nobody to hide an LDS round trip behind: with PF = 1 a read has the 192 cycles of one tap's six MFMAs, with PF = 2 twice that
+    constexpr int PF = (MS == 1) ? PIDM_WS_PF : 1, NS = PF + 1;
+    u32x4 fa[NS][MS][3], fb[NS][3];
 #define PIDM_WS_FRAGS(set_, t_)                                                                                    \
   {                                                                                                                \
-    const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + (size_t)((MODE == 0) ? ((t_) / 3) * rowB + ((t_) % 3) * RB : ((t_) >> 1) * rowB + ((t_) & 1) * RB)); \
+    const size_t to__ = (size_t)((MODE == 0) ? ((t_) / 3) * rowB + ((t_) % 3) * RB : ((t_) >> 1) * rowB + ((t_) & 1) * RB); \
     const u32x4* br__ = reinterpret_cast<const u32x4*>(bfp + (size_t)((t_)*32) * RB);                              \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                \
-      fa[set_][p] = ar__[p];                                                                                       \
-      fb[set_][p] = br__[p];                                                                                       \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) fb[set_][p] = br__[p];                                           \
+    _Pragma("unroll") for (int ms = 0; ms < MS; ++ms) {                                                            \
+      const u32x4* ar__ = reinterpret_cast<const u32x4*>(afp + a_frag[ms] + to__);                                 \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) fa[set_][ms][p] = ar__[p];                                     \
     }                                                                                                              \
   }
     PIDM_WS_FRAGS(0, 0)
+    if (PF == 2) PIDM_WS_FRAGS(1, 1)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < T) PIDM_WS_FRAGS(cur ^ 1, t + 1)
-      // PIDM_SPLIT_CHAINS = 1: the six terms of a tap alternate between the two accumulators (consecutive MFMAs never depend on
-      // each other), 0: even taps -> acc, odd taps -> accb
-#if PIDM_SPLIT_CHAINS
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
-      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
-      accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
-      acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
-      accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
-#else
-      if (t & 1) {
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], accb);
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], accb);
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], accb);
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], accb);
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], accb);
-        accb = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], accb);
-      } else {
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][2], fb[cur][0], acc);
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][2], acc);
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][1], acc);
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][1], fb[cur][0], acc);
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][1], acc);
-        acc = pidm_mfma_bf16_32x32x16(fa[cur][0], fb[cur][0], acc);
+      const int cur = t % NS;
+      if (t + PF < T) PIDM_WS_FRAGS((t + PF) % NS, t + PF)
+      // the six terms of a product smallest first; even taps -> acc, odd taps -> accb (two chains per sub-tile, summed in the epilogue:
+      // conv3x3_split_kernel); the sub-tiles of a wave take turns term by term - consecutive MFMAs never wait for each other's result
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          if (t & 1) accb[ms] = pidm_mfma_bf16_32x32x16(fa[cur][ms][ia[q]], fb[cur][ib[q]], accb[ms]);
+          else acc[ms] = pidm_mfma_bf16_32x32x16(fa[cur][ms][ia[q]], fb[cur][ib[q]], acc[ms]);
+        }
+      }
+      // one fragment read per MFMA: hipcc left to itself puts the tap's 6-8 ds_read_b128 into ONE gap between two MFMAs of the same
+      // accumulator chain - more than the ~5 instructions a 32-cycle MFMA hides, with nobody else on the SIMD to fill the pipe
+#if PIDM_WS_INTERLEAVE
+#pragma unroll
+      for (int q = 0; q < 6 * MS; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA
+        if (t + PF < T && q < 3 + 3 * MS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -655,13 +672,15 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
 #undef PIDM_WS_FRAGS
     if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 1] = clock64();
     if (cs.ch == NCH - 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += accb[r];
       const int zz = (MODE == 2) ? cs.zz : 0;
       const int b0 = cs.bi * g.NI, vy0 = cs.rt * g.TH, n0 = cs.tn * 32;
       const int c = n0 + l31;
       const float bv = bias ? bv_pre : 0.f;
-      const int p0 = wave * 32;
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][r] += accb[ms][r];
+      const int p0 = (wave * MS + ms) * 32;
       const int tx0 = p0 & (g.Wv - 1), ty0 = (p0 >> g.wsh) & (g.TH - 1), img0 = p0 >> (g.wsh + g.tsh);
       const int b = b0 + img0;
       if (b < g.B && img0 < g.NI) {        // wave-uniform
@@ -670,14 +689,14 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
         float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          v[r] = acc[r] + bv;
+          v[r] = acc[ms][r] + bv;
           gs1 += v[r];
           gs2 += v[r] * v[r];
         }
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
         if (g.bn_part) {
           const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
+          PIDM_BN_PARTIAL(acc[ms], bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
@@ -704,7 +723,8 @@ __global__ void __launch_bounds__(64 * NW + 64 * NPW) conv3x3_split_ws_kernel(Co
           }
         }
       }
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc[ms][r] = 0.f; accb[ms][r] = 0.f; }
+      }
     }
     if (tr_c >= 0 && s < 32) g_stream_trace[tr_c + 4 * s + 2] = clock64();
     split_cursor_next<MODE>(cs, NCH, CCH, g.tiles_m, tpi, ntn);
@@ -909,6 +929,14 @@ __global__ void __launch_bounds__(256 + 64 * NPW) conv1x1_split_kernel(ConvGeom 
         acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][1], acc[j][0]);
         acc[j][0] = pidm_mfma_bf16_32x32x16(fa[ca][0], fb[cb][0], acc[j][0]);
       }
+#if PIDM_WS_INTERLEAVE
+      // one fragment read per MFMA (see conv3x3_split_ws_kernel): 3 reads of the next tile's weights, 3 more when the k-step changes
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + 1 < KS * NTG && (q < 3 || (i + 1) % NTG == 0)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef PIDM_G1_FRAG_A
@@ -1084,6 +1112,14 @@ __global__ void __launch_bounds__(512) conv7x7_split_kernel(ConvGeom g, const fl
 // for the 4-wave / 128-pixel tile only (one consumer wave per SIMD cannot hide its own staging: 15-19 % faster there, 8x8 level
 // 22.4 -> 18.4 us, 38.3 -> 31.5, 64.1 -> 51.9), the one-role form for the 8-wave tile (two waves per SIMD already overlap each
 // other and the extra producer waves cost 2-3 %: 63.8 -> 65.7 us; profiles/r03_ws_conv.txt); 1 / 0 force one form everywhere.
+// sub-tiles per consumer wave of the 256-pixel tile (PIDM_SPLIT_MS = 1 / 2, read per launch; the 128-pixel tile has one)
+// (default 1: with two sub-tiles per wave the 256-pixel tile measured 2 % SLOWER per step than the two-role 8-wave kernel - the
+// consumers reach 80-86 % of the pipe, but the producers' staging arithmetic gets one instruction per ~20 cycles beside them and
+// the stage is theirs again: profiles/r06_split_conv_stage_stamps.txt)
+static int split_ms() {
+  const char* e = knob("PIDM_SPLIT_MS");
+  return (e && atoi(e) == 2) ? 2 : 1;
+}
 // PIDM_SPLIT_XCD: item order of the split-form kernels follows the XCDs (split_vblock); read per launch
 static int split_xcd_order() {
   const char* e = knob("PIDM_SPLIT_XCD");
@@ -1101,16 +1137,31 @@ template <int NW, int MODE>
 static void launch_split_ws(int wgs, size_t lds, hipStream_t st, const ConvGeom& gs, const float* src0, const float* src1,
                             const unsigned short* wsplit, const float* bias, const float* residual, float* out, int n_items, int ipw,
                             int trace) {
-  if (split_npw(NW == 4) == 8)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<NW, MODE, 8>), dim3(wgs), dim3(64 * NW + 512), lds, st, gs, src0, src1, wsplit, bias,
-                       residual, out, n_items, ipw, trace);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<NW, MODE, 4>), dim3(wgs), dim3(64 * NW + 256), lds, st, gs, src0, src1, wsplit, bias,
-                       residual, out, n_items, ipw, trace);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NW, MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NW, MODE, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (NW == 8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, MODE, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    }
+    attr = true;
+  }
+  const int ms = (NW == 8) ? split_ms() : 1;
+  const int npw = split_npw(NW == 4 || ms == 2);
+#define PIDM_WS_LAUNCH(NW_, NPW_, MS_)                                                                                               \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_split_ws_kernel<NW_, MODE, NPW_, MS_>), dim3(wgs), dim3(64 * (NW_ / MS_) + 64 * NPW_), lds, st, gs, src0, \
+                     src1, wsplit, bias, residual, out, n_items, ipw, trace)
+  if (NW == 8 && ms == 2) {
+    if (npw == 8) PIDM_WS_LAUNCH(8, 8, 2); else PIDM_WS_LAUNCH(8, 4, 2);
+  } else {
+    if (npw == 8) PIDM_WS_LAUNCH(NW, 8, 1); else PIDM_WS_LAUNCH(NW, 4, 1);
+  }
+#undef PIDM_WS_LAUNCH
 }
 static bool split_ws_on(int nw) {
   const char* e = knob("PIDM_SPLIT_WS");
-  if (!e) return nw == 4;
+  if (!e) return nw == 4 || split_ms() == 2;   // (round 6: the 256-pixel tile as well, with two sub-tiles per consumer wave)
   return atoi(e) != 0;
 }
 // pre-split weights of a 3x3 convolution: [Cout/32][Cin/16][9 taps][32 rows][2 halves][3 pieces][8 channels] bf16, behind the
@@ -1668,18 +1719,6 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 4 * g.nz, st);
         const dim3 bd(64 * nw);
         if (split_ws_on(nw)) {
-          static bool attr_w = false;
-          if (!attr_w) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            attr_w = true;
-          }
           PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 2x2>" : "conv3x3_split_ws_kernel<4, 2x2>");
           if (nw == 8 && mode == 1) launch_split_ws<8, 1>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
           else if (nw == 4 && mode == 1) launch_split_ws<4, 1>(wgs, lds, st, gs, src0, s1, wsplit, bias, residual, out, n_items, ipw, 0);
@@ -1747,14 +1786,6 @@ int launch_conv(const ConvGeom& g, const float* src0, const float* src1, const f
         if (knob("PIDM_TRACE_CONV")) fprintf(stderr, "[pidm]   -> conv3x3_split_kernel<%d>, %d items over %d workgroups, %zu B LDS\n", nw, n_items, wgs, lds);
         if (prof) prof_begin_launch(2, 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Kw * 9, st);
         if (split_ws_on(nw)) {
-          static bool attr_w0 = false;
-          if (!attr_w0) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<8, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<4, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            attr_w0 = true;
-          }
           PIDM_PROF_NAME(nw == 8 ? "conv3x3_split_ws_kernel<8, 0>" : "conv3x3_split_ws_kernel<4, 0>");
           if (nw == 8) launch_split_ws<8, 0>(wgs, lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out, n_items, ipw, trace);
           else launch_split_ws<4, 0>(wgs, lds, st, gs, src0, src1 ? src1 : src0, wsplit, bias, residual, out, n_items, ipw, trace);

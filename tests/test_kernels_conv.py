@@ -154,6 +154,64 @@ def test_conv_3x3_split_forms(backend, monkeypatch, ws, nw, wgs, p, maxns, B, H,
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+WS_VARIANT_CASES = [   # B, H, C0, C1, Cout, K, stride, pad, transposed (GPU sizes: many workgroups, several stages and items each)
+    (16, 16, 128, 0, 128, 3, 1, 1, 0),   # 256-pixel tile by default
+    (8, 8, 128, 128, 256, 3, 1, 1, 0),   # 8x8 level: 128-pixel tile, concat source, 16 stages
+    (8, 16, 64, 0, 128, 4, 2, 1, 0),     # 4x4 / stride 2 as 4 K-phases
+    (8, 8, 128, 0, 64, 4, 2, 1, 1),      # transposed 4x4 / stride 2 as 4 output parities
+    (4, 16, 128, 0, 384, 1, 1, 0, 0),    # 1x1 GEMM, four tiles per item
+    (4, 8, 256, 0, 192, 1, 1, 0, 0),     # 1x1 GEMM, two tiles per item
+]
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", WS_VARIANT_CASES)
+def test_split_ws_variants_are_bit_identical(backend, monkeypatch, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """Round 6: the producer waves of the warp-specialised kernels count their vector-memory operations by hand (untracked loads and
+    LDS-direct copies, s_waitcnt vmcnt(n) with n > 0) and come in 4 or 8; consumers take one or two sub-tiles.  Same staging, same
+    order of the six terms per accumulator: every variant - and every repetition of it, with the previous launches still in flight -
+    must reproduce the two-role kernel's output BIT for bit (a copy that had not landed at the stage barrier would show up here)."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(77 + H + Cout)
+    Cin = C0 + C1
+    Ho = H * 2 if transposed else (H + 2 * pad - K) // stride + 1
+    x0 = torch.randn(B, H, H, C0, generator=g).to(dev)
+    x1 = torch.randn(B, H, H, C1, generator=g).to(dev) if C1 else None
+    w = (torch.randn((Cin, Cout, K, K) if transposed else (Cout, Cin, K, K), generator=g) * 0.05).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    d = ConvDesc(B=B, Hi=H, Wi=H, C0=C0, C1=C1, ld0=C0, ld1=C1, Cout=Cout, KH=K, KW=K, stride=stride, pad=pad, transposed=transposed,
+                 out_nchw=0, ldo=Cout)
+    wp = torch.empty(L.pidm_conv_packed_weight_floats(d), device=dev)
+    L.check(L.pidm_conv_pack_weights(d, ptr(w), ptr(wp), 0, st))
+
+    def run(env, reps):
+        for k in ("PIDM_SPLIT_WS", "PIDM_SPLIT_NPW", "PIDM_SPLIT_MS", "PIDM_SPLIT_NW", "PIDM_SPLIT_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs = []
+        for _ in range(reps):
+            out = torch.full((B, Ho, Ho, Cout), float("nan"), device=dev)
+            L.check(L.pidm_conv_forward(d, ptr(x0), ptr(x1), ptr(wp), ptr(bias), None, ptr(out), st))
+            outs.append(out)
+        return outs
+    ref = run({"PIDM_SPLIT_WS": "0"}, 1)[0]
+    assert torch.isfinite(ref).all()
+    reps = 12 if dev.type == "cuda" else 1
+    variants = [{}, {"PIDM_SPLIT_WS": "1", "PIDM_SPLIT_NPW": "4"}, {"PIDM_SPLIT_WS": "1", "PIDM_SPLIT_NPW": "8"},
+                {"PIDM_SPLIT_WS": "1", "PIDM_SPLIT_MS": "2"}, {"PIDM_SPLIT_WS": "1", "PIDM_SPLIT_NW": "4", "PIDM_SPLIT_NPW": "8"},
+                {"PIDM_SPLIT_XCD": "1"}]
+    if K == 1:
+        variants = [{}, {"PIDM_SPLIT_NPW": "4"}, {"PIDM_SPLIT_NPW": "8"}]
+        if dev.type == "cpu":
+            variants = variants[:2]
+    elif dev.type == "cpu":
+        variants = variants[:1] + variants[3:5]                 # (the emulator runs one fiber per GPU thread: keep the CPU leg short)
+    for env in variants:
+        for out in run(env, reps):
+            assert torch.equal(out, ref), env
+
+
 RS_CASES = [   # the row-streaming forward / dgrad kernel (k_conv_rs.hip): rows of 32 / 64 pixels, 32 / 64 input channels
     (1, 64, 32, 0, 32, 3, 1, 1, 0),      # two strips per row, one n-tile; dgrad the same
     (3, 32, 32, 32, 64, 3, 1, 1, 0),     # concat source = 4 chunks, two n-groups, odd batch; dgrad: 64 -> 64

@@ -42,7 +42,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             tot[c][counter] += v
             cnt[c][counter] += 1
-res = {"batch": batch, "workload": workload, "round": "round 5",
+res = {"batch": batch, "workload": workload, "round": "round 6",
        "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; 2 steps (1 warm-up + 1 timed); kernels before the first / "
                "after the last library kernel (initialisation, calibration copy) are excluded",
        "excluded_outside_the_steps_bytes": (2 * outside["FETCH_SIZE"] + outside["WRITE_SIZE"]) * 1024}

@@ -59,6 +59,9 @@ static int split_row_pad(int Wv) {
   const int on = [] { const char* e = knob("PIDM_SPLIT_ROWPAD"); return e ? atoi(e) : 1; }();
   return (on && Wv <= 16) ? 32 : 0;
 }
+#ifndef PIDM_WS_PRODUCER_PRIO
+#define PIDM_WS_PRODUCER_PRIO 0
+#endif
 #ifndef PIDM_WS_INTERLEAVE
 #define PIDM_WS_INTERLEAVE 1    // fragment reads of the warp-specialised consumers pinned one per MFMA (0: the compiler's placement)
 #endif
@@ -469,6 +472,9 @@ __global__ void __launch_bounds__(64 * (NW / MS) + 64 * NPW) conv3x3_split_ws_ke
   if (producer) {
     // =============================== producer waves: staging only ===============================
     const int pt = tid - 64 * NWC, pw = wave - NWC;         // producer thread / wave index
+#if PIDM_WS_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(PIDM_WS_PRODUCER_PRIO);      // (experiment: the producers' vector instructions win the issue arbitration)
+#endif
     const int SEG = g.NI * g.IHt * g.Wv;                    // staged pixels per tile
     const int hh = pt & 1;
     int a_lds[KA], a_im[KA], a_hy[KA];

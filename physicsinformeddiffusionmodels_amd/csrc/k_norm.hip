@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, const float* __restrict__ ssb, int ldss,
                                                        const float* __restrict__ res, float* __restrict__ y, int HW, int C, int G,
-                                                       int ppb) {
+                                                       int ppb, const float* __restrict__ ln_gamma, float* __restrict__ ln_out) {
   __shared__ float s_stat[64][2];
   const int b = blockIdx.y, tid = threadIdx.x;
   if (partial) {
@@ -181,6 +181,25 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
         o[k] = v * sigmoidf_(v) + rv[k];
       }
       *reinterpret_cast<f32x4*>(y + i) = o;
+      if (ln_out) {
+        // the channel LayerNorm of the attention block that follows (PreNorm, reference src/unet_model.py:139-145,207-210) on the
+        // values just written: the C / 4 lanes of a pixel sit side by side in one wave (launch_gn_apply checks it), same operation
+        // order as layernorm_kernel<false> with one quad per lane - the separate pass, and its read of y, are gone
+        float s = (o[0] + o[1]) + (o[2] + o[3]);
+        for (int off = 1; off < L.qw; off <<= 1) s += __shfl_xor(s, off);
+        const float lmean = s / (float)C;
+        const float d0 = o[0] - lmean, d1 = o[1] - lmean, d2 = o[2] - lmean, d3 = o[3] - lmean;
+        float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        for (int off = 1; off < L.qw; off <<= 1) q += __shfl_xor(q, off);
+        const float lrstd = 1.f / sqrtf(q / (float)C + 1e-5f);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_gamma + c0);
+        f32x4 z;
+        z[0] = d0 * lrstd * gm[0];
+        z[1] = d1 * lrstd * gm[1];
+        z[2] = d2 * lrstd * gm[2];
+        z[3] = d3 * lrstd * gm[3];
+        *reinterpret_cast<f32x4*>(ln_out + i) = z;
+      }
     }
   }
 }
@@ -685,14 +704,22 @@ int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, v
 // ws != null: holds launch_gn_stats' partials, `stats` [B][G][2] is WRITTEN (and used); ws == null: `stats` is read
 // part_chunks > 0: `ws` holds part_chunks partial sums per (image, group) written by the producing convolution's epilogue
 // (ConvGeom::gn_part, 32-pixel chunks) instead of launch_gn_stats' partials
+// the LayerNorm of a following attention block can ride in gn_apply when the C / 4 lanes of a pixel are lanes of one wave
+bool gn_apply_ln_ok(int C) {
+  const int QC = C / 4;
+  return (C % 4) == 0 && QC >= 1 && QC <= 64 && (64 % QC) == 0;
+}
+// ln_gamma / ln_out != null (gn_apply_ln_ok(C)): also writes ln_out = LayerNorm_C(y) * ln_gamma (eps 1e-5, biased variance)
 int launch_gn_apply(const float* x, float* stats, const float* gamma, const float* beta, const float* ss, const float* ssb,
-                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks) {
+                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks,
+                    const float* ln_gamma, float* ln_out) {
   if (gn_check(C, G)) return -1;
+  if ((ln_gamma == nullptr) != (ln_out == nullptr) || (ln_out && !gn_apply_ln_ok(C))) return fail("groupnorm + layernorm: bad arguments (C=%d)", C);
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws),
                      (ws && part_chunks > 0) ? part_chunks : nchunk,
-                     (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb);
+                     (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
   PIDM_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }

@@ -140,8 +140,10 @@ int launch_colsum(const float* x, size_t rows, int C, int ld, float* out, void* 
 // k_norm.hip
 size_t gn_ws_bytes(int B, int HW, int C, int G);
 int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, void* ws, hipStream_t st);
+bool gn_apply_ln_ok(int C);
 int launch_gn_apply(const float* x, float* stats, const float* gamma, const float* beta, const float* ss, const float* ssb,
-                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks = 0);
+                    int ldss, const float* res, float* y, int B, int HW, int C, int G, void* ws, hipStream_t st, int part_chunks = 0,
+                    const float* ln_gamma = nullptr, float* ln_out = nullptr);
 int launch_gn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const float* ss,
                   const float* ssb, int ldss, float* dss, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
                   void* ws, hipStream_t st, float* dgb_persist = nullptr, ReduceQueue* defer = nullptr, int part_chunks = 0);

@@ -59,6 +59,9 @@ struct AttnBlock {
   ConvLayer qkv, out;
   const float* x = nullptr;
   float *xn = nullptr, *qkvb = nullptr, *kstat = nullptr, *qstat = nullptr, *ctx = nullptr, *attn = nullptr;
+  bool xn_ready = false;     // forward: xn was written by the preceding ResnetBlock's last gn_apply (LayerNorm fused, round 6);
+  float* out_pre = nullptr;  // ... which then also allocated this block's output IN FRONT of xn (and took the arena mark between
+  size_t mk_pre = 0;         // them), so that an inference pass can still release xn when the block is done
   float* lsaved = nullptr;   // projected form (k_attn_proj.hip): k statistics | M | ctx | P; qstat as above; no qkv tensor
   bool projected = false;    // form the latest forward took (latched: the backward must match it whatever the knobs say by then)
 };
@@ -674,11 +677,26 @@ static int conv_fwd_gn(Run& r, const ConvLayer& L, const float* x0, const float*
   return 0;
 }
 
-static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, float** out_p) {
+// next_attn: the attention block that consumes this block's output.  Its PreNorm LayerNorm rides in the block's last gn_apply
+// (one launch and one read of the activation less per attention block; PIDM_NO_GN_LN_FUSE=1: off) when the block ends in that
+// kernel (no res_conv) and a pixel's channels fit one wave.
+static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, float** out_p, AttnBlock* next_attn = nullptr) {
   pidm_unet* U = r.U;
   const int B = r.B, HW = m.H * m.H, Co = m.Co, G = U->groups;
   const size_t n = (size_t)B * HW * Co;
   float* out = act_alloc(r, n);
+  float* ln_out = nullptr;
+  if (next_attn) {
+    next_attn->xn_ready = false;
+    const char* nf = knob("PIDM_NO_GN_LN_FUSE");
+    if (!m.has_res && next_attn->C == Co && next_attn->H == m.H && gn_apply_ln_ok(Co) && !(nf && atoi(nf))) {
+      next_attn->out_pre = act_alloc(r, n);
+      next_attn->mk_pre = r.tmp.mark();
+      ln_out = act_alloc(r, n);
+      next_attn->xn = ln_out;
+      next_attn->xn_ready = true;
+    }
+  }
   const size_t mk = r.tmp.mark();
   m.x0 = x0; m.x1 = x1;
   m.a = act_alloc(r, n);
@@ -699,7 +717,8 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
     RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.scratch, r.st, pc2));
     if (conv_fwd(r, m.cr, x0, x1, d, out)) return -1;
   } else {
-    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.scratch, r.st, pc2));
+    RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, x0, out, B, HW, Co, G, r.scratch, r.st, pc2,
+                        ln_out ? U->P[next_attn->gamma] : nullptr, ln_out));
   }
   if (!r.train) r.tmp.release(mk);
   else r.tmp.release(mk);
@@ -739,11 +758,14 @@ static int attn_fwd(Run& r, AttnBlock& a, const float* x, float** out_p) {
   pidm_unet* U = r.U;
   const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
   const size_t npix = (size_t)B * N;
-  float* out = act_alloc(r, npix * C);
-  const size_t mk = r.tmp.mark();
+  float* out = a.xn_ready ? a.out_pre : act_alloc(r, npix * C);
+  const size_t mk = a.xn_ready ? a.mk_pre : r.tmp.mark();
   a.x = x;
-  a.xn = act_alloc(r, npix * C);
-  RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
+  if (!a.xn_ready) {
+    a.xn = act_alloc(r, npix * C);
+    RUN(launch_layernorm_fwd(x, U->P[a.gamma], a.xn, npix, C, r.st));
+  }
+  a.xn_ready = false;
   a.projected = attn_projected(a, heads);
   if (a.projected) {
     a.qkvb = nullptr;
@@ -827,7 +849,7 @@ static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* ou
   int irb = 0, iat = 0;
   for (int i = 0; i < n; ++i) {
     if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
-    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x, &U->attn[iat])) return -1;
     if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
     U->skip[i] = x;
     if (i < n - 1) {
@@ -838,13 +860,13 @@ static int forward_impl(Run& r, const float* x_nhwc, const int64_t* t, float* ou
       x = y;
     }
   }
-  if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+  if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x, &U->attn[iat])) return -1;
   if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
   if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
   for (int j = 0; j < n; ++j) {
     const float* sk = U->skip[n - 1 - j];
     if (resblock_fwd(r, U->rb[irb++], x, sk, &x)) return -1;
-    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x)) return -1;
+    if (resblock_fwd(r, U->rb[irb++], x, nullptr, &x, &U->attn[iat])) return -1;
     if (attn_fwd(r, U->attn[iat++], x, &x)) return -1;
     if (j < n - 1) {
       U->up_in[j] = x;

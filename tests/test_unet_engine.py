@@ -431,3 +431,38 @@ def test_grouped_weight_gradients_toggled_on_a_live_handle(backend, monkeypatch)
     for k in on1:
         assert torch.equal(on1[k], on2[k]), k
         assert (off[k] - on1[k]).abs().max().item() <= 2e-5 * max(on1[k].abs().max().item(), 1e-6), k
+
+
+def test_layernorm_fused_into_groupnorm_apply_is_bit_identical(backend, monkeypatch):
+    """Round 6: the PreNorm LayerNorm of every attention block (src/unet_model.py:139-145,207-210) rides in the last gn_apply of the
+    ResnetBlock in front of it (same operation order as the separate layernorm kernel: one launch and one read of the activation
+    less per attention block).  Output, input gradient and every parameter gradient must equal the unfused path
+    (PIDM_NO_GN_LN_FUSE=1) bit for bit, in training and in inference mode."""
+    L, dev = backend
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 2, generator=g).to(dev)
+    t = torch.tensor([7, 91], device=dev)
+    w = torch.randn(2, 2, 16, 16, generator=g).to(dev)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("PIDM_NO_GN_LN_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("PIDM_NO_GN_LN_FUSE", "1")
+        m = Unet3D(dim=16, channels=2, dim_mults=(1, 2, 4))      # 16 / 32 / 64 channels: 4, 8 and 16 lanes per pixel
+        m.load_state_dict(O.fill_state_dict(m.state_dict()))
+        m = m.to(dev)
+        m._pidm_lib = L if dev.type == "cpu" else None
+        xin = x.clone().requires_grad_(True)
+        out = m(xin, t)
+        (out * w).sum().backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        m.eval()
+        with torch.no_grad():
+            out_eval = m(x, t)
+        return out.detach().clone(), xin.grad.detach().clone(), grads, out_eval.detach().clone()
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 100
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k

@@ -129,6 +129,8 @@ __device__ __forceinline__ void gn_finalize_stats(const double* __restrict__ par
 // scale[b][c] = ss[b*ldss + c] + ssb[c], shift[b][c] = ss[b*ldss + C + c] + ssb[C + c]   (ss may be null)
 // `partial` != null: statistics are finalised here from the stats_partial sums and written to `stats`;
 // `partial` == null: `stats` is read.
+// INPLACE (inference passes: nothing reads x afterwards): y == x, every access goes through the one pointer y
+template <bool INPLACE>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, int nchunk,
                                                        double count, float eps, float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += L.ppi) {
       const size_t i = base + (size_t)p * C;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
       f32x4 rv = {0.f, 0.f, 0.f, 0.f};
       if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
       f32x4 o;
@@ -717,9 +719,14 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
   if ((ln_gamma == nullptr) != (ln_out == nullptr) || (ln_out && !gn_apply_ln_ok(C))) return fail("groupnorm + layernorm: bad arguments (C=%d)", C);
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws),
-                     (ws && part_chunks > 0) ? part_chunks : nchunk,
-                     (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
+  if (x == y)      // in place (the engine's inference passes): one pointer inside the kernel
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_apply_kernel<true>), dim3(nchunk, B), dim3(256), 0, st, nullptr, reinterpret_cast<const double*>(ws),
+                       (ws && part_chunks > 0) ? part_chunks : nchunk,
+                       (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_apply_kernel<false>), dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws),
+                       (ws && part_chunks > 0) ? part_chunks : nchunk,
+                       (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
   PIDM_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }

@@ -641,6 +641,10 @@ static int pack_all(Run& r) {
 // forward building blocks
 // ------------------------------------------------------------------------------------------------------
 static float* act_alloc(Run& r, size_t n) { return r.train ? r.tape.alloc(n) : r.tmp.alloc(n); }
+static bool knob_on(const char* name) {
+  const char* e = knob(name);
+  return e && atoi(e);
+}
 
 static int conv_fwd(Run& r, const ConvLayer& L, const float* x0, const float* x1, const float* residual, float* out,
                     int out_nchw = 0, int sigmoid_last = 0) {
@@ -704,16 +708,19 @@ static int resblock_fwd(Run& r, ResBlock& m, const float* x0, const float* x1, f
   if (conv_fwd_gn(r, m.c1, x0, x1, m.a, G, &pc1)) return -1;
   m.st1 = act_alloc(r, (size_t)B * G * 2);
   if (!pc1) RUN(launch_gn_stats(m.a, B, HW, Co, G, m.st1, r.scratch, r.st));
-  m.bact = act_alloc(r, n);
+  // inference (no tape): GroupNorm + FiLM + SiLU in place - half the footprint of the pass in the caches, a smaller workspace
+  // (PIDM_NO_GN_INPLACE=1: off)
+  const bool inplace = !r.train && !knob_on("PIDM_NO_GN_INPLACE");
+  m.bact = inplace ? m.a : act_alloc(r, n);
   const float* ss = m.has_mlp ? U->ss + m.ss_off : nullptr;
   const float* ssb = m.has_mlp ? U->P[m.mlpb] : nullptr;
   RUN(launch_gn_apply(m.a, m.st1, U->P[m.gn1w], U->P[m.gn1b], ss, ssb, U->ss_total, nullptr, m.bact, B, HW, Co, G, r.scratch, r.st, pc1));
-  m.c = act_alloc(r, n);
+  m.c = (inplace && !m.has_res) ? out : act_alloc(r, n);      // (in place: the second convolution writes the block's output buffer)
   if (conv_fwd_gn(r, m.c2, m.bact, nullptr, m.c, G, &pc2)) return -1;
   m.st2 = act_alloc(r, (size_t)B * G * 2);
   if (!pc2) RUN(launch_gn_stats(m.c, B, HW, Co, G, m.st2, r.scratch, r.st));
   if (m.has_res) {
-    float* d = r.tmp.alloc(n);
+    float* d = inplace ? m.c : r.tmp.alloc(n);
     RUN(launch_gn_apply(m.c, m.st2, U->P[m.gn2w], U->P[m.gn2b], nullptr, nullptr, 0, nullptr, d, B, HW, Co, G, r.scratch, r.st, pc2));
     if (conv_fwd(r, m.cr, x0, x1, d, out)) return -1;
   } else {

@@ -460,6 +460,11 @@ def test_layernorm_fused_into_groupnorm_apply_is_bit_identical(backend, monkeypa
         m.eval()
         with torch.no_grad():
             out_eval = m(x, t)
+            # (inference passes run GroupNorm + FiLM + SiLU in place; PIDM_NO_GN_INPLACE=1 keeps the separate buffers)
+            monkeypatch.setenv("PIDM_NO_GN_INPLACE", "1")
+            out_eval2 = m(x, t)
+            monkeypatch.delenv("PIDM_NO_GN_INPLACE")
+        assert torch.equal(out_eval, out_eval2) and torch.equal(out_eval, out.detach())
         return out.detach().clone(), xin.grad.detach().clone(), grads, out_eval.detach().clone()
     a, b = run(True), run(False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])

@@ -41,9 +41,17 @@ __device__ __forceinline__ float lap_exp(float x) { return __expf(x); }
 __device__ __forceinline__ int lap_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // pixels per workgroup of the pixel-sum kernels: the xn (and dY) slab of the range lives in LDS, rows padded to C + 4 floats
+// PIDM_LAP_NPER_DIV (1, 2, 4; read per call): the pixel ranges of the split pixel-sum kernels (lap_kctx_split, lap_g_split) divided
+// by this - half the LDS per workgroup, two workgroups per CU (one stages while the other computes), twice the range partials
+static int lap_nper_div() {
+  const char* e = knob("PIDM_LAP_NPER_DIV");
+  const int v = e ? atoi(e) : 1;
+  return (v == 2 || v == 4) ? v : 1;
+}
 static int lap_nper(int N, int C, int slabs) {
   int n = (slabs == 1 ? 512 : 256) * 32 / C;
   if (slabs == 3) n = (C == 32) ? 32 : n / 2;   // lap_bwd: C = 32 keeps Wq | Wk | dM of all heads in LDS as well (one tile per staging)
+  if (slabs == 2 && n / lap_nper_div() >= 64) n /= lap_nper_div();
   while (n > 32 && N % n) n >>= 1;
   return n;
 }
@@ -151,6 +159,7 @@ __global__ void __launch_bounds__(512) lap_kctx_kernel(const float* __restrict__
 // - and the B operand follows with two 8-byte reads of XT per piece.
 static int lap_nper_split(int N, int C) {
   int n = 256 * 32 / C;
+  if (n / lap_nper_div() >= 64) n /= lap_nper_div();
   while (n > 32 && N % n) n >>= 1;
   return n;
 }

@@ -751,7 +751,8 @@ static long lap_knob_signature() {
   const char* gw = knob("PIDM_GRAPH_BWD_WIDE");
   return 8 * (off ? -1 : (long)min_n) + (g && !atoi(g) ? 1 : 0) + (gb ? (atoi(gb) ? 2 : 4) : 0) + 1000003L * (gw ? atoi(gw) : 0) +
          7919L * (wgrad_group_on(1, 1, false) ? 1 : 0) +  // (grouped weight gradients keep the backward arena's frames)
-         104729L * (knob("PIDM_WGRAD_GROUP_MAXWORK") ? atol(knob("PIDM_WGRAD_GROUP_MAXWORK")) % 65521 : 0);
+         104729L * (knob("PIDM_WGRAD_GROUP_MAXWORK") ? atol(knob("PIDM_WGRAD_GROUP_MAXWORK")) % 65521 : 0) +
+         15485863L * (knob("PIDM_LAP_NPER_DIV") ? atol(knob("PIDM_LAP_NPER_DIV")) % 8 : 0);   // (scratch of the pixel-sum kernels)
 }
 static bool attn_shape_projectable(const AttnBlock& a, int heads) { return !a.mid && a.out.b >= 0 && lap_ok(a.H * a.H, heads, a.C, a.C); }
 // decided by the FORWARD (and stored in AttnBlock::projected); the backward replays the stored decision

@@ -427,6 +427,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
 // channel LayerNorm (per pixel over C, biased variance, eps, gamma only).  TPP lanes per pixel, each lane
 // owns up to 4 float4 quads.  Requires C % 4 == 0, C/4 a power of two (<= 256).
 // ---------------------------------------------------------------------------------------------------
+// Optional second job of the LayerNorm BACKWARD kernel (round 6): its output is the gradient with respect to the ResnetBlock output in
+// front of the attention block, i.e. dy of that block's second GroupNorm + SiLU - whose backward starts with the per-(image, chunk,
+// channel) sums S1 = sum dv, S2 = sum dv xhat (gn_bwd_reduce_kernel: a pass over x and dy of its own).  With `part` set the sums are
+// taken here, from the values in registers: one launch and one read of the gradient less per attention block.
+struct LnGnSums {
+  const float* x;       // the GroupNorm's input [B][HW][C] (the block's second convolution output)
+  const float* stats;   // [B][G][2] mean, rstd
+  const float* gamma;
+  const float* beta;
+  double* part;         // [B][nchunk][C][2]; null: off
+  int G, cpg, HW, nchunk, ppb;
+};
 template <bool BWD>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ dy,    // BWD: grad wrt LN output
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ rsum_partial,    // BWD, may be null: [gridDim.x][C] column
                                                                                              // sums of `res` (the bias gradient of the
                                                                                              // projection in front of the residual add)
-                                                        size_t npix, int C, float eps) {
+                                                        size_t npix, int C, float eps, LnGnSums gs) {
   __shared__ float dgs[256][16];
   const int C4 = C / 4;
   const int TPP = C4 < 64 ? C4 : 64;
@@ -446,10 +458,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   float dg[16], rs[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) { dg[k] = 0.f; rs[k] = 0.f; }
-  const size_t wave_global = (size_t)blockIdx.x * 4 + wave, nwaves = (size_t)gridDim.x * 4;
-  for (size_t pbase = wave_global * ppw; pbase < npix; pbase += nwaves * ppw) {
+  // gs.part != null (BWD): the block owns ONE chunk of ONE image (block = image * nchunk + chunk, gs.ppb pixels) instead of a stride
+  // over the whole batch, and also leaves the GroupNorm-backward sums of that chunk (see LnGnSums)
+  const bool gsum = BWD && gs.part != nullptr;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  const int gb = gsum ? (int)blockIdx.x / gs.nchunk : 0, gchunk = gsum ? (int)blockIdx.x - gb * gs.nchunk : 0;
+  const size_t p_lo = gsum ? (size_t)gb * gs.HW + (size_t)gchunk * gs.ppb : 0;
+  const size_t p_hi = gsum ? ((size_t)(gchunk + 1) * gs.ppb < (size_t)gs.HW ? p_lo + gs.ppb : (size_t)(gb + 1) * gs.HW) : npix;
+  const size_t wave_global = gsum ? (size_t)wave : (size_t)blockIdx.x * 4 + wave, nwaves = gsum ? 4 : (size_t)gridDim.x * 4;
+  for (size_t pbase = p_lo + wave_global * ppw; pbase < p_hi; pbase += nwaves * ppw) {
     const size_t p = pbase + sub;
-    const bool valid = p < npix;
+    const bool valid = p < p_hi;
     float4 xv[4];
     float s = 0.f;
 #pragma unroll
@@ -527,6 +548,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
             }
           }
           *reinterpret_cast<float4*>(out + p * C + c) = o;
+          if (gsum) {
+            // o = d loss / d (output of the ResnetBlock in front) = dy of that block's second GroupNorm: S1 += dv, S2 += dv xhat
+            const float4 yv = *reinterpret_cast<const float4*>(gs.x + p * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int g = (c + k) / gs.cpg;
+              float xh2, dv;
+              gn_recompute(yv[k], o[k], gs.stats[((size_t)gb * gs.G + g) * 2], gs.stats[((size_t)gb * gs.G + g) * 2 + 1], gs.gamma[c + k],
+                           gs.beta[c + k], 1.f, 0.f, &xh2, &dv);
+              s1[j * 4 + k] += dv;
+              s2[j * 4 + k] += dv * xh2;
+            }
+          }
         }
       }
     }
@@ -553,6 +587,22 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         for (int w = 0; w < 4; ++w)
           for (int sb = 0; sb < ppw; ++sb) a += dgs[w * 64 + sb * TPP + qlane][j * 4 + k];
         rsum_partial[(size_t)blockIdx.x * C + c] = a;
+      }
+    }
+    if (gsum) {
+      // the chunk's sums per channel, lanes added in a fixed order, as doubles where gn_bwd_apply expects them
+      for (int m = 0; m < 2; ++m) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dgs[tid][k] = m ? s2[k] : s1[k];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+          const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
+          double a = 0.0;
+          for (int w = 0; w < 4; ++w)
+            for (int sb = 0; sb < ppw; ++sb) a += (double)dgs[w * 64 + sb * TPP + qlane][j * 4 + k];
+          gs.part[((size_t)blockIdx.x * C + c) * 2 + m] = a;
+        }
       }
     }
   }
@@ -779,7 +829,7 @@ static bool ln_ok(int C) {
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
-                     nullptr, y, nullptr, nullptr, npix, C, 1e-5f);
+                     nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
   PIDM_CHECK_LAUNCH("layernorm_fwd");
   return 0;
 }
@@ -789,15 +839,32 @@ size_t layernorm_bwd_ws_bytes(int C) { return (size_t)2 * 1024 * C * sizeof(floa
 
 // dx = LN_bwd(dy) + res ; dgamma = sum_pix dy * xhat ; res_colsum (may be null) = sum_pix res - the kernel reads `res` anyway, and
 // in the attention blocks that sum is the bias gradient of the to_out projection (a separate column-sum pass over dY otherwise)
+// chunks per image of the GroupNorm-backward sums a fused LayerNorm backward leaves (0: not available for this shape - more than 1024
+// blocks, which is what the per-block partial rows of the LayerNorm's own parameter gradient are sized for)
+int layernorm_bwd_gn_chunks(int B, int HW) {
+  const int nchunk = gn_chunks(HW, B);
+  return ((long)B * nchunk <= 1024) ? nchunk : 0;
+}
+// gn_x .. gn_part != null: also the GroupNorm-backward sums of dx (LnGnSums; B images of HW pixels, layernorm_bwd_gn_chunks(B, HW) > 0
+// chunks each, written to gn_part where launch_gn_bwd(..., part_chunks = that) reads them)
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer, float* res_colsum) {
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer, float* res_colsum, const float* gn_x,
+                         const float* gn_stats, const float* gn_gamma, const float* gn_beta, int gn_G, int gn_B, int gn_HW, void* gn_part) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
   if (res_colsum && !res) return fail("layernorm_bwd: column sums of a null residual");
-  const int nb = ln_blocks(npix, C);
+  LnGnSums gs{};
+  int nb = ln_blocks(npix, C);
+  if (gn_part) {
+    const int nchunk = layernorm_bwd_gn_chunks(gn_B, gn_HW);
+    if (!gn_x || !gn_stats || !gn_gamma || !gn_beta || nchunk <= 0 || (size_t)gn_B * gn_HW != npix || gn_G <= 0 || C % gn_G)
+      return fail("layernorm_bwd: bad GroupNorm-sum arguments");
+    gs = LnGnSums{gn_x, gn_stats, gn_gamma, gn_beta, reinterpret_cast<double*>(gn_part), gn_G, C / gn_G, gn_HW, nchunk, cdiv(gn_HW, nchunk)};
+    nb = gn_B * nchunk;
+  }
   float* partial = reinterpret_cast<float*>(ws);
   float* partial2 = res_colsum ? partial + (size_t)nb * C : nullptr;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
-                     1e-5f);
+                     1e-5f, gs);
   PIDM_CHECK_LAUNCH("layernorm_bwd");
   if (defer) {   // `ws` (the per-block partial rows) stays alive until the caller's reduce_multi launch
     defer->push(partial, dgamma, nullptr, nullptr, (size_t)C, nb, 1, C, 1, 1, C);

@@ -149,8 +149,11 @@ int launch_gn_bwd(const float* x, const float* dy, const float* stats, const flo
                   void* ws, hipStream_t st, float* dgb_persist = nullptr, ReduceQueue* defer = nullptr, int part_chunks = 0);
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st);
 size_t layernorm_bwd_ws_bytes(int C);
+int layernorm_bwd_gn_chunks(int B, int HW);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* res, float* dx, float* dgamma,
-                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer = nullptr, float* res_colsum = nullptr);
+                         size_t npix, int C, void* ws, hipStream_t st, ReduceQueue* defer = nullptr, float* res_colsum = nullptr,
+                         const float* gn_x = nullptr, const float* gn_stats = nullptr, const float* gn_gamma = nullptr,
+                         const float* gn_beta = nullptr, int gn_G = 0, int gn_B = 0, int gn_HW = 0, void* gn_part = nullptr);
 int launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);
 int launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
 int launch_sinusoid(const int64_t* t, float* emb, int B, int dim, hipStream_t st);

@@ -1094,11 +1094,26 @@ static int resblock_bwd(Run& r, ResBlock& m, const float* g_out, float* g_x, flo
 }
 
 // g_out [B,N,C] -> g_x [B,N,C]
-static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
+// prev / pc_prev: the ResnetBlock whose output this attention block consumed (the next one the backward walks).  The LayerNorm
+// backward that ends this function then also leaves the first pass of that block's GroupNorm-2 backward - the per-(image, chunk,
+// channel) sums - in r.scratch and reports the chunk count (resblock_bwd's pc2_in; 0: not produced).  OFF by default
+// (PIDM_LN_GN_SUMS=1 turns it on): 9 launches and 9 reads of a gradient tensor fewer per step, but the LayerNorm kernel then walks one
+// chunk of one image per block instead of striding over the batch and loses more than the separate pass cost - batch 64 +1.0 % per
+// step, batch 256 +-0, mechanics +1.4 % (profiles/r06_ln_gn_sums_ab.txt).
+static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x, const ResBlock* prev = nullptr, int* pc_prev = nullptr) {
   pidm_unet* U = r.U;
   const int B = r.B, N = a.H * a.H, C = a.C, heads = U->heads, HD = heads * 32;
   const size_t npix = (size_t)B * N;
   const size_t mk = r.tmp.mark();
+  if (pc_prev) *pc_prev = 0;
+  // (the sums live in r.scratch like the dgrad epilogue's; the deferred-reduction arena keeps the weight-gradient partials out of it)
+  const int gn_pc = (prev && pc_prev && r.defer_on && !prev->has_res && prev->Co == C && prev->H == a.H && knob_on("PIDM_LN_GN_SUMS"))
+                        ? layernorm_bwd_gn_chunks(B, N) : 0;
+  const float* gn_x = gn_pc ? prev->c : nullptr;
+  const float* gn_st = gn_pc ? prev->st2 : nullptr;
+  const float* gn_gm = gn_pc ? U->P[prev->gn2w] : nullptr;
+  const float* gn_bt = gn_pc ? U->P[prev->gn2b] : nullptr;
+  void* gn_part = gn_pc ? (void*)r.scratch : nullptr;
   float* g_qkv = nullptr;
   float* g_xn = nullptr;
   bool out_bias_with_ln = false;
@@ -1128,7 +1143,8 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
     // the to_out bias gradient (column sums of g_out) rides with the LayerNorm backward, which reads g_out as its residual share
     float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
     RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q(),
-                             (U->have_grads && !r.dry) ? U->G[a.out.b] : nullptr));
+                             (U->have_grads && !r.dry) ? U->G[a.out.b] : nullptr, gn_x, gn_st, gn_gm, gn_bt, U->groups, B, N, gn_part));
+    if (pc_prev) *pc_prev = gn_pc;
     if (!r.keep_frames()) r.tmp.release(mk);
     return 0;
   }
@@ -1167,7 +1183,8 @@ static int attn_bwd(Run& r, AttnBlock& a, const float* g_out, float* g_x) {
   if (conv_dgrad(r, a.qkv, g_qkv, nullptr, g_xn)) return -1;
   float* ln_part = r.part_alloc(layernorm_bwd_ws_bytes(C) + colsum_ws_bytes(1024, C));
   RUN(launch_layernorm_bwd(a.x, U->P[a.gamma], g_xn, g_out, g_x, U->G[a.gamma], npix, C, ln_part, r.st, r.q(),
-                           out_bias_with_ln ? U->G[a.out.b] : nullptr));
+                           out_bias_with_ln ? U->G[a.out.b] : nullptr, gn_x, gn_st, gn_gm, gn_bt, U->groups, B, N, gn_part));
+  if (pc_prev) *pc_prev = gn_pc;
   // side-stream weight gradients may still be reading buffers of this arena frame: with the overlap on, the frame is simply
   // kept until the end of backward (every gradient buffer is then unique; one join before the deferred reduction)
   if (!r.keep_frames()) r.tmp.release(mk);
@@ -1363,10 +1380,11 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
       ld_gx = 0;
     }
     float* g1 = r.tmp.alloc(npix * din);
-    if (attn_bwd(r, U->attn[iat--], g_x, g1)) return -1;
+    int pc_a = 0;              // the attention block's LayerNorm backward sums for block 2's GroupNorm 2
+    if (attn_bwd(r, U->attn[iat--], g_x, g1, &U->rb[irb], &pc_a)) return -1;
     float* g2 = r.tmp.alloc(npix * din);
     int pc_b1 = 0;             // block 2's final input-gradient convolution sums for block 1's GroupNorm 2
-    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, 0, &U->rb[irb - 1], &pc_b1)) return -1;
+    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, pc_a, &U->rb[irb - 1], &pc_b1)) return -1;
     --irb;
     float* gc = r.tmp.alloc(npix * 2 * dout);
     if (resblock_bwd(r, U->rb[irb--], g2, gc, dss, pc_b1)) return -1;
@@ -1389,9 +1407,10 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
     float* g1 = r.tmp.alloc(nn);
     if (resblock_bwd(r, U->rb[irb--], g_x, g1, dss)) return -1;
     float* g2 = r.tmp.alloc(nn);
-    if (attn_bwd(r, U->attn[iat--], g1, g2)) return -1;
+    int pc_a = 0;
+    if (attn_bwd(r, U->attn[iat--], g1, g2, &U->rb[irb], &pc_a)) return -1;
     float* g3 = r.tmp.alloc(nn);
-    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss)) return -1;
+    if (resblock_bwd(r, U->rb[irb--], g2, g3, dss, pc_a)) return -1;
     g_x = g3;
   }
   for (int i = n - 1; i >= 0; --i) {
@@ -1406,10 +1425,11 @@ static int backward_impl(Run& r, const float* grad_out_nchw, float* grad_x_nhwc)
       RUN(launch_copy_add(g_la, dout, g_x, dout, g_skip[i], g_skip_ld[i], npix, dout, r.st));
     }
     float* g1 = r.tmp.alloc(npix * dout);
-    if (attn_bwd(r, U->attn[iat--], g_la, g1)) return -1;
+    int pc_a = 0;
+    if (attn_bwd(r, U->attn[iat--], g_la, g1, &U->rb[irb], &pc_a)) return -1;
     float* g2 = r.tmp.alloc(npix * dout);
     int pc_b1 = 0;
-    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, 0, &U->rb[irb - 1], &pc_b1)) return -1;
+    if (resblock_bwd(r, U->rb[irb], g1, g2, dss, pc_a, &U->rb[irb - 1], &pc_b1)) return -1;
     --irb;
     float* g3 = r.tmp.alloc(npix * din);
     if (resblock_bwd(r, U->rb[irb--], g2, g3, dss, pc_b1)) return -1;

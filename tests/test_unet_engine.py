@@ -471,3 +471,34 @@ def test_layernorm_fused_into_groupnorm_apply_is_bit_identical(backend, monkeypa
     assert a[2].keys() == b[2].keys() and len(a[2]) > 100
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+def test_groupnorm_backward_sums_from_the_layernorm_backward(backend, monkeypatch):
+    """Round 6: the LayerNorm backward that ends an attention block's backward also takes the first pass of the GroupNorm backward
+    of the ResnetBlock in front (per-(image, chunk, channel) sums S1 = sum dv, S2 = sum dv xhat) - gn_bwd_reduce_kernel is not
+    launched there - when PIDM_LN_GN_SUMS=1 asks for it (measured slower per step, so it is off by default).  Same values summed in
+    another grouping: gradients agree with the separate pass to fp32 rounding, and are bit-identical run to run."""
+    L, dev = backend
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 256, 2, generator=g).to(dev)
+    t = torch.tensor([2, 40, 88], device=dev)
+    w = torch.randn(3, 2, 16, 16, generator=g).to(dev)
+
+    def run(fused):
+        if fused:
+            monkeypatch.setenv("PIDM_LN_GN_SUMS", "1")
+        else:
+            monkeypatch.delenv("PIDM_LN_GN_SUMS", raising=False)
+        m = Unet3D(dim=16, channels=2, dim_mults=(1, 2, 4))
+        m.load_state_dict(O.fill_state_dict(m.state_dict()))
+        m = m.to(dev)
+        m._pidm_lib = L if dev.type == "cpu" else None
+        xin = x.clone().requires_grad_(True)
+        (m(xin, t) * w).sum().backward()
+        return xin.grad.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    a, a2, b = run(True), run(True), run(False)
+    assert torch.equal(a[0], a2[0]) and all(torch.equal(a[1][k], a2[1][k]) for k in a[1])
+    assert a[1].keys() == b[1].keys() and len(a[1]) > 100
+    assert (a[0] - b[0]).abs().max().item() <= 2e-5 * b[0].abs().max().item()
+    for k in a[1]:
+        assert (a[1][k] - b[1][k]).abs().max().item() <= 2e-5 * max(b[1][k].abs().max().item(), 1e-6), k

@@ -38,7 +38,8 @@ int pidm_prof_collect(double* ms4, long long* launches4, double* work4);
  * the side-stream overlap are off meanwhile, so launches are back to back on that stream); a launch's time is the interval since
  * the previous launch's event.  _collect writes one line per kernel name, largest total first:
  *   name \t launches \t total_ms \t work \t class \n   (work: FLOPs the launcher declared, 0 = none; class as above, -1 = none)
- * and returns the bytes the table needs incl. the terminating 0 (the text is truncated to `cap`), or -1. */
+ * and returns the bytes the table needs incl. the terminating 0 (the text is truncated to `cap`), or -1.
+ * Single-threaded by contract: between _begin and _collect only ONE host thread may call into the library. */
 int pidm_prof_kernels_begin(void* stream);
 long long pidm_prof_kernels_collect(char* buf, size_t cap);
 

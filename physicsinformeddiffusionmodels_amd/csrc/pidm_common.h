@@ -27,7 +27,9 @@ void prof_cancel_last();                  // nothing was launched after all (the
 extern bool g_prof_marks;
 extern const char* g_prof_name;
 void prof_mark(const char* what);
-#define PIDM_PROF_NAME(n) (::pidm::g_prof_name = (n))
+// (written only while the per-kernel timing is on: with it off a launch touches no process-global state; the timing pass itself is
+// single-threaded by contract - pidm_prof_kernels_begin / _collect bracket launches of ONE host thread on one stream)
+#define PIDM_PROF_NAME(n) (::pidm::g_prof_marks ? (void)(::pidm::g_prof_name = (n)) : (void)0)
 
 // Tuning / A-B knobs (the PIDM_* environment variables listed in DESIGN.md section 4): read from the environment ONCE per process
 // and name - `knob("PIDM_X")` returns what getenv returned the first time it was asked (or null) - until pidm_reload_knobs()

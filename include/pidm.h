@@ -298,6 +298,8 @@ int pidm_debug_stream_trace(unsigned long long* out256);
 /* measurement aid (bench.py roofline.clock_probe): stamps of the last conv3x3_rs_kernel launch made with PIDM_RS_TRACE set -
  * out4 = {shader-clock counter, 100 MHz real-time counter} before and {.., ..} after the row loop of workgroup 0 / wave 0 */
 int pidm_debug_conv_rs_trace(unsigned long long* out4);
+/* cycle stamps of lap_bwd_kernel (PIDM_LAP_TRACE=1; tools/lap_trace.py): [wave slot < 2][tile round < 8][16] */
+int pidm_debug_lap_trace(unsigned long long* out256);
 /* test aid: host-to-device uploads of the deferred-reduction descriptor table since the library was loaded (a second identical
  * backward pass must not upload anything: the table is compared with what the device already holds) */
 long long pidm_debug_reduce_table_uploads(void);

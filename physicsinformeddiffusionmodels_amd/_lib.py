@@ -115,6 +115,7 @@ class PidmLib:
         self._sig("pidm_lap_backward", [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp])
         self._sig("pidm_debug_stream_trace", [vp])
         self._sig("pidm_debug_conv_rs_trace", [C.POINTER(C.c_ulonglong)])
+        self._sig("pidm_debug_lap_trace", [vp])
         self._sig("pidm_reload_knobs", [])
         self._sig("pidm_comm_available", [])
         self._sig("pidm_comm_unique_id", [vp])

@@ -906,6 +906,10 @@ __global__ void __launch_bounds__(kLapSmallNT) lap_mid_kernel(const float* __res
 // split once per tile by the whole workgroup into a pixel-major LDS image ([px][k-step][half][piece] - the B operands, lane = px).
 // The fp32 slabs of xn / dY and the padding of the Wq | Wk | dM rows in LDS (only the register fragments read them row-wise now)
 // make room for it.  The d_xn products keep the fp32 MFMA (their B operands chain from the accumulators).
+// PIDM_LAP_TRACE=1: cycle stamps of lap_bwd, workgroup 0, waves 0 and 4 (the two waves of one SIMD): [wave slot][tile round < 8][16]
+// 0 round start | 1 first half: projections consumed (softmax done) | 2 its d_xn products issued | 3 its weight-gradient share done |
+// 4-6 the same for the second half | 7 d_xn share written | 8 past barrier 1 | 9 head sum stored | 10 past barrier 2
+__device__ unsigned long long g_lap_trace[2 * 8 * 16];
 template <int CB, bool SP>
 __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ dy,
                                                       const float* __restrict__ wqkv, const float* __restrict__ P,
@@ -1053,6 +1057,15 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // the two waves of a SIMD (w and w + 4) walk the two halves of a tile's work in opposite order: the per-tile barriers keep all
   // waves in step, and in the same order their matrix-pipe phases and their vector phases coincide instead of overlapping
   const bool order_flip = (split_dw & 2) != 0;
+  // the second-dispatched half of the workgroup (waves 4-7: the younger wave of every SIMD) loses the issue arbitration against its
+  // older partner on every phase - stamps: 16 700 against 13 400 busy cycles per tile round, the older wave then waits 3300 cycles at
+  // the round's barrier.  Static priority for that half (split_dw bit 3; PIDM_LAP_PRIO=1) only swaps the roles: the round stays at
+  // 18 500 cycles - the SIMD's vector pipe (fp32 MFMAs + softmax + splitting of BOTH waves) is what is full (C = 32 -1.8 %, C = 64
+  // +6 %: profiles/r06_lap_bwd_stamps.txt).  Off by default.
+  if ((split_dw & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  const int tr_base = ((split_dw & 4) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) ? (wave >> 2) * 128 : -1;
+  int tr_round = 0;
+#define PIDM_LAP_STAMP(i_) if (tr_base >= 0 && tr_round < 8) g_lap_trace[tr_base + 16 * tr_round + (i_)] = clock64();
   split_dw &= 1;
   const bool k_first = (wave & 4) != 0 && order_flip;
   for (int sub = 0; sub < nsub; ++sub) {
@@ -1110,6 +1123,8 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   for (int t0 = 0; t0 < nper / 32; t0 += G) {
     const int t = t0 + tg;                 // this wave's tile of the round (act waves only)
     f32x16 dx[CB];
+    PIDM_LAP_STAMP(0)
+    int tr_half = 0;                       // 0 while the first of q_part / k_part runs
     if (act) {
       int z0 = 0;
       if (!WLDS) PIDM_OPAQUE_I32(z0);      // keeps the operand fetches below inside the tile loop
@@ -1174,6 +1189,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       jd = (jd + pidm_other_half(jd)) * rscale;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = qt[r] * (dq[r] - jd);
+      PIDM_LAP_STAMP(1 + 3 * tr_half)
       // d_xn^T[c][px] += Wq_h^T[c][d] dq^T[d][px]  (operand rows fetched as one batch, then the MFMAs)
       if constexpr (WLDS) {
         float wa[16][CB];
@@ -1193,8 +1209,11 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
         }
       }
+      PIDM_LAP_STAMP(2 + 3 * tr_half)
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
       PIDM_LAP_DW(dq, dWq)
+      PIDM_LAP_STAMP(3 + 3 * tr_half)
+      tr_half = 1;
       };
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
       auto k_part = [&]() __attribute__((always_inline)) {
@@ -1235,6 +1254,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           dk[r] = kt[r] * (dk[r] - rd4[i]);
         }
       }
+      PIDM_LAP_STAMP(1 + 3 * tr_half)
       // d_xn^T[c][px] += Wk_h^T[c][d] dk^T[d][px] + dM_h^T[c][d] ks^T[d][px]
       if constexpr (WLDS) {
         float wa[16][CB], ma[16][CB];
@@ -1264,7 +1284,10 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
           }
         }
       }
+      PIDM_LAP_STAMP(2 + 3 * tr_half)
       PIDM_LAP_DW(dk, dWk)
+      PIDM_LAP_STAMP(3 + 3 * tr_half)
+      tr_half = 1;
       };
       if (k_first) { k_part(); q_part(); } else { q_part(); k_part(); }
       // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
@@ -1273,7 +1296,9 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) tw[(cb * 32 + lap_row(r, half)) * kLapTileLd + l31] = dx[cb][r];
     }
+    PIDM_LAP_STAMP(7)
     __syncthreads();
+    PIDM_LAP_STAMP(8)
     // sum over the heads (waves of a group) and store d_xn rows of the round's G tiles: thread -> (pixel, 4 consecutive channels)
     for (int e = tid; e < G * 32 * (C / 4); e += 512) {
       const int px = e / (C / 4), c0 = 4 * (e - px * (C / 4));      // px: 0 .. 32 G - 1 (group = px / 32)
@@ -1286,9 +1311,13 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
       }
       *reinterpret_cast<f32x4*>(dxn + (pix0 + (size_t)t0 * 32 + px) * C + c0) = o;
     }
+    PIDM_LAP_STAMP(9)
     __syncthreads();
+    PIDM_LAP_STAMP(10)
+    ++tr_round;
   }
   }
+#undef PIDM_LAP_STAMP
   // the groups' dWq / dWk shares of a head are summed in group order through the waves' tiles (free after the last barrier above)
   for (int m = 0; m < 2 && G > 1; ++m) {
     if (act && tg > 0) {
@@ -1471,6 +1500,8 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
   const char* ofe = knob("PIDM_LAP_ORDER_FLIP");            // 0: every wave runs a tile's q half before its k half
   const int oflip = (ofe && !atoi(ofe)) ? 0 : 2;
   const int split_dw = !(spe && !atoi(spe)) ? 1 : 0;
+  const char* pre = knob("PIDM_LAP_PRIO");                 // 1: static priority for the younger half of lap_bwd's waves (measured: no gain)
+  const int trbit = (knob("PIDM_LAP_TRACE") ? 4 : 0) | ((pre && atoi(pre)) ? 8 : 0);
   const char* ppe = knob("PIDM_LAP_SPLIT_PROJ");            // 0: the four per-pixel projections of lap_bwd stay on the fp32 MFMA
   if (CB == 1 && split_dw && !(ppe && !atoi(ppe))) {
     const size_t lds3p = ((size_t)8 * 32 * kLapTileLd + 8 * 96 + (size_t)3 * heads * kLapDH * C) * sizeof(float) + (size_t)3 * C * (nslab * 2) +
@@ -1483,7 +1514,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
     }
     PIDM_PROF_NAME("lap_bwd_kernel<1, true>");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<1, true>), dim3(B * NS3), dim3(512), lds3p, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn,
-                       dwqk_part, N, heads, nslab, nsl, scale, 1 | oflip, G3);
+                       dwqk_part, N, heads, nslab, nsl, scale, 1 | oflip | trbit, G3);
     PIDM_CHECK_LAUNCH("lap_bwd_kernel");
     return 0;
   }
@@ -1491,7 +1522,7 @@ static int lap_backward_t(const float* xn, const float* dy, const float* wqkv, c
                       (size_t)3 * C * (nslab * 2 + (CB == 1 ? 0 : 16));
   if (lds3 > 160 * 1024 - 256) return fail("lap_bwd: %zu B of LDS", lds3);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(lap_bwd_kernel<CB, false>), dim3(B * NS3), dim3(512), lds3, st, xn, dy, wqkv, P, kst, dMmat, rowdot, dxn, dwqk_part,
-                     N, heads, nslab, nsl, scale, split_dw | oflip, G3);
+                     N, heads, nslab, nsl, scale, split_dw | oflip | trbit, G3);
   PIDM_CHECK_LAUNCH("lap_bwd_kernel");
   return 0;
 }
@@ -1545,4 +1576,9 @@ extern "C" int pidm_lap_backward(const float* xn, const float* dy, const float* 
   if (launch_split_reduce(dwqk, d_w_qkv, nullptr, nullptr, B * nr, 2 * HD, C, 1, 2 * HD, C, st)) return -1;
   if (launch_split_reduce(dwv, d_w_qkv + (size_t)2 * HD * C, nullptr, nullptr, B, HD, C, 1, HD, C, st)) return -1;
   return launch_split_reduce(dwo, d_w_out, nullptr, nullptr, B, C, HD, 1, C, HD, st);
+}
+
+// measurement aid: the cycle stamps lap_bwd_kernel left (PIDM_LAP_TRACE=1; see g_lap_trace)
+extern "C" int pidm_debug_lap_trace(unsigned long long* out256) {
+  return hipMemcpyFromSymbol(out256, HIP_SYMBOL(pidm::g_lap_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
 }

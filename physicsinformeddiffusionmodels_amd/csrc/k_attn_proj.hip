@@ -906,7 +906,10 @@ __global__ void __launch_bounds__(kLapSmallNT) lap_mid_kernel(const float* __res
 // split once per tile by the whole workgroup into a pixel-major LDS image ([px][k-step][half][piece] - the B operands, lane = px).
 // The fp32 slabs of xn / dY and the padding of the Wq | Wk | dM rows in LDS (only the register fragments read them row-wise now)
 // make room for it.  The d_xn products keep the fp32 MFMA (their B operands chain from the accumulators).
-// PIDM_LAP_TRACE=1: cycle stamps of lap_bwd, workgroup 0, waves 0 and 4 (the two waves of one SIMD): [wave slot][tile round < 8][16]
+#ifndef PIDM_LAP_TRACE_BUILD
+#define PIDM_LAP_TRACE_BUILD 0
+#endif
+// PIDM_LAP_TRACE=1 in a build with -DPIDM_LAP_TRACE_BUILD=1: cycle stamps of lap_bwd, workgroup 0, waves 0 and 4 (the two waves of one SIMD): [wave slot][tile round < 8][16]
 // 0 round start | 1 first half: projections consumed (softmax done) | 2 its d_xn products issued | 3 its weight-gradient share done |
 // 4-6 the same for the second half | 7 d_xn share written | 8 past barrier 1 | 9 head sum stored | 10 past barrier 2
 __device__ unsigned long long g_lap_trace[2 * 8 * 16];
@@ -1063,9 +1066,21 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
   // 18 500 cycles - the SIMD's vector pipe (fp32 MFMAs + softmax + splitting of BOTH waves) is what is full (C = 32 -1.8 %, C = 64
   // +6 %: profiles/r06_lap_bwd_stamps.txt).  Off by default.
   if ((split_dw & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-  const int tr_base = ((split_dw & 4) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) ? (wave >> 2) * 128 : -1;
+  // (the stamps exist in measurement builds only, -DPIDM_LAP_TRACE_BUILD=1: the C = 32 instantiation sits at 256 registers without a
+  // spill, and even scalar stamp code pushed 40 registers into scratch)
+#if PIDM_LAP_TRACE_BUILD
+  const bool tr_on = (split_dw & 4) && blockIdx.x == 0 && (wave & 3) == 0;
   int tr_round = 0;
-#define PIDM_LAP_STAMP(i_) if (tr_base >= 0 && tr_round < 8) g_lap_trace[tr_base + 16 * tr_round + (i_)] = clock64();
+#define PIDM_LAP_STAMP(i_)                                                                                         \
+  if (tr_on && tr_round < 8) {                                                                                     \
+    const unsigned long long c__ = clock64();                                                                      \
+    if (lane == 0) g_lap_trace[(wave >> 2) * 128 + 16 * tr_round + (i_)] = c__;                                    \
+  }
+#define PIDM_LAP_TRACE_ONLY(x_) x_
+#else
+#define PIDM_LAP_STAMP(i_)
+#define PIDM_LAP_TRACE_ONLY(x_)
+#endif
   split_dw &= 1;
   const bool k_first = (wave & 4) != 0 && order_flip;
   for (int sub = 0; sub < nsub; ++sub) {
@@ -1124,7 +1139,7 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     const int t = t0 + tg;                 // this wave's tile of the round (act waves only)
     f32x16 dx[CB];
     PIDM_LAP_STAMP(0)
-    int tr_half = 0;                       // 0 while the first of q_part / k_part runs
+    PIDM_LAP_TRACE_ONLY(int tr_half = 0;)  // 0 while the first of q_part / k_part runs
     if (act) {
       int z0 = 0;
       if (!WLDS) PIDM_OPAQUE_I32(z0);      // keeps the operand fetches below inside the tile loop
@@ -1202,18 +1217,29 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[r][cb], dq[r], dx[cb], 0, 0, 0);
       } else {
+        // operand rows from global memory / L1 (C = 64: 3 x 256 rows of 68 floats do not fit LDS next to the slabs): fetched in chunks of
+        // four rows, the next chunk before the current chunk's MFMAs - one row per MFMA made every MFMA wait for its own load
+        // (stamps: 27 000-40 000 cycles per tile round in these products for 6100 cycles of fp32 MFMAs)
+        float wb[2][4][CB];
+#define PIDM_LAP_LDQ(c4_, sl_)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) wb[sl_][i][cb] = (wqT + (size_t)lap_row(4 * (c4_) + i, half) * ldT)[32 * cb];
+        PIDM_LAP_LDQ(0, 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float* wr = wqT + (size_t)lap_row(r, half) * ldT;
+        for (int c4 = 0; c4 < 4; ++c4) {
+          if (c4 + 1 < 4) PIDM_LAP_LDQ(c4 + 1, (c4 + 1) & 1)
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[c4 & 1][i][cb], dq[4 * c4 + i], dx[cb], 0, 0, 0);
         }
+#undef PIDM_LAP_LDQ
       }
       PIDM_LAP_STAMP(2 + 3 * tr_half)
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
       PIDM_LAP_DW(dq, dWq)
       PIDM_LAP_STAMP(3 + 3 * tr_half)
-      tr_half = 1;
+      PIDM_LAP_TRACE_ONLY(tr_half = 1;)
       };
       // ---- k: ks^T[d][px] from the saved column statistics, dks^T = dM_h xn^T, dk = ks (dks - rowdot) ----
       auto k_part = [&]() __attribute__((always_inline)) {
@@ -1273,21 +1299,32 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
             dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[r][cb], kt[r], dx[cb], 0, 0, 0);
           }
       } else {
+        // (chunks of two rows of both operand matrices, fetched one chunk ahead: see q_part)
+        float wb[2][2][CB], mb[2][2][CB];
+#define PIDM_LAP_LDK(c2_, sl_)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                            \
+      wb[sl_][i][cb] = (wkT + (size_t)lap_row(2 * (c2_) + i, half) * ldT)[32 * cb];                                \
+      mb[sl_][i][cb] = (dmT + (size_t)lap_row(2 * (c2_) + i, half) * ldT)[32 * cb];                                \
+    }
+        PIDM_LAP_LDK(0, 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float* wr = wkT + (size_t)lap_row(r, half) * ldT;
-          const float* mr = dmT + (size_t)lap_row(r, half) * ldT;
+        for (int c2 = 0; c2 < 8; ++c2) {
+          if (c2 + 1 < 8) PIDM_LAP_LDK(c2 + 1, (c2 + 1) & 1)
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) {
-            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dk[r], dx[cb], 0, 0, 0);
-            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[32 * cb], kt[r], dx[cb], 0, 0, 0);
-          }
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+              dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[c2 & 1][i][cb], dk[2 * c2 + i], dx[cb], 0, 0, 0);
+              dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb[c2 & 1][i][cb], kt[2 * c2 + i], dx[cb], 0, 0, 0);
+            }
         }
+#undef PIDM_LAP_LDK
       }
       PIDM_LAP_STAMP(2 + 3 * tr_half)
       PIDM_LAP_DW(dk, dWk)
       PIDM_LAP_STAMP(3 + 3 * tr_half)
-      tr_half = 1;
+      PIDM_LAP_TRACE_ONLY(tr_half = 1;)
       };
       if (k_first) { k_part(); q_part(); } else { q_part(); k_part(); }
       // this head's d_xn^T share -> the wave's tile(s): [cb][c][px]
@@ -1314,10 +1351,11 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
     PIDM_LAP_STAMP(9)
     __syncthreads();
     PIDM_LAP_STAMP(10)
-    ++tr_round;
+    PIDM_LAP_TRACE_ONLY(++tr_round;)
   }
   }
 #undef PIDM_LAP_STAMP
+#undef PIDM_LAP_TRACE_ONLY
   // the groups' dWq / dWk shares of a head are summed in group order through the waves' tiles (free after the last barrier above)
   for (int m = 0; m < 2 && G > 1; ++m) {
     if (act && tg > 0) {

@@ -1,4 +1,6 @@
 """Cycle stamps of lap_bwd_kernel (workgroup 0, waves 0 and 4 = one SIMD): where a (tile, head) unit's time goes.
+Needs a measurement build of k_attn_proj.hip with -DPIDM_LAP_TRACE_BUILD=1 (the stamps cost the C = 32 kernel its last registers;
+e.g. `make -C physicsinformeddiffusionmodels_amd/csrc HIPFLAGS+=-DPIDM_LAP_TRACE_BUILD=1` after touching the file).
 python tools/lap_trace.py [B] [H] [heads] [C]"""
 import ctypes as C_
 import os

@@ -1217,23 +1217,12 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[r][cb], dq[r], dx[cb], 0, 0, 0);
       } else {
-        // operand rows from global memory / L1 (C = 64: 3 x 256 rows of 68 floats do not fit LDS next to the slabs): fetched in chunks of
-        // four rows, the next chunk before the current chunk's MFMAs - one row per MFMA made every MFMA wait for its own load
-        // (stamps: 27 000-40 000 cycles per tile round in these products for 6100 cycles of fp32 MFMAs)
-        float wb[2][4][CB];
-#define PIDM_LAP_LDQ(c4_, sl_)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
-    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) wb[sl_][i][cb] = (wqT + (size_t)lap_row(4 * (c4_) + i, half) * ldT)[32 * cb];
-        PIDM_LAP_LDQ(0, 0)
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-          if (c4 + 1 < 4) PIDM_LAP_LDQ(c4 + 1, (c4 + 1) & 1)
+        for (int r = 0; r < 16; ++r) {
+          const float* wr = wqT + (size_t)lap_row(r, half) * ldT;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[c4 & 1][i][cb], dq[4 * c4 + i], dx[cb], 0, 0, 0);
+          for (int cb = 0; cb < CB; ++cb) dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dq[r], dx[cb], 0, 0, 0);
         }
-#undef PIDM_LAP_LDQ
       }
       PIDM_LAP_STAMP(2 + 3 * tr_half)
       // dWq_h[d][c] += sum_px dq[px][d] xn[px][c]: turn dq^T through the wave's LDS tile (write [d][px], read lane = d)
@@ -1299,27 +1288,16 @@ __global__ void __launch_bounds__(512) lap_bwd_kernel(const float* __restrict__ 
             dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[r][cb], kt[r], dx[cb], 0, 0, 0);
           }
       } else {
-        // (chunks of two rows of both operand matrices, fetched one chunk ahead: see q_part)
-        float wb[2][2][CB], mb[2][2][CB];
-#define PIDM_LAP_LDK(c2_, sl_)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
-    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                            \
-      wb[sl_][i][cb] = (wkT + (size_t)lap_row(2 * (c2_) + i, half) * ldT)[32 * cb];                                \
-      mb[sl_][i][cb] = (dmT + (size_t)lap_row(2 * (c2_) + i, half) * ldT)[32 * cb];                                \
-    }
-        PIDM_LAP_LDK(0, 0)
 #pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) {
-          if (c2 + 1 < 8) PIDM_LAP_LDK(c2 + 1, (c2 + 1) & 1)
+        for (int r = 0; r < 16; ++r) {
+          const float* wr = wkT + (size_t)lap_row(r, half) * ldT;
+          const float* mr = dmT + (size_t)lap_row(r, half) * ldT;
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-              dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[c2 & 1][i][cb], dk[2 * c2 + i], dx[cb], 0, 0, 0);
-              dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb[c2 & 1][i][cb], kt[2 * c2 + i], dx[cb], 0, 0, 0);
-            }
+          for (int cb = 0; cb < CB; ++cb) {
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * cb], dk[r], dx[cb], 0, 0, 0);
+            dx[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[32 * cb], kt[r], dx[cb], 0, 0, 0);
+          }
         }
-#undef PIDM_LAP_LDK
       }
       PIDM_LAP_STAMP(2 + 3 * tr_half)
       PIDM_LAP_DW(dk, dWk)

@@ -66,7 +66,18 @@ enum { DARCY_RES_ONLY = 0, DARCY_BWD = 1, DARCY_LOSS = 2 };
 struct DarcyBands {
   int nb, R;
 };
-static DarcyBands darcy_bands(int B, int P) {
+// one workgroup per sample (darcy_full_kernel): 64 x 64 fields at batches that fill the chip twice over on their own
+static bool darcy_full_on(int B, int P) {
+  const char* e = knob("PIDM_DARCY_FULL");     // smallest batch that takes it (0: never)
+  const int min_b = e ? atoi(e) : 512;
+  return P == 64 && min_b > 0 && B >= min_b;
+}
+static bool darcy_stream_on() {
+  const char* e = knob("PIDM_DARCY_STREAM");     // 0: one workgroup per sample, no cross-sample prefetch (darcy_full_kernel)
+  return !(e && !atoi(e));
+}
+static DarcyBands darcy_bands(int B, int P, bool res_only = false) {
+  if (!res_only && darcy_full_on(B, P)) return DarcyBands{1, P};
   int nb = (1024 + B - 1) / B;              // >= 4 workgroups per CU where the batch alone does not provide them
   static int max_rows = 0;                  // rows per band at large batches (PIDM_DARCY_ROWS, measurement knob; >= 4)
   if (!max_rows) {
@@ -600,6 +611,460 @@ __global__ void __launch_bounds__(512) darcy_quad_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Large batches (round 6): ONE workgroup per 64 x 64 sample, no bands - no halo rows to reload and recompute - and only FIVE fields
+// in LDS (p, K and the three intermediates whose transposed stencils run across rows: -K g, the coefficients on p0 and K0): 80 KB.
+// Everything a pixel's OWN thread needs later stays in its registers - thread (row slot rt, quad q) owns rows rt, rt + NT / 16, ...
+// in every pass: the intermediates of the row-direction stencils (their neighbours come by 16-lane shuffles: the 16 quads of a row
+// are 16 consecutive lanes), the direct K term, prediction - target (read once, for the data loss AND its gradient).
+// Same arithmetic in the same order as darcy_quad_kernel (same taps, same windows, same gathers): residual and gradients are
+// bit-identical; the loss partial sums are per sample instead of per band (one more grouping of the same doubles).
+// Replaces the same reference lines as darcy_quad_kernel for B >= 512 (PIDM_DARCY_FULL=<smallest batch>, 0: off).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quad_window_regs(const float (&v)[4], bool lowq, bool highq, float (&w)[6]) {
+  const float left = __shfl_up(v[3], 1, 16), right = __shfl_down(v[0], 1, 16);
+  w[0] = lowq ? v[0] : left;
+  w[1] = v[0]; w[2] = v[1]; w[3] = v[2]; w[4] = v[3];
+  w[5] = highq ? v[3] : right;
+}
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT, 2) darcy_full_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
+                                                        const float* __restrict__ f_s, const float* __restrict__ grad_res,
+                                                        const float* __restrict__ p2w, const float* __restrict__ inv_var,
+                                                        const long long* __restrict__ tsteps, float c_data, float c_res, float bc1_sign,
+                                                        FdAxis ax0, FdAxis ax1, float* __restrict__ residual, float* __restrict__ grad_pred,
+                                                        double* __restrict__ partial, int B) {
+  constexpr int P = 64, N = P * P, RS = NT / 16, NIT = P / RS;     // row step, rows per thread
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* sp = smem;
+  float* sK = sp + N;
+  float* skg = sp + 2 * N;
+  float* sa0 = sp + 3 * N;
+  float* sb0 = sp + 4 * N;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int q = tid & 15, j0 = 4 * q, rt = tid >> 4;
+  const bool lowq = q == 0, highq = q == 15;
+  const float* pb = pred + (size_t)b * 2 * N;
+  const float* tb = x0 + (size_t)b * 2 * N;
+  f32x4 vp[NIT], vK[NIT], t0[NIT], t1[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int n = (rt + RS * it) * P + j0;
+    vp[it] = *reinterpret_cast<const f32x4*>(pb + n);
+    vK[it] = *reinterpret_cast<const f32x4*>(pb + N + n);
+    if (MODE == DARCY_LOSS) {
+      t0[it] = *reinterpret_cast<const f32x4*>(tb + n);
+      t1[it] = *reinterpret_cast<const f32x4*>(tb + N + n);
+    }
+  }
+  double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int n = (rt + RS * it) * P + j0;
+    *reinterpret_cast<f32x4*>(sp + n) = vp[it];
+    *reinterpret_cast<f32x4*>(sK + n) = vK[it];
+    if (MODE == DARCY_LOSS) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // kept as prediction - target for the gradient below; its square is the reference's (target - prediction)^2 bit for bit
+        t0[it][m] = vp[it][m] - t0[it][m];
+        t1[it][m] = vK[it][m] - t1[it][m];
+        acc_data += (double)(t0[it][m] * t0[it][m]) + (double)(t1[it][m] * t1[it][m]);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float gscale = (MODE == DARCY_LOSS) ? c_res * darcy_inv_var(inv_var, tsteps, b) / ((float)B * (float)N * 3.0f) : 0.f;
+  // own-pixel values kept for the last pass: -K g, coefficients on p1 / K1, the direct K term
+  float rkg[NIT][4], ra1[NIT][4], rb1[NIT][4], rd[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = rt + RS * it, n = i * P + j0;
+    const FdTaps4 ti = fd_taps(ax0, i, P, 0, P - 1);
+    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p00[4] = {0.f, 0.f, 0.f, 0.f}, K0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + ti.idx[k] * P + j0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        p0[m] = fmaf(ti.w1[k], pa[m], p0[m]);
+        p00[m] = fmaf(ti.w2[k], pa[m], p00[m]);
+      }
+      if (k < 3) {
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + ti.idx[k] * P + j0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) K0[m] = fmaf(ti.w1[k], ka[m], K0[m]);
+      }
+    }
+    float wp[6], wk[6], p1[4], p11[4], K1[4];
+    const float pv[4] = {vp[it][0], vp[it][1], vp[it][2], vp[it][3]}, kv[4] = {vK[it][0], vK[it][1], vK[it][2], vK[it][3]};
+    quad_window_regs(pv, lowq, highq, wp);
+    quad_window_regs(kv, lowq, highq, wk);
+    quad_d1(ax1, wp, lowq, highq, p1);
+    quad_d2(ax1, wp, lowq, highq, p11);
+    quad_d1(ax1, wk, lowq, highq, K1);
+    const f32x4 fs4 = *reinterpret_cast<const f32x4*>(f_s + n);
+    const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
+    float eq[4], bc0[4], bc1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float Kv = wk[m + 1];
+      const float vj00 = -Kv * p00[m] - K0[m] * p0[m];
+      const float vj11 = -Kv * p11[m] - K1[m] * p1[m];
+      eq[m] = vj00 + vj11 - fs4[m];
+      const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+      bc0[m] = s0 * p0[m];
+      bc1[m] = s1 * p1[m];
+    }
+    if (MODE != DARCY_BWD) {
+      f32x4* r = reinterpret_cast<f32x4*>(residual + ((size_t)b * N + n) * 3);
+      r[0] = f32x4{eq[0], bc0[0], bc1[0], eq[1]};
+      r[1] = f32x4{bc0[1], bc1[1], eq[2], bc0[2]};
+      r[2] = f32x4{bc1[2], eq[3], bc0[3], bc1[3]};
+    }
+    float g[4], gb0[4], gb1[4];
+    if (MODE == DARCY_BWD) {
+      const f32x4* gr = reinterpret_cast<const f32x4*>(grad_res + ((size_t)b * N + n) * 3);
+      const f32x4 a = gr[0], c = gr[1], e = gr[2];
+      g[0] = a[0]; gb0[0] = a[1]; gb1[0] = a[2]; g[1] = a[3];
+      gb0[1] = c[0]; gb1[1] = c[1]; g[2] = c[2]; gb0[2] = c[3];
+      gb1[2] = e[0]; g[3] = e[1]; gb0[3] = e[2]; gb1[3] = e[3];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // (eq^2 + bc0^2) + bc1^2 in double, as the band kernel: bc0 is an exact zero off the first / last row and bc1 off the
+        // first / last column, and adding those zeros changes no bit - they are skipped
+        double r2 = (double)(eq[m] * eq[m]), ra = (double)fabsf(eq[m]);
+        if (s0 != 0.f) {
+          r2 += (double)(bc0[m] * bc0[m]);
+          ra += (double)fabsf(bc0[m]);
+        }
+        if (m == 0 || m == 3) {
+          r2 += (double)(bc1[m] * bc1[m]);
+          ra += (double)fabsf(bc1[m]);
+        }
+        acc_r2 += r2;
+        acc_rabs += ra;
+        g[m] = gscale * eq[m];
+        gb0[m] = gscale * bc0[m];
+        gb1[m] = gscale * bc1[m];
+      }
+    }
+    f32x4 o_kg, o_a0, o_b0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+      o_kg[m] = -wk[m + 1] * g[m];
+      o_a0[m] = -K0[m] * g[m] + s0 * gb0[m];
+      o_b0[m] = -p0[m] * g[m];
+      rkg[it][m] = o_kg[m];
+      ra1[it][m] = -K1[m] * g[m] + s1 * gb1[m];
+      rb1[it][m] = -p1[m] * g[m];
+      rd[it][m] = -(p00[m] + p11[m]) * g[m];
+      PIDM_OPAQUE_F32(rd[it][m]);     // a ROUNDED product, as the band kernel's round trip through LDS makes it: no fma with the sum below
+    }
+    *reinterpret_cast<f32x4*>(skg + n) = o_kg;
+    *reinterpret_cast<f32x4*>(sa0 + n) = o_a0;
+    *reinterpret_cast<f32x4*>(sb0 + n) = o_b0;
+  }
+  __syncthreads();
+
+  const float dscale = (MODE == DARCY_LOSS) ? 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N) : 0.f;
+  const QuadT tq1 = quad_T(ax1.c1, j0, P, 3), tq2 = quad_T(ax1.c2, j0, P, 4);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = rt + RS * it, n = i * P + j0;
+    const FdTaps5 ti = fd_taps_T(ax0, i, P, 0, P - 1);
+    float g00[4] = {0.f, 0.f, 0.f, 0.f}, ga0[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int c0 = ti.idx[k] * P + j0;
+      const f32x4 vkg = *reinterpret_cast<const f32x4*>(skg + c0), va = *reinterpret_cast<const f32x4*>(sa0 + c0),
+                  vb = *reinterpret_cast<const f32x4*>(sb0 + c0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        g00[m] = fmaf(ti.w2[k], vkg[m], g00[m]);
+        ga0[m] = fmaf(ti.w1[k], va[m], ga0[m]);
+        gb0[m] = fmaf(ti.w1[k], vb[m], gb0[m]);
+      }
+    }
+    // row-direction gathers: the row's own values by 16-lane shuffles (first / last element of the row: lanes 0 / 15 of the group)
+    float w[6], g11[4], ga1[4], gb1[4];
+    quad_window_regs(rkg[it], lowq, highq, w);
+    quad_gather(tq2, __shfl(rkg[it][0], 0, 16), __shfl(rkg[it][3], 15, 16), w, g11);
+    quad_window_regs(ra1[it], lowq, highq, w);
+    quad_gather(tq1, __shfl(ra1[it][0], 0, 16), __shfl(ra1[it][3], 15, 16), w, ga1);
+    quad_window_regs(rb1[it], lowq, highq, w);
+    quad_gather(tq1, __shfl(rb1[it][0], 0, 16), __shfl(rb1[it][3], 15, 16), w, gb1);
+    f32x4 gp, gK;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      gp[m] = ((g00[m] + g11[m]) + ga0[m]) + ga1[m];
+      gK[m] = (rd[it][m] + gb0[m]) + gb1[m];
+    }
+    if (MODE == DARCY_LOSS) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gp[m] += dscale * t0[it][m];
+        gK[m] += dscale * t1[it][m];
+      }
+    }
+    *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + n) = gp;
+    *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + N + n) = gK;
+  }
+
+  if (MODE == DARCY_LOSS) {
+    double (*red)[NT / 64] = reinterpret_cast<double (*)[NT / 64]>(sp);     // p is dead since the second barrier
+    double v[3] = {acc_data, acc_r2, acc_rabs};
+    for (int qq = 0; qq < 3; ++qq) {
+      double x = v[qq];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+      if ((tid & 63) == 0) red[qq][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      double sv = 0.0;
+      for (int w = 0; w < NT / 64; ++w) sv += red[tid][w];     // fixed order
+      partial[(size_t)blockIdx.x * 4 + tid] = sv;
+    }
+  }
+}
+
+// Cycle stamps of workgroup 0's first wave (tools/darcy_trace.py; compiled in only with -DPIDM_DARCY_TRACE_BUILD=1: the product
+// kernel carries none): per sample, [0] past the top barrier, [1] end of the first pass, [2] past the second barrier, [3] end.
+#ifndef PIDM_DARCY_TRACE_BUILD
+#define PIDM_DARCY_TRACE_BUILD 0
+#endif
+#if PIDM_DARCY_TRACE_BUILD
+__device__ unsigned long long g_darcy_trace[4 * 64];
+#define PIDM_DARCY_STAMP(slot_) \
+  do { if (blockIdx.x == 0 && threadIdx.x == 0 && n_done < 64) g_darcy_trace[4 * n_done + (slot_)] = clock64(); } while (0)
+#else
+#define PIDM_DARCY_STAMP(slot_) ((void)0)
+#endif
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused loss at large batches, streaming: darcy_full_kernel<DARCY_LOSS> as a PERSISTENT workgroup per CU that walks samples
+// b, b + gridDim.x, ... and has the NEXT sample's inputs copied global -> LDS (global_load_lds, no registers) while it computes the
+// current one.  One workgroup of 8 waves per CU runs load -> barrier -> stencils -> barrier -> adjoint stencils strictly in turn
+// (PMC, batch 4096: vector ALU busy 37 % of the kernel, memory about as much, nothing overlapped); here the loads of sample s + 1
+// are in flight during passes 1 and 2 of sample s and the stores drain behind the next sample's arithmetic.
+// LDS: prediction (p, K) double-buffered 2 x 32 KB, target 32 KB, the three column-stencil intermediates 48 KB, 192 B of loss sums.
+// The copies are issued as instructions hipcc does not track (pidm_glds_b128_untracked; it would answer the first LDS read behind
+// a tracked copy with vmcnt(0)); nothing else LOADS from global memory inside the loop (f_s of the own rows lives in registers, the
+// per-sample weights are scalar loads), so the only vector-memory wait is the explicit one in front of the top barrier.
+// Arithmetic, order and results: exactly darcy_full_kernel's.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
+                                                              const float* __restrict__ f_s, const float* __restrict__ p2w,
+                                                              const float* __restrict__ inv_var, const long long* __restrict__ tsteps,
+                                                              float c_data, float c_res, float bc1_sign, FdAxis ax0, FdAxis ax1,
+                                                              float* __restrict__ residual, float* __restrict__ grad_pred,
+                                                              double* __restrict__ partial, int B) {
+  constexpr int P = 64, N = P * P, NT = 512, RS = NT / 16, NIT = P / RS;
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* pk = smem;                  // [2][p, K]
+  float* tg = smem + 4 * N;          // target [p, K]
+  float* skg = smem + 6 * N;
+  float* sa0 = smem + 7 * N;
+  float* sb0 = smem + 8 * N;
+  double (*red)[NT / 64] = reinterpret_cast<double (*)[NT / 64]>(smem + 9 * N);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int q0 = tid & 15, rt0 = tid >> 4;
+  // a 32 KB block (two fields of one sample) as 32 pieces of 1 KB: wave w copies pieces w, w + 8, w + 16, w + 24
+  auto fetch = [&](const float* g, float* l) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = wave + 8 * k;
+      pidm_glds_b128_untracked(g + piece * 256 + lane * 4, l + piece * 256);
+    }
+  };
+  f32x4 fs4[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) fs4[it] = *reinterpret_cast<const f32x4*>(f_s + (rt0 + RS * it) * P + 4 * q0);
+  int b = blockIdx.x, b_prev = -1, cur = 0;
+  [[maybe_unused]] int n_done = 0;
+  if (b < B) {
+    fetch(pred + (size_t)b * 2 * N, pk);
+    fetch(x0 + (size_t)b * 2 * N, tg);
+  }
+  for (; b < B; b_prev = b, b += gridDim.x, cur ^= 1) {
+    const float* sp = pk + cur * 2 * N;
+    const float* sK = sp + N;
+    // the stencil taps depend on the thread's rows and columns only, and left to itself the compiler keeps all of them (~100
+    // registers) across the sample loop and spills: a zero it cannot see makes them this iteration's values
+    int zero = 0;
+    PIDM_OPAQUE_I32(zero);
+    const int rt = rt0 + zero, q = q0 + zero, j0 = 4 * q;
+    const bool lowq = q == 0, highq = q == 15;
+    PIDM_WAIT_VMEM_LEAVE(0);     // this sample's copies have landed (leaving the last gradient stores in flight: no gain)
+    __syncthreads();
+    PIDM_DARCY_STAMP(0);
+    if (b_prev >= 0 && tid < 3) {
+      double sv = 0.0;
+      for (int w = 0; w < NT / 64; ++w) sv += red[tid][w];     // fixed order
+      partial[(size_t)b_prev * 4 + tid] = sv;
+    }
+    if (b + (int)gridDim.x < B) fetch(pred + (size_t)(b + gridDim.x) * 2 * N, pk + (cur ^ 1) * 2 * N);
+
+    f32x4 vp[NIT], vK[NIT], t0[NIT], t1[NIT];
+    double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int n = (rt + RS * it) * P + j0;
+      vp[it] = *reinterpret_cast<const f32x4*>(sp + n);
+      vK[it] = *reinterpret_cast<const f32x4*>(sK + n);
+      t0[it] = *reinterpret_cast<const f32x4*>(tg + n);
+      t1[it] = *reinterpret_cast<const f32x4*>(tg + N + n);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        t0[it][m] = vp[it][m] - t0[it][m];
+        t1[it][m] = vK[it][m] - t1[it][m];
+        acc_data += (double)(t0[it][m] * t0[it][m]) + (double)(t1[it][m] * t1[it][m]);
+      }
+    }
+    const float gscale = c_res * darcy_inv_var(inv_var, tsteps, b) / ((float)B * (float)N * 3.0f);
+    float rkg[NIT][4], ra1[NIT][4], rb1[NIT][4], rd[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = rt + RS * it, n = i * P + j0;
+      const FdTaps4 ti = fd_taps(ax0, i, P, 0, P - 1);
+      float p0[4] = {0.f, 0.f, 0.f, 0.f}, p00[4] = {0.f, 0.f, 0.f, 0.f}, K0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(sp + ti.idx[k] * P + j0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          p0[m] = fmaf(ti.w1[k], pa[m], p0[m]);
+          p00[m] = fmaf(ti.w2[k], pa[m], p00[m]);
+        }
+        if (k < 3) {
+          const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + ti.idx[k] * P + j0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) K0[m] = fmaf(ti.w1[k], ka[m], K0[m]);
+        }
+      }
+      float wp[6], wk[6], p1[4], p11[4], K1[4];
+      const float pv[4] = {vp[it][0], vp[it][1], vp[it][2], vp[it][3]}, kv[4] = {vK[it][0], vK[it][1], vK[it][2], vK[it][3]};
+      quad_window_regs(pv, lowq, highq, wp);
+      quad_window_regs(kv, lowq, highq, wk);
+      quad_d1(ax1, wp, lowq, highq, p1);
+      quad_d2(ax1, wp, lowq, highq, p11);
+      quad_d1(ax1, wk, lowq, highq, K1);
+      const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
+      float eq[4], bc0[4], bc1[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float Kv = wk[m + 1];
+        const float vj00 = -Kv * p00[m] - K0[m] * p0[m];
+        const float vj11 = -Kv * p11[m] - K1[m] * p1[m];
+        eq[m] = vj00 + vj11 - fs4[it][m];
+        const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+        bc0[m] = s0 * p0[m];
+        bc1[m] = s1 * p1[m];
+      }
+      f32x4* r = reinterpret_cast<f32x4*>(residual + ((size_t)b * N + n) * 3);
+      r[0] = f32x4{eq[0], bc0[0], bc1[0], eq[1]};
+      r[1] = f32x4{bc0[1], bc1[1], eq[2], bc0[2]};
+      r[2] = f32x4{bc1[2], eq[3], bc0[3], bc1[3]};
+      float g[4], gb0[4], gb1[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // (eq^2 + bc0^2) + bc1^2 in double, as the band kernel: bc0 is an exact zero off the first / last row and bc1 off the
+        // first / last column, and adding those zeros changes no bit - they are skipped
+        double r2 = (double)(eq[m] * eq[m]), ra = (double)fabsf(eq[m]);
+        if (s0 != 0.f) {
+          r2 += (double)(bc0[m] * bc0[m]);
+          ra += (double)fabsf(bc0[m]);
+        }
+        if (m == 0 || m == 3) {
+          r2 += (double)(bc1[m] * bc1[m]);
+          ra += (double)fabsf(bc1[m]);
+        }
+        acc_r2 += r2;
+        acc_rabs += ra;
+        g[m] = gscale * eq[m];
+        gb0[m] = gscale * bc0[m];
+        gb1[m] = gscale * bc1[m];
+      }
+      f32x4 o_kg, o_a0, o_b0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
+        o_kg[m] = -wk[m + 1] * g[m];
+        o_a0[m] = -K0[m] * g[m] + s0 * gb0[m];
+        o_b0[m] = -p0[m] * g[m];
+        rkg[it][m] = o_kg[m];
+        ra1[it][m] = -K1[m] * g[m] + s1 * gb1[m];
+        rb1[it][m] = -p1[m] * g[m];
+        rd[it][m] = -(p00[m] + p11[m]) * g[m];
+        PIDM_OPAQUE_F32(rd[it][m]);     // a ROUNDED product (see darcy_full_kernel)
+      }
+      *reinterpret_cast<f32x4*>(skg + n) = o_kg;
+      *reinterpret_cast<f32x4*>(sa0 + n) = o_a0;
+      *reinterpret_cast<f32x4*>(sb0 + n) = o_b0;
+    }
+    PIDM_DARCY_STAMP(1);
+    __syncthreads();
+    PIDM_DARCY_STAMP(2);
+    // every thread is past its reads of the target: the next sample's may land
+    if (b + (int)gridDim.x < B) fetch(x0 + (size_t)(b + gridDim.x) * 2 * N, tg);
+
+    const float dscale = 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N);
+    const QuadT tq1 = quad_T(ax1.c1, j0, P, 3), tq2 = quad_T(ax1.c2, j0, P, 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = rt + RS * it, n = i * P + j0;
+      const FdTaps5 ti = fd_taps_T(ax0, i, P, 0, P - 1);
+      float g00[4] = {0.f, 0.f, 0.f, 0.f}, ga0[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int c0 = ti.idx[k] * P + j0;
+        const f32x4 vkg = *reinterpret_cast<const f32x4*>(skg + c0), va = *reinterpret_cast<const f32x4*>(sa0 + c0),
+                    vb = *reinterpret_cast<const f32x4*>(sb0 + c0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          g00[m] = fmaf(ti.w2[k], vkg[m], g00[m]);
+          ga0[m] = fmaf(ti.w1[k], va[m], ga0[m]);
+          gb0[m] = fmaf(ti.w1[k], vb[m], gb0[m]);
+        }
+      }
+      float w[6], g11[4], ga1[4], gb1[4];
+      quad_window_regs(rkg[it], lowq, highq, w);
+      quad_gather(tq2, __shfl(rkg[it][0], 0, 16), __shfl(rkg[it][3], 15, 16), w, g11);
+      quad_window_regs(ra1[it], lowq, highq, w);
+      quad_gather(tq1, __shfl(ra1[it][0], 0, 16), __shfl(ra1[it][3], 15, 16), w, ga1);
+      quad_window_regs(rb1[it], lowq, highq, w);
+      quad_gather(tq1, __shfl(rb1[it][0], 0, 16), __shfl(rb1[it][3], 15, 16), w, gb1);
+      f32x4 gp, gK;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gp[m] = ((g00[m] + g11[m]) + ga0[m]) + ga1[m];
+        gK[m] = (rd[it][m] + gb0[m]) + gb1[m];
+        gp[m] += dscale * t0[it][m];
+        gK[m] += dscale * t1[it][m];
+      }
+      *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + n) = gp;
+      *reinterpret_cast<f32x4*>(grad_pred + (size_t)b * 2 * N + N + n) = gK;
+    }
+    // loss sums: per wave now, per sample behind the next barrier (the top of the next sample, or the one below)
+    double v[3] = {acc_data, acc_r2, acc_rabs};
+    for (int qq = 0; qq < 3; ++qq) {
+      double x = v[qq];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+      if (lane == 0) red[qq][wave] = x;
+    }
+    PIDM_DARCY_STAMP(3);
+    ++n_done;
+  }
+  __syncthreads();
+  if (b_prev >= 0 && tid < 3) {
+    double sv = 0.0;
+    for (int w = 0; w < NT / 64; ++w) sv += red[tid][w];
+    partial[(size_t)b_prev * 4 + tid] = sv;
+  }
+}
+
 // out[0] = loss, out[1] = c_data*data_loss, out[2] = mean|r|, out[3] = 0.  One workgroup; fixed summation order (thread tid owns
 // samples tid, tid + 256, ...; bands in order; then a shuffle tree and four wave sums): run-to-run deterministic.
 __global__ void __launch_bounds__(256) darcy_loss_finalize(const double* __restrict__ partial, const float* __restrict__ p2w,
@@ -702,7 +1167,7 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
                         const float* inv_var, const long long* tsteps, float c_data, float c_res, float inv_h0, float inv_h1,
                         float* residual, float* grad_pred, double* partial, int B, int P, hipStream_t st) {
   if (B <= 0 || P < 5) return fail("darcy: need B>0 and P>=5 (got B=%d P=%d)", B, P);
-  const DarcyBands bd = darcy_bands(B, P);
+  const DarcyBands bd = darcy_bands(B, P, MODE == DARCY_RES_ONLY);
   const int rows = darcy_lds_rows(P, bd.R);
   size_t lds = (size_t)(MODE == DARCY_RES_ONLY ? 2 : 8) * rows * P * sizeof(float);
   if (lds > 160 * 1024 - 256) return fail("darcy: P=%d does not fit the 160 KiB LDS", P);
@@ -717,6 +1182,40 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
   const bool quad = (P & 3) == 0 && P >= 8 && QP <= 256 && (QP & (QP - 1)) == 0 && !(qe && !atoi(qe)) &&
                     ((reinterpret_cast<size_t>(pred) | reinterpret_cast<size_t>(x0) | reinterpret_cast<size_t>(f_s) |
                       reinterpret_cast<size_t>(residual) | reinterpret_cast<size_t>(grad_pred) | reinterpret_cast<size_t>(grad_res)) & 15) == 0;
+  if (quad && MODE == DARCY_LOSS && darcy_full_on(B, P) && darcy_stream_on()) {
+    static bool attr_s = false;
+    const size_t lds_s = (size_t)9 * 64 * 64 * sizeof(float) + 3 * 8 * sizeof(double);
+    if (!attr_s) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("darcy_stream_kernel: the device refuses %zu bytes of dynamic LDS", lds_s);
+      }
+      attr_s = true;
+    }
+    const char* e = knob("PIDM_DARCY_STREAM_WGS");     // persistent workgroups (one per CU)
+    int wgs = e ? atoi(e) : 256;
+    if (wgs < 1) wgs = 1;
+    if (wgs > B) wgs = B;
+    hipLaunchKernelGGL(darcy_stream_kernel, dim3((unsigned)wgs), dim3(512), lds_s, st, x0, pred, f_s, p2w, inv_var, tsteps, c_data, c_res,
+                       (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual, grad_pred, partial, B);
+    PIDM_CHECK_LAUNCH("darcy_stream_kernel");
+    return 0;
+  }
+  if (quad && MODE != DARCY_RES_ONLY && darcy_full_on(B, P)) {
+    static bool attr_f = false;
+    const size_t lds_f = (size_t)5 * 64 * 64 * sizeof(float);
+    if (!attr_f) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_full_kernel<MODE, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("darcy_full_kernel: the device refuses %zu bytes of dynamic LDS", lds_f);
+      }
+      attr_f = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(darcy_full_kernel<MODE, 512>), dim3((unsigned)B), dim3(512), lds_f, st, x0, pred, f_s, grad_res, p2w, inv_var,
+                       tsteps, c_data, c_res, (inv_h1 < 0.f) ? 1.f : -1.f, make_axis(inv_h0), make_axis(inv_h1), residual, grad_pred, partial, B);
+    PIDM_CHECK_LAUNCH("darcy_full_kernel");
+    return 0;
+  }
   if (quad) {
     static bool attr_q = false;
     if (!attr_q) {
@@ -810,3 +1309,9 @@ extern "C" int pidm_darcy_jacobian_max(const float* x0, float inv_h0, float inv_
   PIDM_CHECK_LAUNCH("darcy_jacmax_kernel");
   return 0;
 }
+
+#if PIDM_DARCY_TRACE_BUILD
+extern "C" int pidm_debug_darcy_trace(unsigned long long* out256) {
+  return hipMemcpyFromSymbol(out256, HIP_SYMBOL(pidm::g_darcy_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -65,6 +65,63 @@ def test_darcy_adjoint_dot_product_b256():
     assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs))
 
 
+def test_darcy_large_batch_kernels_b1024(monkeypatch):
+    """Batches >= 512 run the fused loss as darcy_stream_kernel and the plain adjoint as darcy_full_kernel (one workgroup per
+    sample): the oracle on the whole batch (north_star's 1e-5 on the loss terms), the band kernel bit for bit, the adjoint
+    identity, and run-to-run determinism."""
+    from oracle import pidm_oracle as O
+    from physicsinformeddiffusionmodels_amd._lib import ptr, stream_ptr
+    m, diff, res, dev = _darcy_setup()
+    lib = res.lib
+    B, P = 1024, 64
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, 2, P, P, generator=g)
+    pred = x0 + 0.3 * torch.randn(B, 2, P, P, generator=g)
+    pred[:, 1] = torch.exp(0.5 * pred[:, 1])
+    t = torch.randint(0, 100, (B,), generator=g)
+    w = torch.randn(B, P * P, 3, generator=g).to(dev)
+    x0d, predd, td = x0.to(dev), pred.to(dev), t.to(dev)
+    dd = diff.diff_dict
+
+    def run():
+        rbuf, gbuf, sc = torch.empty(B, P * P, 3, device=dev), torch.empty_like(predd), torch.empty(4, device=dev)
+        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x0d), ptr(predd), ptr(res._f_s_flat), ptr(td), ptr(dd['p2_loss_weight']),
+                                                ptr(dd['posterior_variance_clipped']), 1.0, 1e-3, res.inv_h0, res.inv_h1, ptr(rbuf),
+                                                ptr(gbuf), ptr(sc), ptr(ws), B, P, stream_ptr(dev)), "darcy loss")
+        jtw = torch.empty_like(predd)
+        lib.check(lib.pidm_darcy_residual_bwd(ptr(predd), ptr(w), res.inv_h0, res.inv_h1, ptr(jtw), B, P, stream_ptr(dev)), "adjoint")
+        return rbuf, gbuf, sc.cpu(), jtw
+
+    got = run()
+    again = run()
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    monkeypatch.setenv("PIDM_DARCY_FULL", "0")
+    band = run()
+    monkeypatch.delenv("PIDM_DARCY_FULL")
+    assert torch.equal(got[0], band[0]) and torch.equal(got[1], band[1]) and torch.equal(got[3], band[3])
+    assert torch.allclose(got[2], band[2], rtol=1e-6, atol=0)
+    pr = pred.clone().requires_grad_(True)
+    o_loss, o_data, o_rabs, o_res = O.darcy_loss_from_pred(O.diffusion_tables(100), x0, pr, t, 1., 1e-3)
+    o_loss.backward()
+    k_loss, k_data, k_rabs = (float(v) for v in got[2][:3])
+    assert abs(k_loss - o_loss.item()) < 1e-5 * abs(o_loss.item())
+    assert abs(k_data - o_data.item()) < 1e-5 * abs(o_data.item())
+    assert abs(k_rabs - o_rabs.item()) < 1e-5 * abs(o_rabs.item())
+    assert (got[0].cpu() - o_res.detach()).abs().max().item() < 2e-6 * o_res.abs().max().item()
+    assert (got[1].cpu() - pr.grad).abs().max().item() < 1e-5 * pr.grad.abs().max().item()
+    # adjoint identity on the kernels themselves: the residual is linear in p for fixed K
+    v = torch.zeros_like(predd)
+    v[:, 0] = torch.randn(B, P, P, generator=g).to(dev)
+    r0, r1 = torch.empty(B, P * P, 3, device=dev), torch.empty(B, P * P, 3, device=dev)
+    pv = (predd + v).contiguous()
+    lib.check(lib.pidm_darcy_residual_fwd(ptr(predd), ptr(res._f_s_flat), res.inv_h0, res.inv_h1, ptr(r0), B, P, stream_ptr(dev)), "fwd")
+    lib.check(lib.pidm_darcy_residual_fwd(ptr(pv), ptr(res._f_s_flat), res.inv_h0, res.inv_h1, ptr(r1), B, P, stream_ptr(dev)), "fwd")
+    lhs = ((r1 - r0).double() * w.double()).sum().item()
+    rhs = (v.double() * got[3].double()).sum().item()
+    assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs))
+
+
 def test_unet_batch_independence_and_determinism_b64():
     m, diff, res, dev = _darcy_setup()
     g = torch.Generator().manual_seed(4)

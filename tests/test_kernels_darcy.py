@@ -102,3 +102,45 @@ def test_darcy_one_pixel_kernel_at_64(backend, monkeypatch):
     test_darcy_residual_fwd_bwd(backend, 64, 2)
     test_darcy_fused_loss(backend, 16, 4)
 
+
+
+@pytest.mark.parametrize("variant", ["stream", "stream_2wgs", "full"])
+def test_darcy_one_workgroup_per_sample_kernels_are_bit_identical(backend, monkeypatch, variant):
+    """Batches >= 512 take one workgroup per 64 x 64 sample (row neighbours by shuffles) - the fused loss as a persistent workgroup
+    per CU that has the next sample copied into LDS while it computes (darcy_stream_kernel), the plain adjoint as
+    darcy_full_kernel; PIDM_DARCY_FULL lowers the batch threshold.  Same taps in the same order: residual and gradients
+    bit-identical to the band kernel; the loss scalars group the same doubles per sample instead of per band."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(16)
+    tables = O.diffusion_tables(100)
+    B, P = 5, 64
+    x0 = torch.randn(B, 2, P, P, generator=g)
+    pred = (x0 + 0.3 * torch.randn(B, 2, P, P, generator=g))
+    pred[:, 1] = torch.exp(0.5 * pred[:, 1])
+    t = torch.tensor([5, 99, 40, 0, 71])
+    fs = O.darcy_source_field(P).reshape(-1).contiguous()
+    inv_h = float(P - 1)
+    x0d, predd, fsd, td = (z.to(dev) for z in (x0, pred, fs, t))
+    tab_w, tab_v = tables["p2_loss_weight"].to(dev), tables["posterior_variance_clipped"].to(dev)
+    gr = torch.randn(B, P * P, 3, generator=g).to(dev)
+
+    def run():
+        res, gpred, out = torch.empty(B, P * P, 3, device=dev), torch.empty_like(predd), torch.zeros(4, device=dev)
+        ws = torch.empty(L.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        L.check(L.pidm_darcy_loss_fwd_bwd_t(ptr(x0d), ptr(predd), ptr(fsd), ptr(td), ptr(tab_w), ptr(tab_v), 1.0, 1e-3, inv_h, -inv_h,
+                                            ptr(res), ptr(gpred), ptr(out), ptr(ws), B, P, st))
+        gx = torch.empty_like(predd)
+        L.check(L.pidm_darcy_residual_bwd(ptr(predd), ptr(gr), inv_h, -inv_h, ptr(gx), B, P, st))
+        return res.cpu(), gpred.cpu(), out.cpu(), gx.cpu()
+
+    monkeypatch.setenv("PIDM_DARCY_FULL", "0")
+    ref = run()
+    monkeypatch.setenv("PIDM_DARCY_FULL", "2")
+    if variant == "stream_2wgs":
+        monkeypatch.setenv("PIDM_DARCY_STREAM_WGS", "2")     # workgroup 0 walks samples 0, 2, 4; workgroup 1 samples 1, 3
+    elif variant == "full":
+        monkeypatch.setenv("PIDM_DARCY_STREAM", "0")
+    got = run()
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[3], ref[3])
+    assert torch.allclose(got[2], ref[2], rtol=1e-6, atol=0)

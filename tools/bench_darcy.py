@@ -1,13 +1,13 @@
 """Fused Darcy residual + loss kernel alone (csrc/k_darcy.hip): us per launch pair and algorithmic GB/s (112 KiB per 64x64 sample)."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from physicsinformeddiffusionmodels_amd._lib import get_lib, ptr, stream_ptr
 from oracle import pidm_oracle as O
 L = get_lib(); dev = torch.device("cuda:0"); P = 64
 fs = O.darcy_source_field(P).reshape(-1).contiguous().to(dev)
 tab = O.diffusion_tables(100)
 tw, tv = tab["p2_loss_weight"].to(dev), tab["posterior_variance_clipped"].to(dev)
-for B in (64, 256, 1024, 4096):
+for B in ([int(a) for a in sys.argv[1:]] or (64, 256, 1024, 4096)):
     g = torch.Generator().manual_seed(B)
     x0 = torch.randn(B, 2, P, P, generator=g).to(dev); pred = x0 + 0.1
     t = torch.randint(0, 100, (B,), generator=g).to(dev)

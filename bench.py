@@ -43,6 +43,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise); the
+# variable must be in place before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

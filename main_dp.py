@@ -21,6 +21,10 @@ import sys
 import time
 from pathlib import Path
 
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise); the
+# variable must be in place before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import yaml
 

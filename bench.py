@@ -279,7 +279,8 @@ def residual_only_rates(lib, residuals, diffusion, dev):
         nbytes = B * (32 + 48 + 32) * 1024
         out[f"b{B}"] = {"us_per_launch_pair": round(us, 2), "GB/s": round(nbytes / us / 1e3, 1),
                         "frac_of_hbm_peak": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
-    out["what"] = ("darcy_quad_kernel<loss> + darcy_loss_finalize (residual, loss terms, d loss/d x0_pred; the scalars by a second 6 us launch: "
+    out["what"] = ("batch 64: darcy_quad_kernel<loss> (row bands), batch 4096: darcy_stream_kernel (one persistent workgroup per CU, whole samples "
+                   "streamed through LDS; profiles/r06_darcy_large_batch.txt), each + darcy_loss_finalize (residual, loss terms, d loss/d x0_pred; the scalars by a second 6 us launch: "
                    "totalling them in the last-arriving workgroup of the first was measured slower twice, profiles/r05_darcy_one_launch_ab.txt), "
                    "algorithmic 112 KiB per sample, back-to-back launch pairs timed with events on the launch stream")
     return out

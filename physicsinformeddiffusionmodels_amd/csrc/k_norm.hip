@@ -716,10 +716,13 @@ static int ew_blocks(size_t n_threads) {
 }
 
 static int gn_chunks(int HW, int B) {
-  // enough blocks to fill the chip, at least 64 pixels per block (PIDM_GN_BLOCKS: the block budget, A/B measurements)
+  // enough blocks to fill the chip, at least 16 pixels per block (PIDM_GN_BLOCKS: the block budget, PIDM_GN_MINPIX: the pixel floor,
+  // A/B measurements).  The floor was 64 until round 6: the 8 x 8 level at batch 64 then ran 64 blocks of 16 dependent iterations
+  // per thread - 11 us for 8 MB - where 256 blocks of 4 iterations take the latency once
   const int budget = [] { const char* e = knob("PIDM_GN_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  const int minpix = [] { const char* e = knob("PIDM_GN_MINPIX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
   int nchunk = (budget + B - 1) / B;
-  if (nchunk > HW / 64) nchunk = HW / 64;
+  if (nchunk > HW / minpix) nchunk = HW / minpix;
   if (nchunk < 1) nchunk = 1;
   return nchunk;
 }

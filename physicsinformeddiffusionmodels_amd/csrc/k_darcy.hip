@@ -849,10 +849,10 @@ __device__ unsigned long long g_darcy_trace[4 * 64];
 // current one.  One workgroup of 8 waves per CU runs load -> barrier -> stencils -> barrier -> adjoint stencils strictly in turn
 // (PMC, batch 4096: vector ALU busy 37 % of the kernel, memory about as much, nothing overlapped); here the loads of sample s + 1
 // are in flight during passes 1 and 2 of sample s and the stores drain behind the next sample's arithmetic.
-// LDS: prediction (p, K) double-buffered 2 x 32 KB, target 32 KB, the three column-stencil intermediates 48 KB, 192 B of loss sums.
+// LDS: p double-buffered 2 x 16 KB, K 16 KB, target 32 KB, the three column-stencil intermediates 48 KB, f_s 16 KB, 192 B of loss sums.
 // The copies are issued as instructions hipcc does not track (pidm_glds_b128_untracked; it would answer the first LDS read behind
-// a tracked copy with vmcnt(0)); nothing else LOADS from global memory inside the loop (f_s of the own rows lives in registers, the
-// per-sample weights are scalar loads), so the only vector-memory wait is the explicit one in front of the top barrier.
+// a tracked copy with vmcnt(0)); nothing else LOADS from global memory inside the loop (f_s sits in LDS, the per-sample weights are
+// scalar loads), so the only vector-memory wait is the explicit one in front of the top barrier.
 // Arithmetic, order and results: exactly darcy_full_kernel's.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __restrict__ x0, const float* __restrict__ pred,
@@ -863,34 +863,36 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
                                                               double* __restrict__ partial, int B) {
   constexpr int P = 64, N = P * P, NT = 512, RS = NT / 16, NIT = P / RS;
   HIP_DYNAMIC_SHARED(float, smem)
-  float* pk = smem;                  // [2][p, K]
-  float* tg = smem + 4 * N;          // target [p, K]
-  float* skg = smem + 6 * N;
-  float* sa0 = smem + 7 * N;
-  float* sb0 = smem + 8 * N;
+  float* spb = smem;                 // [2] p, double-buffered: the next sample's lands while this one's column stencils read
+  float* sKb = smem + 2 * N;         // K: read in the first pass only, the next sample's is copied behind the second barrier
+  float* tg = smem + 3 * N;          // target [p, K]: likewise
+  float* skg = smem + 5 * N;
+  float* sa0 = smem + 6 * N;
+  float* sb0 = smem + 7 * N;
+  float* sfs = smem + 8 * N;         // f_s, the same for every sample (in registers it cost the kernel its last ones: spills)
   double (*red)[NT / 64] = reinterpret_cast<double (*)[NT / 64]>(smem + 9 * N);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int q0 = tid & 15, rt0 = tid >> 4;
-  // a 32 KB block (two fields of one sample) as 32 pieces of 1 KB: wave w copies pieces w, w + 8, w + 16, w + 24
+  // one 16 KB field as 16 pieces of 1 KB: wave w copies pieces w and w + 8
   auto fetch = [&](const float* g, float* l) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2; ++k) {
       const int piece = wave + 8 * k;
       pidm_glds_b128_untracked(g + piece * 256 + lane * 4, l + piece * 256);
     }
   };
-  f32x4 fs4[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) fs4[it] = *reinterpret_cast<const f32x4*>(f_s + (rt0 + RS * it) * P + 4 * q0);
   int b = blockIdx.x, b_prev = -1, cur = 0;
   [[maybe_unused]] int n_done = 0;
   if (b < B) {
-    fetch(pred + (size_t)b * 2 * N, pk);
+    fetch(f_s, sfs);
+    fetch(pred + (size_t)b * 2 * N, spb);
+    fetch(pred + (size_t)b * 2 * N + N, sKb);
     fetch(x0 + (size_t)b * 2 * N, tg);
+    fetch(x0 + (size_t)b * 2 * N + N, tg + N);
   }
   for (; b < B; b_prev = b, b += gridDim.x, cur ^= 1) {
-    const float* sp = pk + cur * 2 * N;
-    const float* sK = sp + N;
+    const float* sp = spb + cur * N;
+    const float* sK = sKb;
     // the stencil taps depend on the thread's rows and columns only, and left to itself the compiler keeps all of them (~100
     // registers) across the sample loop and spills: a zero it cannot see makes them this iteration's values
     int zero = 0;
@@ -905,7 +907,7 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
       for (int w = 0; w < NT / 64; ++w) sv += red[tid][w];     // fixed order
       partial[(size_t)b_prev * 4 + tid] = sv;
     }
-    if (b + (int)gridDim.x < B) fetch(pred + (size_t)(b + gridDim.x) * 2 * N, pk + (cur ^ 1) * 2 * N);
+    if (b + (int)gridDim.x < B) fetch(pred + (size_t)(b + gridDim.x) * 2 * N, spb + (cur ^ 1) * N);
 
     f32x4 vp[NIT], vK[NIT], t0[NIT], t1[NIT];
     double acc_data = 0.0, acc_r2 = 0.0, acc_rabs = 0.0;
@@ -951,6 +953,7 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
       quad_d1(ax1, wp, lowq, highq, p1);
       quad_d2(ax1, wp, lowq, highq, p11);
       quad_d1(ax1, wk, lowq, highq, K1);
+      const f32x4 fs4 = *reinterpret_cast<const f32x4*>(sfs + n);
       const float s0 = (i == 0) ? -1.f : ((i == P - 1) ? 1.f : 0.f);
       float eq[4], bc0[4], bc1[4];
 #pragma unroll
@@ -958,7 +961,7 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
         const float Kv = wk[m + 1];
         const float vj00 = -Kv * p00[m] - K0[m] * p0[m];
         const float vj11 = -Kv * p11[m] - K1[m] * p1[m];
-        eq[m] = vj00 + vj11 - fs4[it][m];
+        eq[m] = vj00 + vj11 - fs4[m];
         const float s1 = (m == 0 && lowq) ? bc1_sign : ((m == 3 && highq) ? -bc1_sign : 0.f);
         bc0[m] = s0 * p0[m];
         bc1[m] = s1 * p1[m];
@@ -1007,8 +1010,12 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
     PIDM_DARCY_STAMP(1);
     __syncthreads();
     PIDM_DARCY_STAMP(2);
-    // every thread is past its reads of the target: the next sample's may land
-    if (b + (int)gridDim.x < B) fetch(x0 + (size_t)(b + gridDim.x) * 2 * N, tg);
+    // every thread is past its reads of K and of the target: the next sample's may land
+    if (b + (int)gridDim.x < B) {
+      fetch(pred + (size_t)(b + gridDim.x) * 2 * N + N, sKb);
+      fetch(x0 + (size_t)(b + gridDim.x) * 2 * N, tg);
+      fetch(x0 + (size_t)(b + gridDim.x) * 2 * N + N, tg + N);
+    }
 
     const float dscale = 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N);
     const QuadT tq1 = quad_T(ax1.c1, j0, P, 3), tq2 = quad_T(ax1.c2, j0, P, 4);

@@ -871,6 +871,13 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
   float* sb0 = smem + 7 * N;
   float* sfs = smem + 8 * N;         // f_s, the same for every sample (in registers it cost the kernel its last ones: spills)
   double (*red)[NT / 64] = reinterpret_cast<double (*)[NT / 64]>(smem + 9 * N);
+  // The stencil taps depend on the row (column stencils) and on the quad (row stencils) only.  Per thread and sample they were ~250
+  // vector instructions of selects; kept in registers across the sample loop they were ~100 registers.  They are computed once per
+  // workgroup into LDS tables (64 rows x (12 + 16) dwords, 16 quads x 40 dwords = 9.5 KB) and read back per sample: the 16 lanes of
+  // a row read one address.
+  FdTaps4* tab4 = reinterpret_cast<FdTaps4*>(smem + 9 * N + 48);
+  int* tab5 = reinterpret_cast<int*>(smem + 9 * N + 48 + 64 * 12);              // FdTaps5 in slots of 16 dwords
+  QuadT* tabq = reinterpret_cast<QuadT*>(smem + 9 * N + 48 + 64 * 12 + 64 * 16);   // [16][2]: c1 (3 taps), c2 (4 taps)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int q0 = tid & 15, rt0 = tid >> 4;
   // one 16 KB field as 16 pieces of 1 KB: wave w copies pieces w and w + 8
@@ -881,6 +888,13 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
       pidm_glds_b128_untracked(g + piece * 256 + lane * 4, l + piece * 256);
     }
   };
+  if (tid < P) {
+    tab4[tid] = fd_taps(ax0, tid, P, 0, P - 1);
+    *reinterpret_cast<FdTaps5*>(tab5 + tid * 16) = fd_taps_T(ax0, tid, P, 0, P - 1);
+  } else if (tid < P + 16) {
+    tabq[2 * (tid - P)] = quad_T(ax1.c1, 4 * (tid - P), P, 3);
+    tabq[2 * (tid - P) + 1] = quad_T(ax1.c2, 4 * (tid - P), P, 4);
+  }
   int b = blockIdx.x, b_prev = -1, cur = 0;
   [[maybe_unused]] int n_done = 0;
   if (b < B) {
@@ -893,11 +907,7 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
   for (; b < B; b_prev = b, b += gridDim.x, cur ^= 1) {
     const float* sp = spb + cur * N;
     const float* sK = sKb;
-    // the stencil taps depend on the thread's rows and columns only, and left to itself the compiler keeps all of them (~100
-    // registers) across the sample loop and spills: a zero it cannot see makes them this iteration's values
-    int zero = 0;
-    PIDM_OPAQUE_I32(zero);
-    const int rt = rt0 + zero, q = q0 + zero, j0 = 4 * q;
+    const int rt = rt0, q = q0, j0 = 4 * q;
     const bool lowq = q == 0, highq = q == 15;
     PIDM_WAIT_VMEM_LEAVE(0);     // this sample's copies have landed (leaving the last gradient stores in flight: no gain)
     __syncthreads();
@@ -930,7 +940,7 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = rt + RS * it, n = i * P + j0;
-      const FdTaps4 ti = fd_taps(ax0, i, P, 0, P - 1);
+      const FdTaps4 ti = tab4[i];
       float p0[4] = {0.f, 0.f, 0.f, 0.f}, p00[4] = {0.f, 0.f, 0.f, 0.f}, K0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1018,11 +1028,11 @@ __global__ void __launch_bounds__(512, 2) darcy_stream_kernel(const float* __res
     }
 
     const float dscale = 2.f * c_data * darcy_p2w(p2w, tsteps, b) / ((float)B * 2.f * (float)N);
-    const QuadT tq1 = quad_T(ax1.c1, j0, P, 3), tq2 = quad_T(ax1.c2, j0, P, 4);
+    const QuadT tq1 = tabq[2 * q], tq2 = tabq[2 * q + 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = rt + RS * it, n = i * P + j0;
-      const FdTaps5 ti = fd_taps_T(ax0, i, P, 0, P - 1);
+      const FdTaps5 ti = *reinterpret_cast<const FdTaps5*>(tab5 + i * 16);
       float g00[4] = {0.f, 0.f, 0.f, 0.f}, ga0[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -1191,7 +1201,7 @@ static int launch_darcy(const float* x0, const float* pred, const float* f_s, co
                       reinterpret_cast<size_t>(residual) | reinterpret_cast<size_t>(grad_pred) | reinterpret_cast<size_t>(grad_res)) & 15) == 0;
   if (quad && MODE == DARCY_LOSS && darcy_full_on(B, P) && darcy_stream_on()) {
     static bool attr_s = false;
-    const size_t lds_s = (size_t)9 * 64 * 64 * sizeof(float) + 3 * 8 * sizeof(double);
+    const size_t lds_s = (size_t)9 * 64 * 64 * sizeof(float) + 3 * 8 * sizeof(double) + (64 * 12 + 64 * 16 + 16 * 40) * sizeof(float);     // + tap tables
     if (!attr_s) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&darcy_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess) {
         (void)hipGetLastError();

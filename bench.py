@@ -266,9 +266,11 @@ def residual_only_rates(lib, residuals, diffusion, dev):
             lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x0), ptr(pred), ptr(residuals._f_s_flat), ptr(t), ptr(dd['p2_loss_weight']),
                                                     ptr(dd['posterior_variance_clipped']), 1.0, 1e-3, residuals.inv_h0, residuals.inv_h1,
                                                     ptr(res), ptr(grad), ptr(sc), ptr(ws), B, P, stream_ptr(dev)), "darcy loss")
-        for _ in range(3):
+        # steady state: the memory-side clocks take tens of milliseconds of streaming to settle (batch 4096: 169 us per launch after
+        # 3 warm-up launches, 152 after 50, 142 after 300 - profiles/r06_darcy_large_batch.txt); ~40 ms of warm-up, 50 timed launches
+        for _ in range(300 if B >= 1024 else 100):
             call()
-        n = 20
+        n = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
@@ -282,7 +284,7 @@ def residual_only_rates(lib, residuals, diffusion, dev):
     out["what"] = ("batch 64: darcy_quad_kernel<loss> (row bands), batch 4096: darcy_stream_kernel (one persistent workgroup per CU, whole samples "
                    "streamed through LDS; profiles/r06_darcy_large_batch.txt), each + darcy_loss_finalize (residual, loss terms, d loss/d x0_pred; the scalars by a second 6 us launch: "
                    "totalling them in the last-arriving workgroup of the first was measured slower twice, profiles/r05_darcy_one_launch_ab.txt), "
-                   "algorithmic 112 KiB per sample, back-to-back launch pairs timed with events on the launch stream")
+                   "algorithmic 112 KiB per sample, back-to-back launch pairs timed with events on the launch stream after 100 / 300 warm-up launches")
     return out
 
 

@@ -1296,8 +1296,30 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, unsigned tile_id, f
   const unsigned tid = threadIdx.x, RUN = 32u * T;
   const unsigned magicT = (T > 1) ? (unsigned)((0x100000000ULL + T - 1) / T) : 0u;     // e / T == __umulhi(e, magicT) for e * T < 2^32
   const unsigned magicR = (unsigned)((0x100000000ULL + RUN - 1) / RUN);
+  // Whole tiles of 16-byte aligned tensors move four floats per lane (round 6: the scalar loops below were 36 + 36 dependent
+  // iterations per thread, the kernel ran at 1.3 TB/s and cost the mechanics step 1.4 ms); edge tiles and odd shapes keep them.
+  const bool whole = n0 + 32u <= N && k0 + 32u <= K;
+  const bool vec_src = whole && ((reinterpret_cast<size_t>(d.src) & 15) == 0) && ((((d.kind == 2) ? N : K) * T) & 3u) == 0;
+  const bool vec_dst = whole && ((reinterpret_cast<size_t>(d.dst) & 15) == 0) && ((unsigned)d.Kp & 3u) == 0 && ((unsigned)d.k_off & 3u) == 0;
   // ---- source tile -> LDS as tile[(nl * 33 + kl) * T + t] (33: the piece pass reads 32 rows nl at one kl) ----
-  if (d.kind == 2) {
+  if (vec_src && d.kind == 2) {
+    for (unsigned e = 4u * tid; e < 32u * RUN; e += 1024u) {
+      const unsigned kl = __umulhi(e, magicR), r = e - kl * RUN;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + ((size_t)(k0 + kl) * N + n0) * T + r);
+#pragma unroll
+      for (unsigned j = 0; j < 4u; ++j) {
+        const unsigned rj = r + j, nl = (T > 1) ? __umulhi(rj, magicT) : rj, ts = rj - nl * T;
+        tile[(nl * 33u + kl) * T + (T - 1u - ts)] = v[j];
+      }
+    }
+  } else if (vec_src) {
+    for (unsigned e = 4u * tid; e < 32u * RUN; e += 1024u) {
+      const unsigned nl = __umulhi(e, magicR), r = e - nl * RUN;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + ((size_t)(n0 + nl) * K + k0) * T + r);
+      float* o = tile + nl * 33u * T + r;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+  } else if (d.kind == 2) {
     // [K][N][T] tensor: run kl = the 32 T floats of rows n0 .. n0 + 31 of column k0 + kl; tap t' of the source is tap T - 1 - t'
     for (unsigned e = tid; e < 32u * RUN; e += 256u) {
       const unsigned kl = __umulhi(e, magicR), r = e - kl * RUN;
@@ -1318,7 +1340,14 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, unsigned tile_id, f
   }
   __syncthreads();
   // ---- fp32 packing: row (n, t) = 32 consecutive columns = one 128-byte line; 8 rows per sweep ----
-  {
+  if (vec_dst) {
+    const unsigned kl = 4u * (tid & 7u);
+    for (unsigned row = tid >> 3; row < RUN; row += 32u) {         // row = nl * T + t; 8 lanes x 16 bytes = the row's 128-byte line
+      const unsigned nl = (T > 1) ? __umulhi(row, magicT) : row, t = row - nl * T;
+      const float* ti = tile + (nl * 33u + kl) * T + t;
+      *reinterpret_cast<f32x4*>(d.dst + ((size_t)(d.n_off + n0 + nl) * T + t) * d.Kp + d.k_off + k0 + kl) = f32x4{ti[0], ti[T], ti[2u * T], ti[3u * T]};
+    }
+  } else {
     const unsigned kl = tid & 31u;
     for (unsigned row = tid >> 5; row < RUN; row += 8u) {          // row = nl * T + t
       const unsigned nl = (T > 1) ? __umulhi(row, magicT) : row, t = row - nl * T;

@@ -1,8 +1,9 @@
 #!/bin/bash
 # per-launch durations of the normalisation kernels grouped by grid (= level): rocprofv3 --kernel-trace of a short bench.py run
-# usage: tools/gn_by_shape.sh <out-name> [batch] [pattern,pattern,...]   (default patterns: gn_,layernorm; 'all' = every kernel)
+# usage: tools/gn_by_shape.sh <out-name> [batch] [pattern,pattern,...] [workload]   (default patterns: gn_,layernorm; 'all' = every kernel;
+# workload darcy (default) / mechanics / sampling; batch 0 = the workload's default)
 R=${GRAFT_REPO_ROOT:-/root/repo}; export TMPDIR=/tmp; o=$R/gpurun_out/$1; mkdir -p $o; b=${2:-64}; export PIDM_SHAPE_PATTERNS=${3:-gn_,layernorm}
-(cd /tmp && PIDM_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $o/trace -o p -- python $R/bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-roofline > $o/run.log 2>&1)
+(cd /tmp && PIDM_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $o/trace -o p -- python $R/bench.py $( [ "$b" != 0 ] && echo --batch $b ) --workload ${4:-darcy} --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-roofline > $o/run.log 2>&1)
 python - $o <<'PY'
 import csv, glob, os, sys, collections
 f = glob.glob(f"{sys.argv[1]}/trace/**/*kernel_trace.csv", recursive=True)[0]

@@ -130,7 +130,9 @@ __device__ __forceinline__ void gn_finalize_stats(const double* __restrict__ par
 // `partial` != null: statistics are finalised here from the stats_partial sums and written to `stats`;
 // `partial` == null: `stats` is read.
 // INPLACE (inference passes: nothing reads x afterwards): y == x, every access goes through the one pointer y
-template <bool INPLACE>
+// LN: the LayerNorm of a following attention block rides along (ln_gamma / ln_out set); an instantiation of its own because its
+// cross-lane sums keep the compiler from unrolling the pixel loop - the plain kernel keeps four pixels in flight
+template <bool INPLACE, bool LN>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, int nchunk,
                                                        double count, float eps, float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -170,37 +172,53 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       }
     }
     const size_t base = (size_t)b * HW * C + c0;
-#pragma unroll 4
-    for (int p = p0 + pl; p < p1; p += L.ppi) {
-      const size_t i = base + (size_t)p * C;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
-      f32x4 o;
+    if (LN) {
+      for (int p = p0 + pl; p < p1; p += L.ppi) {
+        const size_t i = base + (size_t)p * C;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
+        f32x4 o;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float v = ((xv[k] - mean[k]) * a[k] + bt[k]) * sc1[k] + sh[k];
-        o[k] = v * sigmoidf_(v) + rv[k];
+        for (int k = 0; k < 4; ++k) {
+          const float v = ((xv[k] - mean[k]) * a[k] + bt[k]) * sc1[k] + sh[k];
+          o[k] = v * sigmoidf_(v) + rv[k];
+        }
+        *reinterpret_cast<f32x4*>(y + i) = o;
+        {
+          // the channel LayerNorm of the attention block that follows (PreNorm, reference src/unet_model.py:139-145,207-210) on the
+          // values just written: the C / 4 lanes of a pixel sit side by side in one wave (launch_gn_apply checks it), same operation
+          // order as layernorm_kernel<false> with one quad per lane - the separate pass, and its read of y, are gone
+          float s = (o[0] + o[1]) + (o[2] + o[3]);
+          for (int off = 1; off < L.qw; off <<= 1) s += __shfl_xor(s, off);
+          const float lmean = s / (float)C;
+          const float d0 = o[0] - lmean, d1 = o[1] - lmean, d2 = o[2] - lmean, d3 = o[3] - lmean;
+          float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          for (int off = 1; off < L.qw; off <<= 1) q += __shfl_xor(q, off);
+          const float lrstd = 1.f / sqrtf(q / (float)C + 1e-5f);
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_gamma + c0);
+          f32x4 z;
+          z[0] = d0 * lrstd * gm[0];
+          z[1] = d1 * lrstd * gm[1];
+          z[2] = d2 * lrstd * gm[2];
+          z[3] = d3 * lrstd * gm[3];
+          *reinterpret_cast<f32x4*>(ln_out + i) = z;
+        }
       }
-      *reinterpret_cast<f32x4*>(y + i) = o;
-      if (ln_out) {
-        // the channel LayerNorm of the attention block that follows (PreNorm, reference src/unet_model.py:139-145,207-210) on the
-        // values just written: the C / 4 lanes of a pixel sit side by side in one wave (launch_gn_apply checks it), same operation
-        // order as layernorm_kernel<false> with one quad per lane - the separate pass, and its read of y, are gone
-        float s = (o[0] + o[1]) + (o[2] + o[3]);
-        for (int off = 1; off < L.qw; off <<= 1) s += __shfl_xor(s, off);
-        const float lmean = s / (float)C;
-        const float d0 = o[0] - lmean, d1 = o[1] - lmean, d2 = o[2] - lmean, d3 = o[3] - lmean;
-        float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        for (int off = 1; off < L.qw; off <<= 1) q += __shfl_xor(q, off);
-        const float lrstd = 1.f / sqrtf(q / (float)C + 1e-5f);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_gamma + c0);
-        f32x4 z;
-        z[0] = d0 * lrstd * gm[0];
-        z[1] = d1 * lrstd * gm[1];
-        z[2] = d2 * lrstd * gm[2];
-        z[3] = d3 * lrstd * gm[3];
-        *reinterpret_cast<f32x4*>(ln_out + i) = z;
+    } else {
+#pragma unroll 4
+      for (int p = p0 + pl; p < p1; p += L.ppi) {
+        const size_t i = base + (size_t)p * C;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = ((xv[k] - mean[k]) * a[k] + bt[k]) * sc1[k] + sh[k];
+          o[k] = v * sigmoidf_(v) + rv[k];
+        }
+        *reinterpret_cast<f32x4*>(y + i) = o;
       }
     }
   }
@@ -773,13 +791,15 @@ int launch_gn_apply(const float* x, float* stats, const float* gamma, const floa
   const int nchunk = gn_chunks(HW, B);
   const int ppb = cdiv(HW, nchunk);
   if (x == y)      // in place (the engine's inference passes): one pointer inside the kernel
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_apply_kernel<true>), dim3(nchunk, B), dim3(256), 0, st, nullptr, reinterpret_cast<const double*>(ws),
-                       (ws && part_chunks > 0) ? part_chunks : nchunk,
-                       (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_apply_kernel<false>), dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<const double*>(ws),
-                       (ws && part_chunks > 0) ? part_chunks : nchunk,
-                       (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y, HW, C, G, ppb, ln_gamma, ln_out);
+#define PIDM_GN_APPLY(INPL_, LN_, x_)                                                                                                  \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_apply_kernel<INPL_, LN_>), dim3(nchunk, B), dim3(256), 0, st, x_, reinterpret_cast<const double*>(ws), \
+                     (ws && part_chunks > 0) ? part_chunks : nchunk, (double)HW * (C / G), 1e-5f, stats, gamma, beta, ss, ssb, ldss, res, y,     \
+                     HW, C, G, ppb, ln_gamma, ln_out)
+    if (ln_out) PIDM_GN_APPLY(true, true, nullptr);
+    else PIDM_GN_APPLY(true, false, nullptr);
+  else if (ln_out) PIDM_GN_APPLY(false, true, x);
+  else PIDM_GN_APPLY(false, false, x);
+#undef PIDM_GN_APPLY
   PIDM_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }

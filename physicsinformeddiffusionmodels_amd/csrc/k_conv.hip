@@ -1372,6 +1372,9 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, unsigned tile_id, f
       *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
       *reinterpret_cast<u32x4*>(o + 8) = u32x4{q1[0], q1[1], q1[2], q1[3]};
       *reinterpret_cast<u32x4*>(o + 16) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+      // the row's 16 bytes of padding too (nobody reads them: kSplitRow is an LDS stride): with them the wave's 32 rows are 28 WHOLE
+      // 128-byte lines instead of 28 lines with a hole each
+      if (half) *reinterpret_cast<u32x4*>(o + 24) = u32x4{0u, 0u, 0u, 0u};
     }
   }
 }

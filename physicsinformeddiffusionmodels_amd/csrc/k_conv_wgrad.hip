@@ -1424,6 +1424,9 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
                                  : dim3(cdiv(wg.NP, 128) * (wg.MP / 32), wg.nsplit, 1);
     const WgradItem it = wgrad_item(wg, src0, src1, dy, partial, bias_partial, gr.x, gr.y,
                                     smode == 1 ? kWgKindStream : smode == 2 ? kWgKindStream4Dy : kWgKindStream4X);
+    if (knob("PIDM_TRACE_CONV"))
+      fprintf(stderr, "[pidm]   -> 1x1 wgrad stream mode %d: %d pixels, Cin %d (+%d), Cout %d, grid %u x %u, %d tiles per split\n", smode,
+              g.B * g.Hv * g.Wv, g.C0, g.C1, g.Cout, gr.x, gr.y, wg.tiles_per_split);
     if (wq_1x1) {
       wq_1x1->push(kWgFam1x1, it, 0.0);
     } else if (smode == 1) {

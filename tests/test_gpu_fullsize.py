@@ -396,3 +396,183 @@ def test_darcy_step_b64_vs_oracle():
             probes += 1
     assert not bad, bad[:8]
     assert n == 259 and probes >= 20
+
+
+def _step_grads(m, diff, res, x0, eps, t, lo, hi):
+    """model_estimation_loss + backward on samples lo..hi-1 with pinned (t, eps): (loss, flat gradient copy)."""
+    orig = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t[lo:hi].clone()
+    torch.randn_like = lambda *a, **k: eps[lo:hi].clone()
+    try:
+        loss, *_ = diff.model_estimation_loss(x0[lo:hi].contiguous(), residual_func=res, c_data=1., c_residual=1e-3)
+    finally:
+        torch.randint, torch.randn_like = orig
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    eng = next(iter(m.__dict__["_engines"].values()))
+    return loss.item(), eng.flat_grad.clone()
+
+
+@pytest.mark.parametrize("B,cut", [(1, 0), (3, 1), (17, 5), (37, 16), (65, 64), (100, 37), (129, 1)])
+def test_ragged_batches_full_size(B, cut):
+    """The last batch of an epoch is ragged (main.py:116: DataLoader without drop_last) and every batch size picks its own tile
+    variants (row-streaming rows per workgroup, 128- / 256-pixel tiles, grouped weight-gradient splits, GroupNorm block plan):
+    at the full model size a batch of B samples must give (i) per-sample outputs equal to the ones the same samples get inside
+    other batches, (ii) bit-identical gradients run to run, (iii) the gradient of its mean loss = the sample-weighted average of
+    the gradients of the two pieces [0, cut) and [cut, B) - pieces that run through different variants again."""
+    m, diff, res, dev = _darcy_setup()
+    g = torch.Generator().manual_seed(100 + B)
+    x0 = torch.randn(B, 2, 64, 64, generator=g).to(dev)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(B, 2, 64, 64, generator=g).to(dev)
+    t = torch.randint(0, 100, (B,), generator=g).to(dev)
+    x = x0.permute(0, 2, 3, 1).reshape(B, 4096, 2).contiguous()
+    with torch.no_grad():
+        full = m(x, t)
+        one = torch.cat([m(x[i:i + 1].contiguous(), t[i:i + 1].contiguous()) for i in sorted({0, B // 2, B - 1})])
+    pick = full[sorted({0, B // 2, B - 1})]
+    assert torch.isfinite(full).all()
+    assert (pick - one).abs().max().item() <= 1e-5 * full.abs().max().item()
+    l1, g1 = _step_grads(m, diff, res, x0, eps, t, 0, B)
+    l2, g2 = _step_grads(m, diff, res, x0, eps, t, 0, B)
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all()
+    if cut:
+        la, ga = _step_grads(m, diff, res, x0, eps, t, 0, cut)
+        lb, gb = _step_grads(m, diff, res, x0, eps, t, cut, B)
+        wa, wb = cut / B, (B - cut) / B
+        assert abs(wa * la + wb * lb - l1) < 1e-5 * abs(l1)
+        assert (wa * ga + wb * gb - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_small_ragged_batch_step_vs_oracle(B):
+    """Batches of 1 and 3 at the full model size against the oracle's autograd (every used gradient tensor)."""
+    from oracle import pidm_oracle as O
+    m, diff, res, dev = _darcy_setup()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(40 + B)
+    x0 = torch.randn(B, 2, 64, 64, generator=g)
+    x0[:, 1] = torch.exp(0.5 * x0[:, 1])
+    eps = torch.randn(B, 2, 64, 64, generator=g)
+    t = torch.randint(0, 100, (B,), generator=g)
+    loss, _ = _step_grads(m, diff, res, x0.to(dev), eps.to(dev), t.to(dev), 0, B)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    ref, _, _, _ = O.darcy_training_loss(p, O.UnetCfg(dim=32, channels=2), O.diffusion_tables(100), x0, t, eps, 1., 1e-3)
+    ref.backward()
+    assert abs(loss - ref.item()) < 1e-4 * abs(ref.item()), (loss, ref.item())
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    n = 0
+    for k, prm in m.named_parameters():
+        if p[k].grad is None:
+            assert prm.grad is None, k
+            continue
+        a, b = prm.grad.detach().cpu(), p[k].grad
+        assert abs(a.norm().item() - b.norm().item()) <= 1e-3 * b.norm().item() + 2e-6 * gmax, (k, a.norm().item(), b.norm().item())
+        n += 1
+    assert n == 259
+
+
+def test_ragged_batch_sampling_step_b7():
+    """One ancestral step on 7 samples = the same step on each sample alone with the same noise (torch.randn_like pinned: the
+    update is then a function of the sample only); reference: src/denoising_utils.py:388-455."""
+    m, diff, res, dev = _darcy_setup()
+    torch.manual_seed(21)
+    x = torch.randn(7, 2, 64, 64, device=dev)
+    z = torch.randn(7, 2, 64, 64, device=dev)
+
+    def step(lo, hi):
+        orig = torch.randn_like
+        torch.randn_like = lambda a, *aa, **k: z[lo:hi].clone().view(a.shape)
+        try:
+            (nx, _), _ = diff.p_sample(x[lo:hi].contiguous(), None, 57, save_output=False, surpress_noise=True, residual_func=res)
+        finally:
+            torch.randn_like = orig
+        return nx
+
+    nx = step(0, 7)
+    assert torch.isfinite(nx).all()
+    assert torch.equal(nx, step(0, 7))
+    for i in (0, 3, 6):
+        assert (step(i, i + 1)[0] - nx[i]).abs().max().item() <= 1e-5 * nx.abs().max().item()
+
+
+def test_ragged_batch_mechanics_dim128_b5():
+    """The mechanics model (dim 128, 65x65 fields) on a ragged batch of 5 without the sample-coupling inequality term: run-to-run
+    bit-identical, and the gradient of the mean loss = the sample-weighted average over the pieces [0, 2) and [2, 5)."""
+    from physicsinformeddiffusionmodels_amd.denoising_utils import DenoisingDiffusion
+    from physicsinformeddiffusionmodels_amd.residuals_mechanics_K import ResidualsMechanics
+    from physicsinformeddiffusionmodels_amd.unet_model import Unet3D
+    dev = _dev()
+    torch.manual_seed(0)
+    m = Unet3D(dim=128, channels=10, out_dim=3, sigmoid_last_channel=True).to(dev)
+    diff = DenoisingDiffusion(100, dev)
+    res = ResidualsMechanics(model=m, pixels_per_dim=64, pixels_at_boundary=True, no_BC_folder="/nonexistent/", device=dev)
+    B = 5
+    g = torch.Generator().manual_seed(9)
+    inp = torch.zeros(B, 10, 65, 65)
+    inp[:, 0] = torch.rand(B, generator=g).view(B, 1, 1) * 0.3 + 0.2
+    inp[:, 1:3] = torch.randn(B, 2, 65, 65, generator=g)
+    inp[:, 3:5] = 0.1 * torch.randn(B, 2, 65, 65, generator=g)
+    inp[:, 5, :64, :64] = torch.rand(B, 64, 64, generator=g)
+    inp[:, 6, :, 0] = 1.0
+    inp[:, 7, :, 0] = 1.0
+    inp[:, 9, 32, 64] = -1.0
+    inp = inp.to(dev)
+    eps = torch.randn(B, 3, 65, 65, generator=g).to(dev)
+    t = torch.randint(0, 100, (B,), generator=g).to(dev)
+
+    def step(lo, hi):
+        orig = torch.randint, torch.randn_like
+        torch.randint = lambda *a, **k: t[lo:hi].clone()
+        torch.randn_like = lambda *a, **k: eps[lo:hi].clone()
+        try:
+            loss, *_ = diff.model_estimation_loss(inp[lo:hi].contiguous(), residual_func=res, c_data=1., c_residual=1e-3)
+        finally:
+            torch.randint, torch.randn_like = orig
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        eng = next(iter(m.__dict__["_engines"].values()))
+        return loss.item(), eng.flat_grad.clone()
+
+    l1, g1 = step(0, B)
+    l2, g2 = step(0, B)
+    assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all()
+    la, ga = step(0, 2)
+    lb, gb = step(2, B)
+    assert abs(0.4 * la + 0.6 * lb - l1) < 1e-5 * abs(l1)
+    assert (0.4 * ga + 0.6 * gb - g1).abs().max().item() < 2e-4 * g1.abs().max().item()
+
+
+@pytest.mark.parametrize("B", [513, 777])
+def test_darcy_stream_kernel_ragged_batches(B, monkeypatch):
+    """Batches that do not divide by the 256 persistent workgroups of darcy_stream_kernel (some walk one sample more than others;
+    the last round prefetches nothing): residual and gradient bit-identical to the band kernel, loss scalars to 1e-6."""
+    from physicsinformeddiffusionmodels_amd._lib import ptr, stream_ptr
+    m, diff, res, dev = _darcy_setup()
+    lib = res.lib
+    P = 64
+    g = torch.Generator().manual_seed(B)
+    x0 = torch.randn(B, 2, P, P, generator=g)
+    pred = x0 + 0.3 * torch.randn(B, 2, P, P, generator=g)
+    pred[:, 1] = torch.exp(0.5 * pred[:, 1])
+    t = torch.randint(0, 100, (B,), generator=g)
+    x0d, predd, td = x0.to(dev), pred.to(dev), t.to(dev)
+    dd = diff.diff_dict
+
+    def run():
+        rbuf, gbuf, sc = torch.empty(B, P * P, 3, device=dev), torch.empty_like(predd), torch.empty(4, device=dev)
+        ws = torch.empty(lib.pidm_darcy_loss_ws(B, P), dtype=torch.uint8, device=dev)
+        lib.check(lib.pidm_darcy_loss_fwd_bwd_t(ptr(x0d), ptr(predd), ptr(res._f_s_flat), ptr(td), ptr(dd['p2_loss_weight']),
+                                                ptr(dd['posterior_variance_clipped']), 1.0, 1e-3, res.inv_h0, res.inv_h1, ptr(rbuf),
+                                                ptr(gbuf), ptr(sc), ptr(ws), B, P, stream_ptr(dev)), "darcy loss")
+        return rbuf, gbuf, sc.cpu()
+
+    got = run()
+    monkeypatch.setenv("PIDM_DARCY_FULL", "0")
+    band = run()
+    assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all()
+    assert torch.equal(got[0], band[0]) and torch.equal(got[1], band[1])
+    assert torch.allclose(got[2], band[2], rtol=1e-6, atol=0)

@@ -1034,6 +1034,209 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_stream4_kernel(WgradIte
   conv_wgrad_1x1_stream4_body<WIDE_DY>(wg, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
+// The same 128 x 32 wave tile on the bf16 pipe (round 6): the stream above is bound by its fp32 MFMAs - 32 of them (2048 cycles of
+// the SIMD's vector ALUs) per 16 pixels, 45-70 TFLOP/s over the to_qkv / res_conv problems of a step.  Here a k-step is 16 PIXELS:
+// lane (l31, half) loads pixels q + 8 half + 0..7 of its channel(s) - the strided loads ARE the transpose into the MFMA's
+// k-contiguous operand fragment -, splits them into three bf16 pieces (5 fragments x 4 pairs x 11 vector instructions) and issues
+// 4 tiles x 6 v_mfma_f32_32x32x16_bf16 (768 cycles of the matrix pipe).  The next k-step's 16 loads per lane are in flight while
+// this one is split and multiplied (~190 registers: two waves per SIMD).  Same tile mapping, partial layout, cross-wave sum and
+// bias columns as conv_wgrad_1x1_stream4_body; pixels past the wave's range are loaded as zeros.
+template <bool WIDE_DY>
+__device__ __forceinline__ void conv_wgrad_1x1_split4_body(const WgradItem& wg, const int bx, const int split, float (*red)[1024]) {
+  const WgradItem& g = wg;
+  const float* __restrict__ src0 = wg.src0;
+  const float* __restrict__ src1 = wg.src1;
+  const float* __restrict__ dy = wg.dy;
+  float* __restrict__ partial = wg.partial;
+  float* __restrict__ bias_partial = wg.bias_partial;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int n_nar = WIDE_DY ? wg.NP / 32 : wg.MP / 32;
+  const int t_nar = bx % n_nar, t_wid = bx / n_nar;
+  const int w0 = t_wid * 128, r0 = t_nar * 32;
+  const size_t ptot = (size_t)g.B * g.Hv * g.Wv;
+  size_t p_lo = (size_t)split * wg.tiles_per_split * 128, p_hi = p_lo + (size_t)wg.tiles_per_split * 128;
+  if (p_hi > ptot) p_hi = ptot;
+  if (p_lo > p_hi) p_lo = p_hi;
+  const size_t per = ((p_hi - p_lo + 7) / 8) * 2;
+  size_t w_lo = p_lo + (size_t)wave * per, w_hi = w_lo + per;
+  if (w_lo > p_hi) w_lo = p_hi;
+  if (w_hi > p_hi) w_hi = p_hi;
+  const int cw = w0 + 4 * l31, cn = r0 + l31;
+  const float* wsrc;
+  const float* nsrc;
+  size_t wld, nld;
+  bool w_ok, n_ok;
+  if (WIDE_DY) {
+    wsrc = dy + cw; wld = wg.ld_dy; w_ok = cw < g.Cout;
+    nsrc = (cn < g.C0) ? src0 + cn : src1 + (cn - g.C0); nld = (cn < g.C0) ? g.ld0 : g.ld1; n_ok = cn < g.Cin;
+  } else {
+    wsrc = (cw < g.C0) ? src0 + cw : src1 + (cw - g.C0); wld = (cw < g.C0) ? g.ld0 : g.ld1; w_ok = cw < g.Cin;
+    nsrc = dy + cn; nld = wg.ld_dy; n_ok = cn < g.Cout;
+  }
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool do_bias = (bias_partial != nullptr) && ((WIDE_DY ? t_nar : t_wid) == 0);
+  f32x4 bw = {0.f, 0.f, 0.f, 0.f};
+  float bn = 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // Branch-free loads: a lane whose channel does not exist reads channel 0 of its operand (its products land in rows / columns of
+  // the padded slab that nothing reads), a pixel past the wave's range is clamped to the range's last pixel and ZEROED before use
+  // (tail k-step only).  With conditional loads hipcc wrapped every one of the 16 loads in a branch and waited for all of them -
+  // the prefetch included - in front of the arithmetic (s_waitcnt vmcnt(0)): a full memory latency per k-step, 141 us for the
+  // to_qkv problem of the 16 x 16 level at batch 256 where this form takes 122 (fp32 stream: 169; profiles/r06_wgrad1x1_split.txt).
+  const float* const wp = w_ok ? wsrc : (WIDE_DY ? dy : src0);
+  const float* const np = n_ok ? nsrc : (WIDE_DY ? src0 : dy);
+  if (!w_ok) wld = WIDE_DY ? (size_t)wg.ld_dy : (size_t)g.ld0;
+  if (!n_ok) nld = WIDE_DY ? (size_t)g.ld0 : (size_t)wg.ld_dy;
+  f32x4 wa[8], wb[8];
+  float na[8], nb[8];
+#define PIDM_WG1S_LOAD(w_, n_, q_)                                                                                  \
+  {                                                                                                                 \
+    const size_t pb_ = (q_) + 8 * half;                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                 \
+      const size_t pp_ = pb_ + j < w_hi ? pb_ + j : w_hi - 1;                                                       \
+      w_[j] = *reinterpret_cast<const f32x4*>(wp + pp_ * wld);                                                      \
+      n_[j] = np[pp_ * nld];                                                                                        \
+    }                                                                                                               \
+  }
+#define PIDM_WG1S_COMPUTE(w_, n_, q_)                                                                               \
+  {                                                                                                                 \
+    if ((q_) + 16 > w_hi) {                          /* wave-uniform: the range's last, partial k-step */           \
+      const size_t pb_ = (q_) + 8 * half;                                                                           \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
+        const bool in_ = pb_ + j < w_hi;                                                                            \
+        w_[j] = in_ ? w_[j] : zero4;                                                                                \
+        n_[j] = in_ ? n_[j] : 0.f;                                                                                  \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (do_bias) {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
+        if (WIDE_DY) bw += w_[j]; else bn += n_[j];                                                                 \
+      }                                                                                                             \
+    }                                                                                                               \
+    u32x4 nf[3];                                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                 \
+      unsigned p0, p1, p2;                                                                                          \
+      pidm_split3_pk(n_[2 * k], n_[2 * k + 1], p0, p1, p2);                                                         \
+      nf[0][k] = p0; nf[1][k] = p1; nf[2][k] = p2;                                                                  \
+    }                                                                                                               \
+    /* two tiles' pieces, then their 12 MFMAs term by term across the two: consecutive MFMAs write different accumulators (a   \
+       tile's six terms back to back are one dependency chain; all four tiles' pieces at once spill) */                      \
+    _Pragma("unroll") for (int tp = 0; tp < 4; tp += 2) {                                                           \
+      u32x4 wf[2][3];                                                                                               \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                               \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                             \
+          unsigned p0, p1, p2;                                                                                      \
+          pidm_split3_pk(w_[2 * k][tp + t], w_[2 * k + 1][tp + t], p0, p1, p2);                                     \
+          wf[t][0][k] = p0; wf[t][1][k] = p1; wf[t][2][k] = p2;                                                     \
+        }                                                                                                           \
+      }                                                                                                             \
+      /* smallest terms first (the order of every split-form kernel of this library): (2,0) (0,2) (1,1) (1,0) (0,1) (0,0) */ \
+      _Pragma("unroll") for (int term = 0; term < 6; ++term) {                                                      \
+        const int iw = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;                                            \
+        const int in = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
+          acc[tp + t] = WIDE_DY ? pidm_mfma_bf16_32x32x16(wf[t][iw], nf[in], acc[tp + t])                           \
+                                : pidm_mfma_bf16_32x32x16(nf[iw], wf[t][in], acc[tp + t]);                          \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+  // two register sets take turns: the loads of k-step i + 1 are issued in front of the arithmetic of k-step i
+  if (w_lo < w_hi) {
+    size_t q = w_lo;
+    PIDM_WG1S_LOAD(wa, na, q)
+    for (;;) {
+      // (unconditional: past the range the clamp makes these 16 loads of the last pixel's lines.  Behind `if (more)` hipcc's
+      // wait-count pass joins the two paths with the count of the path WITHOUT the prefetch - and the arithmetic waits for it)
+      PIDM_WG1S_LOAD(wb, nb, q + 16)
+      PIDM_WG1S_COMPUTE(wa, na, q)
+      q += 16;
+      if (q >= w_hi) break;                            // wave-uniform
+      PIDM_WG1S_LOAD(wa, na, q + 16)
+      PIDM_WG1S_COMPUTE(wb, nb, q)
+      q += 16;
+      if (q >= w_hi) break;
+    }
+  }
+#undef PIDM_WG1S_LOAD
+#undef PIDM_WG1S_COMPUTE
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      red[wave][row * 32 + l31] = acc[t][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const float sv = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      const int m = WIDE_DY ? w0 + 4 * (e >> 5) + t : r0 + (e >> 5);
+      const int nc = WIDE_DY ? r0 + (e & 31) : w0 + 4 * (e & 31) + t;
+      if (m < wg.MP && nc < wg.NP) partial[((size_t)split * wg.MP + m) * wg.NP + nc] = sv;
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    if (WIDE_DY) {
+      for (int t = 0; t < 4; ++t) red[0][(wave * 2 + half) * 128 + 4 * l31 + t] = bw[t];
+      __syncthreads();
+      if (tid < 128 && w0 + tid < wg.MP) {
+        float sb = 0.f;
+        for (int k = 0; k < 8; ++k) sb += red[0][k * 128 + tid];
+        bias_partial[(size_t)split * wg.MP + w0 + tid] = sb;
+      }
+    } else {
+      red[0][tid] = bn;
+      __syncthreads();
+      if (tid < 32) {
+        float sb = 0.f;
+        for (int k = 0; k < 8; ++k) sb += red[0][k * 32 + tid];
+        bias_partial[(size_t)split * wg.MP + r0 + tid] = sb;
+      }
+    }
+  }
+}
+
+// XCD-aware order of a problem's workgroups (observed, for speed only: hardware block h runs on XCD h % 8, each XCD has its own L2).
+// The n workgroups [first, first + n) of a problem are renumbered so that the ones of XCD k take one CONTIGUOUS range of logical
+// ids: with logical id = split * tiles + tile, the tiles of a split - which read the same pixels - then share an L2 instead of
+// having every XCD fetch every pixel range (number of x < A with x % 8 == i: (A + 7 - i) / 8).
+__device__ __forceinline__ unsigned wgrad_xcd_order(unsigned h, unsigned first, unsigned n) {
+  const unsigned k = h & 7u;
+  unsigned before = 0;
+#pragma unroll
+  for (unsigned i = 0; i < 8; ++i)
+    if (i < k) before += (first + n + 7u - i) / 8u - (first + 7u - i) / 8u;
+  return before + (h + 7u - k) / 8u - (first + 7u - k) / 8u;
+}
+
+template <bool WIDE_DY>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_1x1_split4_kernel(WgradItem wg, int xcd) {
+  __shared__ float red[4][1024];
+  unsigned local = blockIdx.y * gridDim.x + blockIdx.x;
+  if (xcd) local = wgrad_xcd_order(local, 0u, gridDim.x * gridDim.y);
+  conv_wgrad_1x1_split4_body<WIDE_DY>(wg, (int)(local % wg.gx), (int)(local / wg.gx), red);
+}
+
+// the split-form problems of a pass in one launch (family kWgFam1x1Split: its own table - these bodies need two waves per SIMD's
+// registers, the fp32 streams four)
+__global__ void __launch_bounds__(256, 2) conv_wgrad_1x1_split_multi_kernel(const WgradItem* __restrict__ table, int n, unsigned blk_base,
+                                                                            int xcd) {
+  __shared__ float red[4][1024];
+  const unsigned bid = blockIdx.x + blk_base;
+  const int lane_ = threadIdx.x & 63;
+  const unsigned first_ = lane_ < n ? table[lane_].blk0 : 0xffffffffu;
+  const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(bid >= first_)) - 1);
+  const WgradItem wg = table[p];
+  // (the XCD of a workgroup follows its index in THIS launch: blockIdx.x)
+  const unsigned local = xcd ? wgrad_xcd_order(blockIdx.x, wg.blk0 - blk_base, wg.gx * wg.gy) : bid - wg.blk0;
+  const int bx = (int)(local % wg.gx), by = (int)(local / wg.gx);
+  if (wg.kind == kWgKindStream4Dy) conv_wgrad_1x1_split4_body<true>(wg, bx, by, red);
+  else conv_wgrad_1x1_split4_body<false>(wg, bx, by, red);
+}
+
 // The three 1x1 stream kernels for a TABLE of problems in one launch (round 5; WgradQueue, pidm_launch.h; the lookup of
 // conv_wgrad_rs_multi_kernel): a problem's `kind` - wave-uniform - picks the body, its own grid is gx x gy.
 __global__ void __launch_bounds__(256, 4) conv_wgrad_1x1_multi_kernel(const WgradItem* __restrict__ table, int n, unsigned blk_base) {
@@ -1196,6 +1399,20 @@ int launch_split_reduce(const float* partial, float* dst, const float* bias_part
   return 0;
 }
 
+// PIDM_WGRAD1X1_XCD=0: the split-form 1x1 streams keep the dispatch order (tile fastest) instead of wgrad_xcd_order
+static int wgrad_1x1_xcd() {
+  const char* e = knob("PIDM_WGRAD1X1_XCD");
+  return (e && !atoi(e)) ? 0 : 1;
+}
+
+int launch_wgrad_1x1_split_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
+  if (n <= 0 || nblocks == 0) return 0;
+  PIDM_PROF_NAME("conv_wgrad_1x1_split_multi_kernel");
+  hipLaunchKernelGGL(conv_wgrad_1x1_split_multi_kernel, dim3(nblocks), dim3(256), 0, st, table_dev + first, n, blk_base, wgrad_1x1_xcd());
+  PIDM_CHECK_LAUNCH("conv_wgrad_1x1_split_multi_kernel");
+  return 0;
+}
+
 int launch_wgrad_1x1_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
   if (n <= 0 || nblocks == 0) return 0;
   PIDM_PROF_NAME("conv_wgrad_1x1_multi_kernel");
@@ -1342,10 +1559,11 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
   const size_t queued0 = wq ? wq->size() : 0;
   // PIDM_WGRAD_GROUP_FAMS (A/B measurements): bit 0 / 1 / 2 = the 3x3 row-streaming / 4x4-stride-2 row-streaming / 1x1 stream family may queue
   const char* fe = knob("PIDM_WGRAD_GROUP_FAMS");
-  const int fams = fe ? atoi(fe) : 7;
+  const int fams = fe ? atoi(fe) : 15;
   WgradQueue* const wq_rs = (fams & 1) ? wq : nullptr;
   WgradQueue* const wq_rs4 = (fams & 2) ? wq : nullptr;
-  WgradQueue* const wq_1x1 = (fams & 4) ? wq : nullptr;
+  WgradQueue* const wq_1x1f = (fams & 4) ? wq : nullptr;
+  WgradQueue* const wq_1x1s = (fams & 8) ? wq : nullptr;   // bit 3: the split-form 1x1 streams (their own table and launch)
   WgradGeom wg;
   wgrad_plan(g, ld_dy, &wg);
   const int T = wgrad_taps(g);
@@ -1411,8 +1629,15 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     else PIDM_LAUNCH_WG(2, 2, true, false, 2, gridp)
   } else if (smode >= 1 && smode <= 3) {
     // the LDS-free pixel streams; grouped (wq): queued with a quarter of the splits (launch_wgrad_rs)
+    // wide operands (>= 128 channels) on the bf16 pipe: conv_wgrad_1x1_split4_body (PIDM_WGRAD1X1_SPLIT=0 or PIDM_WGRAD_SPLIT=0: the
+    // fp32 streams)
+    const char* s1e = knob("PIDM_WGRAD1X1_SPLIT");
+    const char* wse = knob("PIDM_WGRAD_SPLIT");
+    const bool sp4 = smode >= 2 && !(s1e && !atoi(s1e)) && !(wse && !atoi(wse));
+    WgradQueue* const wq_1x1 = sp4 ? wq_1x1s : wq_1x1f;
     if (wq_1x1) {
-      const int dv = wgrad_group_splitdiv();
+      const char* tme = knob("PIDM_WGRAD1X1_SPLIT_DIV");      // the split-form family's own divisor of the planned split count
+      const int dv = (sp4 && tme && atoi(tme) > 0) ? atoi(tme) : wgrad_group_splitdiv();
       if (dv > 1) {
         wg.tiles_per_split *= dv;
         if (wg.tiles_per_split > g.tiles_m) wg.tiles_per_split = g.tiles_m;
@@ -1428,7 +1653,16 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
       fprintf(stderr, "[pidm]   -> 1x1 wgrad stream mode %d: %d pixels, Cin %d (+%d), Cout %d, grid %u x %u, %d tiles per split\n", smode,
               g.B * g.Hv * g.Wv, g.C0, g.C1, g.Cout, gr.x, gr.y, wg.tiles_per_split);
     if (wq_1x1) {
-      wq_1x1->push(kWgFam1x1, it, 0.0);
+      wq_1x1->push(sp4 ? kWgFam1x1Split : kWgFam1x1, it, sp4 ? 2.0 * g.B * g.Hv * g.Wv * (double)g.Cout * g.Cin : 0.0);
+    } else if (sp4) {
+      if (smode == 2) {
+        PIDM_PROF_NAME("conv_wgrad_1x1_split4_kernel<true>");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_split4_kernel<true>), gr, dim3(256), 0, st, it, wgrad_1x1_xcd());
+      } else {
+        PIDM_PROF_NAME("conv_wgrad_1x1_split4_kernel<false>");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_1x1_split4_kernel<false>), gr, dim3(256), 0, st, it, wgrad_1x1_xcd());
+      }
+      if (prof) prof_reclass_last(3);   // split form on the bf16 pipe
     } else if (smode == 1) {
       PIDM_PROF_NAME("conv_wgrad_1x1_stream_kernel");
       hipLaunchKernelGGL(conv_wgrad_1x1_stream_kernel, gr, dim3(256), 0, st, it);

@@ -792,6 +792,7 @@ int launch_wgrad_rs4_multi(const WgradItem* table_dev, int first, int n, unsigne
 int launch_wgrad_multi(int fam, const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st) {
   return fam == kWgFamRs    ? launch_wgrad_rs_multi(table_dev, first, n, blk_base, nblocks, st)
          : fam == kWgFamRs4 ? launch_wgrad_rs4_multi(table_dev, first, n, blk_base, nblocks, st)
+         : fam == kWgFam1x1Split ? launch_wgrad_1x1_split_multi(table_dev, first, n, blk_base, nblocks, st)
                             : launch_wgrad_1x1_multi(table_dev, first, n, blk_base, nblocks, st);
 }
 

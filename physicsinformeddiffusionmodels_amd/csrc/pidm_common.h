@@ -284,7 +284,7 @@ struct WgradGeom {
 // Only the fields the grouped kernels read (no host pointers, no padding: tables of these are compared with memcmp).  Three kernel
 // families, one table and one launch each: the 3x3 / stride-1 row-streaming kernel, its 4x4 / stride-2 sibling (k_wgrad_rs.hip)
 // and the three 1x1 pixel-stream kernels (k_conv_wgrad.hip; `kind` says which).
-enum { kWgFamRs = 0, kWgFamRs4 = 1, kWgFam1x1 = 2, kWgFams = 3 };
+enum { kWgFamRs = 0, kWgFamRs4 = 1, kWgFam1x1 = 2, kWgFam1x1Split = 3, kWgFams = 4 };   // (1x1Split: the wide-operand 1x1 problems on the bf16 pipe, round 6)
 enum { kWgKindStream = 0, kWgKindStream4Dy = 1, kWgKindStream4X = 2 };
 struct WgradItem {
   const float* src0;

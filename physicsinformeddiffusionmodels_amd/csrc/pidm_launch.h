@@ -59,8 +59,16 @@ struct WgradQueue {
     q.v.push_back(it);
     q.fl.push_back(flops);
   }
-  size_t size() const { return f[0].v.size() + f[1].v.size() + f[2].v.size(); }
-  size_t pending() const { return size() - f[0].done - f[1].done - f[2].done; }
+  size_t size() const {
+    size_t n = 0;
+    for (const auto& q : f) n += q.v.size();
+    return n;
+  }
+  size_t pending() const {
+    size_t n = size();
+    for (const auto& q : f) n -= q.done;
+    return n;
+  }
   void clear() {
     for (auto& q : f) { q.v.clear(); q.fl.clear(); q.nblocks = 0; q.done = 0; }
   }
@@ -70,6 +78,7 @@ int launch_wgrad_multi(int fam, const WgradItem* table_dev, int first, int n, un
 int launch_wgrad_rs_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
 int launch_wgrad_rs4_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
 int launch_wgrad_1x1_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
+int launch_wgrad_1x1_split_multi(const WgradItem* table_dev, int first, int n, unsigned blk_base, unsigned nblocks, hipStream_t st);
 int wgrad_group_splitdiv();     // PIDM_WGRAD_GROUP_SPLITDIV (default 4)
 // the device-side description of one problem: the geometry fields the kernels read + operands + its own grid (k_wgrad_rs.hip)
 WgradItem wgrad_item(const WgradGeom& wg, const float* src0, const float* src1, const float* dy, float* partial, float* bias_partial,

@@ -96,6 +96,53 @@ def test_conv_1x1_stream_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, tran
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+STREAM_SPLIT_CASES = STREAM_CASES + [   # the 16-pixel k-steps of the split-form streams (conv_wgrad_1x1_split4_body)
+    (17, 1, 128, 0, 32, 1, 1, 0, 0),     # wide X operand, 17 pixels: one full k-step on wave 0 + a one-pixel tail on another wave
+    (1, 16, 64, 0, 768, 1, 1, 0, 0),     # to_qkv at 64 channels: six wide dY tiles x two narrow tiles, two 128-pixel tiles
+    (3, 8, 256, 256, 128, 1, 1, 0, 0),   # res_conv of the decoder: 512 concatenated input channels (wide X across the boundary)
+    (130, 1, 256, 0, 96, 1, 1, 0, 0),    # 130 pixels = 128 + 2: second split holds a two-pixel tile
+]
+
+
+@pytest.mark.parametrize("form", ["split", "fp32"])
+@pytest.mark.parametrize("B,H,C0,C1,Cout,K,stride,pad,transposed", STREAM_SPLIT_CASES)
+def test_conv_1x1_stream_wgrad_forms(backend, monkeypatch, form, B, H, C0, C1, Cout, K, stride, pad, transposed):
+    """1x1 weight gradients with a >= 128-channel operand: the bf16-pipe stream (default) and the fp32-MFMA stream
+    (PIDM_WGRAD1X1_SPLIT=0) on the same cases."""
+    monkeypatch.setenv("PIDM_WGRAD1X1_SPLIT", "1" if form == "split" else "0")
+    test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
+
+
+def test_1x1_split_wgrad_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
+    """conv_wgrad_1x1_split4_body against a float64 product next to the fp32-MFMA stream on the same data, at the longest pixel
+    contraction a split of the Darcy model sees (K = 2048 pixels of the 16 x 16 level's to_qkv with 8 images; both operand roles):
+    weight- and bias-gradient errors within 1.25x of the fp32 stream's and below 2e-6 of the result's scale."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(99)
+    for Cin, Cout in ((128, 384), (256, 64)):
+        B, H = 8, 16
+        x = torch.randn(B, Cin, H, H, generator=g)
+        dy = torch.randn(B, Cout, H, H, generator=g)
+        ref = torch.einsum("bmhw,bnhw->mn", dy.double(), x.double())
+        refb = dy.double().sum((0, 2, 3))
+        x0, dyn = nhwc(x).to(dev), nhwc(dy).to(dev)
+        d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=1, KW=1, stride=1, pad=0, transposed=0, out_nchw=0, ldo=Cout)
+        errs = {}
+        for form in ("split", "fp32"):
+            monkeypatch.setenv("PIDM_WGRAD1X1_SPLIT", "1" if form == "split" else "0")
+            ws = torch.empty(L.pidm_conv_wgrad_ws(d), dtype=torch.uint8, device=dev)
+            dw = torch.full((Cout, Cin, 1, 1), float("nan"), device=dev)
+            db = torch.full((Cout,), float("nan"), device=dev)
+            L.check(L.pidm_conv_wgrad(d, ptr(x0), None, ptr(dyn), Cout, ptr(dw), ptr(db), ptr(ws), st))
+            errs[form] = [float((dw.double().cpu().view(Cout, Cin) - ref).abs().max() / ref.abs().max()),
+                          float((db.double().cpu() - refb).abs().max() / refb.abs().max())]
+        print(f"1x1 weight gradient {Cin} -> {Cout}, 2048 pixels: max error / max |reference| (dW, dbias):", errs)
+        for e_split, e_fp32, what in zip(errs["split"], errs["fp32"], ("dW", "dbias")):
+            assert e_split < 1.25 * e_fp32 + 1e-8, (what, errs)
+            assert e_split < 2e-6, (what, errs)
+
+
 PERSIST_CASES = [   # 3x3 convs walked persistently (several m-tiles per workgroup) once the slot count is lowered
     (6, 16, 32, 0, 32, 3, 1, 1, 0),      # 12 m-tiles -> 3 workgroups x 4 tiles, two Cin chunks
     (5, 8, 16, 16, 64, 3, 1, 1, 0),      # two images per tile, ragged last workgroup, two n-tiles, concat source

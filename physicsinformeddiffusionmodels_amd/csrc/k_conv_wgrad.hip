@@ -1110,10 +1110,9 @@ __device__ __forceinline__ void conv_wgrad_1x1_split4_body(const WgradItem& wg, 
         n_[j] = in_ ? n_[j] : 0.f;                                                                                  \
       }                                                                                                             \
     }                                                                                                               \
-    if (do_bias) {                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
-        if (WIDE_DY) bw += w_[j]; else bn += n_[j];                                                                 \
-      }                                                                                                             \
+    if (do_bias) {     /* the k-step's 8 pixels as a tree, then one add to the running sum: a chain of range / 16 adds */ \
+      if (WIDE_DY) bw += ((w_[0] + w_[1]) + (w_[2] + w_[3])) + ((w_[4] + w_[5]) + (w_[6] + w_[7]));                 \
+      else bn += ((n_[0] + n_[1]) + (n_[2] + n_[3])) + ((n_[4] + n_[5]) + (n_[6] + n_[7]));                         \
     }                                                                                                               \
     u32x4 nf[3];                                                                                                    \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                 \
@@ -1450,6 +1449,14 @@ static int wgrad_stream_mode(const ConvGeom& g, int ld_dy) {
   return 1;
 }
 
+// 1x1 problems with a >= 128-channel operand run on the bf16 pipe (conv_wgrad_1x1_split4_body; PIDM_WGRAD1X1_SPLIT=0 or
+// PIDM_WGRAD_SPLIT=0: the fp32 streams)
+static bool wgrad_1x1_split_on(const ConvGeom& g, int ld_dy) {
+  const char* s1e = knob("PIDM_WGRAD1X1_SPLIT");
+  const char* wse = knob("PIDM_WGRAD_SPLIT");
+  return wgrad_stream_mode(g, ld_dy) >= 2 && !(s1e && !atoi(s1e)) && !(wse && !atoi(wse));
+}
+
 static void wgrad_plan(const ConvGeom& g, int ld_dy, WgradGeom* wg) {
   wg->g = g;
   wg->ld_dy = ld_dy;
@@ -1631,9 +1638,7 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
     // the LDS-free pixel streams; grouped (wq): queued with a quarter of the splits (launch_wgrad_rs)
     // wide operands (>= 128 channels) on the bf16 pipe: conv_wgrad_1x1_split4_body (PIDM_WGRAD1X1_SPLIT=0 or PIDM_WGRAD_SPLIT=0: the
     // fp32 streams)
-    const char* s1e = knob("PIDM_WGRAD1X1_SPLIT");
-    const char* wse = knob("PIDM_WGRAD_SPLIT");
-    const bool sp4 = smode >= 2 && !(s1e && !atoi(s1e)) && !(wse && !atoi(wse));
+    const bool sp4 = wgrad_1x1_split_on(g, ld_dy);
     WgradQueue* const wq_1x1 = sp4 ? wq_1x1s : wq_1x1f;
     if (wq_1x1) {
       const char* tme = knob("PIDM_WGRAD1X1_SPLIT_DIV");      // the split-form family's own divisor of the planned split count
@@ -1643,6 +1648,22 @@ int launch_wgrad(const ConvGeom& g, const float* src0, const float* src1, const 
         if (wg.tiles_per_split > g.tiles_m) wg.tiles_per_split = g.tiles_m;
         wg.nsplit = cdiv(g.tiles_m, wg.tiles_per_split);
       }
+    }
+    const char* spe = knob("PIDM_WGRAD1X1_SPLIT_PLAN");
+    if (sp4 && !wq_1x1 && !(spe && !atoi(spe))) {
+      // a launch of its own (large batches): the split form has two workgroups per CU, not the plan's four, and a longer prologue /
+      // epilogue per work item - fewer, longer splits (never more than planned: the workspace is sized for the plan).  Batch 256:
+      // 466 -> 386 us per step over the 16 launches, their reductions 330 -> 310 (profiles/r06_wgrad1x1_split.txt)
+      const int bmn = (smode == 2) ? cdiv(wg.MP, 128) * (wg.NP / 32) : cdiv(wg.NP, 128) * (wg.MP / 32);
+      int best = wg.tiles_per_split;
+      double bc = 1e30;
+      for (int tps = wg.tiles_per_split; tps <= g.tiles_m; ++tps) {
+        const long wgs = (long)bmn * cdiv(g.tiles_m, tps);
+        const double cost = (double)((wgs + 511) / 512) * (tps + 2.0);
+        if (cost < bc - 1e-9) { bc = cost; best = tps; }
+      }
+      wg.tiles_per_split = best;
+      wg.nsplit = cdiv(g.tiles_m, best);
     }
     const dim3 gr = smode == 1   ? dim3(wg.nsplit, (wg.MP / 32) * (wg.NP / 32), 1)
                     : smode == 2 ? dim3(cdiv(wg.MP, 128) * (wg.NP / 32), wg.nsplit, 1)

@@ -81,6 +81,32 @@ __device__ __forceinline__ GnLanes gn_lanes(int C) {
   return l;
 }
 
+// The per-lane channel constants of the GroupNorm apply kernels (4 consecutive channels from c0: gamma, beta and - with a FiLM input -
+// the scale / shift rows ss[b][c] + ssb[c], ss[b][C + c] + ssb[C + c]) as ONE batch of loads without branches: behind `if (ss)` hipcc
+// gave every channel's loads a branch and a wait of their own - 6-8 memory round trips in the prologue of every block of a 10 us
+// kernel (ISA of round 6).  Without a FiLM input the four ss slots read gamma (any readable address) and are ignored.  The callers
+// issue this at the TOP of the kernel, in front of the statistics reduction and its barriers.
+struct GnConsts {
+  float gm[4], bt[4], s0[4], b0[4], s1[4], b1[4];
+};
+__device__ __forceinline__ void gn_load_consts(GnConsts& k, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               const float* __restrict__ ss, const float* __restrict__ ssb, int ldss, int b, int C,
+                                               int c0) {
+  const float* const sp = ss ? ss + (size_t)b * ldss : gamma;
+  const float* const bp = ss ? ssb : gamma;
+  const int oC = ss ? C : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + i;
+    k.gm[i] = gamma[c];
+    k.bt[i] = beta[c];
+    k.s0[i] = sp[c];
+    k.b0[i] = bp[c];
+    k.s1[i] = sp[oC + c];
+    k.b1[i] = bp[oC + c];
+  }
+}
+
 // group statistics from the per-chunk partial sums (every block of a sample repeats this tiny reduction instead of a
 // separate "final" launch); block x == 0 also publishes (mean, rstd) for the backward pass
 __device__ __forceinline__ void gn_finalize_stats(const double* __restrict__ partial, int nchunk, int G, int b, double count,
@@ -141,6 +167,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        int ppb, const float* __restrict__ ln_gamma, float* __restrict__ ln_out) {
   __shared__ float s_stat[64][2];
   const int b = blockIdx.y, tid = threadIdx.x;
+  const GnLanes L = gn_lanes(C);
+  GnConsts kc;
+  gn_load_consts(kc, gamma, beta, ss, ssb, ldss, b, C, 4 * (tid % L.qw));      // (rep 0; in flight across the statistics barriers)
   if (partial) {
     gn_finalize_stats(partial, nchunk, G, b, count, eps, stats, s_stat);
   } else {
@@ -151,25 +180,21 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     __syncthreads();
   }
   const int cpg = C / G;
-  const GnLanes L = gn_lanes(C);
   const int pl = tid / L.qw;
   const int p0 = blockIdx.x * ppb;
   const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
   for (int rep = 0; rep < L.nrep; ++rep) {
     const int c0 = 4 * (rep * 256 + tid % L.qw);
+    if (rep) gn_load_consts(kc, gamma, beta, ss, ssb, ldss, b, C, c0);
     float mean[4], a[4], bt[4], sc1[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k, g = c / cpg;
       mean[k] = s_stat[g][0];
-      a[k] = s_stat[g][1] * gamma[c];
-      bt[k] = beta[c];
-      sc1[k] = 1.f;
-      sh[k] = 0.f;
-      if (ss) {
-        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
-        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
-      }
+      a[k] = s_stat[g][1] * kc.gm[k];
+      bt[k] = kc.bt[k];
+      sc1[k] = ss ? 1.f + (kc.s0[k] + kc.b0[k]) : 1.f;
+      sh[k] = ss ? kc.s1[k] + kc.b1[k] : 0.f;
     }
     const size_t base = (size_t)b * HW * C + c0;
     if (LN) {
@@ -250,19 +275,20 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
   for (int rep = 0; rep < L.nrep; ++rep) {
     const int c0 = 4 * (rep * 256 + ql);
     float mean[4], rstd[4], gm[4], bt[4], sc1[4], sh[4];
+    GnConsts kc;
+    gn_load_consts(kc, gamma, beta, ss, ssb, ldss, b, C, c0);       // one batch of loads, no branches
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = c0 + k, g = c / cpg;
+      const int g = (c0 + k) / cpg;
       mean[k] = stats[((size_t)b * G + g) * 2];
       rstd[k] = stats[((size_t)b * G + g) * 2 + 1];
-      gm[k] = gamma[c];
-      bt[k] = beta[c];
-      sc1[k] = 1.f;
-      sh[k] = 0.f;
-      if (ss) {
-        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
-        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
-      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gm[k] = kc.gm[k];
+      bt[k] = kc.bt[k];
+      sc1[k] = ss ? 1.f + (kc.s0[k] + kc.b0[k]) : 1.f;
+      sh[k] = ss ? kc.s1[k] + kc.b1[k] : 0.f;
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const size_t base = (size_t)b * HW * C + c0;
@@ -337,6 +363,29 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   __shared__ float s_coef[64][2];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
+  // the per-lane constants of the apply loop below depend on nothing computed here: requested first (gn_load_consts), they arrive
+  // while the chunk partials are summed
+  const GnLanes L = gn_lanes(C);
+  GnConsts kc;
+  float st_m[4], st_r[4];
+  {
+    const int c0 = 4 * (tid % L.qw);
+    gn_load_consts(kc, gamma, beta, ss, ssb, ldss, b, C, c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c0 + k) / cpg;
+      st_m[k] = stats[((size_t)b * G + g) * 2];
+      st_r[k] = stats[((size_t)b * G + g) * 2 + 1];
+    }
+  }
+  // ... and so do the constants of the coefficient pass (channel tid; wider layers take the rest inside the loop)
+  float pg = 0.f, pb = 0.f, ps0 = 0.f, psb0 = 0.f;
+  if (tid < C) {
+    pg = gamma[tid];
+    pb = beta[tid];
+    ps0 = (ss ? ss + (size_t)b * ldss : gamma)[tid];
+    psb0 = (ss ? ssb : gamma)[tid];
+  }
   if (C < 256) {
     // few channels: 256/C threads per channel share the chunk loop (fixed order: lane k sums chunks k, k + nl, ...; lanes added
     // in order) instead of C threads walking all chunks while the rest of the block waits
@@ -374,9 +423,14 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
         S2 += p[1];
       }
     }
-    const double gm = gamma[c], bt = beta[c];
-    double sc1 = 1.0;
-    if (ss) sc1 = 1.0 + ((double)ss[(size_t)b * ldss + c] + (double)ssb[c]);
+    if (c != tid) {
+      pg = gamma[c];
+      pb = beta[c];
+      ps0 = (ss ? ss + (size_t)b * ldss : gamma)[c];
+      psb0 = (ss ? ssb : gamma)[c];
+    }
+    const double gm = pg, bt = pb;
+    const double sc1 = ss ? 1.0 + ((double)ps0 + (double)psb0) : 1.0;
     if (blockIdx.x == 0) {
       if (ss) {
         dss[(size_t)b * ldss + c] = (float)(gm * S2 + bt * S1);      // d scale
@@ -400,26 +454,30 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
     s_coef[tid][1] = (float)(d / n);
   }
   __syncthreads();
-  const GnLanes L = gn_lanes(C);
   const int pl = tid / L.qw;
   const int p0 = blockIdx.x * ppb;
   const int p1 = (p0 + ppb < HW) ? p0 + ppb : HW;
   for (int rep = 0; rep < L.nrep; ++rep) {
     const int c0 = 4 * (rep * 256 + tid % L.qw);
+    if (rep) {
+      gn_load_consts(kc, gamma, beta, ss, ssb, ldss, b, C, c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int g = (c0 + k) / cpg;
+        st_m[k] = stats[((size_t)b * G + g) * 2];
+        st_r[k] = stats[((size_t)b * G + g) * 2 + 1];
+      }
+    }
     float mean[4], rstd[4], gm[4], bt[4], sc1[4], sh[4], k1[4], k2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k, g = c / cpg;
-      mean[k] = stats[((size_t)b * G + g) * 2];
-      rstd[k] = stats[((size_t)b * G + g) * 2 + 1];
-      gm[k] = gamma[c];
-      bt[k] = beta[c];
-      sc1[k] = 1.f;
-      sh[k] = 0.f;
-      if (ss) {
-        sc1[k] = 1.f + (ss[(size_t)b * ldss + c] + ssb[c]);
-        sh[k] = ss[(size_t)b * ldss + C + c] + ssb[C + c];
-      }
+      mean[k] = st_m[k];
+      rstd[k] = st_r[k];
+      gm[k] = kc.gm[k];
+      bt[k] = kc.bt[k];
+      sc1[k] = ss ? 1.f + (kc.s0[k] + kc.b0[k]) : 1.f;
+      sh[k] = ss ? kc.s1[k] + kc.b1[k] : 0.f;
       k1[k] = s_coef[g][0];
       k2[k] = s_coef[g][1];
     }

@@ -367,8 +367,27 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
     float bv[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) bv[s4] = (bias && c + s4 < g.Cout) ? bias[c + s4] : 0.f;
+    // the residual quads of four rows at a time as one batch of loads (rows outside the batch / image re-read the first quad of
+    // the tensor and are skipped below): per row hipcc emitted branch - load - s_waitcnt vmcnt(0) - store, a memory round trip each
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+    f32x4 rq[4];
+    if (residual && vec) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int p = wave * 32 + row;
+        const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
+        const int b = b0 + img;
+        const int oy = (vy0 + ty) * g.os + g.ooy[z], ox = tx * g.os + g.oox[z];
+        const float* q = (b < g.B && img < g.NI) ? residual + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr + c : residual;
+        rq[i] = *reinterpret_cast<const f32x4*>(q);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + i;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int p = wave * 32 + row;
       const int tx = p & (g.Wv - 1), ty = (p >> g.wsh) & (g.TH - 1), img = p >> (g.wsh + g.tsh);
@@ -379,7 +398,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
       const float* rp = residual ? residual + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.ldr : nullptr;
       if (vec) {
         f32x4 o = {acc[0][r] + bv[0], acc[1][r] + bv[1], acc[2][r] + bv[2], acc[3][r] + bv[3]};
-        if (rp) o += *reinterpret_cast<const f32x4*>(rp + c);
+        if (rp) o += rq[i];
         if (sigmoid_last && c + 4 == g.Cout) o[3] = 1.f / (1.f + expf(-o[3]));
         *reinterpret_cast<f32x4*>(op + c) = o;
       } else {
@@ -392,6 +411,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
           op[(size_t)(c + s4) * g.soc] = o;
         }
       }
+    }
     }
   } else if (g.Wv >= 32) {
     // the wave's 32 pixels are consecutive in x inside one image row: one 64-bit base per (wave, n-tile), then
@@ -415,11 +435,20 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         const float* rp = residual ? residual + rpix + c : nullptr;
         const bool sig = sigmoid_last && c == g.Cout - 1;
         float gs1 = 0.f, gs2 = 0.f;
+        // the 16 residual values as ONE batch of loads (one branch): inside the row loop hipcc gave every row its own branch, load
+        // and s_waitcnt vmcnt(0) - which also waits for the previous row's store: 16 memory round trips per tile in a 18 us kernel
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        if (rp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = rp[((r & 3) + 8 * (r >> 2)) * rrstep];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rowc = (r & 3) + 8 * (r >> 2);   // compile-time part of the row index
           float v = acc[mt * NT + ni][r] + bv;
-          if (rp) v += rp[rowc * rrstep];
+          if (rp) v += rv[r];
           if (sig) v = 1.f / (1.f + expf(-v));
           if (!(kAblate & 2) || v == 1.2345e30f) op[rowc * rstep] = v;
           gs1 += v;

@@ -525,7 +525,9 @@ struct LnGnSums {
   double* part;         // [B][nchunk][C][2]; null: off
   int G, cpg, HW, nchunk, ppb;
 };
-template <bool BWD>
+// NQM: the most quads a lane may own (NQ <= NQM): 1 for C <= 256 - every LayerNorm of the Darcy model - keeps the per-lane sums at 4
+// registers each instead of 16 (the backward kernel sat at 210 registers: two waves per SIMD)
+template <bool BWD, int NQM>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ dy,    // BWD: grad wrt LN output
                                                         const float* __restrict__ res,   // BWD: added to dx (residual path)
@@ -541,15 +543,15 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   const int NQ = C4 / TPP;  // quads per lane (1..4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane / TPP, ql = lane % TPP, ppw = 64 / TPP;
-  float dg[16], rs[16];
+  float dg[4 * NQM], rs[4 * NQM];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { dg[k] = 0.f; rs[k] = 0.f; }
+  for (int k = 0; k < 4 * NQM; ++k) { dg[k] = 0.f; rs[k] = 0.f; }
   // gs.part != null (BWD): the block owns ONE chunk of ONE image (block = image * nchunk + chunk, gs.ppb pixels) instead of a stride
   // over the whole batch, and also leaves the GroupNorm-backward sums of that chunk (see LnGnSums)
   const bool gsum = BWD && gs.part != nullptr;
-  float s1[16], s2[16];
+  float s1[4 * NQM], s2[4 * NQM];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int k = 0; k < 4 * NQM; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   const int gb = gsum ? (int)blockIdx.x / gs.nchunk : 0, gchunk = gsum ? (int)blockIdx.x - gb * gs.nchunk : 0;
   const size_t p_lo = gsum ? (size_t)gb * gs.HW + (size_t)gchunk * gs.ppb : 0;
   const size_t p_hi = gsum ? ((size_t)(gchunk + 1) * gs.ppb < (size_t)gs.HW ? p_lo + gs.ppb : (size_t)(gb + 1) * gs.HW) : npix;
@@ -557,19 +559,33 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   for (size_t pbase = p_lo + wave_global * ppw; pbase < p_hi; pbase += nwaves * ppw) {
     const size_t p = pbase + sub;
     const bool valid = p < p_hi;
-    float4 xv[4];
+    float4 xv[NQM];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQM; ++j) {
       xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < NQ && valid) xv[j] = *reinterpret_cast<const float4*>(x + p * C + (size_t)(ql + j * TPP) * 4);
       s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+    }
+    // BWD: the gradient (and the residual-path term) of the same pixels are requested here, with x - behind the two cross-lane
+    // reductions below they were a second and a third memory round trip per pixel group
+    float4 dvv[NQM], rvv[NQM];
+    if (BWD) {
+#pragma unroll
+      for (int j = 0; j < NQM; ++j) {
+        dvv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rvv[j] = dvv[j];
+        if (j < NQ && valid) {
+          dvv[j] = *reinterpret_cast<const float4*>(dy + p * C + (size_t)(ql + j * TPP) * 4);
+          if (res) rvv[j] = *reinterpret_cast<const float4*>(res + p * C + (size_t)(ql + j * TPP) * 4);
+        }
+      }
     }
     for (int off = 1; off < TPP; off <<= 1) s += __shfl_xor(s, off);
     const float mean = s / (float)C;
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQM; ++j) {
       if (j < NQ) {
         const float a = xv[j].x - mean, b2 = xv[j].y - mean, c2 = xv[j].z - mean, d2 = xv[j].w - mean;
         v += (a * a + b2 * b2) + (c2 * c2 + d2 * d2);
@@ -579,7 +595,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     const float rstd = 1.f / sqrtf(v / (float)C + eps);
     if (!BWD) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NQM; ++j) {
         if (j < NQ && valid) {
           const int c = (ql + j * TPP) * 4;
           const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
@@ -592,16 +608,16 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         }
       }
     } else {
-      float4 gv[4], xh[4];
+      float4 gv[NQM], xh[NQM];
       float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NQM; ++j) {
         gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         xh[j] = gv[j];
         if (j < NQ && valid) {
           const int c = (ql + j * TPP) * 4;
           const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-          const float4 d = *reinterpret_cast<const float4*>(dy + p * C + c);
+          const float4 d = dvv[j];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             xh[j][k] = (xv[j][k] - mean) * rstd;
@@ -619,14 +635,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       m1 /= (float)C;
       m2 /= (float)C;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NQM; ++j) {
         if (j < NQ && valid) {
           const int c = (ql + j * TPP) * 4;
           float4 o;
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = rstd * (gv[j][k] - m1 - xh[j][k] * m2);
           if (res) {
-            const float4 r = *reinterpret_cast<const float4*>(res + p * C + c);
+            const float4 r = rvv[j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               o[k] += r[k];
@@ -653,7 +669,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
   if (BWD) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dgs[tid][k] = dg[k];
+    for (int k = 0; k < 4 * NQM; ++k) dgs[tid][k] = dg[k];
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
       const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
@@ -665,7 +681,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     if (rsum_partial) {
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 16; ++k) dgs[tid][k] = rs[k];
+      for (int k = 0; k < 4 * NQM; ++k) dgs[tid][k] = rs[k];
       __syncthreads();
       for (int c = tid; c < C; c += 256) {
         const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
@@ -680,7 +696,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       for (int m = 0; m < 2; ++m) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dgs[tid][k] = m ? s2[k] : s1[k];
+        for (int k = 0; k < 4 * NQM; ++k) dgs[tid][k] = m ? s2[k] : s1[k];
         __syncthreads();
         for (int c = tid; c < C; c += 256) {
           const int q = c / 4, k = c % 4, j = q / TPP, qlane = q % TPP;
@@ -919,7 +935,11 @@ static bool ln_ok(int C) {
 
 int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t npix, int C, hipStream_t st) {
   if (!ln_ok(C)) return fail("layernorm: C=%d must be 4*2^k <= 1024", C);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
+  if (C <= 256)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false, 1>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
+                     nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false, 4>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
                      nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
   PIDM_CHECK_LAUNCH("layernorm_fwd");
   return 0;
@@ -954,7 +974,11 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
   }
   float* partial = reinterpret_cast<float*>(ws);
   float* partial2 = res_colsum ? partial + (size_t)nb * C : nullptr;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
+  if (C <= 256)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true, 1>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
+                     1e-5f, gs);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true, 4>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
                      1e-5f, gs);
   PIDM_CHECK_LAUNCH("layernorm_bwd");
   if (defer) {   // `ws` (the per-block partial rows) stays alive until the caller's reduce_multi launch

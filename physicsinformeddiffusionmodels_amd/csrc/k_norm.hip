@@ -938,6 +938,9 @@ int launch_layernorm_fwd(const float* x, const float* gamma, float* y, size_t np
   if (C <= 256)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false, 1>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
                      nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
+  else if (C <= 512)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false, 2>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
+                     nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<false, 4>), dim3(ln_blocks(npix, C)), dim3(256), 0, st, x, gamma, nullptr,
                      nullptr, y, nullptr, nullptr, npix, C, 1e-5f, LnGnSums{});
@@ -976,6 +979,9 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
   float* partial2 = res_colsum ? partial + (size_t)nb * C : nullptr;
   if (C <= 256)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true, 1>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
+                     1e-5f, gs);
+  else if (C <= 512)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true, 2>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,
                      1e-5f, gs);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_kernel<true, 4>), dim3(nb), dim3(256), 0, st, x, gamma, dy, res, dx, partial, partial2, npix, C,

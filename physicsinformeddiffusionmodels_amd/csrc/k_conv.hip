@@ -371,11 +371,18 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
         if (g.bn_part) {
           const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
+          PIDM_BN_PARTIAL(acc, bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual != nullptr), residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c, g.ldr)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);
         const size_t rpix = ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + n0 + 4 * (l31 >> 2);
+        // (stride-1 forms: the four residual quads of the tile as one batch of loads - inside the q4 loop each was a branch, a load
+        //  and a wait behind the previous quad's store)
+        f32x4 rres[4];
+        if (MODE != 2 && residual) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) rres[q4] = *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)(8 * q4 + 4 * half + (l31 & 3)) * g.ldr);
+        }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           float x0 = v[4 * q4], x1 = v[4 * q4 + 1], x2 = v[4 * q4 + 2], x3 = v[4 * q4 + 3];
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(64 * NW) conv3x3_split_kernel(ConvGeom g, cons
             if (residual) o += *reinterpret_cast<const f32x4*>(residual + ((size_t)b * g.Ho * g.Wo + opx) * g.ldr + n0 + 4 * (l31 >> 2));
             *reinterpret_cast<f32x4*>(out + (size_t)b * g.sob + opx * g.sox + n0 + 4 * (l31 >> 2)) = o;
           } else {
-          if (residual) o += *reinterpret_cast<const f32x4*>(residual + rpix + (size_t)prow * g.ldr);
+          if (residual) o += rres[q4];
           *reinterpret_cast<f32x4*>(out + opix + (size_t)prow * g.sox) = o;
           }
         }
@@ -702,7 +709,7 @@ __global__ void __launch_bounds__(64 * (NW / MS) + 64 * NPW) conv3x3_split_ws_ke
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, pin, c)
         if (g.bn_part) {
           const float* xrow = g.bn_x + ((size_t)b * g.Ho * g.Wo + pin) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc[ms], bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual) ? residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c : (const float*)nullptr, g.ldr)
+          PIDM_BN_PARTIAL(acc[ms], bv, b, pin, c, xrow, g.Cout, (g.bn_res && residual != nullptr), residual + ((size_t)b * g.Ho * g.Wo + pin) * g.ldr + c, g.ldr)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);

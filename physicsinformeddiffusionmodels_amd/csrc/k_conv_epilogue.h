@@ -24,7 +24,11 @@ namespace pidm {
 // GroupNorm-backward partial sums from a dgrad epilogue (ConvGeom::bn_part).  acc_ = the lane's 16 rows of dy for channel c_
 // (rows (r&3) + 8(r>>2) + 4half of the wave's 32 pixels), xrow_ = &x[first pixel of the wave][c_], xstep_ = floats between
 // consecutive pixels of the wave in x.  Same arithmetic as gn_recompute (k_norm.hip).
-#define PIDM_BN_PARTIAL(acc_, bv_, b_, pix_in_img_, c_, xrow_, xstep_, rrow_, rstep_)                               \
+// res_on_ (wave-uniform, from kernel arguments): the epilogue adds a residual; rrow_ is evaluated only then.  The optional loads
+// (FiLM rows, residual rows) sit behind SCALAR conditions as batches: with a per-lane `ptr ? ptr[..] : 0` hipcc gave each of the 16
+// residual rows a branch, a reload of its spilled offset and s_waitcnt vmcnt(0) - 16 memory round trips in the epilogue of every
+// input-gradient launch that leaves these sums (ISA of conv3x3_split_ws_kernel, round 6).
+#define PIDM_BN_PARTIAL(acc_, bv_, b_, pix_in_img_, c_, xrow_, xstep_, res_on_, rrow_, rstep_)                      \
   {                                                                                                                 \
     const int gI__ = (c_) / g.bn_cpg;                                                                               \
     const float mean__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2], rstd__ = g.bn_stats[((size_t)(b_) * g.bn_G + gI__) * 2 + 1]; \
@@ -36,10 +40,13 @@ namespace pidm {
     }                                                                                                               \
     float xv__[16], rv__[16];                                                                                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
-        xv__[r] = (xrow_)[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * (xstep_)];                                  \
-    const float* rr__ = (rrow_);      /* wave-uniform: the residual the epilogue adds to the result, or null */     \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
-        rv__[r] = rr__ ? rr__[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * (rstep_)] : 0.f;                        \
+        xv__[r] = (xrow_)[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * half) * (unsigned)(xstep_)];   /* 32-bit row offsets */ \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) rv__[r] = 0.f;                                                   \
+    if (res_on_) {                                                                                                  \
+      const float* rr__ = (rrow_);                                                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+          rv__[r] = rr__[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * half) * (unsigned)(rstep_)];                       \
+    }                                                                                                               \
     float a1__ = 0.f, a2__ = 0.f;                                                                                   \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
       const float xh__ = (xv__[r] - mean__) * rstd__;                                                               \

@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         if (g.gn_part) PIDM_GN_PARTIAL(gs1, gs2, b, (vy0 + ty) * g.Wv + tx0, c)
         if (g.bn_part) {   // plain stride-1 geometry (os == 1, output grid == x grid): the wave's pixels are consecutive in x
           const float* xrow = g.bn_x + (((size_t)b * g.Ho + oy) * g.Wo + tx0) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout, (const float*)nullptr, 0)
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b, (vy0 + ty) * g.Wv + tx0, c, xrow, g.Cout, false, (const float*)nullptr, 0)
         }
       }
     }
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) conv_igemm_pipe_kernel(ConvGeom g, int si
         const int ty0 = (p0w >> g.wsh) & (g.TH - 1), img0 = p0w >> (g.wsh + g.tsh);
         if (b0 + img0 < g.B && img0 < g.NI) {
           const float* xrow = g.bn_x + (((size_t)(b0 + img0) * g.Ho + (vy0 + ty0)) * g.Wo) * g.Cout + c;
-          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout, (const float*)nullptr, 0)
+          PIDM_BN_PARTIAL(acc[mt * NT + ni], bv, b0 + img0, (vy0 + ty0) * g.Wv, c, xrow, g.Cout, false, (const float*)nullptr, 0)
         }
       }
     }
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(256) conv3x3_stream_kernel(ConvGeom g, int sig
           f32x16 accs;
 #pragma unroll
           for (int r = 0; r < 16; ++r) accs[r] = acc[r] + acc1[r];
-          PIDM_BN_PARTIAL(accs, bv, b, pin, c, xrow, g.Cout, (const float*)nullptr, 0)
+          PIDM_BN_PARTIAL(accs, bv, b, pin, c, xrow, g.Cout, false, (const float*)nullptr, 0)
         }
         const bool odd1 = (l31 & 1) != 0, odd2 = (l31 & 2) != 0;
         const size_t opix = (size_t)b * g.sob + (size_t)pin * g.sox + n0 + 4 * (l31 >> 2);

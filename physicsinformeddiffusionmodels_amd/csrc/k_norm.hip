@@ -249,8 +249,29 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
         }
       }
     } else {
-#pragma unroll 4
-      for (int p = p0 + pl; p < p1; p += L.ppi) {
+      // four pixels per trip: their loads (x and, behind ONE branch, the residual) are all requested before the first is used -
+      // left to `#pragma unroll 4` hipcc kept one or two in flight (load, optional load in a branch, wait, arithmetic, store, ...)
+      int p = p0 + pl;
+      for (; p + 3 * L.ppi < p1; p += 4 * L.ppi) {
+        f32x4 xv[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + base + (size_t)(p + u * L.ppi) * C);
+        if (res) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rv[u] = *reinterpret_cast<const f32x4*>(res + base + (size_t)(p + u * L.ppi) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v = ((xv[u][k] - mean[k]) * a[k] + bt[k]) * sc1[k] + sh[k];
+            o[k] = v * sigmoidf_(v) + (res ? rv[u][k] : 0.f);
+          }
+          *reinterpret_cast<f32x4*>(y + base + (size_t)(p + u * L.ppi) * C) = o;
+        }
+      }
+      for (; p < p1; p += L.ppi) {
         const size_t i = base + (size_t)p * C;
         const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
@@ -492,8 +513,27 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
       k2[k] = s_coef[g][1];
     }
     const size_t base = (size_t)b * HW * C + c0;
-#pragma unroll 4
-    for (int p = p0 + pl; p < p1; p += L.ppi) {
+    int p = p0 + pl;
+    for (; p + 3 * L.ppi < p1; p += 4 * L.ppi) {        // four pixels per trip, their eight loads requested together (see gn_apply_kernel)
+      f32x4 xv[4], dv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const f32x4*>(x + base + (size_t)(p + u * L.ppi) * C);
+        dv4[u] = *reinterpret_cast<const f32x4*>(dy + base + (size_t)(p + u * L.ppi) * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xh, dv;
+          gn_recompute(xv[u][k], dv4[u][k], mean[k], rstd[k], gm[k], bt[k], sc1[k], sh[k], &xh, &dv);
+          o[k] = rstd[k] * (dv * sc1[k] * gm[k] - k1[k] - xh * k2[k]);
+        }
+        *reinterpret_cast<f32x4*>(dx + base + (size_t)(p + u * L.ppi) * C) = o;
+      }
+    }
+    for (; p < p1; p += L.ppi) {
       const size_t i = base + (size_t)p * C;
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
       const f32x4 dv4 = *reinterpret_cast<const f32x4*>(dy + i);

@@ -216,11 +216,30 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     }
     const size_t base = (size_t)b * HW * C + c0;
     if (LN) {
-      for (int p = p0 + pl; p < p1; p += L.ppi) {
+      // (groups of four pixels whose x / residual quads are requested together; a lane whose last pixels do not exist re-reads its
+      //  first one and skips them)
+      for (int pg = p0 + pl; pg < p1; pg += 4 * L.ppi) {
+      f32x4 xq[4], rq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pu = pg + u * L.ppi < p1 ? pg + u * L.ppi : pg;
+        xq[u] = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + base + (size_t)pu * C);
+      }
+      if (res) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pu = pg + u * L.ppi < p1 ? pg + u * L.ppi : pg;
+          rq[u] = *reinterpret_cast<const f32x4*>(res + base + (size_t)pu * C);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = pg + u * L.ppi;
+        if (p >= p1) break;
         const size_t i = base + (size_t)p * C;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>((INPLACE ? y : x) + i);
+        const f32x4 xv = xq[u];
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if (res) rv = *reinterpret_cast<const f32x4*>(res + i);
+        if (res) rv = rq[u];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -247,6 +266,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
           z[3] = d3 * lrstd * gm[3];
           *reinterpret_cast<f32x4*>(ln_out + i) = z;
         }
+      }
       }
     } else {
       // four pixels per trip: their loads (x and, behind ONE branch, the residual) are all requested before the first is used -
@@ -331,8 +351,26 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const size_t base = (size_t)b * HW * C + c0;
-#pragma unroll 4
-    for (int p = p0 + pl; p < p1; p += L.ppi) {
+    int p = p0 + pl;
+    for (; p + 3 * L.ppi < p1; p += 4 * L.ppi) {        // four pixels per trip, their eight loads requested together; same order of the sums
+      f32x4 xv[4], dv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const f32x4*>(x + base + (size_t)(p + u * L.ppi) * C);
+        dv4[u] = *reinterpret_cast<const f32x4*>(dy + base + (size_t)(p + u * L.ppi) * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float xh, dv;
+          gn_recompute(xv[u][k], dv4[u][k], mean[k], rstd[k], gm[k], bt[k], sc1[k], sh[k], &xh, &dv);
+          s1[k] += dv;
+          s2[k] += dv * xh;
+        }
+      }
+    }
+    for (; p < p1; p += L.ppi) {
       const size_t i = base + (size_t)p * C;
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
       const f32x4 dv4 = *reinterpret_cast<const f32x4*>(dy + i);

@@ -113,6 +113,30 @@ def test_conv_1x1_stream_wgrad_forms(backend, monkeypatch, form, B, H, C0, C1, C
     test_conv_fwd_dgrad_wgrad(backend, B, H, C0, C1, Cout, K, stride, pad, transposed)
 
 
+def test_1x1_split_wgrad_xcd_order_is_a_pure_renumbering(backend, monkeypatch):
+    """wgrad_xcd_order only renumbers a problem's workgroups (which XCD runs which (split, tile)): with PIDM_WGRAD1X1_XCD=0 every
+    workgroup does the same work and the gradients are bit-identical - also for grids that are not multiples of 8."""
+    L, dev = backend
+    st = stream_ptr(dev)
+    g = torch.Generator().manual_seed(97)
+    for B, H, Cin, Cout in ((3, 16, 128, 96), (5, 8, 64, 384), (1, 16, 256, 256)):
+        x = torch.randn(B, Cin, H, H, generator=g)
+        dy = torch.randn(B, Cout, H, H, generator=g)
+        x0, dyn = nhwc(x).to(dev), nhwc(dy).to(dev)
+        d = ConvDesc(B=B, Hi=H, Wi=H, C0=Cin, C1=0, ld0=Cin, ld1=0, Cout=Cout, KH=1, KW=1, stride=1, pad=0, transposed=0, out_nchw=0, ldo=Cout)
+        got = {}
+        for xcd in ("1", "0"):
+            monkeypatch.setenv("PIDM_WGRAD1X1_XCD", xcd)
+            ws = torch.empty(L.pidm_conv_wgrad_ws(d), dtype=torch.uint8, device=dev)
+            dw = torch.full((Cout, Cin, 1, 1), float("nan"), device=dev)
+            db = torch.full((Cout,), float("nan"), device=dev)
+            L.check(L.pidm_conv_wgrad(d, ptr(x0), None, ptr(dyn), Cout, ptr(dw), ptr(db), ptr(ws), st))
+            got[xcd] = (dw.cpu(), db.cpu())
+        assert torch.equal(got["1"][0], got["0"][0]) and torch.equal(got["1"][1], got["0"][1])
+        ref = torch.einsum("bmhw,bnhw->mn", dy.double(), x.double())
+        assert float((got["1"][0].double().view(Cout, Cin) - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
 def test_1x1_split_wgrad_is_as_accurate_as_the_fp32_mfma(backend, monkeypatch):
     """conv_wgrad_1x1_split4_body against a float64 product next to the fp32-MFMA stream on the same data, at the longest pixel
     contraction a split of the Darcy model sees (K = 2048 pixels of the 16 x 16 level's to_qkv with 8 images; both operand roles):
